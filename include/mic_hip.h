@@ -1,0 +1,215 @@
+/* mic_hip.h — C ABI of libmic_hip.so: the MI355X (gfx950) kernels behind the CLIP-Vision + mBART-50
+ * captioning hot path (train step and KV-cached greedy / beam generate).
+ *
+ * The reference (gchhablani/multilingual-image-captioning) is pure Python/Flax: it has NO native boundary
+ * for this path — XLA emits every kernel.  The boundary below is therefore build-defined
+ * (SURVEY §8b): one entry point per fused op that the reference's module graph implies; each comment cites
+ * the reference lines whose arithmetic the op replaces.  `modeling:` =
+ * models/flax_clip_vision_mbart/modeling_clip_vision_mbart.py, `gen:` = .../generation_clip_vision_utils.py,
+ * 3P = transformers@0085e71 (modeling_flax_clip.py / modeling_flax_mbart.py), un-vendored.
+ *
+ * Conventions
+ *  - All pointers are caller-owned DEVICE pointers; outputs and workspaces are caller-allocated.
+ *  - Every call is asynchronous on `stream` (a hipStream_t passed as void*); no global mutable state,
+ *    re-entrant across streams/threads.  Return 0 on success, negative MIC_E* on bad arguments
+ *    (never throws, never exits); mic_last_error() gives a thread-local message.
+ *  - Activations are row-major [rows][width]; `dtype` selects the storage type of activations
+ *    (MIC_BF16 = bf16 storage, fp32 accumulate/statistics;  MIC_F32 = the reference's default dtype).
+ *  - Linear weights are stored [out][in] (k-contiguous); LayerNorm / bias vectors and optimizer state fp32.
+ */
+#ifndef MIC_HIP_H
+#define MIC_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIC_OK 0
+#define MIC_EINVAL (-1)   /* bad argument / unsupported shape */
+#define MIC_ELAUNCH (-2)  /* HIP launch failure */
+
+#define MIC_BF16 0
+#define MIC_F32 1
+
+/* activation ids for GEMM epilogues */
+#define MIC_ACT_NONE 0
+#define MIC_ACT_GELU_ERF 1   /* PT-twin mBART "gelu" */
+#define MIC_ACT_GELU_TANH 2  /* jax.nn.gelu default at the pinned commit [UNVERIFIED-3P] */
+#define MIC_ACT_QUICK_GELU 3 /* CLIP: x*sigmoid(1.702x) */
+
+int mic_version(void);
+const char* mic_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue:  C[M,N] = epi( op(A)[M,K] * op(B)[K,N] )
+ *   a_kmajor = 0: A stored [M][lda>=K] (k contiguous);  1: A stored [K][lda>=M] (m contiguous)
+ *   b_kmajor = 0: B stored [N][ldb>=K] (k contiguous);  1: B stored [K][ldb>=N] (n contiguous)
+ *   Linear fwd  y = x W^T      : a_kmajor=0, b_kmajor=0  (nn.Dense, 3P; modeling:53-59, 90)
+ *   Linear dX   dx = dy W      : a_kmajor=0, b_kmajor=1
+ *   Linear dW   dW = dy^T x    : a_kmajor=1, b_kmajor=1
+ * epilogue, in this order (each optional):
+ *   v = acc (+ bias[n]);  Zout[m,n] = v (pre-activation, saved for backward);  v = act(v);
+ *   v *= act'(Zin[m,n]) (activation backward);  v = dropout(v; seed, p, index m*N+n);
+ *   v += R[m,n];  v += C_old[m,n] (accumulate);  C[m,n] = v  (c_dtype)
+ * Requirements: K % 64 == 0 for MIC_BF16 (callers zero-pad the reduction dimension); lda/ldb % 8 == 0 (bf16).
+ * bf16 path: LDS-staged 128x128x64 tiles (direct global->LDS DMA, XOR-swizzled), v_mfma_f32_32x32x16_bf16,
+ * k-major operands through ds_read_b64_tr_b16.  f32 path: v_mfma_f32_32x32x2_f32 (exact fp32).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int dtype;         /* dtype of A, B, R, Zin, Zout */
+  int c_dtype;       /* dtype of C */
+  int M, N, K;
+  int a_kmajor, b_kmajor;
+  const void* A; int lda;
+  const void* B; int ldb;
+  void* C; int ldc;
+  const float* bias;       /* [N] or NULL */
+  int act;                 /* MIC_ACT_* applied to v */
+  void* Zout; int ldz;     /* pre-activation out or NULL */
+  const void* Zin; int dact; /* multiply by act'(Zin) with activation id `dact` (0 = off) */
+  const void* R; int ldr;  /* residual or NULL */
+  int accumulate;          /* add existing C */
+  float dropout_p; uint32_t dropout_seed; /* p = 0 disables */
+  float alpha;             /* scale on acc before bias (0 means 1) */
+} mic_gemm_args;
+int mic_gemm(const mic_gemm_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * LayerNorm (flax nn.LayerNorm: biased variance, fp32 statistics; 3P).
+ *   fwd: y = (x-mean)*rstd*gamma + beta, then optional dropout; saves mean/rstd [rows] (may be NULL).
+ *   bwd: dx = LNbwd(dy) (+ dres if given);  dgamma/dbeta accumulated with fp32 atomics (caller zeroes);
+ *        optional second output dxm = dropout_mask(seed_m) * dx / (1-p_m): the gradient entering the
+ *        residual branch that produced x (its epilogue applied that dropout in forward).
+ * ------------------------------------------------------------------------------------------- */
+int mic_layernorm_fwd(int dtype, int rows, int width, const void* x, const float* gamma, const float* beta,
+                      float eps, void* y, float* mean, float* rstd, float dropout_p, uint32_t dropout_seed,
+                      void* stream);
+int mic_layernorm_bwd(int dtype, int rows, int width, const void* x, const float* gamma, const float* mean,
+                      const float* rstd, const void* dy, const void* dres, void* dx, float* dgamma, float* dbeta,
+                      void* dxm, float dropout_p, uint32_t dropout_seed, float in_dropout_p, uint32_t in_dropout_seed,
+                      void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Attention core (flax dot_product_attention_weights): q scaled by 1/sqrt(D) first,
+ * softmax(q k^T + bias) v, heads merged.  q [B*Tq][ldq], k/v [B*Tk][ldk/ldv] with head h at column
+ * h*64 (head_dim is 64 for both models); out [B*Tq][ldo].  causal: key j allowed iff j <= i.
+ * key_mask int32 [B][Tk] (1 = attend) or NULL.  Disallowed -> -inf bias.  lse [B][H][Tq] saved for bwd.
+ * Tq, Tk <= 64.  Covers K4 (ViT, 50x50), K9 (decoder causal+padding, 64x64), K10 (cross, 64x50).
+ * ------------------------------------------------------------------------------------------- */
+int mic_attn_fwd(int dtype, int B, int H, int Tq, int Tk, const void* q, int ldq, const void* k, int ldk,
+                 const void* v, int ldv, void* out, int ldo, const int32_t* key_mask, int causal, float* lse,
+                 void* stream);
+int mic_attn_bwd(int dtype, int B, int H, int Tq, int Tk, const void* q, int ldq, const void* k, int ldk,
+                 const void* v, int ldv, const void* out, int ldo, const void* dout, int lddo, const float* lse,
+                 const int32_t* key_mask, int causal, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv,
+                 void* stream);
+
+/* Decode-time self-attention over the static max_len-slot cache (3P _concatenate_to_cache; modeling:249-282;
+ * SURVEY App. B7): one query per row, validity slot <= cur (cache_index).  The cache is NOT physically
+ * reordered by beam (gen:945-953): src_row [R][max_len] int32 says in which row slot s of row r's
+ * history lives (beam-parent indirection); NULL = row r reads cache row r / row_div (cross-attention K/V are
+ * computed once per image and shared by its beams: row_div = num_beams, cur = S-1).  kc/vc: [rows][max_len][H*64]. */
+int mic_attn_decode(int dtype, int R, int H, int max_len, int cur, const void* q, int ldq, const void* kc,
+                    const void* vc, const int32_t* src_row, int row_div, void* out, int ldo, void* stream);
+/* writes this step's k,v (columns of the fused qkv projection) into slot `cur` of every row's own cache */
+int mic_kv_append(int dtype, int R, int HD, int max_len, int cur, const void* k, int ldk, const void* v, int ldv,
+                  void* kc, void* vc, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * ViT embeddings (3P FlaxCLIPVisionEmbeddings)
+ *   im2col: pixels NHWC fp32 [B][img][img][3] -> patches [B*g*g][ps*ps*3] (dtype), k order (u,v,c) = HWIO.
+ *           trunc_int32 = 1 reproduces encode()'s cast of pixel_values to int32 (modeling:330).
+ *   assemble: x[b,0] = cls + pos[0]; x[b,1+p] = patch_out[b,p] + pos[1+p]
+ *   assemble_bwd: dpatch = dx[:,1:], dpos += sum_b dx, dcls += sum_b dx[:,0]   (fp32 atomics; caller zeroes)
+ * ------------------------------------------------------------------------------------------- */
+int mic_im2col(int dtype, int B, int img, int ps, const float* pixels, void* patches, int ldp, int trunc_int32,
+               void* stream);
+int mic_vit_assemble(int dtype, int B, int S, int width, const void* patch_out, int ldp, const float* cls,
+                     const float* pos, void* x, void* stream);
+int mic_vit_assemble_bwd(int dtype, int B, int S, int width, const void* dx, void* dpatch, int ldp, float* dcls,
+                         float* dpos, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Decoder token embedding (3P FlaxMBartDecoder):
+ *   h[r] = table[ids[r]] * scale + pos_table[pos_ids[r] + 2]        (table in `dtype`, pos_table fp32)
+ *   bwd: dtable[ids[r]] += dh[r]*scale ; dpos_table[pos+2] += dh[r]  (fp32 atomics into the grad buffers)
+ * ------------------------------------------------------------------------------------------- */
+int mic_embed_fwd(int dtype, int rows, int width, const int32_t* ids, const int32_t* pos_ids, const void* table,
+                  const float* pos_table, float scale, void* h, void* stream);
+int mic_embed_bwd(int dtype, int rows, int width, const int32_t* ids, const int32_t* pos_ids, const void* dh,
+                  float scale, float* dtable, float* dpos_table, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Masked (label-smoothed) softmax cross-entropy over materialised logits (main.py:658-680).
+ *   logits [rows][ld] (dtype), columns >= V are padding.  Pass 1 (mic_ce_rows): per-row lse, nll(ls) -> row_loss,
+ *   Pass 2 (mic_ce_bwd): logits <- dlogits = mask/denom * (softmax - soft_label) in place, padding columns <- 0,
+ *   where denom = sum(mask) is read from device (denom[0]).  loss = sum(row_loss*mask)/denom by mic_ce_reduce.
+ * ------------------------------------------------------------------------------------------- */
+int mic_ce_rows(int dtype, int rows, int V, const void* logits, int ld, const int32_t* labels,
+                const int32_t* mask, float label_smoothing, float* row_lse, float* row_loss, void* stream);
+int mic_ce_reduce(int rows, const float* row_loss, const int32_t* mask, float* loss_out, float* denom_out,
+                  void* stream);
+int mic_ce_bwd(int dtype, int rows, int V, int Vpad, void* logits, int ld, const int32_t* labels,
+               const int32_t* mask, float label_smoothing, const float* row_lse, const float* denom,
+               float loss_scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Small reductions / elementwise
+ * ------------------------------------------------------------------------------------------- */
+/* out[n] (+)= sum_m x[m,n]  (bias gradients).  accumulate=0 overwrites. */
+int mic_colsum(int dtype, int rows, int cols, const void* x, int ld, float* out, int accumulate, void* stream);
+/* keep-mask (uint8, 1 = keep) that the fused dropout epilogues use for (seed, p) over n elements */
+int mic_dropout_mask(uint8_t* out, int64_t n, float p, uint32_t seed, void* stream);
+int mic_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);
+/* dst[r][c] (dst_dtype, ld_dst) = src[r][c] (src_dtype, ld_src) */
+int mic_cast2d(int src_dtype, int dst_dtype, int rows, int cols, const void* src, int ld_src, void* dst, int ld_dst,
+               void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * AdamW over a flat fp32 parameter buffer (optax.adamw, main.py:629-635):
+ *   m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr * ( m/(1-b1^t) / (sqrt(v/(1-b2^t)) + eps) + wd p )
+ * `lr` and `t` are read from device scalars (hyper[0] = lr, hyper[1] = t as float) so the step is graph-capturable.
+ * b1/b2/eps/wd are doubles so that (1-b1), (1-b2) are formed in double like optax does before rounding to fp32.
+ * Also refreshes the bf16 compute copy (p_lp, may be NULL) and scales g by grad_scale (e.g. 1/world).
+ * ------------------------------------------------------------------------------------------- */
+int mic_adamw(int64_t n, float* p, float* m, float* v, const float* g, void* p_lp, const float* hyper, double b1,
+              double b2, double eps, double wd, float grad_scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Generation epilogues
+ *   mic_row_lse_topk: per row of logits [R][ld] (dtype): lse over V and the top-k (k <= 8) of
+ *       processed log-probs (forced_token >= 0: everything -inf except forced_token := 0; min-length: eos := -inf
+ *       when suppress_eos), plus row_bias[row] (the beam's running score, gen:857) — candidates ordered
+ *       (value desc, index asc), i.e. lax.top_k (gen:850-873).  raw_logits = 1: no log-softmax (greedy, gen:497-499).
+ *   mic_beam_step: the whole bookkeeping of one beam_search_body_fn iteration (gen:857-966) per batch item.
+ *   mic_greedy_step: argmax + EOS->PAD substitution + append (gen:499-512).
+ * ------------------------------------------------------------------------------------------- */
+int mic_row_lse_topk(int dtype, int R, int V, const void* logits, int ld, int k, int forced_token,
+                     int suppress_eos, int eos_token_id, int raw_logits, const float* row_bias, float* top_val,
+                     int32_t* top_idx, void* stream);
+
+typedef struct {
+  int B, K, max_len, V;
+  int cur_len;                /* tokens already in running_sequences */
+  int eos_token_id, pad_token_id;
+  float length_penalty; int early_stopping;
+  const float* cand_val;      /* [B*K][2K] per-row top candidates: processed log-prob + running score (row_bias) */
+  const int32_t* cand_idx;    /* [B*K][2K] */
+  int32_t* running_seq;       /* [B][K][max_len] in/out */
+  float* running_scores;      /* [B][K] in/out */
+  int32_t* seq;               /* [B][K][max_len] finished, in/out */
+  float* scores;              /* [B][K] in/out */
+  int32_t* finished;          /* [B][K] in/out (0/1) */
+  int32_t* src_row;           /* [B*K][max_len] in/out: KV-cache slot ownership (beam-parent indirection) */
+  int32_t* next_token;        /* [B*K] out: token each running beam feeds next step */
+  int32_t* flags;             /* [B][2] out: per item {all finished, improvement impossible} for the loop cond */
+} mic_beam_step_args;
+int mic_beam_step(const mic_beam_step_args* a, void* stream);
+
+int mic_greedy_step(int B, int max_len, int cur_len, int eos_token_id, int pad_token_id, const int32_t* top_idx,
+                    int ld_top, int32_t* sequences, int32_t* finished, int32_t* next_token, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,93 @@
+"""ctypes binding of libmic_hip.so (C ABI in include/mic_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmic_hip.so")
+
+MIC_BF16, MIC_F32 = 0, 1
+ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_QUICK_GELU = 0, 1, 2, 3
+ACT_IDS = {"none": 0, None: 0, "gelu": 1, "erf": 1, "gelu_erf": 1, "tanh": 2, "gelu_tanh": 2, "gelu_new": 2, "quick_gelu": 3}
+
+
+class MicError(RuntimeError):
+    pass
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int), ("c_dtype", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("a_kmajor", C.c_int), ("b_kmajor", C.c_int),
+        ("A", C.c_void_p), ("lda", C.c_int), ("B", C.c_void_p), ("ldb", C.c_int), ("C", C.c_void_p), ("ldc", C.c_int),
+        ("bias", C.c_void_p), ("act", C.c_int), ("Zout", C.c_void_p), ("ldz", C.c_int), ("Zin", C.c_void_p),
+        ("dact", C.c_int), ("R", C.c_void_p), ("ldr", C.c_int), ("accumulate", C.c_int), ("dropout_p", C.c_float),
+        ("dropout_seed", C.c_uint32), ("alpha", C.c_float),
+    ]
+
+
+class BeamStepArgs(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("K", C.c_int), ("max_len", C.c_int), ("V", C.c_int), ("cur_len", C.c_int),
+        ("eos_token_id", C.c_int), ("pad_token_id", C.c_int), ("length_penalty", C.c_float), ("early_stopping", C.c_int),
+        ("cand_val", C.c_void_p), ("cand_idx", C.c_void_p), ("running_seq", C.c_void_p), ("running_scores", C.c_void_p),
+        ("seq", C.c_void_p), ("scores", C.c_void_p), ("finished", C.c_void_p), ("src_row", C.c_void_p),
+        ("next_token", C.c_void_p), ("flags", C.c_void_p),
+    ]
+
+
+_i, _f, _p, _u32, _i64 = C.c_int, C.c_float, C.c_void_p, C.c_uint32, C.c_int64
+_SIGS = {
+    "mic_version": ([], C.c_int),
+    "mic_last_error": ([], C.c_char_p),
+    "mic_gemm": ([C.POINTER(GemmArgs), _p], C.c_int),
+    "mic_layernorm_fwd": ([_i, _i, _i, _p, _p, _p, _f, _p, _p, _p, _f, _u32, _p], C.c_int),
+    "mic_layernorm_bwd": ([_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _u32, _f, _u32, _p], C.c_int),
+    "mic_attn_fwd": ([_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p], C.c_int),
+    "mic_attn_bwd": ([_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p], C.c_int),
+    "mic_attn_decode": ([_i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _i, _p, _i, _p], C.c_int),
+    "mic_kv_append": ([_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p], C.c_int),
+    "mic_im2col": ([_i, _i, _i, _i, _p, _p, _i, _i, _p], C.c_int),
+    "mic_vit_assemble": ([_i, _i, _i, _i, _p, _i, _p, _p, _p, _p], C.c_int),
+    "mic_vit_assemble_bwd": ([_i, _i, _i, _i, _p, _p, _i, _p, _p, _p], C.c_int),
+    "mic_embed_fwd": ([_i, _i, _i, _p, _p, _p, _p, _f, _p, _p], C.c_int),
+    "mic_embed_bwd": ([_i, _i, _i, _p, _p, _p, _f, _p, _p, _p], C.c_int),
+    "mic_ce_rows": ([_i, _i, _i, _p, _i, _p, _p, _f, _p, _p, _p], C.c_int),
+    "mic_ce_reduce": ([_i, _p, _p, _p, _p, _p], C.c_int),
+    "mic_ce_bwd": ([_i, _i, _i, _i, _p, _i, _p, _p, _f, _p, _p, _f, _p], C.c_int),
+    "mic_colsum": ([_i, _i, _i, _p, _i, _p, _i, _p], C.c_int),
+    "mic_dropout_mask": ([_p, _i64, _f, _u32, _p], C.c_int),
+    "mic_cast": ([_i, _i, _p, _p, _i64, _p], C.c_int),
+    "mic_cast2d": ([_i, _i, _i, _i, _p, _i, _p, _i, _p], C.c_int),
+    "mic_adamw": ([_i64, _p, _p, _p, _p, _p, _p, C.c_double, C.c_double, C.c_double, C.c_double, _f, _p], C.c_int),
+    "mic_row_lse_topk": ([_i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p], C.c_int),
+    "mic_beam_step": ([C.POINTER(BeamStepArgs), _p], C.c_int),
+    "mic_greedy_step": ([_i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p], C.c_int),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libmic_hip.so (once).  Raises MicError when it has not been built — there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MicError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950).  The HIP path has no fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (args, res) in _SIGS.items():
+            fn = getattr(l, name)  # AttributeError if the symbol is not exported
+            fn.argtypes, fn.restype = args, res
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise MicError(f"{what} failed (rc={rc}): {lib().mic_last_error().decode()}")

@@ -1,0 +1,417 @@
+// attention.hip — attention cores for the three tiny tile shapes of this model (ViT 50x50, decoder causal 64x64,
+// cross 64x50; head_dim 64).  Occupancy comes from batching (B*H workgroups), not from tiling: one wave owns one
+// (batch, head) problem, stages Q/K/V (and dO) as 64x64 tiles in LDS (zero padded), and runs every contraction on the
+// matrix cores:  S^T = K Q^T  (lane <-> query, so the softmax row reduction is in-register + one cross-half
+// shuffle),  O = P V,  and in backward  dP^T = V dO^T, dQ = dS K, dK = dS^T Q, dV = P^T dO  — transposed operands
+// come from the same LDS tiles through ds_read_b64_tr_b16.  bf16: v_mfma_f32_32x32x16_bf16; f32 (parity mode):
+// v_mfma_f32_32x32x2_f32.
+#include "common.h"
+#include <type_traits>
+
+#define SCALE 0.125f  // 1/sqrt(64): q is scaled before q.k^T (power of two: exact either side of the product)
+
+// ------------------------------------------------------------------ 64x64 LDS tiles
+template <typename T> struct Tile;
+
+template <> struct Tile<uint16_t> {
+  static constexpr int BYTES = 64 * 64 * 2;
+  // element (row, col) -> byte offset; 16-B chunk index XOR-swizzled by row (conflict-free ds_read_b128 fragments)
+  static __device__ __forceinline__ int off(int row, int col) { return row * 128 + ((((col >> 3) ^ (row & 7)) << 4) | ((col & 7) << 1)); }
+  // stage rows [0,nrows) x 64 cols from src (row stride ld); rows >= nrows are zero
+  static __device__ __forceinline__ void stage(char* t, const uint16_t* src, int ld, int nrows, int lane) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int idx = it * 64 + lane, row = idx >> 3, c = idx & 7;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (row < nrows) v = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + c * 8);
+      *reinterpret_cast<uint4*>(t + row * 128 + ((c ^ (row & 7)) << 4)) = v;
+    }
+  }
+  template <bool KM>
+  static __device__ __forceinline__ bf16x8 frag(const char* t, int xb, int kk, int lane) {
+    if (!KM) {
+      const int row = xb + (lane & 31), kc = kk * 2 + (lane >> 5);
+      return *reinterpret_cast<const bf16x8*>(t + row * 128 + ((kc ^ (row & 7)) << 4));
+    } else {
+      const int g = lane >> 4, p = lane & 15;
+      const int x = xb + 16 * (g & 1) + (p & 3) * 4;
+      const int k = kk * 16 + 8 * (g >> 1) + (p >> 2);
+      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, t + off(k, x)));
+      s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, t + off(k + 4, x)));
+      s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      return __builtin_bit_cast(bf16x8, r);
+    }
+  }
+  // acc(32x32) += sum_k A(a0+i, k) * B(k, b0+j) over k in [0,64).  AKM: A tile stored [k][i]; BKM: B tile stored [k][j]
+  // (non-KM B tile is stored [j][k]).
+  template <bool AKM, bool BKM>
+  static __device__ __forceinline__ void mma(f32x16& acc, const char* At, int a0, const char* Bt, int b0, int lane) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag<AKM>(At, a0, kk, lane), frag<BKM>(Bt, b0, kk, lane), acc, 0, 0, 0);
+  }
+  static __device__ __forceinline__ void store4(char* t, int row, int col0, const float* v) {
+    uint2 o;
+    o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    *reinterpret_cast<uint2*>(t + off(row, col0)) = o;
+  }
+};
+
+template <> struct Tile<float> {
+  static constexpr int BYTES = 64 * 64 * 4;
+  static __device__ __forceinline__ void stage(char* t, const float* src, int ld, int nrows, int lane) {
+    float* f = reinterpret_cast<float*>(t);
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int idx = it * 64 + lane, row = idx >> 4, c = idx & 15;
+      float4 v = make_float4(0, 0, 0, 0);
+      if (row < nrows) v = *reinterpret_cast<const float4*>(src + (size_t)row * ld + c * 4);
+      *reinterpret_cast<float4*>(f + row * 64 + c * 4) = v;
+    }
+  }
+  template <bool AKM, bool BKM>
+  static __device__ __forceinline__ void mma(f32x16& acc, const char* At, int a0, const char* Bt, int b0, int lane) {
+    const float* A = reinterpret_cast<const float*>(At);
+    const float* B = reinterpret_cast<const float*>(Bt);
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll 8
+    for (int s = 0; s < 32; ++s) {
+      const int k = 2 * s + h;
+      const float a = AKM ? A[k * 64 + a0 + i] : A[(a0 + i) * 64 + k];
+      const float b = BKM ? B[k * 64 + b0 + i] : B[(b0 + i) * 64 + k];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+  }
+  static __device__ __forceinline__ void store4(char* t, int row, int col0, const float* v) {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(t) + row * 64 + col0) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+
+__device__ __forceinline__ void zero16(f32x16& a) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+// accumulator element r of a 32x32 block: row (r&3) + 8*(r>>2) + 4*(lane>>5), col lane&31
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ unsigned long long load_key_mask(const int32_t* key_mask, int b, int Tk, int lane) {
+  if (!key_mask) return ~0ull;
+  const int mv = lane < Tk ? key_mask[b * Tk + lane] : 0;
+  return __ballot(mv != 0);
+}
+
+// ------------------------------------------------------------------ forward
+template <typename T>
+__global__ __launch_bounds__(64) void attn_fwd_kernel(int H, int Tq, int Tk, const T* __restrict__ q, int ldq,
+                                                      const T* __restrict__ k, int ldk, const T* __restrict__ v, int ldv,
+                                                      T* __restrict__ out, int ldo, const int32_t* __restrict__ key_mask,
+                                                      int causal, float* __restrict__ lse_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qt = smem;
+  char* Kt = smem + Tile<T>::BYTES;
+  char* Vt = smem + 2 * Tile<T>::BYTES;
+  char* Pt = smem + 3 * Tile<T>::BYTES;
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  Tile<T>::stage(Qt, q + (size_t)b * Tq * ldq + h * 64, ldq, Tq, lane);
+  Tile<T>::stage(Kt, k + (size_t)b * Tk * ldk + h * 64, ldk, Tk, lane);
+  Tile<T>::stage(Vt, v + (size_t)b * Tk * ldv + h * 64, ldv, Tk, lane);
+  const unsigned long long km = load_key_mask(key_mask, b, Tk, lane);
+  __syncthreads();
+  const int nib = (Tq + 31) >> 5, njb = (Tk + 31) >> 5;
+  for (int ib = 0; ib < nib; ++ib) {
+    f32x16 s[2];
+    zero16(s[0]); zero16(s[1]);
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+      if (jb < njb) Tile<T>::template mma<false, false>(s[jb], Kt, jb * 32, Qt, ib * 32, lane);
+    const int i = ib * 32 + (lane & 31);
+    float m = -INFINITY;
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = jb * 32 + acc_row(r, lane);
+        const bool ok = jb < njb && j < Tk && (!causal || j <= i) && ((km >> j) & 1ull);
+        const float x = ok ? s[jb][r] * SCALE : -INFINITY;
+        s[jb][r] = x;
+        m = fmaxf(m, x);
+      }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const float p = __expf(s[jb][r] - m); s[jb][r] = p; l += p; }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    if (lse_out && lane < 32 && i < Tq) lse_out[((size_t)b * H + h) * Tq + i] = m + logf(l);
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        float pv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pv[e] = s[jb][g4 * 4 + e] * inv;
+        Tile<T>::store4(Pt, i, jb * 32 + 8 * g4 + 4 * (lane >> 5), pv);
+      }
+  }
+  __syncthreads();
+  for (int ib = 0; ib < nib; ++ib)
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      f32x16 o;
+      zero16(o);
+      Tile<T>::template mma<false, true>(o, Pt, ib * 32, Vt, db * 32, lane);
+      const int d = db * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = ib * 32 + acc_row(r, lane);
+        if (i < Tq) ElemT<T>::st(out + ((size_t)b * Tq + i) * ldo + h * 64 + d, o[r]);
+      }
+    }
+}
+
+// ------------------------------------------------------------------ backward
+template <typename T>
+__global__ __launch_bounds__(64) void attn_bwd_kernel(int H, int Tq, int Tk, const T* __restrict__ q, int ldq,
+                                                      const T* __restrict__ k, int ldk, const T* __restrict__ v, int ldv,
+                                                      const T* __restrict__ out, int ldo, const T* __restrict__ dout, int lddo,
+                                                      const float* __restrict__ lse_in, const int32_t* __restrict__ key_mask,
+                                                      int causal, T* __restrict__ dq, int lddq, T* __restrict__ dk, int lddk,
+                                                      T* __restrict__ dv, int lddv) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TB = Tile<T>::BYTES;
+  char* Qt = smem;
+  char* Kt = smem + TB;
+  char* Vt = smem + 2 * TB;
+  char* dOt = smem + 3 * TB;
+  char* Pt = smem + 4 * TB;
+  char* dSt = smem + 5 * TB;
+  float* lse_s = reinterpret_cast<float*>(smem + 6 * TB);
+  float* delta_s = lse_s + 64;
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  Tile<T>::stage(Qt, q + (size_t)b * Tq * ldq + h * 64, ldq, Tq, lane);
+  Tile<T>::stage(Kt, k + (size_t)b * Tk * ldk + h * 64, ldk, Tk, lane);
+  Tile<T>::stage(Vt, v + (size_t)b * Tk * ldv + h * 64, ldv, Tk, lane);
+  Tile<T>::stage(dOt, dout + (size_t)b * Tq * lddo + h * 64, lddo, Tq, lane);
+  {
+    float dl = 0.f, ls = 0.f;
+    if (lane < Tq) {
+      const T* orow = out + ((size_t)b * Tq + lane) * ldo + h * 64;
+      const T* drow = dout + ((size_t)b * Tq + lane) * lddo + h * 64;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float a[8], g[8];
+        ld8(orow + c * 8, a);
+        ld8(drow + c * 8, g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += a[e] * g[e];
+      }
+      ls = lse_in[((size_t)b * H + h) * Tq + lane];
+    }
+    lse_s[lane] = ls;
+    delta_s[lane] = dl;
+  }
+  const unsigned long long km = load_key_mask(key_mask, b, Tk, lane);
+  __syncthreads();
+  const int nib = (Tq + 31) >> 5, njb = (Tk + 31) >> 5;
+  // P and dS tiles (rows = queries); rows >= Tq and keys >= Tk are exact zeros
+  for (int ib = 0; ib < 2; ++ib) {
+    const int i = ib * 32 + (lane & 31);
+    const float lse_i = lse_s[i], delta_i = delta_s[i];
+    for (int jb = 0; jb < 2; ++jb) {
+      f32x16 s, dp;
+      zero16(s); zero16(dp);
+      const bool live = ib < nib && jb < njb;
+      if (live) {
+        Tile<T>::template mma<false, false>(s, Kt, jb * 32, Qt, ib * 32, lane);
+        Tile<T>::template mma<false, false>(dp, Vt, jb * 32, dOt, ib * 32, lane);
+      }
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        float pv[4], dsv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = g4 * 4 + e;
+          const int j = jb * 32 + acc_row(r, lane);
+          const bool ok = live && i < Tq && j < Tk && (!causal || j <= i) && ((km >> j) & 1ull);
+          const float p = ok ? __expf(s[r] * SCALE - lse_i) : 0.f;
+          pv[e] = p;
+          dsv[e] = p * (dp[r] - delta_i) * SCALE;
+        }
+        Tile<T>::store4(Pt, i, jb * 32 + 8 * g4 + 4 * (lane >> 5), pv);
+        Tile<T>::store4(dSt, i, jb * 32 + 8 * g4 + 4 * (lane >> 5), dsv);
+      }
+    }
+  }
+  __syncthreads();
+  for (int ib = 0; ib < nib; ++ib)
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      f32x16 a;
+      zero16(a);
+      Tile<T>::template mma<false, true>(a, dSt, ib * 32, Kt, db * 32, lane);  // dQ = dS K
+      const int d = db * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = ib * 32 + acc_row(r, lane);
+        if (i < Tq) ElemT<T>::st(dq + ((size_t)b * Tq + i) * lddq + h * 64 + d, a[r]);
+      }
+    }
+  for (int jb = 0; jb < njb; ++jb)
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      f32x16 a, c;
+      zero16(a); zero16(c);
+      Tile<T>::template mma<true, true>(a, dSt, jb * 32, Qt, db * 32, lane);   // dK = dS^T Q
+      Tile<T>::template mma<true, true>(c, Pt, jb * 32, dOt, db * 32, lane);   // dV = P^T dO
+      const int d = db * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = jb * 32 + acc_row(r, lane);
+        if (j < Tk) {
+          ElemT<T>::st(dk + ((size_t)b * Tk + j) * lddk + h * 64 + d, a[r]);
+          ElemT<T>::st(dv + ((size_t)b * Tk + j) * lddv + h * 64 + d, c[r]);
+        }
+      }
+    }
+}
+
+template <typename K>
+static int set_lds(K kernel, size_t bytes) {
+  if (bytes > 65536) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { mic_set_error("hipFuncSetAttribute(%zu): %s", bytes, hipGetErrorString(e)); return MIC_ELAUNCH; }
+  }
+  return MIC_OK;
+}
+
+extern "C" int mic_attn_fwd(int dtype, int B, int H, int Tq, int Tk, const void* q, int ldq, const void* k, int ldk,
+                            const void* v, int ldv, void* out, int ldo, const int32_t* key_mask, int causal, float* lse,
+                            void* stream) {
+  MIC_CHECK(B > 0 && H > 0 && Tq > 0 && Tq <= 64 && Tk > 0 && Tk <= 64, "mic_attn_fwd: bad shape B=%d H=%d Tq=%d Tk=%d", B, H, Tq, Tk);
+  MIC_CHECK(q && k && v && out, "mic_attn_fwd: null pointer");
+  const int align = dtype == MIC_BF16 ? 8 : 4;
+  MIC_CHECK(ldq % align == 0 && ldk % align == 0 && ldv % align == 0, "mic_attn_fwd: row strides must keep 16-B alignment");
+  dim3 grid(B * H), block(64);
+  if (dtype == MIC_BF16) {
+    hipLaunchKernelGGL(attn_fwd_kernel<uint16_t>, grid, block, 4 * Tile<uint16_t>::BYTES, (hipStream_t)stream, H, Tq, Tk, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk, (const uint16_t*)v, ldv, (uint16_t*)out, ldo, key_mask, causal, lse);
+  } else if (dtype == MIC_F32) {
+    const size_t lds = 4 * Tile<float>::BYTES;
+    if (int rc = set_lds(attn_fwd_kernel<float>, lds)) return rc;
+    hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, block, lds, (hipStream_t)stream, H, Tq, Tk, (const float*)q, ldq, (const float*)k, ldk, (const float*)v, ldv, (float*)out, ldo, key_mask, causal, lse);
+  } else MIC_CHECK(false, "mic_attn_fwd: bad dtype");
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}
+
+extern "C" int mic_attn_bwd(int dtype, int B, int H, int Tq, int Tk, const void* q, int ldq, const void* k, int ldk,
+                            const void* v, int ldv, const void* out, int ldo, const void* dout, int lddo, const float* lse,
+                            const int32_t* key_mask, int causal, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv,
+                            void* stream) {
+  MIC_CHECK(B > 0 && H > 0 && Tq > 0 && Tq <= 64 && Tk > 0 && Tk <= 64, "mic_attn_bwd: bad shape");
+  MIC_CHECK(q && k && v && out && dout && lse && dq && dk && dv, "mic_attn_bwd: null pointer");
+  const int align = dtype == MIC_BF16 ? 8 : 4;
+  MIC_CHECK(ldq % align == 0 && ldk % align == 0 && ldv % align == 0 && ldo % align == 0 && lddo % align == 0, "mic_attn_bwd: row strides must keep 16-B alignment");
+  dim3 grid(B * H), block(64);
+  if (dtype == MIC_BF16) {
+    const size_t lds = 6 * Tile<uint16_t>::BYTES + 512;
+    hipLaunchKernelGGL(attn_bwd_kernel<uint16_t>, grid, block, lds, (hipStream_t)stream, H, Tq, Tk, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk, (const uint16_t*)v, ldv, (const uint16_t*)out, ldo, (const uint16_t*)dout, lddo, lse, key_mask, causal, (uint16_t*)dq, lddq, (uint16_t*)dk, lddk, (uint16_t*)dv, lddv);
+  } else if (dtype == MIC_F32) {
+    const size_t lds = 6 * Tile<float>::BYTES + 512;
+    if (int rc = set_lds(attn_bwd_kernel<float>, lds)) return rc;
+    hipLaunchKernelGGL(attn_bwd_kernel<float>, grid, block, lds, (hipStream_t)stream, H, Tq, Tk, (const float*)q, ldq, (const float*)k, ldk, (const float*)v, ldv, (const float*)out, ldo, (const float*)dout, lddo, lse, key_mask, causal, (float*)dq, lddq, (float*)dk, lddk, (float*)dv, lddv);
+  } else MIC_CHECK(false, "mic_attn_bwd: bad dtype");
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}
+
+// ------------------------------------------------------------------ decode-time attention (K9d): one wave per (row, head)
+// scores: lane = cache slot (each lane reads its slot's 64 contiguous elements); softmax by wave reductions;
+// output: lane = head-dim element, loop over valid slots with coalesced 64-element rows.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_decode_kernel(int R, int H, int max_len, int cur, const T* __restrict__ q, int ldq,
+                                                          const T* __restrict__ kc, const T* __restrict__ vc,
+                                                          const int32_t* __restrict__ src_row, int row_div,
+                                                          T* __restrict__ out, int ldo) {
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= R * H) return;
+  const int r = wid / H, h = wid % H;
+  const int HD = H * 64;
+  float qv[64];
+  {
+    const T* qr = q + (size_t)r * ldq + h * 64;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) ld8(qr + c * 8, qv + c * 8);
+  }
+  float s = -INFINITY;
+  int my_src = 0;
+  if (lane <= cur && lane < max_len) {
+    my_src = src_row ? src_row[(size_t)r * max_len + lane] : r / row_div;
+    const T* kr = kc + ((size_t)my_src * max_len + lane) * HD + h * 64;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float kv[8];
+      ld8(kr + c * 8, kv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += (qv[c * 8 + e] * SCALE) * kv[e];
+    }
+    s = acc;
+  }
+  const float m = wave_max(s);
+  const float p = (lane <= cur && lane < max_len) ? __expf(s - m) : 0.f;
+  const float l = wave_sum(p);
+  const float pn = p / l;
+  float o = 0.f;
+  const int n = min(cur + 1, max_len);
+  for (int t = 0; t < n; ++t) {
+    const float pt = __shfl(pn, t, 64);
+    const int sr = __shfl(my_src, t, 64);
+    o += pt * ElemT<T>::ld(vc + ((size_t)sr * max_len + t) * HD + h * 64 + lane);
+  }
+  ElemT<T>::st(out + (size_t)r * ldo + h * 64 + lane, o);
+}
+extern "C" int mic_attn_decode(int dtype, int R, int H, int max_len, int cur, const void* q, int ldq, const void* kc,
+                                const void* vc, const int32_t* src_row, int row_div, void* out, int ldo, void* stream) {
+  MIC_CHECK(R > 0 && H > 0 && max_len > 0 && max_len <= 64 && cur >= 0 && row_div >= 1, "mic_attn_decode: bad shape");
+  MIC_CHECK(q && kc && vc && out, "mic_attn_decode: null pointer");
+  dim3 grid((R * H + 3) / 4), block(256);
+  if (dtype == MIC_BF16)
+    hipLaunchKernelGGL(attn_decode_kernel<uint16_t>, grid, block, 0, (hipStream_t)stream, R, H, max_len, cur, (const uint16_t*)q, ldq, (const uint16_t*)kc, (const uint16_t*)vc, src_row, row_div, (uint16_t*)out, ldo);
+  else if (dtype == MIC_F32)
+    hipLaunchKernelGGL(attn_decode_kernel<float>, grid, block, 0, (hipStream_t)stream, R, H, max_len, cur, (const float*)q, ldq, (const float*)kc, (const float*)vc, src_row, row_div, (float*)out, ldo);
+  else MIC_CHECK(false, "mic_attn_decode: bad dtype");
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}
+
+template <typename T>
+__global__ void kv_append_kernel(int R, int HD, int max_len, int cur, const T* __restrict__ k, int ldk, const T* __restrict__ v,
+                                 int ldv, T* __restrict__ kc, T* __restrict__ vc) {
+  const long total = (long)R * HD;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % HD);
+    const int r = (int)(e / HD);
+    kc[((size_t)r * max_len + cur) * HD + c] = k[(size_t)r * ldk + c];
+    vc[((size_t)r * max_len + cur) * HD + c] = v[(size_t)r * ldv + c];
+  }
+}
+extern "C" int mic_kv_append(int dtype, int R, int HD, int max_len, int cur, const void* k, int ldk, const void* v, int ldv,
+                             void* kc, void* vc, void* stream) {
+  MIC_CHECK(R > 0 && HD > 0 && cur >= 0 && cur < max_len && k && v && kc && vc, "mic_kv_append: bad args");
+  const long total = (long)R * HD;
+  int nb = (int)((total + 255) / 256); if (nb > 4096) nb = 4096;
+  dim3 grid(nb), block(256);
+  if (dtype == MIC_BF16)
+    hipLaunchKernelGGL(kv_append_kernel<uint16_t>, grid, block, 0, (hipStream_t)stream, R, HD, max_len, cur, (const uint16_t*)k, ldk, (const uint16_t*)v, ldv, (uint16_t*)kc, (uint16_t*)vc);
+  else if (dtype == MIC_F32)
+    hipLaunchKernelGGL(kv_append_kernel<float>, grid, block, 0, (hipStream_t)stream, R, HD, max_len, cur, (const float*)k, ldk, (const float*)v, ldv, (float*)kc, (float*)vc);
+  else MIC_CHECK(false, "mic_kv_append: bad dtype");
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}

@@ -1,0 +1,208 @@
+// common.h — shared device helpers for libmic_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/mic_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+void mic_set_error(const char* fmt, ...);
+#define MIC_CHECK(cond, ...) do { if (!(cond)) { mic_set_error(__VA_ARGS__); return MIC_EINVAL; } } while (0)
+#define MIC_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
+  mic_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); return MIC_ELAUNCH; } } while (0)
+
+// ---- bf16 <-> f32 (round-to-nearest-even; NaN preserved)
+__device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+template <typename T> struct ElemT;
+template <> struct ElemT<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct ElemT<uint16_t> {
+  static __device__ __forceinline__ float ld(const uint16_t* p) { return bf2f(*p); }
+  static __device__ __forceinline__ void st(uint16_t* p, float v) { *p = f2bf(v); }
+};
+// rounding through the storage type (what a store+load would give)
+template <typename T> __device__ __forceinline__ float round_to(float v);
+template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
+template <> __device__ __forceinline__ float round_to<uint16_t>(float v) { return bf2f(f2bf(v)); }
+
+// ---- vector loads of 8 (bf16: one 16-B load) / 4 (f32: one 16-B load) contiguous elements
+__device__ __forceinline__ void ld8(const uint16_t* p, float* o) {
+  uint4 u = *reinterpret_cast<const uint4*>(p);
+  o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xffff0000u);
+  o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xffff0000u);
+  o[4] = __uint_as_float(u.z << 16); o[5] = __uint_as_float(u.z & 0xffff0000u);
+  o[6] = __uint_as_float(u.w << 16); o[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ void ld8(const float* p, float* o) {
+  float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+__device__ __forceinline__ void st8(uint16_t* p, const float* v) {
+  uint4 u;
+  u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16); u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+  *reinterpret_cast<uint4*>(p) = u;
+}
+__device__ __forceinline__ void st8(float* p, const float* v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// ---- wave (64-lane) reductions by xor-shuffle
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- counter-based dropout: keep iff hash(seed, idx) >= p * 2^32  (same function in every fused epilogue and in
+// mic_dropout_mask, so a mask can be materialised for the oracle)
+__device__ __forceinline__ uint32_t mic_hash(uint32_t seed, uint32_t idx) {
+  uint32_t x = idx * 0x9E3779B1u ^ seed;
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  x += seed * 0x27D4EB2Fu; x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12;
+  return x;
+}
+__device__ __forceinline__ uint32_t dropout_threshold(float p) { return (uint32_t)fminf(p * 4294967296.0f, 4294967295.0f); }
+__device__ __forceinline__ bool dropout_keep(uint32_t seed, uint32_t idx, uint32_t thr) { return mic_hash(seed, idx) >= thr; }
+
+// ---- activations
+__device__ __forceinline__ float act_fwd(int act, float x) {
+  switch (act) {
+    case MIC_ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+    case MIC_ACT_GELU_TANH: { float u = 0.7978845608028654f * (x + 0.044715f * x * x * x); return 0.5f * x * (1.0f + tanhf(u)); }
+    case MIC_ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
+    default: return x;
+  }
+}
+__device__ __forceinline__ float act_bwd(int act, float x) {
+  switch (act) {
+    case MIC_ACT_GELU_ERF: {
+      float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+      return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    }
+    case MIC_ACT_GELU_TANH: {
+      float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+      float t = tanhf(u);
+      return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
+    }
+    case MIC_ACT_QUICK_GELU: { float s = 1.0f / (1.0f + __expf(-1.702f * x)); return s + 1.702f * x * s * (1.0f - s); }
+    default: return 1.0f;
+  }
+}
+
+// ---- GEMM epilogue (shared by the bf16-MFMA and f32-MFMA kernels)
+struct EpiArgs {
+  void* C; int ldc; int c_f32;
+  const float* bias; int act;
+  void* Zout; int ldz;
+  const void* Zin; int dact;
+  const void* R; int ldr;
+  int accumulate;
+  uint32_t drop_thr; uint32_t drop_seed; float drop_scale;
+  float alpha;
+  int N;
+};
+template <typename T>
+__device__ __forceinline__ void epilogue_store(const EpiArgs& e, int m, int n, float v) {
+  v *= e.alpha;
+  if (e.bias) v += e.bias[n];
+  if (e.Zout) ElemT<T>::st((T*)e.Zout + (size_t)m * e.ldz + n, v);
+  if (e.act) v = act_fwd(e.act, round_to<T>(v));  // act sees the stored (rounded) pre-activation, as backward will
+  if (e.dact) v *= act_bwd(e.dact, ElemT<T>::ld((const T*)e.Zin + (size_t)m * e.ldz + n));
+  if (e.drop_thr) v = dropout_keep(e.drop_seed, (uint32_t)m * (uint32_t)e.N + (uint32_t)n, e.drop_thr) ? v * e.drop_scale : 0.0f;
+  if (e.R) v += ElemT<T>::ld((const T*)e.R + (size_t)m * e.ldr + n);
+  if (e.c_f32) {
+    float* c = (float*)e.C + (size_t)m * e.ldc + n;
+    if (e.accumulate) v += *c;
+    *c = v;
+  } else {
+    T* c = (T*)e.C + (size_t)m * e.ldc + n;
+    if (e.accumulate) v += ElemT<T>::ld(c);
+    ElemT<T>::st(c, v);
+  }
+}
+
+// 8 consecutive columns [n, n+cnt) of row m.  Vector (16-B) path when all 8 are in range and every touched pointer is
+// 16-B aligned; scalar fallback otherwise.
+template <typename T>
+__device__ __forceinline__ void epilogue_store8(const EpiArgs& e, int m, int n, float* v, int cnt) {
+  const bool vec = cnt == 8 && (e.ldc & 7) == 0 && (!e.Zout || (e.ldz & 7) == 0) && (!e.Zin || (e.ldz & 7) == 0) &&
+                   (!e.R || (e.ldr & 7) == 0);
+  if (!vec) {
+    for (int i = 0; i < cnt; ++i) epilogue_store<T>(e, m, n + i, v[i]);
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] *= e.alpha;
+  if (e.bias) {
+    float b[8];
+    ld8(e.bias + n, b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += b[i];
+  }
+  if (e.Zout) st8((T*)e.Zout + (size_t)m * e.ldz + n, v);
+  if (e.act) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = act_fwd(e.act, round_to<T>(v[i]));
+  }
+  if (e.dact) {
+    float z[8];
+    ld8((const T*)e.Zin + (size_t)m * e.ldz + n, z);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] *= act_bwd(e.dact, z[i]);
+  }
+  if (e.drop_thr) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      v[i] = dropout_keep(e.drop_seed, (uint32_t)m * (uint32_t)e.N + (uint32_t)(n + i), e.drop_thr) ? v[i] * e.drop_scale : 0.0f;
+  }
+  if (e.R) {
+    float r[8];
+    ld8((const T*)e.R + (size_t)m * e.ldr + n, r);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += r[i];
+  }
+  if (e.c_f32) {
+    float* c = (float*)e.C + (size_t)m * e.ldc + n;
+    if (e.accumulate) {
+      float o[8];
+      ld8(c, o);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += o[i];
+    }
+    st8(c, v);
+  } else {
+    T* c = (T*)e.C + (size_t)m * e.ldc + n;
+    if (e.accumulate) {
+      float o[8];
+      ld8(c, o);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += o[i];
+    }
+    st8(c, v);
+  }
+}

@@ -1,0 +1,262 @@
+// decode.hip — generation epilogues: log-softmax + index-stable top-k over the 250 054-wide head output (K16/K19) and
+// the beam-search bookkeeping of gen:857-966 (K17) as ONE small kernel per step; the KV cache is never gathered
+// (K18) — a [rows][max_len] slot-ownership table is updated instead (see attention.hip / mic_attn_decode).
+#include "common.h"
+
+#define TOPK_MAX 8
+#define NEG_BIG (-1.0e7f)
+
+__device__ __forceinline__ bool better(float av, int ai, float bv, int bi) { return av > bv || (av == bv && ai < bi); }
+
+// ------------------------------------------------------------------ per-row lse + top-k
+template <typename T>
+__global__ __launch_bounds__(256) void row_lse_topk_kernel(int V, const T* __restrict__ logits, int ld, int k, int forced,
+                                                           int suppress_eos, int eos, int raw, const float* __restrict__ row_bias,
+                                                           float* __restrict__ top_val, int32_t* __restrict__ top_idx) {
+  __shared__ float sm[256], ss[256];
+  __shared__ int si[256];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const T* lr = logits + (size_t)row * ld;
+  const int nchunk = (V + 7) >> 3;
+  float mx = 0.f, logsum = 0.f;
+  if (!raw) {
+    float m = -INFINITY, s = 0.f;
+    for (int ch = tid; ch < nchunk; ch += 256) {
+      float v[8];
+      ld8(lr + ch * 8, v);
+      float cm = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) if (ch * 8 + i < V) cm = fmaxf(cm, v[i]);
+      const float mn = fmaxf(m, cm);
+      float add = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) if (ch * 8 + i < V) add += __expf(v[i] - mn);
+      s = s * __expf(m - mn) + add;
+      m = mn;
+    }
+    sm[tid] = m; ss[tid] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) {
+        const float m1 = sm[tid], m2 = sm[tid + o], mn = fmaxf(m1, m2);
+        ss[tid] = ss[tid] * __expf(m1 - mn) + ss[tid + o] * __expf(m2 - mn);
+        sm[tid] = mn;
+      }
+      __syncthreads();
+    }
+    mx = sm[0];
+    logsum = logf(ss[0]);
+    __syncthreads();
+  }
+  const float bias = row_bias ? row_bias[row] : 0.f;
+  float bv[TOPK_MAX];
+  int bi[TOPK_MAX];
+#pragma unroll
+  for (int i = 0; i < TOPK_MAX; ++i) { bv[i] = -INFINITY; bi[i] = 0x7fffffff; }
+  for (int ch = tid; ch < nchunk; ch += 256) {
+    float v[8];
+    ld8(lr + ch * 8, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = ch * 8 + i;
+      if (c >= V) continue;
+      float x = raw ? v[i] : (v[i] - mx) - logsum;   // log_softmax (gen:850)
+      if (suppress_eos && c == eos) x = -INFINITY;     // MinLength
+      if (forced >= 0) x = (c == forced) ? 0.f : -INFINITY;  // ForcedBOS / ForcedEOS
+      x += bias;                                       // + running score (gen:857)
+      if (better(x, c, bv[TOPK_MAX - 1], bi[TOPK_MAX - 1])) {
+        bv[TOPK_MAX - 1] = x; bi[TOPK_MAX - 1] = c;
+#pragma unroll
+        for (int p = TOPK_MAX - 1; p > 0; --p) {
+          if (better(bv[p], bi[p], bv[p - 1], bi[p - 1])) {
+            const float tv = bv[p]; bv[p] = bv[p - 1]; bv[p - 1] = tv;
+            const int ti = bi[p]; bi[p] = bi[p - 1]; bi[p - 1] = ti;
+          }
+        }
+      }
+    }
+  }
+  // k rounds of block-wide arg-best over the threads' list heads
+  for (int round = 0; round < k; ++round) {
+    sm[tid] = bv[0]; si[tid] = bi[0]; ss[tid] = __int_as_float(tid);
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o && better(sm[tid + o], si[tid + o], sm[tid], si[tid])) { sm[tid] = sm[tid + o]; si[tid] = si[tid + o]; ss[tid] = ss[tid + o]; }
+      __syncthreads();
+    }
+    const int winner = __float_as_int(ss[0]);
+    if (tid == 0) { top_val[(size_t)row * k + round] = sm[0]; top_idx[(size_t)row * k + round] = si[0]; }
+    if (tid == winner) {
+#pragma unroll
+      for (int p = 0; p < TOPK_MAX - 1; ++p) { bv[p] = bv[p + 1]; bi[p] = bi[p + 1]; }
+      bv[TOPK_MAX - 1] = -INFINITY; bi[TOPK_MAX - 1] = 0x7fffffff;
+    }
+    __syncthreads();
+  }
+}
+extern "C" int mic_row_lse_topk(int dtype, int R, int V, const void* logits, int ld, int k, int forced_token,
+                                int suppress_eos, int eos_token_id, int raw_logits, const float* row_bias, float* top_val,
+                                int32_t* top_idx, void* stream) {
+  MIC_CHECK(R > 0 && V > 0 && ld >= V && ld % 8 == 0 && k >= 1 && k <= TOPK_MAX && logits && top_val && top_idx, "mic_row_lse_topk: bad args");
+  dim3 grid(R), block(256);
+  if (dtype == MIC_BF16)
+    hipLaunchKernelGGL(row_lse_topk_kernel<uint16_t>, grid, block, 0, (hipStream_t)stream, V, (const uint16_t*)logits, ld, k, forced_token, suppress_eos, eos_token_id, raw_logits, row_bias, top_val, top_idx);
+  else if (dtype == MIC_F32)
+    hipLaunchKernelGGL(row_lse_topk_kernel<float>, grid, block, 0, (hipStream_t)stream, V, (const float*)logits, ld, k, forced_token, suppress_eos, eos_token_id, raw_logits, row_bias, top_val, top_idx);
+  else MIC_CHECK(false, "mic_row_lse_topk: bad dtype");
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}
+
+// ------------------------------------------------------------------ one beam_search_body_fn iteration (gen:857-966)
+// One 128-thread block per batch item; K <= 4 beams... (K <= 8: 2K*K <= 128 candidates).  All arithmetic is fp32 in
+// the reference's operation order so scores are bit-identical to the oracle.
+__global__ __launch_bounds__(128) void beam_step_kernel(mic_beam_step_args a) {
+  extern __shared__ int32_t lds_i[];
+  const int K = a.K, C = 2 * K, L = a.max_len, V = a.V;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  int32_t* old_run = lds_i;                 // [K][L]
+  int32_t* old_seq = old_run + K * L;       // [K][L]
+  int32_t* old_src = old_seq + K * L;       // [K][L]
+  int32_t* cand_seq_parent = old_src + K * L;  // [C] parent beam of candidate
+  int32_t* cand_tok = cand_seq_parent + C;     // [C]
+  float* cand_lp = reinterpret_cast<float*>(cand_tok + C);  // [C] (after the just-finished penalty, gen:890)
+  int32_t* cand_fin = reinterpret_cast<int32_t*>(cand_lp + C);  // [C]
+  float* fin_score = reinterpret_cast<float*>(cand_fin + C);    // [C] finished-candidate scores (gen:910-919)
+  int32_t* run_pick = reinterpret_cast<int32_t*>(fin_score + C);  // [K] candidate index of new running beam nb
+  int32_t* mrg_pick = run_pick + K;                               // [K] merged index of new finished slot
+  float* old_scores = reinterpret_cast<float*>(mrg_pick + K);     // [K]
+  int32_t* old_fin = reinterpret_cast<int32_t*>(old_scores + K);  // [K]
+  float* new_run_scores = reinterpret_cast<float*>(old_fin + K);  // [K]
+
+  for (int e = tid; e < K * L; e += blockDim.x) {
+    old_run[e] = a.running_seq[(size_t)b * K * L + e];
+    old_seq[e] = a.seq[(size_t)b * K * L + e];
+    old_src[e] = a.src_row[(size_t)b * K * L + e];
+  }
+  if (tid < K) { old_scores[tid] = a.scores[b * K + tid]; old_fin[tid] = a.finished[b * K + tid]; }
+  __syncthreads();
+  // 1. top-2K of the K*2K per-row candidates, ordered (value desc, flat index asc)  (gen:872-874)
+  const int N = K * C;
+  float myv = 0.f; int mybeam = 0, mytok = 0; long myflat = 0;
+  if (tid < N) {
+    mybeam = tid / C;
+    myv = a.cand_val[(size_t)(b * K + mybeam) * C + tid % C];
+    mytok = a.cand_idx[(size_t)(b * K + mybeam) * C + tid % C];
+    myflat = (long)mybeam * V + mytok;
+  }
+  {
+    int rank = 0;
+    if (tid < N) {
+      for (int o = 0; o < N; ++o) {
+        const int ob = o / C;
+        const float ov = a.cand_val[(size_t)(b * K + ob) * C + o % C];
+        const long of = (long)ob * V + a.cand_idx[(size_t)(b * K + ob) * C + o % C];
+        if (ov > myv || (ov == myv && of < myflat)) ++rank;
+      }
+      if (rank < C) {
+        cand_seq_parent[rank] = mybeam;
+        cand_tok[rank] = mytok;
+        const int jf = (mytok == a.eos_token_id);
+        cand_fin[rank] = jf;                                   // gen:889
+        cand_lp[rank] = myv + (float)jf * NEG_BIG;             // gen:890
+      }
+    }
+  }
+  __syncthreads();
+  // all beams of this item finished (old state) & early stopping  (gen:911-917)
+  int all_fin_old = 1;
+  for (int kx = 0; kx < K; ++kx) all_fin_old &= (old_fin[kx] != 0);
+  const int full = all_fin_old && a.early_stopping;
+  // 5. next running beams: top-K of cand_lp (value desc, candidate index asc), stored ascending (gen:895-903)
+  // 6. finished-candidate scores (gen:910-919)
+  if (tid < C) {
+    const float v = cand_lp[tid];
+    int rank = 0;
+    for (int o = 0; o < C; ++o) { const float ov = cand_lp[o]; if (ov > v || (ov == v && o < tid)) ++rank; }
+    if (rank < K) { run_pick[K - 1 - rank] = tid; new_run_scores[K - 1 - rank] = v; }
+    float fs = v / powf((float)a.cur_len, a.length_penalty);
+    const int add_pen = (!cand_fin[tid]) || full;
+    fs += (float)add_pen * NEG_BIG;
+    fin_score[tid] = fs;
+  }
+  __syncthreads();
+  // 7. merge [old finished (K) | candidates (2K)], top-K (value desc, merged index asc), stored ascending (gen:925-940)
+  if (tid < K + C) {
+    const float v = tid < K ? old_scores[tid] : fin_score[tid - K];
+    int rank = 0;
+    for (int o = 0; o < K + C; ++o) { const float ov = o < K ? old_scores[o] : fin_score[o - K]; if (ov > v || (ov == v && o < tid)) ++rank; }
+    if (rank < K) mrg_pick[K - 1 - rank] = tid;
+  }
+  __syncthreads();
+  // write back: running beams
+  for (int e = tid; e < K * L; e += blockDim.x) {
+    const int nb = e / L, pos = e % L;
+    const int c = run_pick[nb];
+    const int pb = cand_seq_parent[c];
+    a.running_seq[(size_t)b * K * L + e] = (pos == a.cur_len) ? cand_tok[c] : old_run[pb * L + pos];
+    // slot ownership: inherit the parent's history, own the next slot (slot index = position of the fed token)
+    a.src_row[(size_t)b * K * L + e] = (pos == a.cur_len) ? (b * K + nb) : old_src[pb * L + pos];
+    const int mi = mrg_pick[nb];
+    int sv;
+    if (mi < K) sv = old_seq[mi * L + pos];
+    else { const int cc = mi - K; sv = (pos == a.cur_len) ? cand_tok[cc] : old_run[cand_seq_parent[cc] * L + pos]; }
+    a.seq[(size_t)b * K * L + e] = sv;
+  }
+  if (tid < K) {
+    const int c = run_pick[tid];
+    a.running_scores[b * K + tid] = new_run_scores[tid];
+    a.next_token[b * K + tid] = cand_tok[c];
+    const int mi = mrg_pick[tid];
+    a.scores[b * K + tid] = mi < K ? old_scores[mi] : fin_score[mi - K];
+    a.finished[b * K + tid] = mi < K ? old_fin[mi] : cand_fin[mi - K];
+  }
+  __syncthreads();
+  // loop-condition inputs on the NEW state (gen:798-820), per item
+  if (tid == 0) {
+    int all_fin = 1; float mn = INFINITY;
+    float ns[TOPK_MAX]; int nf[TOPK_MAX];
+    for (int kx = 0; kx < K; ++kx) {
+      const int mi = mrg_pick[kx];
+      ns[kx] = mi < K ? old_scores[mi] : fin_score[mi - K];
+      nf[kx] = mi < K ? old_fin[mi] : cand_fin[mi - K];
+      all_fin &= (nf[kx] != 0);
+      mn = fminf(mn, ns[kx]);
+    }
+    const float best_running = new_run_scores[K - 1] / powf((float)L, a.length_penalty);
+    int improve = 1;
+    for (int kx = 0; kx < K; ++kx) { const float worst = nf[kx] ? mn : NEG_BIG; improve &= (worst < best_running); }
+    a.flags[b * 2 + 0] = all_fin;
+    a.flags[b * 2 + 1] = improve;
+  }
+}
+extern "C" int mic_beam_step(const mic_beam_step_args* a, void* stream) {
+  MIC_CHECK(a && a->B > 0 && a->K >= 1 && a->K <= TOPK_MAX / 2 * 2 && 2 * a->K <= TOPK_MAX && a->max_len > 1 && a->cur_len >= 1 && a->cur_len < a->max_len,
+            "mic_beam_step: bad shape (K <= 4 supported: per-row candidates come from mic_row_lse_topk with k = 2K <= 8)");
+  MIC_CHECK(a->cand_val && a->cand_idx && a->running_seq && a->running_scores && a->seq && a->scores && a->finished && a->src_row && a->next_token && a->flags, "mic_beam_step: null pointer");
+  const size_t lds = (size_t)(3 * a->K * a->max_len + 8 * 2 * a->K + 8 * a->K) * 4;
+  MIC_CHECK(lds <= 65536, "mic_beam_step: max_len too large for the LDS staging");
+  hipLaunchKernelGGL(beam_step_kernel, dim3(a->B), dim3(128), lds, (hipStream_t)stream, *a);
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}
+
+// ------------------------------------------------------------------ greedy step (gen:499-512)
+__global__ void greedy_step_kernel(int B, int max_len, int cur_len, int eos, int pad, const int32_t* __restrict__ top_idx,
+                                   int ld_top, int32_t* sequences, int32_t* finished, int32_t* next_token) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int tok = top_idx[(size_t)b * ld_top];
+  const int fin = finished[b] | (tok == eos);   // gen:501-503
+  tok = fin ? pad : tok;                        // gen:504-507: the EOS step itself writes PAD
+  finished[b] = fin;
+  sequences[(size_t)b * max_len + cur_len] = tok;
+  next_token[b] = tok;
+}
+extern "C" int mic_greedy_step(int B, int max_len, int cur_len, int eos_token_id, int pad_token_id, const int32_t* top_idx,
+                               int ld_top, int32_t* sequences, int32_t* finished, int32_t* next_token, void* stream) {
+  MIC_CHECK(B > 0 && cur_len >= 1 && cur_len < max_len && top_idx && sequences && finished && next_token, "mic_greedy_step: bad args");
+  hipLaunchKernelGGL(greedy_step_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, max_len, cur_len, eos_token_id, pad_token_id, top_idx, ld_top, sequences, finished, next_token);
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}

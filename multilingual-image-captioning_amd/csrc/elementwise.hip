@@ -1,0 +1,383 @@
+// elementwise.hip — HBM-bound ops around the GEMMs: ViT im2col/assemble, decoder token embedding fwd/bwd,
+// cross-entropy rows/backward, bias column sums, casts, dropout-mask materialisation, fused AdamW.
+#include "common.h"
+#include <stdarg.h>
+#include <type_traits>
+
+// ------------------------------------------------------------------ error plumbing
+static thread_local char g_err[512] = "";
+void mic_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* mic_last_error(void) { return g_err; }
+extern "C" int mic_version(void) { return 1; }
+
+template <typename F>
+static int dispatch_t(int dtype, F&& f) {
+  if (dtype == MIC_BF16) f((uint16_t*)nullptr);
+  else if (dtype == MIC_F32) f((float*)nullptr);
+  else { mic_set_error("bad dtype %d", dtype); return MIC_EINVAL; }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { mic_set_error("launch failed: %s", hipGetErrorString(e)); return MIC_ELAUNCH; }
+  return MIC_OK;
+}
+#define TYPE_OF(tag) typename std::remove_pointer<decltype(tag)>::type
+
+// ------------------------------------------------------------------ im2col (K1 gather)
+// patches[(b*g+pi)*g+pj][(u*ps+v)*3+c] = pixels[b][pi*ps+u][pj*ps+v][c]; one row of a patch = ps*3 contiguous floats.
+template <typename T>
+__global__ void im2col_kernel(int B, int img, int ps, const float* __restrict__ px, T* __restrict__ out, int ldp, int trunc) {
+  const int g = img / ps;
+  const int rowlen = ps * 3;
+  const long total = (long)B * g * g * ps * rowlen;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int w = (int)(e % rowlen);
+    long t = e / rowlen;
+    const int u = (int)(t % ps); t /= ps;
+    const int pj = (int)(t % g); t /= g;
+    const int pi = (int)(t % g);
+    const int b = (int)(t / g);
+    float v = px[(((long)b * img + pi * ps + u) * img + pj * ps) * 3 + w];
+    if (trunc) v = truncf(v);
+    ElemT<T>::st(out + (size_t)((b * g + pi) * g + pj) * ldp + u * rowlen + w, v);
+  }
+}
+extern "C" int mic_im2col(int dtype, int B, int img, int ps, const float* pixels, void* patches, int ldp,
+                          int trunc_int32, void* stream) {
+  MIC_CHECK(B > 0 && img > 0 && ps > 0 && img % ps == 0 && pixels && patches, "mic_im2col: bad args");
+  return dispatch_t(dtype, [&](auto* tag) {
+    using T = TYPE_OF(tag);
+    hipLaunchKernelGGL(im2col_kernel<T>, dim3(2048), dim3(256), 0, (hipStream_t)stream, B, img, ps, pixels, (T*)patches, ldp, trunc_int32);
+  });
+}
+
+// ------------------------------------------------------------------ ViT assemble (class token + position embedding)
+template <typename T>
+__global__ void vit_assemble_kernel(int B, int S, int width, const T* __restrict__ patch, int ldp,
+                                    const float* __restrict__ cls, const float* __restrict__ pos, T* __restrict__ x) {
+  const long total = (long)B * S * width;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % width);
+    const long r = e / width;
+    const int s = (int)(r % S), b = (int)(r / S);
+    const float v = (s == 0 ? cls[c] : ElemT<T>::ld(patch + (size_t)(b * (S - 1) + s - 1) * ldp + c)) + pos[s * width + c];
+    ElemT<T>::st(x + e, v);
+  }
+}
+extern "C" int mic_vit_assemble(int dtype, int B, int S, int width, const void* patch_out, int ldp, const float* cls,
+                                const float* pos, void* x, void* stream) {
+  MIC_CHECK(B > 0 && S > 1 && width > 0 && patch_out && cls && pos && x, "mic_vit_assemble: bad args");
+  return dispatch_t(dtype, [&](auto* tag) {
+    using T = TYPE_OF(tag);
+    hipLaunchKernelGGL(vit_assemble_kernel<T>, dim3(1024), dim3(256), 0, (hipStream_t)stream, B, S, width, (const T*)patch_out, ldp, cls, pos, (T*)x);
+  });
+}
+// dpatch[b,p] = dx[b,1+p]; dpos[s] += sum_b dx[b,s]; dcls += sum_b dx[b,0].  One thread per (s, c) column sums over b.
+template <typename T>
+__global__ void vit_assemble_bwd_kernel(int B, int S, int width, const T* __restrict__ dx, T* __restrict__ dpatch, int ldp,
+                                        float* __restrict__ dcls, float* __restrict__ dpos) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= S * width) return;
+  const int s = e / width, c = e % width;
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const T raw = dx[((size_t)b * S + s) * width + c];
+    acc += ElemT<T>::ld(&raw);
+    if (s > 0) dpatch[(size_t)(b * (S - 1) + s - 1) * ldp + c] = raw;
+  }
+  atomicAdd(dpos + e, acc);
+  if (s == 0) atomicAdd(dcls + c, acc);
+}
+extern "C" int mic_vit_assemble_bwd(int dtype, int B, int S, int width, const void* dx, void* dpatch, int ldp,
+                                    float* dcls, float* dpos, void* stream) {
+  MIC_CHECK(B > 0 && S > 1 && width > 0 && dx && dpatch && dcls && dpos, "mic_vit_assemble_bwd: bad args");
+  return dispatch_t(dtype, [&](auto* tag) {
+    using T = TYPE_OF(tag);
+    hipLaunchKernelGGL(vit_assemble_bwd_kernel<T>, dim3((S * width + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, S, width, (const T*)dx, (T*)dpatch, ldp, dcls, dpos);
+  });
+}
+
+// ------------------------------------------------------------------ decoder token embedding (K8)
+template <typename T>
+__global__ void embed_fwd_kernel(int rows, int width, const int32_t* __restrict__ ids, const int32_t* __restrict__ pos_ids,
+                                 const T* __restrict__ table, const float* __restrict__ pos_table, float scale,
+                                 T* __restrict__ h) {
+  const int nchunk = width >> 3;
+  const long total = (long)rows * nchunk;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(e % nchunk);
+    const int r = (int)(e / nchunk);
+    float a[8], p[8], o[8];
+    ld8(table + (size_t)ids[r] * width + ch * 8, a);
+    ld8(pos_table + (size_t)(pos_ids[r] + 2) * width + ch * 8, p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = a[i] * scale + p[i];
+    st8(h + (size_t)r * width + ch * 8, o);
+  }
+}
+extern "C" int mic_embed_fwd(int dtype, int rows, int width, const int32_t* ids, const int32_t* pos_ids, const void* table,
+                             const float* pos_table, float scale, void* h, void* stream) {
+  MIC_CHECK(rows > 0 && width > 0 && width % 8 == 0 && ids && pos_ids && table && pos_table && h, "mic_embed_fwd: bad args");
+  return dispatch_t(dtype, [&](auto* tag) {
+    using T = TYPE_OF(tag);
+    const long total = (long)rows * (width / 8);
+    int nb = (int)((total + 255) / 256); if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(embed_fwd_kernel<T>, dim3(nb), dim3(256), 0, (hipStream_t)stream, rows, width, ids, pos_ids, (const T*)table, pos_table, scale, (T*)h);
+  });
+}
+template <typename T>
+__global__ void embed_bwd_kernel(int rows, int width, const int32_t* __restrict__ ids, const int32_t* __restrict__ pos_ids,
+                                 const T* __restrict__ dh, float scale, float* __restrict__ dtable, float* __restrict__ dpos) {
+  const long total = (long)rows * width;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % width);
+    const int r = (int)(e / width);
+    const float g = ElemT<T>::ld(dh + e);
+    atomicAdd(dtable + (size_t)ids[r] * width + c, g * scale);
+    atomicAdd(dpos + (size_t)(pos_ids[r] + 2) * width + c, g);
+  }
+}
+extern "C" int mic_embed_bwd(int dtype, int rows, int width, const int32_t* ids, const int32_t* pos_ids, const void* dh,
+                             float scale, float* dtable, float* dpos_table, void* stream) {
+  MIC_CHECK(rows > 0 && width > 0 && ids && pos_ids && dh && dtable && dpos_table, "mic_embed_bwd: bad args");
+  return dispatch_t(dtype, [&](auto* tag) {
+    using T = TYPE_OF(tag);
+    const long total = (long)rows * width;
+    int nb = (int)((total + 255) / 256); if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(embed_bwd_kernel<T>, dim3(nb), dim3(256), 0, (hipStream_t)stream, rows, width, ids, pos_ids, (const T*)dh, scale, dtable, dpos_table);
+  });
+}
+
+// ------------------------------------------------------------------ cross-entropy over materialised logits (K13)
+// One 256-thread block per row; 16-B vector loads; online (max, sum-exp) per thread, combined through LDS.
+__device__ __forceinline__ void online_merge(float& m, float& s, float m2, float s2) {
+  const float mn = fmaxf(m, m2);
+  if (mn == -INFINITY) { s = 0.f; m = mn; return; }
+  s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
+  m = mn;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void ce_rows_kernel(int V, const T* __restrict__ logits, int ld,
+                                                      const int32_t* __restrict__ labels, const int32_t* __restrict__ mask,
+                                                      float ls, float* __restrict__ row_lse, float* __restrict__ row_loss) {
+  __shared__ float sm[256], ss[256], st[256];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const T* lr = logits + (size_t)row * ld;
+  float m = -INFINITY, s = 0.f, tot = 0.f;
+  const int nchunk = (V + 7) >> 3;
+  for (int ch = tid; ch < nchunk; ch += 256) {
+    float v[8];
+    ld8(lr + ch * 8, v);  // ld is padded to a multiple of 8 columns
+    float cm = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (ch * 8 + i < V) cm = fmaxf(cm, v[i]);
+    const float mn = fmaxf(m, cm);
+    float add = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (ch * 8 + i < V) { add += __expf(v[i] - mn); tot += v[i]; }
+    s = s * __expf(m - mn) + add;
+    m = mn;
+  }
+  sm[tid] = m; ss[tid] = s; st[tid] = tot;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) {
+      float a = sm[tid], b = ss[tid];
+      online_merge(a, b, sm[tid + o], ss[tid + o]);
+      sm[tid] = a; ss[tid] = b; st[tid] += st[tid + o];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const float lse = sm[0] + logf(ss[0]);
+    row_lse[row] = lse;
+    const float xl = ElemT<T>::ld(lr + labels[row]);
+    const float nll = lse - xl;
+    float loss = nll;
+    if (ls > 0.f) {  // main.py:666-675
+      const float conf = 1.0f - ls, low = ls / (float)(V - 1);
+      const float norm = -(conf * logf(conf) + (float)(V - 1) * low * logf(low + 1e-20f));
+      const float sum_neg_logp = (float)V * lse - st[0];  // -sum_v logp_v
+      loss = conf * nll + low * (sum_neg_logp - nll) - norm;
+    }
+    row_loss[row] = loss;
+    (void)mask;
+  }
+}
+extern "C" int mic_ce_rows(int dtype, int rows, int V, const void* logits, int ld, const int32_t* labels,
+                           const int32_t* mask, float label_smoothing, float* row_lse, float* row_loss, void* stream) {
+  MIC_CHECK(rows > 0 && V > 1 && ld >= V && ld % 8 == 0 && logits && labels && row_lse && row_loss, "mic_ce_rows: bad args");
+  return dispatch_t(dtype, [&](auto* tag) {
+    using T = TYPE_OF(tag);
+    hipLaunchKernelGGL(ce_rows_kernel<T>, dim3(rows), dim3(256), 0, (hipStream_t)stream, V, (const T*)logits, ld, labels, mask, label_smoothing, row_lse, row_loss);
+  });
+}
+__global__ __launch_bounds__(256) void ce_reduce_kernel(int rows, const float* __restrict__ row_loss,
+                                                        const int32_t* __restrict__ mask, float* loss_out, float* denom_out) {
+  __shared__ float sl[256], sd[256];
+  float l = 0.f, d = 0.f;
+  for (int r = threadIdx.x; r < rows; r += 256) { const float mk = (float)mask[r]; l += row_loss[r] * mk; d += mk; }
+  sl[threadIdx.x] = l; sd[threadIdx.x] = d;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sd[threadIdx.x] += sd[threadIdx.x + o]; } __syncthreads(); }
+  if (threadIdx.x == 0) { denom_out[0] = sd[0]; loss_out[0] = sl[0] / sd[0]; }
+}
+extern "C" int mic_ce_reduce(int rows, const float* row_loss, const int32_t* mask, float* loss_out, float* denom_out, void* stream) {
+  MIC_CHECK(rows > 0 && row_loss && mask && loss_out && denom_out, "mic_ce_reduce: bad args");
+  hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rows, row_loss, mask, loss_out, denom_out);
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}
+// dlogits = mask/denom * loss_scale * (softmax - soft_label); soft_label = conf at label, low elsewhere.
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(int V, int Vpad, T* __restrict__ logits, int ld,
+                                                     const int32_t* __restrict__ labels, const int32_t* __restrict__ mask,
+                                                     float ls, const float* __restrict__ row_lse, const float* __restrict__ denom,
+                                                     float loss_scale) {
+  const int row = blockIdx.x;
+  T* lr = logits + (size_t)row * ld;
+  const float w = mask[row] ? loss_scale / denom[0] : 0.f;
+  const float lse = row_lse[row];
+  const int label = labels[row];
+  const float conf = 1.0f - ls, low = ls > 0.f ? ls / (float)(V - 1) : 0.f;
+  const int nchunk = Vpad >> 3;
+  for (int ch = threadIdx.x; ch < nchunk; ch += 256) {
+    float v[8], o[8];
+    ld8(lr + ch * 8, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = ch * 8 + i;
+      o[i] = c < V ? w * (__expf(v[i] - lse) - (c == label ? conf : low)) : 0.f;
+    }
+    st8(lr + ch * 8, o);
+  }
+}
+extern "C" int mic_ce_bwd(int dtype, int rows, int V, int Vpad, void* logits, int ld, const int32_t* labels,
+                          const int32_t* mask, float label_smoothing, const float* row_lse, const float* denom,
+                          float loss_scale, void* stream) {
+  MIC_CHECK(rows > 0 && V > 1 && Vpad >= V && Vpad % 8 == 0 && ld >= Vpad && logits && labels && mask && row_lse && denom, "mic_ce_bwd: bad args");
+  return dispatch_t(dtype, [&](auto* tag) {
+    using T = TYPE_OF(tag);
+    hipLaunchKernelGGL(ce_bwd_kernel<T>, dim3(rows), dim3(256), 0, (hipStream_t)stream, V, Vpad, (T*)logits, ld, labels, mask, label_smoothing, row_lse, denom, loss_scale);
+  });
+}
+
+// ------------------------------------------------------------------ column sums (bias gradients)
+// grid.x covers 64-column strips, grid.y splits rows; each thread sums a column over its row slice; fp32 atomics combine.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(int rows, int cols, const T* __restrict__ x, int ld, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  const int rows_per = (rows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  float acc = 0.f;
+  if (c < cols)
+    for (int r = r0 + w; r < r1; r += 4) acc += ElemT<T>::ld(x + (size_t)r * ld + c);
+  red[w][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (w == 0 && c < cols) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+extern "C" int mic_colsum(int dtype, int rows, int cols, const void* x, int ld, float* out, int accumulate, void* stream) {
+  MIC_CHECK(rows > 0 && cols > 0 && x && out, "mic_colsum: bad args");
+  if (!accumulate) hipMemsetAsync(out, 0, sizeof(float) * cols, (hipStream_t)stream);
+  return dispatch_t(dtype, [&](auto* tag) {
+    using T = TYPE_OF(tag);
+    int gy = (rows + 127) / 128; if (gy > 64) gy = 64;
+    hipLaunchKernelGGL(colsum_kernel<T>, dim3((cols + 63) / 64, gy), dim3(256), 0, (hipStream_t)stream, rows, cols, (const T*)x, ld, out);
+  });
+}
+
+// ------------------------------------------------------------------ dropout mask, casts
+__global__ void dropout_mask_kernel(uint8_t* out, long n, uint32_t thr, uint32_t seed) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+    out[e] = dropout_keep(seed, (uint32_t)e, thr) ? 1 : 0;
+}
+extern "C" int mic_dropout_mask(uint8_t* out, int64_t n, float p, uint32_t seed, void* stream) {
+  MIC_CHECK(out && n > 0 && p >= 0.f && p < 1.f, "mic_dropout_mask: bad args");
+  const uint32_t thr = p > 0.f ? (uint32_t)fminf(p * 4294967296.0f, 4294967295.0f) : 0u;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, out, (long)n, thr, seed);
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}
+template <typename S, typename D>
+__global__ void cast2d_kernel(int rows, int cols, const S* __restrict__ src, long ld_src, D* __restrict__ dst, long ld_dst) {
+  const long total = (long)rows * cols;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long r = e / cols, c = e % cols;
+    ElemT<D>::st(dst + r * ld_dst + c, ElemT<S>::ld(src + r * ld_src + c));
+  }
+}
+extern "C" int mic_cast2d(int src_dtype, int dst_dtype, int rows, int cols, const void* src, int ld_src, void* dst,
+                          int ld_dst, void* stream) {
+  MIC_CHECK(rows > 0 && cols > 0 && src && dst, "mic_cast2d: bad args");
+  const long total = (long)rows * cols;
+  int nb = (int)((total + 255) / 256); if (nb > 4096) nb = 4096;
+  dim3 grid(nb), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (src_dtype == MIC_F32 && dst_dtype == MIC_BF16) hipLaunchKernelGGL((cast2d_kernel<float, uint16_t>), grid, block, 0, s, rows, cols, (const float*)src, (long)ld_src, (uint16_t*)dst, (long)ld_dst);
+  else if (src_dtype == MIC_BF16 && dst_dtype == MIC_F32) hipLaunchKernelGGL((cast2d_kernel<uint16_t, float>), grid, block, 0, s, rows, cols, (const uint16_t*)src, (long)ld_src, (float*)dst, (long)ld_dst);
+  else if (src_dtype == MIC_F32 && dst_dtype == MIC_F32) hipLaunchKernelGGL((cast2d_kernel<float, float>), grid, block, 0, s, rows, cols, (const float*)src, (long)ld_src, (float*)dst, (long)ld_dst);
+  else if (src_dtype == MIC_BF16 && dst_dtype == MIC_BF16) hipLaunchKernelGGL((cast2d_kernel<uint16_t, uint16_t>), grid, block, 0, s, rows, cols, (const uint16_t*)src, (long)ld_src, (uint16_t*)dst, (long)ld_dst);
+  else MIC_CHECK(false, "mic_cast2d: bad dtypes");
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}
+extern "C" int mic_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream) {
+  MIC_CHECK(n > 0 && n < (1LL << 40), "mic_cast: bad n");
+  // split into rows of <= 2^20 so the 2-D kernel's int shape holds
+  const int64_t cols = n < (1 << 20) ? n : (1 << 20);
+  const int64_t rows = n / cols;
+  int rc = mic_cast2d(src_dtype, dst_dtype, (int)rows, (int)cols, src, (int)cols, dst, (int)cols, stream);
+  if (rc) return rc;
+  const int64_t rem = n - rows * cols;
+  if (rem > 0) {
+    const size_t ss = src_dtype == MIC_F32 ? 4 : 2, ds = dst_dtype == MIC_F32 ? 4 : 2;
+    return mic_cast2d(src_dtype, dst_dtype, 1, (int)rem, (const char*)src + rows * cols * ss, (int)rem, (char*)dst + rows * cols * ds, (int)rem, stream);
+  }
+  return MIC_OK;
+}
+
+// ------------------------------------------------------------------ fused AdamW over the flat parameter buffer (K15)
+__global__ __launch_bounds__(256) void adamw_kernel(long n, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                    const float* __restrict__ g, uint16_t* __restrict__ p_lp,
+                                                    const float* __restrict__ hyper, float b1, float b2, float omb1, float omb2,
+                                                    float eps, float wd, float gscale) {
+  const float lr = hyper[0], t = hyper[1];
+  const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
+  const long n4 = n >> 2;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long)gridDim.x * blockDim.x) {
+    float4 pp = reinterpret_cast<float4*>(p)[e], mm = reinterpret_cast<float4*>(m)[e], vv = reinterpret_cast<float4*>(v)[e];
+    const float4 gg = reinterpret_cast<const float4*>(g)[e];
+    float pa[4] = {pp.x, pp.y, pp.z, pp.w}, ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+    const float ga[4] = {gg.x * gscale, gg.y * gscale, gg.z * gscale, gg.w * gscale};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ma[i] = b1 * ma[i] + omb1 * ga[i];
+      va[i] = b2 * va[i] + omb2 * ga[i] * ga[i];
+      const float upd = (ma[i] / bc1) / (sqrtf(va[i] / bc2) + eps) + wd * pa[i];
+      pa[i] -= lr * upd;
+    }
+    reinterpret_cast<float4*>(p)[e] = make_float4(pa[0], pa[1], pa[2], pa[3]);
+    reinterpret_cast<float4*>(m)[e] = make_float4(ma[0], ma[1], ma[2], ma[3]);
+    reinterpret_cast<float4*>(v)[e] = make_float4(va[0], va[1], va[2], va[3]);
+    if (p_lp) {
+      uint2 o;
+      o.x = (uint32_t)f2bf(pa[0]) | ((uint32_t)f2bf(pa[1]) << 16);
+      o.y = (uint32_t)f2bf(pa[2]) | ((uint32_t)f2bf(pa[3]) << 16);
+      reinterpret_cast<uint2*>(p_lp)[e] = o;
+    }
+  }
+}
+extern "C" int mic_adamw(int64_t n, float* p, float* m, float* v, const float* g, void* p_lp, const float* hyper, double b1,
+                         double b2, double eps, double wd, float grad_scale, void* stream) {
+  MIC_CHECK(n > 0 && n % 4 == 0 && p && m && v && g && hyper, "mic_adamw: bad args (n must be a multiple of 4)");
+  long nb = (n / 4 + 255) / 256; if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(adamw_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, (long)n, p, m, v, g, (uint16_t*)p_lp, hyper, (float)b1, (float)b2,
+                     (float)(1.0 - b1), (float)(1.0 - b2), (float)eps, (float)wd, grad_scale);
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}

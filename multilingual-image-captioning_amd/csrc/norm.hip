@@ -1,0 +1,195 @@
+// norm.hip — LayerNorm forward/backward (K2).  HBM-bound: one wave per row, 16-B vector loads, the row lives in
+// registers, statistics by wave xor-shuffle reductions in fp32 (flax nn.LayerNorm semantics: biased variance).
+#include "common.h"
+
+#define LN_MAXC 4  // 16-B chunks of 8 elements per lane: width <= 64*8*4 = 2048
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int width, const T* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float eps, T* __restrict__ y, float* __restrict__ mean_out,
+                                                     float* __restrict__ rstd_out, uint32_t thr, uint32_t seed,
+                                                     float dscale) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  const int nchunk = width >> 3;
+  const T* xr = x + (size_t)row * width;
+  float v[LN_MAXC][8];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < LN_MAXC; ++c) {
+    const int ch = lane + c * 64;
+    if (ch < nchunk) {
+      ld8(xr + ch * 8, v[c]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += v[c][i];
+    }
+  }
+  const float mean = wave_sum(s) / (float)width;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < LN_MAXC; ++c) {
+    const int ch = lane + c * 64;
+    if (ch < nchunk) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float d = v[c][i] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)width + eps);
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+  T* yr = y + (size_t)row * width;
+#pragma unroll
+  for (int c = 0; c < LN_MAXC; ++c) {
+    const int ch = lane + c * 64;
+    if (ch < nchunk) {
+      float g[8], b[8], o[8];
+      ld8(gamma + ch * 8, g);
+      ld8(beta + ch * 8, b);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        o[i] = (v[c][i] - mean) * rstd * g[i] + b[i];
+        if (thr) o[i] = dropout_keep(seed, (uint32_t)row * (uint32_t)width + (uint32_t)(ch * 8 + i), thr) ? o[i] * dscale : 0.f;
+      }
+      st8(yr + ch * 8, o);
+    }
+  }
+}
+
+// dx = (dres) + rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat));  dgamma += dy*xhat, dbeta += dy.
+// Each wave walks rows with a grid stride keeping per-column partial dgamma/dbeta in registers; the block combines
+// its 4 waves through LDS and issues one fp32 atomic per column.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int width, const T* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const T* __restrict__ dy,
+                                                     const T* __restrict__ dres, T* __restrict__ dx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     T* __restrict__ dxm, uint32_t thr_m, uint32_t seed_m, float scale_m,
+                                                     uint32_t thr_in, uint32_t seed_in, float scale_in) {
+  __shared__ float red[2][4][64 * 8 + 8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = width >> 3;
+  float dg[LN_MAXC][8], db[LN_MAXC][8];
+#pragma unroll
+  for (int c = 0; c < LN_MAXC; ++c)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { dg[c][i] = 0.f; db[c][i] = 0.f; }
+
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const T* xr = x + (size_t)row * width;
+    const T* dyr = dy + (size_t)row * width;
+    const float mu = mean[row], rs = rstd[row];
+    float xh[LN_MAXC][8], gdy[LN_MAXC][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+        float xv[8], dv[8], g[8];
+        ld8(xr + ch * 8, xv);
+        ld8(dyr + ch * 8, dv);
+        ld8(gamma + ch * 8, g);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float d = dv[i];
+          if (thr_in) d = dropout_keep(seed_in, (uint32_t)row * (uint32_t)width + (uint32_t)(ch * 8 + i), thr_in) ? d * scale_in : 0.f;
+          const float h = (xv[i] - mu) * rs;
+          xh[c][i] = h;
+          dg[c][i] += d * h;
+          db[c][i] += d;
+          const float gd = d * g[i];
+          gdy[c][i] = gd;
+          s1 += gd;
+          s2 += gd * h;
+        }
+      }
+    }
+    const float c1 = wave_sum(s1) / (float)width, c2 = wave_sum(s2) / (float)width;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+        float o[8], r[8];
+        if (dres) ld8(dres + (size_t)row * width + ch * 8, r);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          o[i] = rs * (gdy[c][i] - c1 - xh[c][i] * c2);
+          if (dres) o[i] += r[i];
+        }
+        st8(dx + (size_t)row * width + ch * 8, o);
+        if (dxm) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float ov = round_to<T>(o[i]);
+            o[i] = dropout_keep(seed_m, (uint32_t)row * (uint32_t)width + (uint32_t)(ch * 8 + i), thr_m) ? ov * scale_m : 0.f;
+          }
+          st8(dxm + (size_t)row * width + ch * 8, o);
+        }
+      }
+    }
+  }
+  // combine the 4 waves' column partials
+#pragma unroll
+  for (int c = 0; c < LN_MAXC; ++c) {
+    const int ch = lane + c * 64;
+    __syncthreads();
+    if (ch < nchunk) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { red[0][wave][lane * 8 + i] = dg[c][i]; red[1][wave][lane * 8 + i] = db[c][i]; }
+    }
+    __syncthreads();
+    // 512 columns of this chunk group; thread t handles columns t and t+256
+    for (int col = threadIdx.x; col < 512; col += 256) {
+      const int gcol = c * 512 + col;  // = (lane' + c*64)*8 + i with lane'*8+i = col
+      if (gcol < width) {
+        const float a = red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col];
+        const float b = red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col];
+        if (dgamma) atomicAdd(dgamma + gcol, a);
+        if (dbeta) atomicAdd(dbeta + gcol, b);
+      }
+    }
+  }
+}
+
+static inline uint32_t thr_of(float p) { return p > 0.f ? (uint32_t)fminf(p * 4294967296.0f, 4294967295.0f) : 0u; }
+
+extern "C" int mic_layernorm_fwd(int dtype, int rows, int width, const void* x, const float* gamma, const float* beta,
+                                 float eps, void* y, float* mean, float* rstd, float dropout_p, uint32_t dropout_seed,
+                                 void* stream) {
+  MIC_CHECK(rows > 0 && width > 0 && width % 8 == 0 && width <= 64 * 8 * LN_MAXC, "mic_layernorm_fwd: bad shape rows=%d width=%d", rows, width);
+  MIC_CHECK(x && gamma && beta && y, "mic_layernorm_fwd: null pointer");
+  dim3 grid((rows + 3) / 4), block(256);
+  const uint32_t thr = thr_of(dropout_p);
+  const float sc = 1.0f / (1.0f - dropout_p);
+  if (dtype == MIC_BF16)
+    hipLaunchKernelGGL(ln_fwd_kernel<uint16_t>, grid, block, 0, (hipStream_t)stream, rows, width, (const uint16_t*)x, gamma, beta, eps, (uint16_t*)y, mean, rstd, thr, dropout_seed, sc);
+  else if (dtype == MIC_F32)
+    hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, (hipStream_t)stream, rows, width, (const float*)x, gamma, beta, eps, (float*)y, mean, rstd, thr, dropout_seed, sc);
+  else MIC_CHECK(false, "mic_layernorm_fwd: bad dtype");
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}
+
+extern "C" int mic_layernorm_bwd(int dtype, int rows, int width, const void* x, const float* gamma, const float* mean,
+                                 const float* rstd, const void* dy, const void* dres, void* dx, float* dgamma,
+                                 float* dbeta, void* dxm, float dropout_p, uint32_t dropout_seed, float in_dropout_p,
+                                 uint32_t in_dropout_seed, void* stream) {
+  MIC_CHECK(rows > 0 && width > 0 && width % 8 == 0 && width <= 64 * 8 * LN_MAXC, "mic_layernorm_bwd: bad shape rows=%d width=%d", rows, width);
+  MIC_CHECK(x && gamma && mean && rstd && dy && dx, "mic_layernorm_bwd: null pointer");
+  int nblk = (rows + 3) / 4;
+  if (nblk > 1024) nblk = 1024;
+  dim3 grid(nblk), block(256);
+  const uint32_t thr_m = dxm ? thr_of(dropout_p) : 0u, thr_in = thr_of(in_dropout_p);
+  const float sm = 1.0f / (1.0f - dropout_p), si = 1.0f / (1.0f - in_dropout_p);
+  if (dtype == MIC_BF16)
+    hipLaunchKernelGGL(ln_bwd_kernel<uint16_t>, grid, block, 0, (hipStream_t)stream, rows, width, (const uint16_t*)x, gamma, mean, rstd, (const uint16_t*)dy, (const uint16_t*)dres, (uint16_t*)dx, dgamma, dbeta, (uint16_t*)dxm, thr_m, dropout_seed, sm, thr_in, in_dropout_seed, si);
+  else if (dtype == MIC_F32)
+    hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, 0, (hipStream_t)stream, rows, width, (const float*)x, gamma, mean, rstd, (const float*)dy, (const float*)dres, (float*)dx, dgamma, dbeta, (float*)dxm, thr_m, dropout_seed, sm, thr_in, in_dropout_seed, si);
+  else MIC_CHECK(false, "mic_layernorm_bwd: bad dtype");
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}

@@ -1,0 +1,172 @@
+"""Thin torch-tensor wrappers over the C ABI (include/mic_hip.h).  Tensors give device memory and the current
+HIP stream; all arithmetic happens in libmic_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+
+def _dt(t_or_dtype) -> int:
+    d = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
+    if d == torch.bfloat16:
+        return L.MIC_BF16
+    if d == torch.float32:
+        return L.MIC_F32
+    raise L.MicError(f"unsupported dtype {d}")
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise L.MicError("libmic_hip ops need device tensors (no CPU fallback)")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, *, a_kmajor=False, b_kmajor=False,
+         bias=None, act=0, zout=None, zin=None, dact=0, residual=None, accumulate=False, dropout_p=0.0, dropout_seed=0,
+         alpha=1.0, lda=None, ldb=None, ldc=None, ldz=None, ldr=None):
+    """out[M,N] = epi(op(a) @ op(b)); a: [M,K] (or [K,M] if a_kmajor); b: [N,K] (or [K,N] if b_kmajor)."""
+    g = L.GemmArgs()
+    g.dtype, g.c_dtype = _dt(a), _dt(out)
+    g.M, g.N, g.K = M, N, K
+    g.a_kmajor, g.b_kmajor = int(a_kmajor), int(b_kmajor)
+    g.A, g.lda = _p(a), lda if lda is not None else a.stride(0)
+    g.B, g.ldb = _p(b), ldb if ldb is not None else b.stride(0)
+    g.C, g.ldc = _p(out), ldc if ldc is not None else out.stride(0)
+    g.bias, g.act = _p(bias), act
+    zz = zout if zout is not None else zin
+    g.Zout, g.Zin, g.dact = _p(zout), _p(zin), dact
+    g.ldz = ldz if ldz is not None else (zz.stride(0) if zz is not None else 0)
+    g.R, g.ldr = _p(residual), ldr if ldr is not None else (residual.stride(0) if residual is not None else 0)
+    g.accumulate, g.dropout_p, g.dropout_seed, g.alpha = int(accumulate), float(dropout_p), int(dropout_seed) & 0xFFFFFFFF, float(alpha)
+    L.check(L.lib().mic_gemm(C.byref(g), _stream()), "mic_gemm")
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, eps, y, mean=None, rstd=None, rows=None, dropout_p=0.0, dropout_seed=0):
+    rows = rows if rows is not None else x.shape[0]
+    L.check(L.lib().mic_layernorm_fwd(_dt(x), rows, x.shape[-1], _p(x), _p(gamma), _p(beta), float(eps), _p(y), _p(mean), _p(rstd),
+                                      float(dropout_p), int(dropout_seed) & 0xFFFFFFFF, _stream()), "mic_layernorm_fwd")
+    return y
+
+
+def layernorm_bwd(x, gamma, mean, rstd, dy, dx, dgamma, dbeta, rows=None, dres=None, dxm=None, dropout_p=0.0, dropout_seed=0,
+                  in_dropout_p=0.0, in_dropout_seed=0):
+    rows = rows if rows is not None else x.shape[0]
+    L.check(L.lib().mic_layernorm_bwd(_dt(x), rows, x.shape[-1], _p(x), _p(gamma), _p(mean), _p(rstd), _p(dy), _p(dres), _p(dx),
+                                      _p(dgamma), _p(dbeta), _p(dxm), float(dropout_p), int(dropout_seed) & 0xFFFFFFFF,
+                                      float(in_dropout_p), int(in_dropout_seed) & 0xFFFFFFFF, _stream()), "mic_layernorm_bwd")
+    return dx
+
+
+def attn_fwd(q, k, v, out, B, H, Tq, Tk, *, ldq, ldk, ldv, ldo, key_mask=None, causal=False, lse=None):
+    L.check(L.lib().mic_attn_fwd(_dt(q), B, H, Tq, Tk, _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), ldo, _p(key_mask), int(causal),
+                                 _p(lse), _stream()), "mic_attn_fwd")
+    return out
+
+
+def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, Tq, Tk, *, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, key_mask=None,
+             causal=False):
+    L.check(L.lib().mic_attn_bwd(_dt(q), B, H, Tq, Tk, _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), ldo, _p(dout), lddo, _p(lse),
+                                 _p(key_mask), int(causal), _p(dq), lddq, _p(dk), lddk, _p(dv), lddv, _stream()), "mic_attn_bwd")
+
+
+def attn_decode(q, kc, vc, out, R, H, max_len, cur, *, ldq, ldo, src_row=None, row_div=1):
+    L.check(L.lib().mic_attn_decode(_dt(q), R, H, max_len, cur, _p(q), ldq, _p(kc), _p(vc), _p(src_row), row_div, _p(out), ldo,
+                                    _stream()), "mic_attn_decode")
+    return out
+
+
+def kv_append(k, v, kc, vc, R, HD, max_len, cur, *, ldk, ldv):
+    L.check(L.lib().mic_kv_append(_dt(k), R, HD, max_len, cur, _p(k), ldk, _p(v), ldv, _p(kc), _p(vc), _stream()), "mic_kv_append")
+
+
+def im2col(pixels, patches, B, img, ps, ldp, trunc_int32=False):
+    L.check(L.lib().mic_im2col(_dt(patches), B, img, ps, _p(pixels), _p(patches), ldp, int(trunc_int32), _stream()), "mic_im2col")
+
+
+def vit_assemble(patch_out, cls, pos, x, B, S, width, ldp):
+    L.check(L.lib().mic_vit_assemble(_dt(x), B, S, width, _p(patch_out), ldp, _p(cls), _p(pos), _p(x), _stream()), "mic_vit_assemble")
+
+
+def vit_assemble_bwd(dx, dpatch, dcls, dpos, B, S, width, ldp):
+    L.check(L.lib().mic_vit_assemble_bwd(_dt(dx), B, S, width, _p(dx), _p(dpatch), ldp, _p(dcls), _p(dpos), _stream()), "mic_vit_assemble_bwd")
+
+
+def embed_fwd(ids, pos_ids, table, pos_table, scale, h, rows, width):
+    L.check(L.lib().mic_embed_fwd(_dt(h), rows, width, _p(ids), _p(pos_ids), _p(table), _p(pos_table), float(scale), _p(h), _stream()), "mic_embed_fwd")
+
+
+def embed_bwd(ids, pos_ids, dh, scale, dtable, dpos_table, rows, width):
+    L.check(L.lib().mic_embed_bwd(_dt(dh), rows, width, _p(ids), _p(pos_ids), _p(dh), float(scale), _p(dtable), _p(dpos_table), _stream()), "mic_embed_bwd")
+
+
+def ce_rows(logits, ld, V, labels, mask, ls, row_lse, row_loss, rows):
+    L.check(L.lib().mic_ce_rows(_dt(logits), rows, V, _p(logits), ld, _p(labels), _p(mask), float(ls), _p(row_lse), _p(row_loss), _stream()), "mic_ce_rows")
+
+
+def ce_reduce(row_loss, mask, loss_out, denom_out, rows):
+    L.check(L.lib().mic_ce_reduce(rows, _p(row_loss), _p(mask), _p(loss_out), _p(denom_out), _stream()), "mic_ce_reduce")
+
+
+def ce_bwd(logits, ld, V, Vpad, labels, mask, ls, row_lse, denom, rows, loss_scale=1.0):
+    L.check(L.lib().mic_ce_bwd(_dt(logits), rows, V, Vpad, _p(logits), ld, _p(labels), _p(mask), float(ls), _p(row_lse), _p(denom),
+                               float(loss_scale), _stream()), "mic_ce_bwd")
+
+
+def colsum(x, out, rows, cols, ld, accumulate=False):
+    L.check(L.lib().mic_colsum(_dt(x), rows, cols, _p(x), ld, _p(out), int(accumulate), _stream()), "mic_colsum")
+
+
+def dropout_mask(n: int, p: float, seed: int, device) -> torch.Tensor:
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    L.check(L.lib().mic_dropout_mask(_p(out), n, float(p), int(seed) & 0xFFFFFFFF, _stream()), "mic_dropout_mask")
+    return out
+
+
+def cast(src, dst, n=None):
+    n = n if n is not None else src.numel()
+    L.check(L.lib().mic_cast(_dt(src), _dt(dst), _p(src), _p(dst), n, _stream()), "mic_cast")
+    return dst
+
+
+def cast2d(src, dst, rows, cols, ld_src, ld_dst):
+    L.check(L.lib().mic_cast2d(_dt(src), _dt(dst), rows, cols, _p(src), ld_src, _p(dst), ld_dst, _stream()), "mic_cast2d")
+    return dst
+
+
+def adamw(p, m, v, g, p_lp, hyper, b1, b2, eps, wd, grad_scale=1.0, n=None):
+    n = n if n is not None else p.numel()
+    L.check(L.lib().mic_adamw(n, _p(p), _p(m), _p(v), _p(g), _p(p_lp), _p(hyper), float(b1), float(b2), float(eps), float(wd),
+                              float(grad_scale), _stream()), "mic_adamw")
+
+
+def row_lse_topk(logits, ld, V, k, top_val, top_idx, R, *, forced_token=-1, suppress_eos=False, eos_token_id=2, raw_logits=False,
+                 row_bias=None):
+    L.check(L.lib().mic_row_lse_topk(_dt(logits), R, V, _p(logits), ld, k, int(forced_token), int(suppress_eos), eos_token_id,
+                                     int(raw_logits), _p(row_bias), _p(top_val), _p(top_idx), _stream()), "mic_row_lse_topk")
+
+
+def beam_step(B, K, max_len, V, cur_len, eos, pad, length_penalty, early_stopping, cand_val, cand_idx, running_seq, running_scores,
+              seq, scores, finished, src_row, next_token, flags):
+    a = L.BeamStepArgs()
+    a.B, a.K, a.max_len, a.V, a.cur_len = B, K, max_len, V, cur_len
+    a.eos_token_id, a.pad_token_id, a.length_penalty, a.early_stopping = eos, pad, float(length_penalty), int(bool(early_stopping))
+    a.cand_val, a.cand_idx = _p(cand_val), _p(cand_idx)
+    a.running_seq, a.running_scores, a.seq, a.scores = _p(running_seq), _p(running_scores), _p(seq), _p(scores)
+    a.finished, a.src_row, a.next_token, a.flags = _p(finished), _p(src_row), _p(next_token), _p(flags)
+    L.check(L.lib().mic_beam_step(C.byref(a), _stream()), "mic_beam_step")
+
+
+def greedy_step(B, max_len, cur_len, eos, pad, top_idx, ld_top, sequences, finished, next_token):
+    L.check(L.lib().mic_greedy_step(B, max_len, cur_len, eos, pad, _p(top_idx), ld_top, _p(sequences), _p(finished), _p(next_token),
+                                    _stream()), "mic_greedy_step")

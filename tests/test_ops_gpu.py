@@ -1,0 +1,388 @@
+"""Per-kernel parity: every HIP op of libmic_hip.so (through the C ABI) against a plain torch fp32 reference of
+the same op on the same seeded inputs.  Tolerances: f32 path 2e-5 relative-to-scale (exact-fp32 MFMA, different
+summation order); bf16 path = inputs rounded to bf16 on both sides, fp32 accumulate, output rounded to bf16:
+<= 1 bf16 ulp of the output scale (2^-8 relative) + accumulation-order noise."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 1.2e-2
+
+
+def relerr(got, ref):
+    ref = ref.float()
+    return ((got.float().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-6)).item()
+
+
+def rnd(shape, g, dtype, scale=1.0):
+    x = torch.randn(shape, generator=g) * scale
+    return x.to(dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("akm,bkm", [(False, False), (False, True), (True, True), (True, False)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 192), (384, 1000, 128), (37, 72, 64)])
+def test_gemm_layouts(dev, dtype, akm, bkm, M, N, K):
+    from mic_amd import ops
+
+    if dtype == torch.bfloat16 and ((akm and M % 8) or (bkm and N % 8)):
+        pytest.skip("k-major bf16 operands need the contiguous dim % 8 == 0")
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + akm * 2 + bkm)
+    A = rnd((K, M) if akm else (M, K), g, dtype)
+    B = rnd((K, N) if bkm else (N, K), g, dtype)
+    ref = (A.float().T if akm else A.float()) @ (B.float() if bkm else B.float().T)
+    out = torch.full((M, N), float("nan"), dtype=dtype, device=dev)
+    ops.gemm(A.to(dev), B.to(dev), out, M, N, K, a_kmajor=akm, b_kmajor=bkm)
+    torch.cuda.synchronize()
+    assert relerr(out, ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_epilogue_full(dev, dtype):
+    """bias + save pre-activation + activation + dropout + residual, then the backward-side options."""
+    from mic_amd import ops
+
+    M, N, K = 192, 256, 128
+    g = torch.Generator().manual_seed(5)
+    A, B = rnd((M, K), g, dtype), rnd((N, K), g, dtype, 0.1)
+    bias = torch.randn(N, generator=g)
+    R = rnd((M, N), g, dtype)
+    for act_id, act in ((1, lambda x: torch.nn.functional.gelu(x)), (2, lambda x: torch.nn.functional.gelu(x, approximate="tanh")),
+                        (3, lambda x: x * torch.sigmoid(1.702 * x))):
+        out = torch.empty((M, N), dtype=dtype, device=dev)
+        z = torch.empty((M, N), dtype=dtype, device=dev)
+        ops.gemm(A.to(dev), B.to(dev), out, M, N, K, bias=bias.to(dev), act=act_id, zout=z, residual=R.to(dev), dropout_p=0.25,
+                 dropout_seed=77)
+        keep = ops.dropout_mask(M * N, 0.25, 77, dev).cpu().reshape(M, N).float()
+        torch.cuda.synchronize()
+        assert abs(keep.mean().item() - 0.75) < 0.02
+        zr = A.float() @ B.float().T + bias
+        zr_s = zr.to(dtype).float()
+        ref = act(zr_s) * keep / 0.75 + R.float()
+        assert relerr(z, zr) < tol(dtype)
+        assert relerr(out, ref) < tol(dtype)
+        # backward: dz = (dy @ W) * act'(z)
+        dY = rnd((M, K), g, dtype)
+        W = rnd((K, N), g, dtype, 0.1)  # stored [out=K][in=N]; dX = dY @ W  -> b_kmajor
+        dz = torch.empty((M, N), dtype=dtype, device=dev)
+        ops.gemm(dY.to(dev), W.to(dev), dz, M, N, K, b_kmajor=True, zin=z, dact=act_id)
+        zz = z.float().cpu().requires_grad_(True)
+        act(zz).backward(torch.ones_like(zz))
+        refdz = (dY.float() @ W.float()) * zz.grad
+        torch.cuda.synchronize()
+        assert relerr(dz, refdz) < tol(dtype) * 1.5
+    # fp32 output with accumulate (weight gradients), bf16/f32 inputs
+    dW = torch.ones((N, K), dtype=torch.float32, device=dev)
+    dYm = rnd((M, N), g, dtype)
+    ops.gemm(dYm.to(dev), A.to(dev), dW, N, K, M if M % 64 == 0 else M, a_kmajor=True, b_kmajor=True, accumulate=True)
+    torch.cuda.synchronize()
+    assert relerr(dW, dYm.float().T @ A.float() + 1.0) < (2e-5 if dtype == torch.float32 else 2e-3)
+
+
+def test_gemm_rejects_bad_args(dev):
+    from mic_amd import _lib, ops
+
+    a = torch.zeros(64, 40, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(_lib.MicError):
+        ops.gemm(a, a, torch.zeros(64, 64, dtype=torch.bfloat16, device=dev), 64, 64, 40)  # K % 64 != 0
+    with pytest.raises(_lib.MicError):
+        ops.gemm(a.cpu(), a, torch.zeros(64, 64, dtype=torch.bfloat16, device=dev), 64, 64, 64)  # host pointer
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("rows,width", [(50, 768), (64, 1024), (7, 128)])
+def test_layernorm_fwd_bwd(dev, dtype, rows, width):
+    from mic_amd import ops
+
+    g = torch.Generator().manual_seed(rows + width)
+    x = rnd((rows, width), g, dtype, 2.0)
+    gamma, beta = 1 + 0.1 * torch.randn(width, generator=g), 0.1 * torch.randn(width, generator=g)
+    dy, dres = rnd((rows, width), g, dtype), rnd((rows, width), g, dtype)
+    y = torch.empty_like(x, device=dev)
+    mean, rstd = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    ops.layernorm_fwd(x.to(dev), gamma.to(dev), beta.to(dev), 1e-5, y, mean, rstd)
+    xr = x.float().clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (width,), gr, br, 1e-5)
+    assert relerr(y, yr.detach()) < tol(dtype)
+    yr.backward(dy.float())
+    dx, dxm = torch.empty_like(x, device=dev), torch.empty_like(x, device=dev)
+    dg, db = torch.zeros(width, device=dev), torch.zeros(width, device=dev)
+    ops.layernorm_bwd(x.to(dev), gamma.to(dev), mean, rstd, dy.to(dev), dx, dg, db, dres=dres.to(dev), dxm=dxm, dropout_p=0.1,
+                      dropout_seed=9)
+    keep = ops.dropout_mask(rows * width, 0.1, 9, dev).cpu().reshape(rows, width).float()
+    torch.cuda.synchronize()
+    refdx = xr.grad + dres.float()
+    assert relerr(dx, refdx) < tol(dtype)
+    assert relerr(dxm, refdx.to(dtype).float() * keep / 0.9) < tol(dtype)
+    assert relerr(dg, gr.grad) < (1e-4 if dtype == torch.float32 else 2e-2)
+    assert relerr(db, br.grad) < (1e-4 if dtype == torch.float32 else 2e-2)
+    # dropout after LN (embedding LN) and its backward
+    y2 = torch.empty_like(x, device=dev)
+    ops.layernorm_fwd(x.to(dev), gamma.to(dev), beta.to(dev), 1e-5, y2, mean, rstd, dropout_p=0.1, dropout_seed=3)
+    keep2 = ops.dropout_mask(rows * width, 0.1, 3, dev).cpu().reshape(rows, width).float()
+    assert relerr(y2, yr.detach().to(dtype).float() * keep2 / 0.9) < tol(dtype)
+    dx2 = torch.empty_like(x, device=dev)
+    ops.layernorm_bwd(x.to(dev), gamma.to(dev), mean, rstd, dy.to(dev), dx2, None, None, in_dropout_p=0.1, in_dropout_seed=3)
+    xr2 = x.float().clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr2, (width,), gamma, beta, 1e-5).backward(dy.float() * keep2 / 0.9)
+    torch.cuda.synchronize()
+    assert relerr(dx2, xr2.grad) < tol(dtype)
+
+
+def _attn_ref(q, k, v, causal, key_mask):
+    # q [B,Tq,H,64] k,v [B,Tk,H,64]
+    s = torch.einsum("bthd,bshd->bhts", q / 8.0, k)
+    Tq, Tk = q.shape[1], k.shape[1]
+    allowed = torch.ones(q.shape[0], 1, Tq, Tk, dtype=torch.bool)
+    if causal:
+        allowed = allowed & torch.tril(torch.ones(Tq, Tk, dtype=torch.bool))[None, None]
+    if key_mask is not None:
+        allowed = allowed & key_mask.bool()[:, None, None, :]
+    s = s.masked_fill(~allowed, float("-inf"))
+    return torch.einsum("bhts,bshd->bthd", torch.softmax(s, -1), v)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("Tq,Tk,H,causal,masked", [(50, 50, 12, False, False), (64, 64, 16, True, True), (64, 50, 16, False, False),
+                                                   (12, 12, 2, True, True), (12, 10, 2, False, False), (33, 64, 3, False, True)])
+def test_attention_fwd_bwd(dev, dtype, Tq, Tk, H, causal, masked):
+    from mic_amd import ops
+
+    B, D = 3, 64
+    g = torch.Generator().manual_seed(Tq * 100 + Tk)
+    fused = Tq == Tk  # self-attention reads q,k,v out of one fused [rows][3*H*D] projection
+    if fused:
+        qkv = rnd((B * Tq, 3 * H * D), g, dtype)
+        q, k, v = qkv[:, : H * D], qkv[:, H * D: 2 * H * D], qkv[:, 2 * H * D:]
+        ldq = ldk = ldv = 3 * H * D
+        qkv_d = qkv.to(dev)
+        qd, kd, vd = qkv_d[:, : H * D], qkv_d[:, H * D: 2 * H * D], qkv_d[:, 2 * H * D:]
+    else:
+        q = rnd((B * Tq, H * D), g, dtype)
+        kv = rnd((B * Tk, 2 * H * D), g, dtype)
+        k, v = kv[:, : H * D], kv[:, H * D:]
+        ldq, ldk, ldv = H * D, 2 * H * D, 2 * H * D
+        qd, kv_d = q.to(dev), kv.to(dev)
+        kd, vd = kv_d[:, : H * D], kv_d[:, H * D:]
+    key_mask = None
+    if masked:
+        key_mask = torch.ones(B, Tk, dtype=torch.int32)
+        key_mask[1, Tk - 3:] = 0
+        key_mask[2, Tk // 2:] = 0
+    out = torch.empty((B * Tq, H * D), dtype=dtype, device=dev)
+    lse = torch.empty((B, H, Tq), device=dev)
+    km_d = key_mask.to(dev) if key_mask is not None else None
+    ops.attn_fwd(qd, kd, vd, out, B, H, Tq, Tk, ldq=ldq, ldk=ldk, ldv=ldv, ldo=H * D, key_mask=km_d, causal=causal, lse=lse)
+    qr = q.float().reshape(B, Tq, H, D).clone().requires_grad_(True)
+    kr = k.float().reshape(B, Tk, H, D).clone().requires_grad_(True)
+    vr = v.float().reshape(B, Tk, H, D).clone().requires_grad_(True)
+    ref = _attn_ref(qr, kr, vr, causal, key_mask)
+    torch.cuda.synchronize()
+    assert relerr(out, ref.detach().reshape(B * Tq, H * D)) < tol(dtype)
+    do = rnd((B * Tq, H * D), g, dtype)
+    ref.backward(do.float().reshape(B, Tq, H, D))
+    dq = torch.empty((B * Tq, H * D), dtype=dtype, device=dev)
+    dkv = torch.empty((B * Tk, 2 * H * D), dtype=dtype, device=dev)
+    ops.attn_bwd(qd, kd, vd, out, do.to(dev), lse, dq, dkv[:, : H * D], dkv[:, H * D:], B, H, Tq, Tk, ldq=ldq, ldk=ldk, ldv=ldv,
+                 ldo=H * D, lddo=H * D, lddq=H * D, lddk=2 * H * D, lddv=2 * H * D, key_mask=km_d, causal=causal)
+    torch.cuda.synchronize()
+    t = tol(dtype) * (1 if dtype == torch.float32 else 2.5)
+    assert relerr(dq, qr.grad.reshape(B * Tq, H * D)) < t
+    assert relerr(dkv[:, : H * D], kr.grad.reshape(B * Tk, H * D)) < t
+    assert relerr(dkv[:, H * D:], vr.grad.reshape(B * Tk, H * D)) < t
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_attn_decode_and_kv_append(dev, dtype):
+    from mic_amd import ops
+
+    R, H, D, L = 8, 4, 64, 16
+    g = torch.Generator().manual_seed(3)
+    kc = torch.zeros((R, L, H * D), dtype=dtype, device=dev)
+    vc = torch.zeros_like(kc)
+    hist_k = rnd((R, L, H * D), g, dtype)
+    hist_v = rnd((R, L, H * D), g, dtype)
+    for t in range(6):
+        ops.kv_append(hist_k[:, t].contiguous().to(dev), hist_v[:, t].contiguous().to(dev), kc, vc, R, H * D, L, t, ldk=H * D, ldv=H * D)
+    src = torch.randint(0, R, (R, L), generator=g, dtype=torch.int32)
+    q = rnd((R, H * D), g, dtype)
+    out = torch.empty((R, H * D), dtype=dtype, device=dev)
+    cur = 5
+    ops.attn_decode(q.to(dev), kc, vc, out, R, H, L, cur, ldq=H * D, ldo=H * D, src_row=src.to(dev))
+    torch.cuda.synchronize()
+    kk = torch.stack([hist_k[src[r, : cur + 1].long(), torch.arange(cur + 1)] for r in range(R)]).float().reshape(R, cur + 1, H, D)
+    vv = torch.stack([hist_v[src[r, : cur + 1].long(), torch.arange(cur + 1)] for r in range(R)]).float().reshape(R, cur + 1, H, D)
+    ref = _attn_ref(q.float().reshape(R, 1, H, D), kk, vv, False, None).reshape(R, H * D)
+    assert relerr(out, ref) < tol(dtype)
+    # cross-attention form: rows share cache row r // row_div, all S slots valid
+    ops.attn_decode(q.to(dev), kc, vc, out, R, H, L, 5, ldq=H * D, ldo=H * D, row_div=4)
+    torch.cuda.synchronize()
+    idx = torch.arange(R) // 4
+    ref = _attn_ref(q.float().reshape(R, 1, H, D), hist_k[idx, :6].float().reshape(R, 6, H, D), hist_v[idx, :6].float().reshape(R, 6, H, D),
+                    False, None).reshape(R, H * D)
+    assert relerr(out, ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_vit_embed_ops(dev, dtype):
+    from mic_amd import ops
+
+    B, img, ps, W = 2, 64, 32, 128
+    g = torch.Generator().manual_seed(0)
+    px = torch.randn(B, img, img, 3, generator=g) * 1.5
+    gg = img // ps
+    patches = torch.empty((B * gg * gg, ps * ps * 3), dtype=dtype, device=dev)
+    for trunc in (False, True):
+        ops.im2col(px.to(dev), patches, B, img, ps, ps * ps * 3, trunc_int32=trunc)
+        src = torch.trunc(px) if trunc else px
+        ref = src.reshape(B, gg, ps, gg, ps, 3).permute(0, 1, 3, 2, 4, 5).reshape(B * gg * gg, -1)
+        torch.cuda.synchronize()
+        assert torch.equal(patches.float().cpu(), ref.to(dtype).float())
+    S = gg * gg + 1
+    po = rnd((B * gg * gg, W), g, dtype)
+    cls, pos = torch.randn(W, generator=g), torch.randn(S, W, generator=g)
+    x = torch.empty((B * S, W), dtype=dtype, device=dev)
+    ops.vit_assemble(po.to(dev), cls.to(dev), pos.to(dev), x, B, S, W, W)
+    ref = torch.cat([cls.expand(B, 1, W), po.float().reshape(B, S - 1, W)], 1) + pos
+    torch.cuda.synchronize()
+    assert relerr(x, ref.reshape(B * S, W)) < tol(dtype)
+    dx = rnd((B * S, W), g, dtype)
+    dpatch = torch.empty((B * (S - 1), W), dtype=dtype, device=dev)
+    dcls, dpos = torch.zeros(W, device=dev), torch.zeros(S, W, device=dev)
+    ops.vit_assemble_bwd(dx.to(dev), dpatch, dcls, dpos, B, S, W, W)
+    torch.cuda.synchronize()
+    d3 = dx.float().reshape(B, S, W)
+    assert torch.equal(dpatch.float().cpu(), d3[:, 1:].reshape(-1, W))
+    assert relerr(dpos, d3.sum(0)) < 1e-5 and relerr(dcls, d3[:, 0].sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_token_embed_fwd_bwd(dev, dtype):
+    from mic_amd import ops
+
+    V, W, rows = 300, 128, 40
+    g = torch.Generator().manual_seed(1)
+    table = rnd((V, W), g, dtype)
+    pos_table = torch.randn(66, W, generator=g)
+    ids = torch.randint(0, V, (rows,), generator=g, dtype=torch.int32)
+    ids[5] = ids[6] = ids[7]  # repeated rows must accumulate in backward
+    pos = torch.randint(0, 64, (rows,), generator=g, dtype=torch.int32)
+    h = torch.empty((rows, W), dtype=dtype, device=dev)
+    ops.embed_fwd(ids.to(dev), pos.to(dev), table.to(dev), pos_table.to(dev), math.sqrt(W), h, rows, W)
+    ref = table.float()[ids.long()] * math.sqrt(W) + pos_table[pos.long() + 2]
+    torch.cuda.synchronize()
+    assert relerr(h, ref) < tol(dtype)
+    dh = rnd((rows, W), g, dtype)
+    dt, dp = torch.zeros((V, W), device=dev), torch.zeros((66, W), device=dev)
+    ops.embed_bwd(ids.to(dev), pos.to(dev), dh.to(dev), math.sqrt(W), dt, dp, rows, W)
+    rt, rp = torch.zeros(V, W), torch.zeros(66, W)
+    rt.index_add_(0, ids.long(), dh.float() * math.sqrt(W))
+    rp.index_add_(0, pos.long() + 2, dh.float())
+    torch.cuda.synchronize()
+    assert relerr(dt, rt) < 1e-5 and relerr(dp, rp) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("ls", [0.0, 0.1])
+def test_cross_entropy(dev, dtype, ls):
+    from mic_amd import ops
+    from oracle import train_ref
+
+    rows, V, Vpad = 24, 1003, 1024
+    g = torch.Generator().manual_seed(2)
+    logits = torch.zeros((rows, Vpad), dtype=dtype)
+    logits[:, :V] = rnd((rows, V), g, dtype, 3.0)
+    labels = torch.randint(0, V, (rows,), generator=g, dtype=torch.int32)
+    mask = (torch.rand(rows, generator=g) > 0.3).to(torch.int32)
+    ld = logits.to(dev)
+    lse, rl = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    loss, denom = torch.empty(1, device=dev), torch.empty(1, device=dev)
+    ops.ce_rows(ld, Vpad, V, labels.to(dev), mask.to(dev), ls, lse, rl, rows)
+    ops.ce_reduce(rl, mask.to(dev), loss, denom, rows)
+    ops.ce_bwd(ld, Vpad, V, Vpad, labels.to(dev), mask.to(dev), ls, lse, denom, rows)
+    lr = logits[:, :V].float().clone().requires_grad_(True)
+    ref = train_ref.loss_fn(lr[None], labels[None], mask[None], ls)
+    ref.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - ref.item()) < 2e-5 * max(1.0, abs(ref.item()))
+    assert denom.item() == mask.sum().item()
+    assert relerr(ld[:, :V], lr.grad) < (1e-4 if dtype == torch.float32 else 1.2e-2)
+    assert ld[:, V:].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_colsum_cast(dev, dtype):
+    from mic_amd import ops
+
+    g = torch.Generator().manual_seed(4)
+    x = rnd((300, 200), g, dtype)
+    out = torch.empty(200, device=dev)
+    ops.colsum(x.to(dev), out, 300, 200, 200)
+    torch.cuda.synchronize()
+    assert relerr(out, x.float().sum(0)) < 1e-5
+    y = torch.empty((300, 200), dtype=torch.bfloat16, device=dev)
+    ops.cast(x.float().to(dev), y)
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu(), x.float().to(torch.bfloat16))
+
+
+def test_adamw_matches_oracle(dev):
+    from mic_amd import ops
+    from oracle import train_ref
+
+    n = 4096
+    g = torch.Generator().manual_seed(6)
+    p, m, v, gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 0.1, torch.rand(n, generator=g) * 0.01, torch.randn(n, generator=g)
+    pd, md, vd = p.to(dev), m.to(dev), v.to(dev)
+    plp = torch.empty(n, dtype=torch.bfloat16, device=dev)
+    count, lr = 6, 3e-4
+    hyper = torch.tensor([lr, float(count + 1)], device=dev)
+    ops.adamw(pd, md, vd, gr.to(dev), plp, hyper, 0.9, 0.999, 1e-8, 0.01)
+    rp, rm, rv = train_ref.adamw_update(p, gr, m, v, count, lr, 0.9, 0.999, 1e-8, 0.01)
+    torch.cuda.synchronize()
+    assert relerr(pd, rp) < 1e-6 and relerr(md, rm) < 1e-6 and relerr(vd, rv) < 1e-6, (relerr(pd, rp), relerr(md, rm), relerr(vd, rv))
+    assert torch.equal(plp.cpu(), pd.cpu().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_row_lse_topk(dev, dtype):
+    from mic_amd import ops
+    from oracle import generation_ref as G
+
+    R, V, Vpad, k = 6, 5003, 5008, 8
+    g = torch.Generator().manual_seed(8)
+    logits = torch.zeros((R, Vpad), dtype=dtype)
+    logits[:, :V] = rnd((R, V), g, dtype, 2.0)
+    logits[2, 100:140] = logits[2, :V].max() + 1  # exact ties at the top: lowest index first
+    bias = torch.tensor([0.0, -1e7, -3.5, 0.0, -1e7, 2.0])
+    tv, ti = torch.empty((R, k), device=dev), torch.empty((R, k), dtype=torch.int32, device=dev)
+    x = logits[:, :V].float().numpy()
+    for forced, sup in ((-1, False), (17, False), (-1, True)):
+        ops.row_lse_topk(logits.to(dev), Vpad, V, k, tv, ti, R, forced_token=forced, suppress_eos=sup, eos_token_id=2, row_bias=bias.to(dev))
+        lp = G.log_softmax(x)
+        if sup:
+            lp[:, 2] = -np.inf
+        if forced >= 0:
+            lp = G.ForcedBOS(forced)(None, lp, 1)
+        lp = lp + bias.numpy()[:, None]
+        rv, ri = G.top_k(lp, k)
+        torch.cuda.synchronize()
+        assert np.array_equal(ti.cpu().numpy(), ri.astype(np.int32)), (forced, sup)
+        got = tv.cpu().numpy()
+        fin = np.isfinite(rv)
+        assert np.array_equal(np.isfinite(got), fin)
+        assert np.allclose(got[fin], rv[fin], rtol=0, atol=2e-5 * max(1.0, np.abs(rv[fin]).max()))
+    # greedy form: raw logits, k = 1 == first-max argmax
+    tv1, ti1 = torch.empty((R, 1), device=dev), torch.empty((R, 1), dtype=torch.int32, device=dev)
+    ops.row_lse_topk(logits.to(dev), Vpad, V, 1, tv1, ti1, R, raw_logits=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(ti1.cpu().numpy()[:, 0], np.argmax(x, axis=-1))
