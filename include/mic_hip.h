@@ -108,9 +108,10 @@ int mic_attn_bwd(int dtype, int B, int H, int Tq, int Tk, const void* q, int ldq
  * SURVEY App. B7): one query per row, validity slot <= cur (cache_index).  The cache is NOT physically
  * reordered by beam (gen:945-953): src_row [R][max_len] int32 says in which row slot s of row r's
  * history lives (beam-parent indirection); NULL = row r reads cache row r / row_div (cross-attention K/V are
- * computed once per image and shared by its beams: row_div = num_beams, cur = S-1).  kc/vc: [rows][max_len][H*64]. */
+ * computed once per image and shared by its beams: row_div = num_beams, cur = S-1).  kc/vc: [rows][max_len] slots of
+ * ldc elements each (ldc = H*64 for the self cache; 2*H*64 when k and v are the halves of a fused projection). */
 int mic_attn_decode(int dtype, int R, int H, int max_len, int cur, const void* q, int ldq, const void* kc,
-                    const void* vc, const int32_t* src_row, int row_div, void* out, int ldo, void* stream);
+                    const void* vc, int ldc, const int32_t* src_row, int row_div, void* out, int ldo, void* stream);
 /* writes this step's k,v (columns of the fused qkv projection) into slot `cur` of every row's own cache */
 int mic_kv_append(int dtype, int R, int HD, int max_len, int cur, const void* k, int ldk, const void* v, int ldv,
                   void* kc, void* vc, void* stream);

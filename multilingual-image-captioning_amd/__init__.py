@@ -5,5 +5,9 @@ hand-written HIP for gfx950 in `csrc/`, reached through the C ABI of `include/mi
 Importable as `mic_amd` (see the `mic_amd.py` shim at the repo root: the directory name has a hyphen).
 """
 from . import _lib  # noqa: F401
+from .configuration_clip_vision_mbart import CLIPVisionMBartConfig  # noqa: F401
+from .modeling_clip_vision_mbart import FlaxCLIPVisionMBartForConditionalGeneration  # noqa: F401
+from .train import Trainer, create_learning_rate_fn, shift_tokens_right  # noqa: F401
 
-__all__ = ["_lib"]
+__all__ = ["CLIPVisionMBartConfig", "FlaxCLIPVisionMBartForConditionalGeneration", "Trainer", "create_learning_rate_fn",
+           "shift_tokens_right"]

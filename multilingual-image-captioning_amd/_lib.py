@@ -49,7 +49,7 @@ _SIGS = {
     "mic_layernorm_bwd": ([_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _u32, _f, _u32, _p], C.c_int),
     "mic_attn_fwd": ([_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p], C.c_int),
     "mic_attn_bwd": ([_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p], C.c_int),
-    "mic_attn_decode": ([_i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _i, _p, _i, _p], C.c_int),
+    "mic_attn_decode": ([_i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p], C.c_int),
     "mic_kv_append": ([_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p], C.c_int),
     "mic_im2col": ([_i, _i, _i, _i, _p, _p, _i, _i, _p], C.c_int),
     "mic_vit_assemble": ([_i, _i, _i, _i, _p, _i, _p, _p, _p, _p], C.c_int),

@@ -334,14 +334,13 @@ extern "C" int mic_attn_bwd(int dtype, int B, int H, int Tq, int Tk, const void*
 // output: lane = head-dim element, loop over valid slots with coalesced 64-element rows.
 template <typename T>
 __global__ __launch_bounds__(256) void attn_decode_kernel(int R, int H, int max_len, int cur, const T* __restrict__ q, int ldq,
-                                                          const T* __restrict__ kc, const T* __restrict__ vc,
+                                                          const T* __restrict__ kc, const T* __restrict__ vc, int ldc,
                                                           const int32_t* __restrict__ src_row, int row_div,
                                                           T* __restrict__ out, int ldo) {
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wid >= R * H) return;
   const int r = wid / H, h = wid % H;
-  const int HD = H * 64;
   float qv[64];
   {
     const T* qr = q + (size_t)r * ldq + h * 64;
@@ -352,7 +351,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(int R, int H, int max_
   int my_src = 0;
   if (lane <= cur && lane < max_len) {
     my_src = src_row ? src_row[(size_t)r * max_len + lane] : r / row_div;
-    const T* kr = kc + ((size_t)my_src * max_len + lane) * HD + h * 64;
+    const T* kr = kc + ((size_t)my_src * max_len + lane) * ldc + h * 64;
     float acc = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -372,19 +371,19 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(int R, int H, int max_
   for (int t = 0; t < n; ++t) {
     const float pt = __shfl(pn, t, 64);
     const int sr = __shfl(my_src, t, 64);
-    o += pt * ElemT<T>::ld(vc + ((size_t)sr * max_len + t) * HD + h * 64 + lane);
+    o += pt * ElemT<T>::ld(vc + ((size_t)sr * max_len + t) * ldc + h * 64 + lane);
   }
   ElemT<T>::st(out + (size_t)r * ldo + h * 64 + lane, o);
 }
 extern "C" int mic_attn_decode(int dtype, int R, int H, int max_len, int cur, const void* q, int ldq, const void* kc,
-                                const void* vc, const int32_t* src_row, int row_div, void* out, int ldo, void* stream) {
+                               const void* vc, int ldc, const int32_t* src_row, int row_div, void* out, int ldo, void* stream) {
   MIC_CHECK(R > 0 && H > 0 && max_len > 0 && max_len <= 64 && cur >= 0 && row_div >= 1, "mic_attn_decode: bad shape");
   MIC_CHECK(q && kc && vc && out, "mic_attn_decode: null pointer");
   dim3 grid((R * H + 3) / 4), block(256);
   if (dtype == MIC_BF16)
-    hipLaunchKernelGGL(attn_decode_kernel<uint16_t>, grid, block, 0, (hipStream_t)stream, R, H, max_len, cur, (const uint16_t*)q, ldq, (const uint16_t*)kc, (const uint16_t*)vc, src_row, row_div, (uint16_t*)out, ldo);
+    hipLaunchKernelGGL(attn_decode_kernel<uint16_t>, grid, block, 0, (hipStream_t)stream, R, H, max_len, cur, (const uint16_t*)q, ldq, (const uint16_t*)kc, (const uint16_t*)vc, ldc, src_row, row_div, (uint16_t*)out, ldo);
   else if (dtype == MIC_F32)
-    hipLaunchKernelGGL(attn_decode_kernel<float>, grid, block, 0, (hipStream_t)stream, R, H, max_len, cur, (const float*)q, ldq, (const float*)kc, (const float*)vc, src_row, row_div, (float*)out, ldo);
+    hipLaunchKernelGGL(attn_decode_kernel<float>, grid, block, 0, (hipStream_t)stream, R, H, max_len, cur, (const float*)q, ldq, (const float*)kc, (const float*)vc, ldc, src_row, row_div, (float*)out, ldo);
   else MIC_CHECK(false, "mic_attn_decode: bad dtype");
   MIC_LAUNCH_CHECK();
   return MIC_OK;

@@ -1,0 +1,347 @@
+"""Kernel sequencing for the captioning hot path: ViT encoder -> projection -> mBART decoder -> tied head, forward
+(+loss) and the hand-derived backward.  Pure orchestration: every tensor op is a libmic_hip.so kernel (ops.*);
+torch supplies device memory and the current HIP stream only.
+
+Module graph restated from `modeling_clip_vision_mbart.py:67-115, 146-192` (composition) and SURVEY Appendix B
+(third-party block structure).  Activations live in row-padded [rows_pad][width] buffers (rows_pad = multiple of 128,
+pad rows stay zero) so weight-gradient GEMMs can reduce over the padded row count.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .params import ParamStore, _rup
+
+ROWPAD = 128
+
+
+def _mix(seed: int, site: int) -> int:
+    x = (seed * 0x9E3779B1 + site * 0x85EBCA6B + 0x27D4EB2F) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x2C1B3C6D) & 0xFFFFFFFF
+    x ^= x >> 12
+    return x & 0xFFFFFFFF
+
+
+class Engine:
+    def __init__(self, store: ParamStore):
+        self.P = store
+        self.dt = store.dtype
+        self.dev = store.device
+        self._bufs: Dict[str, torch.Tensor] = {}
+        mc = store.cfg.mbart_config
+        self.gelu = L.ACT_IDS[getattr(mc, "gelu_variant", "tanh")]
+        self.dec_eps = float(getattr(mc, "decoder_ln_eps", 1e-6))
+        self.vit_eps = float(store.cfg.clip_vision_config.layer_norm_eps)
+        self.p_drop = float(mc.dropout)
+        self.embed_scale = math.sqrt(store.d) if mc.scale_embedding else 1.0
+        self.grad_progress = None  # callable(offset): every gradient with flat offset < offset is final (DDP overlap)
+
+    def _done(self, seg_name: str):
+        """Report that the gradient segment `seg_name` (and, by layout order, everything before it) is final."""
+        if self.grad_progress is not None:
+            s = self.P.segs[seg_name]
+            self.grad_progress(s.offset + s.numel)
+
+    # ------------------------------------------------------------------ buffers
+    def buf(self, name: str, rows: int, cols: int, dtype=None) -> torch.Tensor:
+        dtype = dtype or self.dt
+        rp = _rup(max(rows, 1), ROWPAD)
+        key = f"{name}:{rows}:{cols}:{dtype}"
+        t = self._bufs.get(key)
+        if t is None:
+            t = torch.zeros((rp, cols), dtype=dtype, device=self.dev)
+            self._bufs[key] = t
+        return t
+
+    def vec(self, name: str, n: int, dtype=torch.float32) -> torch.Tensor:
+        key = f"{name}:{n}:{dtype}"
+        t = self._bufs.get(key)
+        if t is None:
+            t = torch.zeros(n, dtype=dtype, device=self.dev)
+            self._bufs[key] = t
+        return t
+
+    def free_buffers(self):
+        self._bufs.clear()
+
+    # ------------------------------------------------------------------ small helpers
+    def linear(self, x, wname, out, M, *, act=0, zout=None, residual=None, drop_seed=None, bias=True):
+        P = self.P
+        w = P.w(wname + ".w")
+        N, K = w.shape
+        p = self.p_drop if drop_seed is not None else 0.0
+        return ops.gemm(x, w, out, M, N, K, bias=P.f32(wname + ".b") if bias else None, act=act, zout=zout,
+                        residual=residual, dropout_p=p, dropout_seed=drop_seed or 0)
+
+    def linear_bwd(self, wname, x, dy, M, *, dx=None, zin=None, dact=0, dx_accumulate=False, bias=True):
+        """dW = dy^T x (fp32, overwrite), db = colsum(dy), optionally dx = (dy W) [* act'(zin)]."""
+        P = self.P
+        w = P.w(wname + ".w")
+        N, K = w.shape
+        Mp = _rup(M, ROWPAD)
+        ops.gemm(dy, x, P.g(wname + ".w"), N, K, Mp, a_kmajor=True, b_kmajor=True)
+        if bias:
+            ops.colsum(dy, P.g(wname + ".b"), M, N, dy.stride(0))
+        if dx is not None:
+            ops.gemm(dy, w, dx, M, K, N, b_kmajor=True, zin=zin, dact=dact, accumulate=dx_accumulate)
+        self._done(wname + (".b" if bias else ".w"))
+        return dx
+
+    # ------------------------------------------------------------------ ViT
+    def vit_forward(self, pixels: torch.Tensor, save: bool, trunc_int32: bool = False):
+        """pixels [B,img,img,3] fp32 NHWC -> (last hidden [B*S,vd] NOT post-layernormed, ehs [B*S,d])."""
+        P = self.P
+        B = pixels.shape[0]
+        S, vd, vf, H = P.S, P.vd, P.vffn, P.vH
+        Mv, Mp = B * S, B * (S - 1)
+        pk = P.ps * P.ps * 3
+        patches = self.buf("v.patches", Mp, pk)
+        ops.im2col(pixels, patches, B, P.img, P.ps, pk, trunc_int32)
+        pe = self.buf("v.pe", Mp, vd)
+        ops.gemm(patches, P.w("patch.w"), pe, Mp, vd, pk)
+        emb = self.buf("v.emb", Mv, vd)
+        ops.vit_assemble(pe, P.f32("vit.cls"), P.f32("vit.pos"), emb, B, S, vd, vd)
+        x = self.buf("v.x0", Mv, vd)
+        st = self.buf("v.pre.stats", 2, _rup(Mv, ROWPAD), torch.float32)
+        ops.layernorm_fwd(emb, P.f32("vit.pre_ln.g"), P.f32("vit.pre_ln.b"), self.vit_eps, x, st[0], st[1], rows=Mv)
+        for l in range(P.vL):
+            tag = f"v{l}." if save else "v_."
+            p = f"vit{l}."
+            a1 = self.buf(tag + "a1", Mv, vd)
+            st1 = self.buf(tag + "st1", 2, _rup(Mv, ROWPAD), torch.float32)
+            ops.layernorm_fwd(x, P.f32(p + "ln1.g"), P.f32(p + "ln1.b"), self.vit_eps, a1, st1[0], st1[1], rows=Mv)
+            qkv = self.buf(tag + "qkv", Mv, 3 * vd)
+            self.linear(a1, p + "qkv", qkv, Mv)
+            ctx = self.buf(tag + "ctx", Mv, vd)
+            lse = self.vec(tag + "lse", B * H * S)
+            ops.attn_fwd(qkv, qkv[:, vd:], qkv[:, 2 * vd:], ctx, B, H, S, S, ldq=3 * vd, ldk=3 * vd, ldv=3 * vd, ldo=vd, lse=lse)
+            xm = self.buf(tag + "xm", Mv, vd)
+            self.linear(ctx, p + "o", xm, Mv, residual=x)
+            a2 = self.buf(tag + "a2", Mv, vd)
+            st2 = self.buf(tag + "st2", 2, _rup(Mv, ROWPAD), torch.float32)
+            ops.layernorm_fwd(xm, P.f32(p + "ln2.g"), P.f32(p + "ln2.b"), self.vit_eps, a2, st2[0], st2[1], rows=Mv)
+            z = self.buf(tag + "z", Mv, vf)
+            u = self.buf(tag + "u", Mv, vf)
+            self.linear(a2, p + "fc1", u, Mv, act=L.ACT_QUICK_GELU, zout=z)
+            xo = self.buf(f"v{l}.xo" if save else f"v_.xo{l & 1}", Mv, vd)
+            self.linear(u, p + "fc2", xo, Mv, residual=xm)
+            x = xo
+        ehs = self.buf("v.ehs", Mv, P.d)
+        self.linear(x, "vp", ehs, Mv)
+        return x, ehs
+
+    def vit_pooler(self, last: torch.Tensor, B: int) -> torch.Tensor:
+        """pooler_output = post_layernorm(CLS) (only `encode()` exposes it; unused by captioning)."""
+        P = self.P
+        cls_rows = last[: B * P.S].view(B, P.S, P.vd)[:, 0].contiguous()
+        out = torch.empty_like(cls_rows)
+        ops.layernorm_fwd(cls_rows, P.f32("vit.post_ln.g"), P.f32("vit.post_ln.b"), self.vit_eps, out, rows=B)
+        return out
+
+    def vit_backward(self, B: int, dehs: torch.Tensor):
+        P = self.P
+        S, vd, vf, H = P.S, P.vd, P.vffn, P.vH
+        Mv, Mp = B * S, B * (S - 1)
+        x_last = self.buf(f"v{P.vL - 1}.xo", Mv, vd)
+        dx = self.buf("vb.dx", Mv, vd)
+        self.linear_bwd("vp", x_last, dehs, Mv, dx=dx)
+        for l in reversed(range(P.vL)):
+            tag, p = f"v{l}.", f"vit{l}."
+            a1, qkv, ctx, xm = (self.buf(tag + n, Mv, c) for n, c in (("a1", vd), ("qkv", 3 * vd), ("ctx", vd), ("xm", vd)))
+            a2, z, u = self.buf(tag + "a2", Mv, vd), self.buf(tag + "z", Mv, vf), self.buf(tag + "u", Mv, vf)
+            st1, st2 = self.buf(tag + "st1", 2, _rup(Mv, ROWPAD), torch.float32), self.buf(tag + "st2", 2, _rup(Mv, ROWPAD), torch.float32)
+            lse = self.vec(tag + "lse", B * H * S)
+            x_in = self.buf(f"v{l - 1}.xo", Mv, vd) if l > 0 else self.buf("v.x0", Mv, vd)
+            dz = self.buf("vb.dz", Mv, vf)
+            self.linear_bwd(p + "fc2", u, dx, Mv, dx=dz, zin=z, dact=L.ACT_QUICK_GELU)
+            da = self.buf("vb.da", Mv, vd)
+            self.linear_bwd(p + "fc1", a2, dz, Mv, dx=da)
+            dxm = self.buf("vb.dxm", Mv, vd)
+            ops.layernorm_bwd(xm, P.f32(p + "ln2.g"), st2[0], st2[1], da, dxm, P.g(p + "ln2.g"), P.g(p + "ln2.b"), rows=Mv, dres=dx)
+            dctx = self.buf("vb.dctx", Mv, vd)
+            self.linear_bwd(p + "o", ctx, dxm, Mv, dx=dctx)
+            dqkv = self.buf("vb.dqkv", Mv, 3 * vd)
+            ops.attn_bwd(qkv, qkv[:, vd:], qkv[:, 2 * vd:], ctx, dctx, lse, dqkv, dqkv[:, vd:], dqkv[:, 2 * vd:], B, H, S, S,
+                         ldq=3 * vd, ldk=3 * vd, ldv=3 * vd, ldo=vd, lddo=vd, lddq=3 * vd, lddk=3 * vd, lddv=3 * vd)
+            self.linear_bwd(p + "qkv", a1, dqkv, Mv, dx=da)
+            ops.layernorm_bwd(x_in, P.f32(p + "ln1.g"), st1[0], st1[1], da, dx, P.g(p + "ln1.g"), P.g(p + "ln1.b"), rows=Mv, dres=dxm)
+        emb = self.buf("v.emb", Mv, vd)
+        st = self.buf("v.pre.stats", 2, _rup(Mv, ROWPAD), torch.float32)
+        demb = self.buf("vb.demb", Mv, vd)
+        ops.layernorm_bwd(emb, P.f32("vit.pre_ln.g"), st[0], st[1], dx, demb, P.g("vit.pre_ln.g"), P.g("vit.pre_ln.b"), rows=Mv)
+        dpe = self.buf("vb.dpe", Mp, vd)
+        ops.vit_assemble_bwd(demb, dpe, P.g("vit.cls"), P.g("vit.pos"), B, S, vd, vd)
+        pk = P.ps * P.ps * 3
+        patches = self.buf("v.patches", Mp, pk)
+        ops.gemm(dpe, patches, P.g("patch.w"), vd, pk, _rup(Mp, ROWPAD), a_kmajor=True, b_kmajor=True)
+        self._done("patch.w")
+
+    # ------------------------------------------------------------------ decoder (teacher forced)
+    def decoder_forward(self, ids, pos_ids, key_mask, ehs, B: int, T: int, save: bool, seed: Optional[int]):
+        """ids/pos_ids/key_mask int32 [B*T]/[B*T]/[B,T]; ehs [B*S,d].  Returns final-layer-normed hidden [B*T,d]."""
+        P = self.P
+        d, f, H, S = P.d, P.ffn, P.H, P.S
+        M, Mv = B * T, B * S
+        drop = seed is not None and self.p_drop > 0
+
+        def sd(site):
+            return _mix(seed, site) if drop else None
+
+        h0 = self.buf("d.h0", M, d)
+        ops.embed_fwd(ids, pos_ids, P.w("shared"), P.f32("dec.pos"), self.embed_scale, h0, M, d)
+        x = self.buf("d.x0", M, d)
+        ste = self.buf("d.emb.stats", 2, _rup(M, ROWPAD), torch.float32)
+        ops.layernorm_fwd(h0, P.f32("dec.ln_emb.g"), P.f32("dec.ln_emb.b"), self.dec_eps, x, ste[0], ste[1], rows=M,
+                          dropout_p=self.p_drop if drop else 0.0, dropout_seed=sd(1) or 0)
+        for l in range(P.L):
+            tag = f"d{l}." if save else "d_."
+            p = f"dec{l}."
+            stats = self.buf(tag + "stats", 6, _rup(M, ROWPAD), torch.float32)
+            a = self.buf(tag + "a_sa", M, d)
+            ops.layernorm_fwd(x, P.f32(p + "ln_sa.g"), P.f32(p + "ln_sa.b"), self.dec_eps, a, stats[0], stats[1], rows=M)
+            qkv = self.buf(tag + "qkv", M, 3 * d)
+            self.linear(a, p + "qkv", qkv, M)
+            ctx = self.buf(tag + "ctx", M, d)
+            lse = self.vec(tag + "lse", B * H * T)
+            ops.attn_fwd(qkv, qkv[:, d:], qkv[:, 2 * d:], ctx, B, H, T, T, ldq=3 * d, ldk=3 * d, ldv=3 * d, ldo=d, key_mask=key_mask,
+                         causal=True, lse=lse)
+            x1 = self.buf(tag + "x1", M, d)
+            self.linear(ctx, p + "so", x1, M, residual=x, drop_seed=sd(10 + 3 * l))
+            a = self.buf(tag + "a_ca", M, d)
+            ops.layernorm_fwd(x1, P.f32(p + "ln_ca.g"), P.f32(p + "ln_ca.b"), self.dec_eps, a, stats[2], stats[3], rows=M)
+            q = self.buf(tag + "cq", M, d)
+            self.linear(a, p + "cq", q, M)
+            kv = self.buf(tag + "ckv", Mv, 2 * d)
+            self.linear(ehs, p + "ckv", kv, Mv)
+            cctx = self.buf(tag + "cctx", M, d)
+            clse = self.vec(tag + "clse", B * H * T)
+            ops.attn_fwd(q, kv, kv[:, d:], cctx, B, H, T, S, ldq=d, ldk=2 * d, ldv=2 * d, ldo=d, lse=clse)
+            x2 = self.buf(tag + "x2", M, d)
+            self.linear(cctx, p + "co", x2, M, residual=x1, drop_seed=sd(11 + 3 * l))
+            a = self.buf(tag + "a_ff", M, d)
+            ops.layernorm_fwd(x2, P.f32(p + "ln_ff.g"), P.f32(p + "ln_ff.b"), self.dec_eps, a, stats[4], stats[5], rows=M)
+            z, u = self.buf(tag + "z", M, f), self.buf(tag + "u", M, f)
+            self.linear(a, p + "fc1", u, M, act=self.gelu, zout=z)
+            x3 = self.buf(f"d{l}.x3" if save else f"d_.x3{l & 1}", M, d)
+            self.linear(u, p + "fc2", x3, M, residual=x2, drop_seed=sd(12 + 3 * l))
+            x = x3
+        hf = self.buf("d.hf", M, d)
+        stf = self.buf("d.f.stats", 2, _rup(M, ROWPAD), torch.float32)
+        ops.layernorm_fwd(x, P.f32("dec.ln_f.g"), P.f32("dec.ln_f.b"), self.dec_eps, hf, stf[0], stf[1], rows=M)
+        return hf
+
+    def head_logits(self, hf, M: int, name: str = "d.logits"):
+        """Tied head (modeling:170-178): logits[M, Vpad] = hf @ shared^T + final_logits_bias (compute dtype)."""
+        P = self.P
+        logits = self.buf(name, M, P.Vpad)
+        ops.gemm(hf, P.w("shared"), logits, M, P.Vpad, P.d, bias=P.f32("flb"))
+        return logits
+
+    def decoder_backward(self, B: int, T: int, ids, pos_ids, key_mask, ehs, dlogits, seed: Optional[int]):
+        """Consumes dlogits [M,Vpad]; writes all decoder/embedding/head grads; returns dehs [B*S,d]."""
+        P = self.P
+        d, f, H, S = P.d, P.ffn, P.H, P.S
+        M, Mv = B * T, B * S
+        Mp = _rup(M, ROWPAD)
+        drop = seed is not None and self.p_drop > 0
+        pd = self.p_drop if drop else 0.0
+
+        def sd(site):
+            return _mix(seed, site) if drop else 0
+
+        hf = self.buf("d.hf", M, d)
+        ops.colsum(dlogits, P.g("flb"), M, P.Vpad, dlogits.stride(0))
+        ops.gemm(dlogits, hf, P.g("shared"), P.Vpad, d, Mp, a_kmajor=True, b_kmajor=True)
+        dhf = self.buf("db.dhf", M, d)
+        ops.gemm(dlogits, P.w("shared"), dhf, M, d, P.Vpad, b_kmajor=True)
+        dx = self.buf("db.dx", M, d)
+        dxm = self.buf("db.dxm", M, d)
+        stf = self.buf("d.f.stats", 2, _rup(M, ROWPAD), torch.float32)
+        x_last = self.buf(f"d{P.L - 1}.x3", M, d)
+        ops.layernorm_bwd(x_last, P.f32("dec.ln_f.g"), stf[0], stf[1], dhf, dx, P.g("dec.ln_f.g"), P.g("dec.ln_f.b"), rows=M,
+                          dxm=dxm, dropout_p=pd, dropout_seed=sd(12 + 3 * (P.L - 1)))
+        dehs = self.buf("db.dehs", Mv, d)
+        for l in reversed(range(P.L)):
+            tag, p = f"d{l}.", f"dec{l}."
+            stats = self.buf(tag + "stats", 6, _rup(M, ROWPAD), torch.float32)
+            a_sa, qkv, ctx, x1 = (self.buf(tag + n, M, c) for n, c in (("a_sa", d), ("qkv", 3 * d), ("ctx", d), ("x1", d)))
+            a_ca, cq, cctx, x2 = (self.buf(tag + n, M, d) for n in ("a_ca", "cq", "cctx", "x2"))
+            ckv = self.buf(tag + "ckv", Mv, 2 * d)
+            a_ff, z, u = self.buf(tag + "a_ff", M, d), self.buf(tag + "z", M, f), self.buf(tag + "u", M, f)
+            lse, clse = self.vec(tag + "lse", B * H * T), self.vec(tag + "clse", B * H * T)
+            x_in = self.buf(f"d{l - 1}.x3", M, d) if l > 0 else self.buf("d.x0", M, d)
+            # --- FFN branch: x3 = x2 + drop(fc2(gelu(fc1(LN(x2)))));  dxm = dropout-masked dx3
+            dz = self.buf("db.dz", M, f)
+            self.linear_bwd(p + "fc2", u, dxm, M, dx=dz, zin=z, dact=self.gelu)
+            da = self.buf("db.da", M, d)
+            self.linear_bwd(p + "fc1", a_ff, dz, M, dx=da)
+            dx2 = self.buf("db.dx2", M, d)
+            ops.layernorm_bwd(x2, P.f32(p + "ln_ff.g"), stats[4], stats[5], da, dx2, P.g(p + "ln_ff.g"), P.g(p + "ln_ff.b"), rows=M,
+                              dres=dx, dxm=dxm, dropout_p=pd, dropout_seed=sd(11 + 3 * l))
+            # --- cross-attention branch
+            dctx = self.buf("db.dctx", M, d)
+            self.linear_bwd(p + "co", cctx, dxm, M, dx=dctx)
+            dq = self.buf("db.dq", M, d)
+            dkv = self.buf("db.dkv", Mv, 2 * d)
+            ops.attn_bwd(cq, ckv, ckv[:, d:], cctx, dctx, clse, dq, dkv, dkv[:, d:], B, H, T, S, ldq=d, ldk=2 * d, ldv=2 * d, ldo=d,
+                         lddo=d, lddq=d, lddk=2 * d, lddv=2 * d)
+            self.linear_bwd(p + "cq", a_ca, dq, M, dx=da)
+            self.linear_bwd(p + "ckv", ehs, dkv, Mv, dx=dehs, dx_accumulate=(l != P.L - 1))
+            dx1 = self.buf("db.dx1", M, d)
+            ops.layernorm_bwd(x1, P.f32(p + "ln_ca.g"), stats[2], stats[3], da, dx1, P.g(p + "ln_ca.g"), P.g(p + "ln_ca.b"), rows=M,
+                              dres=dx2, dxm=dxm, dropout_p=pd, dropout_seed=sd(10 + 3 * l))
+            # --- self-attention branch
+            self.linear_bwd(p + "so", ctx, dxm, M, dx=dctx)
+            dqkv = self.buf("db.dqkv", M, 3 * d)
+            ops.attn_bwd(qkv, qkv[:, d:], qkv[:, 2 * d:], ctx, dctx, lse, dqkv, dqkv[:, d:], dqkv[:, 2 * d:], B, H, T, T, ldq=3 * d,
+                         ldk=3 * d, ldv=3 * d, ldo=d, lddo=d, lddq=3 * d, lddk=3 * d, lddv=3 * d, key_mask=key_mask, causal=True)
+            self.linear_bwd(p + "qkv", a_sa, dqkv, M, dx=da)
+            if l > 0:
+                ops.layernorm_bwd(x_in, P.f32(p + "ln_sa.g"), stats[0], stats[1], da, dx, P.g(p + "ln_sa.g"), P.g(p + "ln_sa.b"), rows=M,
+                                  dres=dx1, dxm=dxm, dropout_p=pd, dropout_seed=sd(12 + 3 * (l - 1)))
+            else:
+                ops.layernorm_bwd(x_in, P.f32(p + "ln_sa.g"), stats[0], stats[1], da, dx, P.g(p + "ln_sa.g"), P.g(p + "ln_sa.b"), rows=M,
+                                  dres=dx1)
+        # embedding LayerNorm (+ its dropout) and the token/position embedding scatter
+        h0 = self.buf("d.h0", M, d)
+        ste = self.buf("d.emb.stats", 2, _rup(M, ROWPAD), torch.float32)
+        dh0 = self.buf("db.dh0", M, d)
+        ops.layernorm_bwd(h0, P.f32("dec.ln_emb.g"), ste[0], ste[1], dx, dh0, P.g("dec.ln_emb.g"), P.g("dec.ln_emb.b"), rows=M,
+                          in_dropout_p=pd, in_dropout_seed=sd(1))
+        ops.embed_bwd(ids, pos_ids, dh0, self.embed_scale, P.g("shared"), P.g("dec.pos"), M, d)
+        self._done("shared")
+        return dehs
+
+    # ------------------------------------------------------------------ loss (main.py:658-680) on materialised logits
+    def loss_and_dlogits(self, logits, labels, mask, M: int, label_smoothing: float, backward: bool):
+        P = self.P
+        lse, rl = self.vec("ce.lse", _rup(M, ROWPAD)), self.vec("ce.rowloss", _rup(M, ROWPAD))
+        loss, denom = self.vec("ce.loss", 1), self.vec("ce.denom", 1)
+        ops.ce_rows(logits, logits.stride(0), P.V, labels, mask, label_smoothing, lse, rl, M)
+        ops.ce_reduce(rl, mask, loss, denom, M)
+        if backward:
+            ops.ce_bwd(logits, logits.stride(0), P.V, P.Vpad, labels, mask, label_smoothing, lse, denom, M)
+        return loss
+
+    # ------------------------------------------------------------------ full passes
+    def forward_logits(self, pixels, ids, pos_ids, key_mask, B, T, *, save=False, seed=None, trunc_int32=False):
+        _, ehs = self.vit_forward(pixels, save, trunc_int32)
+        hf = self.decoder_forward(ids, pos_ids, key_mask, ehs, B, T, save, seed)
+        return self.head_logits(hf, B * T), ehs
+
+    def loss_and_grads(self, pixels, ids, pos_ids, key_mask, labels, B, T, *, label_smoothing=0.0, seed=None):
+        """value_and_grad(compute_loss) of train_step (main.py:688-697): grads land in ParamStore.grad."""
+        P = self.P
+        P.ensure_grads()
+        P.grad[P.atomic_begin:].zero_()
+        logits, ehs = self.forward_logits(pixels, ids, pos_ids, key_mask, B, T, save=True, seed=seed)
+        loss = self.loss_and_dlogits(logits, labels, key_mask.reshape(-1), B * T, label_smoothing, backward=True)
+        dehs = self.decoder_backward(B, T, ids, pos_ids, key_mask, ehs, logits, seed)
+        self.vit_backward(B, dehs)
+        return loss

@@ -1,0 +1,155 @@
+"""`.generate()` — greedy and beam search with the reference's semantics
+(`models/flax_clip_vision_mbart/generation_clip_vision_utils.py:128-336, 368-420, 422-535, 665-990`), driven from the
+host as a fixed sequence of HIP launches per step:
+
+    decoder step (KV-cached)  ->  tied head GEMM  ->  mic_row_lse_topk (log-softmax + processors + running score +
+    index-stable top-2K)  ->  mic_beam_step (all of gen:872-966 for one step, on device)
+
+Differences in mechanism, not in results: cross-attention K/V are projected once (the reference re-projects every
+step), and the self-attention cache is never gathered by beam (gen:945-953) — a slot-ownership table is updated
+instead.  `_sample` / warpers are outside the hot-path scope.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+
+NEG = -1.0e7
+
+
+class FlaxCLIPVisionMBartGenerationMixin:
+    # ------------------------------------------------------------------ gen:128-336
+    def generate(self, input_ids, max_length: Optional[int] = None, pad_token_id: Optional[int] = None,
+                 bos_token_id: Optional[int] = None, eos_token_id: Optional[int] = None,
+                 decoder_start_token_id: Optional[int] = None, do_sample: Optional[bool] = None, prng_key=None,
+                 top_k: Optional[int] = None, top_p: Optional[float] = None, temperature: Optional[float] = None,
+                 num_beams: Optional[int] = None, no_repeat_ngram_size: Optional[int] = None, min_length: Optional[int] = None,
+                 forced_bos_token_id: Optional[int] = None, forced_eos_token_id: Optional[int] = None,
+                 length_penalty: Optional[float] = None, early_stopping: Optional[bool] = None, trace: bool = True,
+                 params=None, **model_kwargs):
+        mc = self.config.mbart_config
+        max_length = max_length if max_length is not None else mc.max_length  # gen:205-209
+        bos_token_id = bos_token_id if bos_token_id is not None else mc.bos_token_id
+        pad_token_id = pad_token_id if pad_token_id is not None else mc.pad_token_id
+        eos_token_id = eos_token_id if eos_token_id is not None else mc.eos_token_id
+        decoder_start_token_id = decoder_start_token_id if decoder_start_token_id else mc.decoder_start_token_id  # gen:225-229
+        if decoder_start_token_id is None and self.config.is_encoder_decoder:
+            raise ValueError("`decoder_start_token_id` has to be defined for encoder-decoder generation.")  # gen:232-235
+        do_sample = do_sample if do_sample is not None else mc.do_sample
+        num_beams = num_beams if num_beams is not None else mc.num_beams
+        # gen:109-120: `params=` is NOT forwarded to encode (the encoder always uses self.params); the decoder uses it.
+        enc = self.encode(input_ids, return_dict=True, **{k: v for k, v in model_kwargs.items()
+                                                          if not (k.startswith("decoder_") or k.startswith("cross_attn"))})
+        self._use_params(params)
+        ehs = enc["last_hidden_state"]
+        B = ehs.shape[0]
+        # processors (gen:368-420); `no_repeat_ngram_size` is accepted and ignored like in the reference
+        min_length = min_length if min_length is not None else mc.min_length
+        forced_bos_token_id = forced_bos_token_id if forced_bos_token_id is not None else mc.forced_bos_token_id
+        forced_eos_token_id = forced_eos_token_id if forced_eos_token_id is not None else mc.forced_eos_token_id
+        procs = dict(min_length=min_length if (min_length is not None and eos_token_id is not None and min_length > -1) else None,
+                     forced_bos=forced_bos_token_id, forced_eos=forced_eos_token_id)
+        if not do_sample and num_beams == 1:
+            return self._greedy_search(ehs, B, decoder_start_token_id, max_length, pad_token_id, eos_token_id, procs)
+        elif do_sample and num_beams == 1:
+            raise NotImplementedError("sampling (`_sample`, gen:537-663) is outside the hot-path scope")
+        elif not do_sample and num_beams > 1:
+            length_penalty = length_penalty if length_penalty is not None else mc.length_penalty  # gen:733-742
+            early_stopping = early_stopping if early_stopping is not None else mc.early_stopping
+            return self._beam_search(ehs, B, num_beams, decoder_start_token_id, max_length, pad_token_id, eos_token_id,
+                                     length_penalty, early_stopping, procs)
+        else:
+            raise NotImplementedError("`Beam sampling is currently not implemented.")  # gen:336
+
+    @staticmethod
+    def _proc_args(procs, cur_len: int, max_length: int, eos_token_id: int):
+        """(forced_token, suppress_eos) for this step: MinLength -> ForcedBOS -> ForcedEOS (gen:412-419)."""
+        forced = -1
+        suppress = procs["min_length"] is not None and cur_len < procs["min_length"]
+        if procs["forced_bos"] is not None and cur_len == 1:
+            forced = procs["forced_bos"]
+        if procs["forced_eos"] is not None and cur_len == max_length - 1:
+            forced = procs["forced_eos"]
+        return forced, suppress
+
+    # ------------------------------------------------------------------ gen:422-535
+    def _greedy_search(self, ehs, B, start_token, max_length, pad_token_id, eos_token_id, procs):
+        from .modeling_clip_vision_mbart import ModelOutput
+
+        dev, st = self.device, self.store
+        sequences = torch.full((B, max_length), pad_token_id, dtype=torch.int32, device=dev)  # gen:457
+        sequences[:, 0] = start_token
+        finished = torch.zeros(B, dtype=torch.int32, device=dev)
+        next_token = torch.full((B,), start_token, dtype=torch.int32, device=dev)
+        cache = self.init_cache(B, max_length)
+        self._decode_set_encoder(cache, ehs.reshape(B * st.S, st.d), B, 1)
+        top_val = torch.empty((B, 1), dtype=torch.float32, device=dev)
+        top_idx = torch.empty((B, 1), dtype=torch.int32, device=dev)
+        pos = torch.zeros(B, dtype=torch.int32, device=dev)
+        cur_len = 1
+        while True:
+            if cur_len == max_length or bool(finished.all().item()):  # gen:480-487
+                break
+            logits = self._decode_step(cache, next_token, pos)
+            forced, suppress = self._proc_args(procs, cur_len, max_length, eos_token_id)
+            ops.row_lse_topk(logits, logits.stride(0), st.V, 1, top_val, top_idx, B, forced_token=forced, suppress_eos=suppress,
+                             eos_token_id=eos_token_id, raw_logits=True)
+            ops.greedy_step(B, max_length, cur_len, eos_token_id, pad_token_id, top_idx, 1, sequences, finished, next_token)
+            pos += 1
+            cur_len += 1
+        return ModelOutput(sequences=sequences)
+
+    # ------------------------------------------------------------------ gen:665-990
+    def _beam_search(self, ehs, B, K, start_token, max_length, pad_token_id, eos_token_id, length_penalty, early_stopping, procs):
+        from .modeling_clip_vision_mbart import ModelOutput
+
+        if 2 * K > 8:
+            raise NotImplementedError("num_beams > 4 needs a wider per-row top-k than this build ships (k <= 8)")
+        dev, st = self.device, self.store
+        R = B * K
+        running_seq = torch.full((B, K, max_length), pad_token_id, dtype=torch.int32, device=dev)  # gen:751-757
+        running_seq[:, :, 0] = start_token
+        seq = torch.full((B, K, max_length), pad_token_id, dtype=torch.int32, device=dev)
+        finished = torch.zeros((B, K), dtype=torch.int32, device=dev)  # gen:760
+        running_scores = torch.tensor([0.0] + [NEG] * (K - 1), dtype=torch.float32, device=dev).repeat(B, 1).contiguous()  # gen:763-765
+        scores = torch.full((B, K), NEG, dtype=torch.float32, device=dev)  # gen:766
+        next_token = torch.full((R,), start_token, dtype=torch.int32, device=dev)
+        src_row = torch.zeros((R, max_length), dtype=torch.int32, device=dev)
+        src_row[:, 0] = torch.arange(R, dtype=torch.int32, device=dev)
+        flags = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+        cache = self.init_cache(R, max_length)
+        cache["src_row"] = src_row
+        # encoder states are shared by an image's K beams (gen:299-307 broadcasts them; here: row r reads image r // K)
+        self._decode_set_encoder(cache, ehs.reshape(B * st.S, st.d), B, K)
+        cand_val = torch.empty((R, 2 * K), dtype=torch.float32, device=dev)
+        cand_idx = torch.empty((R, 2 * K), dtype=torch.int32, device=dev)
+        pos = torch.zeros(R, dtype=torch.int32, device=dev)
+        cur_len = 1
+        steps = 0
+        while True:
+            logits = self._decode_step(cache, next_token, pos)  # gen:830-840
+            forced, suppress = self._proc_args(procs, cur_len, max_length, eos_token_id)
+            ops.row_lse_topk(logits, logits.stride(0), st.V, 2 * K, cand_val, cand_idx, R, forced_token=forced, suppress_eos=suppress,
+                             eos_token_id=eos_token_id, row_bias=running_scores.reshape(-1))  # gen:850-873 (per row)
+            ops.beam_step(B, K, max_length, st.V, cur_len, eos_token_id, pad_token_id, length_penalty, early_stopping, cand_val,
+                          cand_idx, running_seq, running_scores, seq, scores, finished, src_row, next_token, flags)  # gen:872-966
+            pos += 1
+            cur_len += 1
+            steps += 1
+            # beam_search_cond_fn (gen:798-820) on the new state
+            if not (cur_len < max_length):
+                break
+            fl = flags.cpu()
+            all_finished = bool(fl[:, 0].all().item())
+            improve = bool(fl[:, 1].all().item())
+            if (all_finished and early_stopping) or not improve:
+                break
+        any_fin = finished.bool().any(dim=1)  # gen:980
+        out_seq = torch.where(any_fin[:, None, None], seq, running_seq)  # gen:981-983
+        out_scores = torch.where(any_fin[:, None], scores, running_scores)  # gen:984
+        out = ModelOutput(sequences=out_seq[:, -1].contiguous(), scores=out_scores[:, -1].contiguous())  # gen:987-990
+        out["steps"] = steps
+        return out

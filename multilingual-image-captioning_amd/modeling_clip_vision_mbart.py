@@ -1,0 +1,368 @@
+"""`FlaxCLIPVisionMBartForConditionalGeneration` on MI355X — same class name, method names, keyword arguments and
+return shapes as the reference's model (`models/flax_clip_vision_mbart/modeling_clip_vision_mbart.py:195-773`,
+base class `modeling_clip_vision_utils.py:36-117`), so `main.py` / `evaluation.py` call sites read unchanged:
+
+    model = FlaxCLIPVisionMBartForConditionalGeneration.from_clip_vision_mbart_pretrained(...)   # main.py:421-427
+    logits = model(pixel_values, decoder_input_ids, attention_mask, params=..., train=True)[0]   # main.py:692
+    ids = model.generate(pixel_values, forced_bos_token_id=lang, num_beams=4, max_length=64).sequences  # evaluation.py:81
+
+Arrays in: numpy / torch (NHWC pixels, int ids).  Arrays out: torch tensors on the model's device (`.cpu().numpy()` for
+numpy).  All arithmetic runs in libmic_hip.so; there is no CPU path.
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+from typing import Any, Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from .configuration_clip_vision_mbart import CLIPVisionMBartConfig
+from .engine import Engine
+from .generation_clip_vision_utils import FlaxCLIPVisionMBartGenerationMixin
+from .params import ParamStore, flatten_tree, unflatten_tree
+
+
+class ModelOutput(dict):
+    """dict with attribute access and positional indexing (what the call sites use: `[0]`, `.logits`, `.sequences`)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def __getitem__(self, k):
+        if isinstance(k, int):
+            return [v for v in self.values() if v is not None][k]
+        return super().__getitem__(k)
+
+    def to_tuple(self):
+        return tuple(v for v in self.values() if v is not None)
+
+
+def _torch_dtype(dtype) -> torch.dtype:
+    if isinstance(dtype, torch.dtype):
+        return dtype
+    name = getattr(dtype, "__name__", None) or getattr(dtype, "name", None) or str(dtype)
+    name = name.replace("jnp.", "").replace("torch.", "")
+    if name in ("float32", "f32", "float"):
+        return torch.float32
+    if name in ("bfloat16", "bf16"):
+        return torch.bfloat16
+    if name in ("float16", "f16", "half"):
+        raise NotImplementedError("float16 compute is not built for gfx950 here: use float32 or bfloat16")
+    raise ValueError(f"unknown dtype {dtype}")
+
+
+def _seed_from(rng) -> Optional[int]:
+    if rng is None:
+        return None
+    if isinstance(rng, (int, np.integer)):
+        return int(rng) & 0xFFFFFFFF
+    b = np.asarray(rng.cpu() if isinstance(rng, torch.Tensor) else rng).tobytes()
+    return int.from_bytes(hashlib.blake2s(b, digest_size=4).digest(), "little")
+
+
+class FlaxCLIPVisionMBartPreTrainedModel(FlaxCLIPVisionMBartGenerationMixin):
+    """Host mirror of `modeling_clip_vision_utils.py:36-117` (params property/validation, save/load)."""
+
+    config_class = CLIPVisionMBartConfig
+    base_model_prefix = "model"
+
+    def __init__(self, config: CLIPVisionMBartConfig, input_shape: Tuple = None, seed: int = 0, dtype=torch.float32,
+                 device=None, _do_init: bool = True):
+        if config is None:
+            raise ValueError("config cannot be None")  # utils:60-61
+        self._config = config
+        self.dtype = _torch_dtype(dtype)
+        self.seed = seed
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("FlaxCLIPVisionMBartForConditionalGeneration needs an MI355X (no CPU fallback)")
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        self.store = ParamStore(config, self.dtype, self.device)
+        self.engine = Engine(self.store)
+        self._required_params = set(tuple(k.split("/")) for k in self.store.flax_shapes())  # utils:78
+        self._params_cache = None
+        if _do_init:
+            self.store.init_random(seed, float(config.mbart_config.init_std))
+
+    # ------------------------------------------------------------------ properties (utils:91-117)
+    @property
+    def config(self) -> CLIPVisionMBartConfig:
+        return self._config
+
+    @property
+    def required_params(self):
+        return self._required_params
+
+    @property
+    def params(self) -> Dict[str, Any]:
+        """The reference's nested parameter pytree (numpy leaves, Flax layouts), exported from the device buffers."""
+        if self._params_cache is None:
+            self._params_cache = unflatten_tree(self.store.export_flat("master"))
+        return self._params_cache
+
+    @params.setter
+    def params(self, params: Dict[str, Any]):
+        if params is self._params_cache and params is not None:
+            return
+        flat = flatten_tree(params)
+        keys = set(tuple(k.split("/")) for k in flat)
+        missing = self.required_params - keys
+        if len(missing) > 0:
+            raise ValueError("Some parameters are missing. Make sure that `params` include the following "
+                             f"parameters {missing}")  # utils:112-116
+        self.store.load_flat(flat)
+        self._params_cache = params
+
+    def invalidate_params_cache(self):
+        self._params_cache = None
+
+    def _use_params(self, params):
+        if params is not None and params is not self._params_cache:
+            self.params = params
+
+    # ------------------------------------------------------------------ save / load (utils:398-451, 120-396)
+    def save_pretrained(self, save_directory: str, params=None, push_to_hub: bool = False, **kwargs):
+        if os.path.isfile(save_directory):
+            raise EnvironmentError(f"Provided path ({save_directory}) should be a directory, not a file")
+        if push_to_hub:
+            raise NotImplementedError("hub push is out of scope (no network)")
+        os.makedirs(save_directory, exist_ok=True)
+        self.config.save_pretrained(save_directory)
+        from .checkpoint import save_flax_msgpack
+
+        flat = flatten_tree(params) if params is not None else self.store.export_flat("master")
+        save_flax_msgpack(os.path.join(save_directory, "flax_model.msgpack"), unflatten_tree(flat))
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, dtype=torch.float32, *model_args, **kwargs):
+        if not os.path.isdir(pretrained_model_name_or_path):
+            raise EnvironmentError(f"{pretrained_model_name_or_path}: only local directories are supported (no network)")
+        config = kwargs.pop("config", None) or CLIPVisionMBartConfig.from_pretrained(pretrained_model_name_or_path)
+        from .checkpoint import load_flax_msgpack
+
+        path = os.path.join(pretrained_model_name_or_path, "flax_model.msgpack")
+        if not os.path.isfile(path):
+            raise EnvironmentError(f"Error no file named flax_model.msgpack found in directory {pretrained_model_name_or_path}")
+        model = cls(config, *model_args, dtype=dtype, _do_init=True, **kwargs)
+        state = flatten_tree(load_flax_msgpack(path))
+        cur = model.store.export_flat("master")
+        for k in list(state):  # unexpected keys dropped, missing keys keep their random init (utils:355-364)
+            if k not in cur:
+                state.pop(k)
+        cur.update(state)
+        model.store.load_flat(cur)
+        model._params_cache = None
+        return model
+
+
+class FlaxCLIPVisionMBartForConditionalGeneration(FlaxCLIPVisionMBartPreTrainedModel):
+    # ------------------------------------------------------------------ input plumbing
+    def _dev(self, x, dtype) -> torch.Tensor:
+        if isinstance(x, torch.Tensor):
+            return x.to(device=self.device, dtype=dtype).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(x))).to(device=self.device, dtype=dtype).contiguous()
+
+    def _check_pixels(self, px: torch.Tensor):
+        img = self.config.clip_vision_config.image_size
+        if px.dim() != 4 or tuple(px.shape[1:]) != (img, img, 3):
+            raise ValueError(f"pixel_values must be NHWC [B,{img},{img},3], got {tuple(px.shape)}")
+
+    # ------------------------------------------------------------------ __call__ (modeling:447-510)
+    def __call__(self, pixel_values, decoder_input_ids=None, decoder_attention_mask=None, decoder_position_ids=None,
+                 output_attentions=None, output_hidden_states=None, return_dict=None, train: bool = False, params=None,
+                 dropout_rng=None):
+        self._use_params(params)
+        px = self._dev(pixel_values, torch.float32)  # modeling:501
+        self._check_pixels(px)
+        ids = self._dev(decoder_input_ids, torch.int32)  # modeling:502
+        B, T = ids.shape
+        mask = torch.ones_like(ids) if decoder_attention_mask is None else self._dev(decoder_attention_mask, torch.int32)  # 488-489
+        if decoder_position_ids is None:
+            pos = torch.arange(T, dtype=torch.int32, device=self.device)[None].expand(B, T).contiguous()  # 490-494
+        else:
+            pos = self._dev(decoder_position_ids, torch.int32)
+        seed = _seed_from(dropout_rng) if train else None  # deterministic = not train (508)
+        logits, _ = self.engine.forward_logits(px, ids.reshape(-1), pos.reshape(-1), mask, B, T, save=False, seed=seed)
+        V = self.store.V
+        out = logits[: B * T, :V].reshape(B, T, V)
+        if return_dict is False:
+            return (out,)
+        return ModelOutput(logits=out)
+
+    # ------------------------------------------------------------------ encode (modeling:284-337)
+    def encode(self, pixel_values, output_attentions=None, output_hidden_states=None, return_dict=None, train: bool = False,
+               params=None, dropout_rng=None, _int32_cast: bool = True):
+        self._use_params(params)
+        px = self._dev(pixel_values, torch.float32)
+        self._check_pixels(px)
+        B = px.shape[0]
+        # modeling:330 — `jnp.array(pixel_values, dtype="i4")`: truncation toward zero, reproduced inside im2col
+        last, ehs = self.engine.vit_forward(px, save=False, trunc_int32=_int32_cast)
+        S, d = self.store.S, self.store.d
+        pooled = self.engine.vit_pooler(last, B)
+        out = ModelOutput(last_hidden_state=ehs[: B * S].reshape(B, S, d).clone(), pooler_output=pooled)
+        return out if return_dict is not False else out.to_tuple()
+
+    # ------------------------------------------------------------------ decode (modeling:519-651)
+    def decode(self, decoder_input_ids, encoder_outputs, encoder_attention_mask=None, decoder_attention_mask=None,
+               decoder_position_ids=None, past_key_values: dict = None, output_attentions=None, output_hidden_states=None,
+               return_dict=None, deterministic: bool = True, params=None, dropout_rng=None):
+        self._use_params(params)
+        ehs = encoder_outputs[0]
+        ids = self._dev(decoder_input_ids, torch.int32)
+        R, T = ids.shape
+        if decoder_position_ids is None:
+            if past_key_values is not None:
+                raise ValueError("Make sure to provide `decoder_position_ids` when passing `past_key_values`.")  # 558-562
+            pos = torch.arange(T, dtype=torch.int32, device=self.device)[None].expand(R, T).contiguous()
+        else:
+            pos = self._dev(decoder_position_ids, torch.int32)
+        ehs = self._dev(ehs, self.dtype)
+        S, d, V = self.store.S, self.store.d, self.store.V
+        if past_key_values:
+            if T != 1:
+                raise ValueError("cached decode takes one token per row")
+            cache = past_key_values
+            if cache.get("cross") is None:
+                self._decode_set_encoder(cache, ehs.reshape(R * S, d), R, 1)
+            logits = self._decode_step(cache, ids.reshape(-1), pos.reshape(-1))
+            out = ModelOutput(logits=logits[:R, :V].reshape(R, 1, V), past_key_values=cache)
+            return out if return_dict is not False else (out["logits"], cache)
+        mask = torch.ones_like(ids) if decoder_attention_mask is None else self._dev(decoder_attention_mask, torch.int32)
+        ehs_buf = self.engine.buf("v.ehs", R * S, d)
+        ehs_buf[: R * S].copy_(ehs.reshape(R * S, d))
+        hf = self.engine.decoder_forward(ids.reshape(-1), pos.reshape(-1), mask, ehs_buf, R, T, save=False, seed=None)
+        logits = self.engine.head_logits(hf, R * T)
+        out = ModelOutput(logits=logits[: R * T, :V].reshape(R, T, V))
+        return out if return_dict is not False else out.to_tuple()
+
+    # ------------------------------------------------------------------ cache protocol (modeling:249-282, 653-693)
+    def init_cache(self, batch_size: int, max_length: int, encoder_outputs=None) -> dict:
+        """Zero self-attention cache with static length `max_length` (modeling:249-282) + cache_index."""
+        st = self.store
+        return {
+            "k": [torch.zeros((batch_size, max_length, st.d), dtype=self.dtype, device=self.device) for _ in range(st.L)],
+            "v": [torch.zeros((batch_size, max_length, st.d), dtype=self.dtype, device=self.device) for _ in range(st.L)],
+            "cache_index": 0, "max_length": max_length, "rows": batch_size, "src_row": None, "cross": None, "row_div": 1,
+        }
+
+    def prepare_inputs_for_generation(self, decoder_input_ids, max_length, attention_mask=None, decoder_attention_mask=None,
+                                      encoder_outputs=None, **kwargs):
+        ids = self._dev(decoder_input_ids, torch.int32)
+        batch_size, seq_length = ids.shape
+        past = self.init_cache(batch_size, max_length, encoder_outputs)
+        ext = torch.ones((batch_size, max_length), dtype=torch.int32, device=self.device)  # modeling:669
+        if decoder_attention_mask is not None:
+            dam = self._dev(decoder_attention_mask, torch.int32)
+            position_ids = dam.cumsum(-1) - 1
+            ext[:, : dam.shape[1]] = dam
+        else:
+            position_ids = torch.arange(seq_length, dtype=torch.int32, device=self.device)[None].expand(batch_size, seq_length)
+        return {"past_key_values": past, "encoder_outputs": encoder_outputs, "encoder_attention_mask": attention_mask,
+                "decoder_attention_mask": ext, "decoder_position_ids": position_ids}
+
+    def update_inputs_for_generation(self, model_outputs, model_kwargs):
+        model_kwargs["past_key_values"] = model_outputs.past_key_values
+        model_kwargs["decoder_position_ids"] = model_kwargs["decoder_position_ids"][:, -1:] + 1  # modeling:690-692
+        return model_kwargs
+
+    # ------------------------------------------------------------------ one cached decoder step (R rows, one token each)
+    def _decode_set_encoder(self, cache: dict, ehs_rows: torch.Tensor, n_img: int, row_div: int):
+        """Cross-attention K/V projected ONCE per generate call for the n_img distinct images (the reference re-projects
+        them every step; same values).  ehs_rows: [n_img*S, d]."""
+        eng, st = self.engine, self.store
+        S, d = st.S, st.d
+        ehs_b = eng.buf("g.ehs", n_img * S, d)
+        ehs_b[: n_img * S].copy_(ehs_rows)
+        cross = []
+        for l in range(st.L):
+            kv = eng.buf(f"g.ckv{l}", n_img * S, 2 * d)
+            eng.linear(ehs_b, f"dec{l}.ckv", kv, n_img * S)
+            cross.append(kv)
+        cache["cross"], cache["row_div"] = cross, row_div
+
+    def _decode_step(self, cache: dict, tokens: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
+        eng, st = self.engine, self.store
+        P = st
+        R, Lmax, cur = cache["rows"], cache["max_length"], cache["cache_index"]
+        d, f, H, S = st.d, st.ffn, st.H, st.S
+        h0 = eng.buf("g.h0", R, d)
+        ops.embed_fwd(tokens, pos, P.w("shared"), P.f32("dec.pos"), eng.embed_scale, h0, R, d)
+        x = eng.buf("g.x", R, d)
+        ops.layernorm_fwd(h0, P.f32("dec.ln_emb.g"), P.f32("dec.ln_emb.b"), eng.dec_eps, x, rows=R)
+        a, qkv, ctx = eng.buf("g.a", R, d), eng.buf("g.qkv", R, 3 * d), eng.buf("g.ctx", R, d)
+        x1, x2, q = eng.buf("g.x1", R, d), eng.buf("g.x2", R, d), eng.buf("g.q", R, d)
+        u = eng.buf("g.u", R, f)
+        for l in range(st.L):
+            p = f"dec{l}."
+            ops.layernorm_fwd(x, P.f32(p + "ln_sa.g"), P.f32(p + "ln_sa.b"), eng.dec_eps, a, rows=R)
+            eng.linear(a, p + "qkv", qkv, R)
+            ops.kv_append(qkv[:, d:], qkv[:, 2 * d:], cache["k"][l], cache["v"][l], R, d, Lmax, cur, ldk=3 * d, ldv=3 * d)
+            ops.attn_decode(qkv, cache["k"][l], cache["v"][l], ctx, R, H, Lmax, cur, ldq=3 * d, ldo=d, src_row=cache["src_row"])
+            eng.linear(ctx, p + "so", x1, R, residual=x)
+            ops.layernorm_fwd(x1, P.f32(p + "ln_ca.g"), P.f32(p + "ln_ca.b"), eng.dec_eps, a, rows=R)
+            eng.linear(a, p + "cq", q, R)
+            kv = cache["cross"][l]
+            ops.attn_decode(q, kv, kv[:, d:], ctx, R, H, S, S - 1, ldq=d, ldo=d, ldc=2 * d, row_div=cache["row_div"])
+            eng.linear(ctx, p + "co", x2, R, residual=x1)
+            ops.layernorm_fwd(x2, P.f32(p + "ln_ff.g"), P.f32(p + "ln_ff.b"), eng.dec_eps, a, rows=R)
+            eng.linear(a, p + "fc1", u, R, act=eng.gelu)
+            eng.linear(u, p + "fc2", x, R, residual=x2)
+        hf = eng.buf("g.hf", R, d)
+        ops.layernorm_fwd(x, P.f32("dec.ln_f.g"), P.f32("dec.ln_f.b"), eng.dec_eps, hf, rows=R)
+        cache["cache_index"] = cur + 1
+        return eng.head_logits(hf, R, name="g.logits")
+
+    # ------------------------------------------------------------------ construction (modeling:703-773)
+    @classmethod
+    def from_clip_vision_mbart_pretrained(cls, clip_vision_model_name_or_path: str = None, mbart_model_name_or_path: str = None,
+                                          *model_args, **kwargs):
+        """Builds the composite model from a CLIP-vision and an mBART checkpoint *directory* (local msgpack / config.json;
+        there is no network here) or from `mbart_model=` / `clip_vision_model=` objects exposing `.config` and `.params`
+        (modeling:730-758).  visual_projection and final_logits_bias keep their random/zero init (modeling:766-770)."""
+        kwargs_mbart = {k[len("mbart_"):]: v for k, v in kwargs.items() if k.startswith("mbart_")}
+        kwargs_clip = {k[len("clip_vision_"):]: v for k, v in kwargs.items() if k.startswith("clip_vision_")}
+        for k in kwargs_mbart:
+            del kwargs["mbart_" + k]
+        for k in kwargs_clip:
+            del kwargs["clip_vision_" + k]
+        kwargs_mbart.pop("from_pt", None)
+        from .checkpoint import load_component
+
+        mbart_model = kwargs_mbart.pop("model", None)
+        if mbart_model is None:
+            assert mbart_model_name_or_path is not None, \
+                "If `model` is not defined as an argument, a `mbart_model_name_or_path` has to be defined"
+            mbart_model = load_component(mbart_model_name_or_path, kwargs_mbart.get("config"))
+        clip_model = kwargs_clip.pop("model", None)
+        if clip_model is None:
+            assert clip_vision_model_name_or_path is not None, \
+                "If `model` is not defined as an argument, a `clip_vision_model_name_or_path` has to be defined"
+            clip_model = load_component(clip_vision_model_name_or_path, kwargs_clip.get("config"))
+        dtype = kwargs.pop("dtype", torch.float32)
+        seed = kwargs.pop("seed", 0)
+        device = kwargs.pop("device", None)
+        config = CLIPVisionMBartConfig.from_clip_vision_mbart_configs(clip_model.config, mbart_model.config, **kwargs)
+        model = cls(config, *model_args, seed=seed, dtype=dtype, device=device)
+        flat = model.store.export_flat("master")
+        for k, v in flatten_tree(clip_model.params).items():
+            flat["model/encoder/" + k] = np.asarray(v)  # modeling:768
+        mp = mbart_model.params
+        for k, v in flatten_tree(mp["decoder"]).items():
+            flat["model/decoder/" + k] = np.asarray(v)  # modeling:769
+        for k, v in flatten_tree(mp["shared"]).items():
+            flat["model/shared/" + k] = np.asarray(v)  # modeling:770
+        model.store.load_flat(flat)
+        model._params_cache = None
+        return model

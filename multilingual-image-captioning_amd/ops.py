@@ -80,8 +80,9 @@ def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, Tq, Tk, *, ldq, ldk, ldv
                                  _p(key_mask), int(causal), _p(dq), lddq, _p(dk), lddk, _p(dv), lddv, _stream()), "mic_attn_bwd")
 
 
-def attn_decode(q, kc, vc, out, R, H, max_len, cur, *, ldq, ldo, src_row=None, row_div=1):
-    L.check(L.lib().mic_attn_decode(_dt(q), R, H, max_len, cur, _p(q), ldq, _p(kc), _p(vc), _p(src_row), row_div, _p(out), ldo,
+def attn_decode(q, kc, vc, out, R, H, max_len, cur, *, ldq, ldo, ldc=None, src_row=None, row_div=1):
+    ldc = ldc if ldc is not None else H * 64
+    L.check(L.lib().mic_attn_decode(_dt(q), R, H, max_len, cur, _p(q), ldq, _p(kc), _p(vc), ldc, _p(src_row), row_div, _p(out), ldo,
                                     _stream()), "mic_attn_decode")
     return out
 

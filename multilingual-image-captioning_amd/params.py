@@ -1,0 +1,294 @@
+"""Parameter store: the reference's Flax parameter pytree (`modeling:36-59, 123-135, 768-770`)
+<-> flat device buffers laid out for the MI355X path.
+
+Device layout (one flat fp32 master buffer; same offsets for the compute copy, gradients and AdamW moments):
+  * Dense kernels are stored [out][in] (k-contiguous: the layout the MFMA GEMM streams without transposes);
+    self-attention q/k/v are fused into one [3d][d] weight + [3d] bias, cross-attention k/v into [2d][d];
+    the patch conv HWIO [ps,ps,3,hid] is stored [hid][ps*ps*3]; the shared embedding is zero-padded to a multiple of
+    128 rows (V = 250054 -> 250112) so the tied LM-head GEMM needs no tail tiles.
+  * Segments are ordered as backward produces their gradients (logits bias, decoder top->bottom, embedding,
+    projection, ViT top->bottom) so gradient all-reduce buckets are contiguous slices that complete in order; every
+    parameter whose gradient is accumulated with atomics (LayerNorm scale/bias, class/position embeddings) lives in one
+    trailing region that a single memset clears.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Tuple
+
+import numpy as np
+import torch
+
+ALIGN = 64  # elements
+
+
+def _rup(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class Seg:
+    name: str
+    offset: int
+    shape: Tuple[int, ...]  # device shape
+
+    @property
+    def numel(self) -> int:
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+
+def flatten_tree(tree, prefix="") -> Dict[str, np.ndarray]:
+    out = {}
+    for k, v in tree.items():
+        key = f"{prefix}/{k}" if prefix else str(k)
+        if isinstance(v, dict):
+            out.update(flatten_tree(v, key))
+        else:
+            out[key] = v
+    return out
+
+
+def unflatten_tree(flat: Dict[str, np.ndarray]):
+    tree: Dict = {}
+    for k, v in flat.items():
+        parts = k.split("/")
+        d = tree
+        for p in parts[:-1]:
+            d = d.setdefault(p, {})
+        d[parts[-1]] = v
+    return tree
+
+
+V_ = "model/encoder/vision_model/"
+D_ = "model/decoder/"
+
+
+class ParamStore:
+    def __init__(self, config, dtype: torch.dtype, device):
+        self.cfg, self.dtype, self.device = config, dtype, device
+        mc, vc = config.mbart_config, config.clip_vision_config
+        self.d, self.ffn, self.L, self.H = mc.d_model, mc.decoder_ffn_dim, mc.decoder_layers, mc.decoder_attention_heads
+        self.vd, self.vffn, self.vL, self.vH = vc.hidden_size, vc.intermediate_size, vc.num_hidden_layers, vc.num_attention_heads
+        self.V, self.Vpad = mc.vocab_size, _rup(mc.vocab_size, 128)
+        self.ps, self.img = vc.patch_size, vc.image_size
+        self.S = (self.img // self.ps) ** 2 + 1
+        self.npos = mc.max_position_embeddings + 2
+        self.segs: Dict[str, Seg] = {}
+        self._order: List[str] = []
+        off = 0
+
+        def add(name, shape):
+            nonlocal off
+            self.segs[name] = Seg(name, off, tuple(shape))
+            self._order.append(name)
+            off = _rup(off + self.segs[name].numel, ALIGN)
+
+        d, f, vd, vf = self.d, self.ffn, self.vd, self.vffn
+        # ---- dense region, in backward-completion order
+        add("flb", (self.Vpad,))
+        for l in reversed(range(self.L)):
+            p = f"dec{l}."
+            for n, shp in (("fc2.w", (d, f)), ("fc2.b", (d,)), ("fc1.w", (f, d)), ("fc1.b", (f,)),
+                           ("co.w", (d, d)), ("co.b", (d,)), ("cq.w", (d, d)), ("cq.b", (d,)), ("ckv.w", (2 * d, d)), ("ckv.b", (2 * d,)),
+                           ("so.w", (d, d)), ("so.b", (d,)), ("qkv.w", (3 * d, d)), ("qkv.b", (3 * d,))):
+                add(p + n, shp)
+        add("shared", (self.Vpad, d))
+        add("vp.w", (d, vd))
+        add("vp.b", (d,))
+        for l in reversed(range(self.vL)):
+            p = f"vit{l}."
+            for n, shp in (("fc2.w", (vd, vf)), ("fc2.b", (vd,)), ("fc1.w", (vf, vd)), ("fc1.b", (vf,)),
+                           ("o.w", (vd, vd)), ("o.b", (vd,)), ("qkv.w", (3 * vd, vd)), ("qkv.b", (3 * vd,))):
+                add(p + n, shp)
+        add("patch.w", (vd, self.ps * self.ps * 3))
+        self.atomic_begin = off
+        # ---- gradients accumulated with atomics: cleared by one memset
+        add("dec.ln_f.g", (d,)); add("dec.ln_f.b", (d,))
+        for l in range(self.L):
+            for n in ("ln_sa", "ln_ca", "ln_ff"):
+                add(f"dec{l}.{n}.g", (d,)); add(f"dec{l}.{n}.b", (d,))
+        add("dec.ln_emb.g", (d,)); add("dec.ln_emb.b", (d,))
+        add("dec.pos", (self.npos, d))
+        for l in range(self.vL):
+            for n in ("ln1", "ln2"):
+                add(f"vit{l}.{n}.g", (vd,)); add(f"vit{l}.{n}.b", (vd,))
+        add("vit.pre_ln.g", (vd,)); add("vit.pre_ln.b", (vd,))
+        add("vit.post_ln.g", (vd,)); add("vit.post_ln.b", (vd,))
+        add("vit.pos", (self.S, vd))
+        add("vit.cls", (vd,))
+        self.numel = _rup(off, 256)
+        self.master = torch.zeros(self.numel, dtype=torch.float32, device=device)
+        self.lp = self.master if dtype == torch.float32 else torch.zeros(self.numel, dtype=dtype, device=device)
+        self.grad = None
+        self.m = None
+        self.v = None
+
+    # ------------------------------------------------------------------ views
+    def w(self, name: str) -> torch.Tensor:
+        """compute-dtype view (what the kernels read)"""
+        s = self.segs[name]
+        return self.lp[s.offset: s.offset + s.numel].view(s.shape)
+
+    def f32(self, name: str) -> torch.Tensor:
+        s = self.segs[name]
+        return self.master[s.offset: s.offset + s.numel].view(s.shape)
+
+    def g(self, name: str) -> torch.Tensor:
+        s = self.segs[name]
+        return self.grad[s.offset: s.offset + s.numel].view(s.shape)
+
+    def ensure_grads(self):
+        if self.grad is None:
+            self.grad = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
+
+    def ensure_opt_state(self):
+        if self.m is None:
+            self.m = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
+            self.v = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
+
+    def refresh_lp(self):
+        if self.lp is not self.master:
+            from . import ops
+            ops.cast(self.master, self.lp)
+
+    # ------------------------------------------------------------------ Flax pytree <-> device layout
+    def flax_shapes(self) -> Dict[str, Tuple[int, ...]]:
+        """Required leaves of the reference's params pytree ('/'-joined)."""
+        s: Dict[str, Tuple[int, ...]] = {}
+        d, f, vd, vf = self.d, self.ffn, self.vd, self.vffn
+        s["final_logits_bias"] = (1, self.V)
+        s["model/shared/embedding"] = (self.V, d)
+        s["model/visual_projection/kernel"] = (vd, d)
+        s["model/visual_projection/bias"] = (d,)
+        s[V_ + "embeddings/class_embedding"] = (vd,)
+        s[V_ + "embeddings/patch_embedding/kernel"] = (self.ps, self.ps, 3, vd)
+        s[V_ + "embeddings/position_embedding/embedding"] = (self.S, vd)
+        for ln in ("pre_layrnorm", "post_layernorm"):
+            s[V_ + ln + "/scale"] = (vd,); s[V_ + ln + "/bias"] = (vd,)
+        for i in range(self.vL):
+            Lp = f"{V_}encoder/layers/{i}/"
+            for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                s[Lp + f"self_attn/{n}/kernel"] = (vd, vd); s[Lp + f"self_attn/{n}/bias"] = (vd,)
+            for ln in ("layer_norm1", "layer_norm2"):
+                s[Lp + ln + "/scale"] = (vd,); s[Lp + ln + "/bias"] = (vd,)
+            s[Lp + "mlp/fc1/kernel"] = (vd, vf); s[Lp + "mlp/fc1/bias"] = (vf,)
+            s[Lp + "mlp/fc2/kernel"] = (vf, vd); s[Lp + "mlp/fc2/bias"] = (vd,)
+        s[D_ + "embed_positions/embedding"] = (self.npos, d)
+        for ln in ("layernorm_embedding", "layer_norm"):
+            s[D_ + ln + "/scale"] = (d,); s[D_ + ln + "/bias"] = (d,)
+        for i in range(self.L):
+            Lp = f"{D_}layers/{i}/"
+            for blk in ("self_attn", "encoder_attn"):
+                for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                    s[Lp + f"{blk}/{n}/kernel"] = (d, d); s[Lp + f"{blk}/{n}/bias"] = (d,)
+                s[Lp + blk + "_layer_norm/scale"] = (d,); s[Lp + blk + "_layer_norm/bias"] = (d,)
+            s[Lp + "fc1/kernel"] = (d, f); s[Lp + "fc1/bias"] = (f,)
+            s[Lp + "fc2/kernel"] = (f, d); s[Lp + "fc2/bias"] = (d,)
+            s[Lp + "final_layer_norm/scale"] = (d,); s[Lp + "final_layer_norm/bias"] = (d,)
+        return s
+
+    def _mapping(self):
+        """(device seg, [(flax leaf, transform)]) pairs.  transform: 'T' transpose [in,out]->[out,in]; 'id'; row-block
+        index for fused weights."""
+        m = []
+        d = self.d
+        m.append(("flb", [("final_logits_bias", "flb")]))
+        m.append(("shared", [("model/shared/embedding", "pad_rows")]))
+        m.append(("vp.w", [("model/visual_projection/kernel", "T")]))
+        m.append(("vp.b", [("model/visual_projection/bias", "id")]))
+        m.append(("vit.cls", [(V_ + "embeddings/class_embedding", "id")]))
+        m.append(("patch.w", [(V_ + "embeddings/patch_embedding/kernel", "conv")]))
+        m.append(("vit.pos", [(V_ + "embeddings/position_embedding/embedding", "id")]))
+        for a, b in (("pre_ln", "pre_layrnorm"), ("post_ln", "post_layernorm")):
+            m.append((f"vit.{a}.g", [(V_ + b + "/scale", "id")])); m.append((f"vit.{a}.b", [(V_ + b + "/bias", "id")]))
+        for i in range(self.vL):
+            Lp, p = f"{V_}encoder/layers/{i}/", f"vit{i}."
+            m.append((p + "qkv.w", [(Lp + f"self_attn/{n}/kernel", "T") for n in ("q_proj", "k_proj", "v_proj")]))
+            m.append((p + "qkv.b", [(Lp + f"self_attn/{n}/bias", "id") for n in ("q_proj", "k_proj", "v_proj")]))
+            m.append((p + "o.w", [(Lp + "self_attn/out_proj/kernel", "T")])); m.append((p + "o.b", [(Lp + "self_attn/out_proj/bias", "id")]))
+            for a, b in (("ln1", "layer_norm1"), ("ln2", "layer_norm2")):
+                m.append((p + a + ".g", [(Lp + b + "/scale", "id")])); m.append((p + a + ".b", [(Lp + b + "/bias", "id")]))
+            for n in ("fc1", "fc2"):
+                m.append((p + n + ".w", [(Lp + f"mlp/{n}/kernel", "T")])); m.append((p + n + ".b", [(Lp + f"mlp/{n}/bias", "id")]))
+        m.append(("dec.pos", [(D_ + "embed_positions/embedding", "id")]))
+        for a, b in (("ln_emb", "layernorm_embedding"), ("ln_f", "layer_norm")):
+            m.append((f"dec.{a}.g", [(D_ + b + "/scale", "id")])); m.append((f"dec.{a}.b", [(D_ + b + "/bias", "id")]))
+        for i in range(self.L):
+            Lp, p = f"{D_}layers/{i}/", f"dec{i}."
+            m.append((p + "qkv.w", [(Lp + f"self_attn/{n}/kernel", "T") for n in ("q_proj", "k_proj", "v_proj")]))
+            m.append((p + "qkv.b", [(Lp + f"self_attn/{n}/bias", "id") for n in ("q_proj", "k_proj", "v_proj")]))
+            m.append((p + "so.w", [(Lp + "self_attn/out_proj/kernel", "T")])); m.append((p + "so.b", [(Lp + "self_attn/out_proj/bias", "id")]))
+            m.append((p + "cq.w", [(Lp + "encoder_attn/q_proj/kernel", "T")])); m.append((p + "cq.b", [(Lp + "encoder_attn/q_proj/bias", "id")]))
+            m.append((p + "ckv.w", [(Lp + f"encoder_attn/{n}/kernel", "T") for n in ("k_proj", "v_proj")]))
+            m.append((p + "ckv.b", [(Lp + f"encoder_attn/{n}/bias", "id") for n in ("k_proj", "v_proj")]))
+            m.append((p + "co.w", [(Lp + "encoder_attn/out_proj/kernel", "T")])); m.append((p + "co.b", [(Lp + "encoder_attn/out_proj/bias", "id")]))
+            for a, b in (("ln_sa", "self_attn_layer_norm"), ("ln_ca", "encoder_attn_layer_norm"), ("ln_ff", "final_layer_norm")):
+                m.append((p + a + ".g", [(Lp + b + "/scale", "id")])); m.append((p + a + ".b", [(Lp + b + "/bias", "id")]))
+            for n in ("fc1", "fc2"):
+                m.append((p + n + ".w", [(Lp + f"{n}/kernel", "T")])); m.append((p + n + ".b", [(Lp + f"{n}/bias", "id")]))
+        return m
+
+    def load_flat(self, flat: Dict[str, np.ndarray]) -> None:
+        """flat: {'/'-joined flax leaf: array-like} in the reference layout -> device buffers."""
+        for seg_name, parts in self._mapping():
+            dst = self.f32(seg_name)
+            r0 = 0
+            for leaf, tr in parts:
+                a = flat[leaf]
+                t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.asarray(a, dtype=np.float32))
+                t = t.to(torch.float32)
+                if tr == "T":
+                    t = t.T
+                elif tr == "conv":
+                    t = t.reshape(-1, t.shape[-1]).T  # [ps*ps*3, hid] -> [hid, ps*ps*3]
+                elif tr == "flb":
+                    t = t.reshape(-1)
+                n = t.shape[0]
+                dst[r0: r0 + n].copy_(t.to(self.device), non_blocking=False)
+                r0 += n
+        self.refresh_lp()
+
+    def export_flat(self, source: str = "master") -> Dict[str, np.ndarray]:
+        """device buffers -> {'/'-joined flax leaf: np.ndarray} in the reference layout (source: master | grad)."""
+        out: Dict[str, np.ndarray] = {}
+        shapes = self.flax_shapes()
+        for seg_name, parts in self._mapping():
+            src = (self.f32(seg_name) if source == "master" else self.g(seg_name)).detach().cpu()
+            r0 = 0
+            for leaf, tr in parts:
+                shp = shapes[leaf]
+                if tr == "T":
+                    n = shp[1]
+                    t = src[r0: r0 + n].T
+                elif tr == "conv":
+                    n = shp[-1]
+                    t = src[r0: r0 + n].T.reshape(shp)
+                elif tr == "flb":
+                    n = self.V
+                    t = src[: self.V].reshape(1, self.V)
+                elif tr == "pad_rows":
+                    n = self.V
+                    t = src[: self.V]
+                else:
+                    n = shp[0]
+                    t = src[r0: r0 + n]
+                out[leaf] = np.ascontiguousarray(t.numpy())
+                r0 += n
+        return out
+
+    def init_random(self, seed: int = 0, std: float = 0.02) -> None:
+        """normal(std) Dense/Embed kernels, LayerNorm scale 1 / bias 0, zero biases — generated on device."""
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        self.master.zero_()
+        for name, s in self.segs.items():
+            v = self.f32(name)
+            if name.endswith(".w") or name in ("vit.pos", "vit.cls", "dec.pos"):
+                v.normal_(0.0, std, generator=g)
+            elif name == "shared":
+                v[: self.V].normal_(0.0, std, generator=g)
+            elif name.endswith(".g"):
+                v.fill_(1.0)
+        self.refresh_lp()

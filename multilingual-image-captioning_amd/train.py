@@ -1,0 +1,177 @@
+"""Data-parallel training step with the reference's semantics (`main.py:281-292, 629-635, 658-707, 710-721`):
+
+    loss, grads = value_and_grad(compute_loss)(params)      # per-rank masked-mean loss on the local shard (main.py:679)
+    grads = pmean(grads)                                     # RCCL all-reduce over xGMI, bucketed, overlapped (main.py:698)
+    params = adamw(params, grads)                            # identical local update on every rank (main.py:701)
+    metrics = pmean({loss, learning_rate})                   # main.py:703-704
+
+One process per GPU (`torch.distributed`, backend "nccl" = RCCL on ROCm; "gloo" on CPU for the tests of the host logic).
+Gradients live in ONE flat fp32 buffer ordered as backward completes them, so buckets are contiguous slices; each
+bucket's all-reduce is issued on a side HIP stream as soon as backward has produced it (event-ordered), overlapping the
+rest of backward; AdamW waits on the side stream once.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+def shift_tokens_right(input_ids: np.ndarray, pad_token_id: int) -> np.ndarray:
+    """main.py:362-369."""
+    shifted = np.zeros(input_ids.shape, dtype=np.int64)
+    shifted[:, 1:] = input_ids[:, :-1]
+    shifted[:, 0] = pad_token_id
+    return shifted
+
+
+def create_learning_rate_fn(train_ds_size: int, train_batch_size: int, num_train_epochs: int, num_warmup_steps: int,
+                            learning_rate: float) -> Callable[[int], float]:
+    """main.py:281-292: linear warmup 0->lr over `num_warmup_steps`, then linear decay lr->0 over the remaining steps."""
+    steps_per_epoch = train_ds_size // train_batch_size
+    num_train_steps = steps_per_epoch * num_train_epochs
+
+    def schedule(step: int) -> float:
+        if step < num_warmup_steps:
+            frac = min(max(step / num_warmup_steps, 0.0), 1.0) if num_warmup_steps > 0 else 1.0
+            return learning_rate * frac
+        n = num_train_steps - num_warmup_steps
+        frac = min(max((step - num_warmup_steps) / n, 0.0), 1.0) if n > 0 else 1.0
+        return learning_rate + (0.0 - learning_rate) * frac
+
+    return schedule
+
+
+def plan_buckets(numel: int, bucket_elems: int, boundaries: List[int]) -> List[Tuple[int, int]]:
+    """Contiguous [begin, end) slices of the flat gradient buffer, cut at segment boundaries, each >= bucket_elems
+    (except the last).  Pure host logic (tested on CPU)."""
+    cuts, start = [], 0
+    for b in sorted(set(boundaries)):
+        if b - start >= bucket_elems and b < numel:
+            cuts.append((start, b))
+            start = b
+    cuts.append((start, numel))
+    return cuts
+
+
+class GradReducer:
+    """Bucketed all-reduce(mean) of the flat gradient buffer on a side stream (C1 of SURVEY §2.3)."""
+
+    def __init__(self, flat_grad: torch.Tensor, buckets: List[Tuple[int, int]], group=None):
+        import torch.distributed as dist
+
+        self.dist, self.group = dist, group
+        self.grad, self.buckets = flat_grad, buckets
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.cuda = flat_grad.is_cuda
+        self.stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
+        self.next = 0
+        self.handles = []
+
+    def start_step(self):
+        self.next = 0
+        self.handles = []
+
+    def progress(self, offset_done: int):
+        """Backward reports that every gradient with flat offset < offset_done is final."""
+        if self.world == 1:
+            return
+        while self.next < len(self.buckets) and self.buckets[self.next][1] <= offset_done:
+            b, e = self.buckets[self.next]
+            if self.cuda:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                with torch.cuda.stream(self.stream):
+                    self.stream.wait_event(ev)
+                    self.dist.all_reduce(self.grad[b:e], op=self.dist.ReduceOp.SUM, group=self.group)
+            else:
+                self.handles.append(self.dist.all_reduce(self.grad[b:e], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.next += 1
+
+    def finish(self):
+        self.progress(self.grad.numel())
+        if self.world == 1:
+            return
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        else:
+            for h in self.handles:
+                h.wait()
+
+
+class Trainer:
+    """TrainState + train_step/eval_step of main.py, for one rank."""
+
+    def __init__(self, model, learning_rate_fn: Callable[[int], float], b1=0.9, b2=0.999, eps=1e-8, weight_decay=0.0,
+                 label_smoothing_factor=0.0, seed: int = 42, bucket_mb: float = 64.0, group=None):
+        import torch.distributed as dist
+
+        self.model, self.lr_fn = model, learning_rate_fn
+        self.b1, self.b2, self.eps, self.wd, self.ls = b1, b2, eps, weight_decay, label_smoothing_factor
+        self.step = 0  # state.step
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.group = group
+        self.dropout_seed = (seed * 1000003 + self.rank * 7919) & 0xFFFFFFFF  # per-device dropout stream (main.py:251)
+        st = model.store
+        st.ensure_grads()
+        st.ensure_opt_state()
+        self.hyper = torch.zeros(2, dtype=torch.float32, device=model.device)
+        bounds = [s.offset for s in st.segs.values()]
+        self.buckets = plan_buckets(st.numel, int(bucket_mb * 1024 * 1024 / 4), bounds)
+        self.reducer = GradReducer(st.grad, self.buckets, group)
+        self.metrics_buf = torch.zeros(2, dtype=torch.float32, device=model.device)
+
+    def _prep(self, batch):
+        m = self.model
+        px = m._dev(batch["pixel_values"], torch.float32)
+        labels = m._dev(batch["input_ids"], torch.int32)
+        mask = m._dev(batch["attention_mask"], torch.int32)
+        dec_in = m._dev(batch["decoder_input_ids"], torch.int32)
+        B, T = labels.shape
+        pos = torch.arange(T, dtype=torch.int32, device=m.device)[None].expand(B, T).contiguous()
+        return px, labels, mask, dec_in, pos, B, T
+
+    def train_step(self, batch: Dict) -> Dict[str, float]:
+        """main.py:684-707."""
+        m, st, eng = self.model, self.model.store, self.model.engine
+        px, labels, mask, dec_in, pos, B, T = self._prep(batch)
+        seed = (self.dropout_seed + self.step * 0x9E3779B1) & 0xFFFFFFFF  # split(dropout_rng) per step (main.py:686)
+        self.reducer.start_step()
+        eng.grad_progress = self.reducer.progress if self.world > 1 else None
+        loss = eng.loss_and_grads(px, dec_in.reshape(-1), pos.reshape(-1), mask, labels.reshape(-1), B, T,
+                                  label_smoothing=self.ls, seed=seed)
+        self.reducer.finish()  # pmean(grad) (main.py:698): SUM here, 1/world folded into AdamW's grad_scale
+        lr = float(self.lr_fn(self.step))
+        self.hyper.copy_(torch.tensor([lr, float(self.step + 1)], dtype=torch.float32), non_blocking=True)
+        ops.adamw(st.master, st.m, st.v, st.grad, None if st.lp is st.master else st.lp, self.hyper, self.b1, self.b2, self.eps,
+                  self.wd, grad_scale=1.0 / self.world)
+        m.invalidate_params_cache()
+        self.step += 1
+        self.metrics_buf[0:1].copy_(loss)
+        self.metrics_buf[1] = lr
+        return self._pmean_metrics()
+
+    def eval_step(self, batch: Dict) -> Dict[str, float]:
+        """main.py:710-721 (train=False, no dropout)."""
+        m, eng = self.model, self.model.engine
+        px, labels, mask, dec_in, pos, B, T = self._prep(batch)
+        logits, _ = eng.forward_logits(px, dec_in.reshape(-1), pos.reshape(-1), mask, B, T, save=False, seed=None)
+        loss = eng.loss_and_dlogits(logits, labels.reshape(-1), mask.reshape(-1), B * T, self.ls, backward=False)
+        self.metrics_buf[0:1].copy_(loss)
+        self.metrics_buf[1] = 0.0
+        out = self._pmean_metrics()
+        out.pop("learning_rate")
+        return out
+
+    def _pmean_metrics(self) -> Dict[str, torch.Tensor]:
+        """pmean of the 2 scalars (main.py:703-704, 719).  Returned as device tensors (no host sync in the step)."""
+        if self.world > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(self.metrics_buf, op=dist.ReduceOp.SUM, group=self.group)
+            self.metrics_buf /= self.world
+        return {"loss": self.metrics_buf[0], "learning_rate": self.metrics_buf[1]}
