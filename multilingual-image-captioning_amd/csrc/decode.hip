@@ -39,7 +39,8 @@ __global__ __launch_bounds__(256) void row_lse_topk_kernel(int V, const T* __res
     for (int o = 128; o > 0; o >>= 1) {
       if (tid < o) {
         const float m1 = sm[tid], m2 = sm[tid + o], mn = fmaxf(m1, m2);
-        ss[tid] = ss[tid] * __expf(m1 - mn) + ss[tid + o] * __expf(m2 - mn);
+        // threads that saw no column carry (-inf, 0): exp(-inf - -inf) would be NaN
+        ss[tid] = mn == -INFINITY ? 0.f : ss[tid] * __expf(m1 - mn) + ss[tid + o] * __expf(m2 - mn);
         sm[tid] = mn;
       }
       __syncthreads();

@@ -1,0 +1,125 @@
+"""Generation parity on the GPU: KV-cached decode steps, greedy and beam-4 `.generate()` of the HIP path vs the oracle's
+restatement of the reference algorithm (`generation_clip_vision_utils.py`) driving the CPU model oracle.
+float32 mode: token ids bit-exact, beam scores within 1e-4.  bfloat16 mode: ids are compared against the oracle
+as an agreement rate (bf16 logits tie massively; exactness is defined in float32 — SURVEY §7 hard parts)."""
+import numpy as np
+import pytest
+import torch
+
+from util_small import batch, make_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_gen(rc, p, px, B, **kw):
+    from oracle import generation_ref as G
+    from oracle import model_ref as M
+
+    with torch.no_grad():
+        ehs, _ = M.encode(rc, p, px)
+    K = kw.get("num_beams", 1)
+    L = kw["max_length"]
+    return G.generate(lambda rows: G.ModelStepper(rc, p, ehs.repeat_interleave(rows // B, 0), L), B, G.GenDefaults(), **kw)
+
+
+def test_cached_decode_steps_match_oracle(dev):
+    """decode() with past_key_values (modeling:519-651): per-step logits vs the oracle's static-cache decode."""
+    from oracle import model_ref as M
+
+    rc, p, model = make_pair(torch.float32, dev, gelu="tanh", decoder_ln_eps=1e-6)
+    B, L = 3, 8
+    px, *_ = batch(rc, B, 12, seed=11)
+    with torch.no_grad():
+        ehs, _ = M.encode(rc, p, px)
+    enc = model.encode(px.numpy())
+    state = M.DecodeState(rc, B, L)
+    cache = model.init_cache(B, L, enc)
+    g = torch.Generator().manual_seed(0)
+    with pytest.raises(ValueError):
+        model.decode(np.zeros((B, 1), dtype=np.int32), enc, past_key_values=cache)  # positions are mandatory with a cache
+    for t in range(5):
+        tok = torch.randint(4, rc.vocab_size, (B, 1), generator=g)
+        pos = torch.full((B, 1), t)
+        with torch.no_grad():
+            ref = M.decode_step(rc, p, state, tok, pos, ehs)
+        out = model.decode(tok.numpy(), enc, decoder_position_ids=pos.numpy(), past_key_values=cache)
+        cache = out.past_key_values
+        err = (out.logits.cpu() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 2e-4, (t, err)
+    # without a cache: teacher-forced decode == __call__'s decoder
+    ids = torch.randint(4, rc.vocab_size, (B, 6), generator=g)
+    out = model.decode(ids.numpy(), enc)
+    with torch.no_grad():
+        h = M.decoder_forward(rc, p, ids, torch.ones_like(ids), torch.arange(6)[None].expand(B, 6), ehs)
+        ref = M.lm_head(rc, p, h)
+    assert ((out.logits.cpu() - ref).abs().max() / ref.abs().max()).item() < 2e-4
+
+
+@pytest.mark.parametrize("kw", [dict(max_length=10), dict(max_length=12, forced_bos_token_id=996),
+                                dict(max_length=9, decoder_start_token_id=997, forced_eos_token_id=None), dict(max_length=10, min_length=4)])
+def test_greedy_ids_exact(dev, kw):
+    rc, p, model = make_pair(torch.float32, dev, gelu="tanh", decoder_ln_eps=1e-6)
+    B = 3
+    px, *_ = batch(rc, B, 12, seed=21)
+    ref = _oracle_gen(rc, p, px, B, num_beams=1, **kw)
+    out = model.generate(px.numpy(), num_beams=1, **kw)
+    assert np.array_equal(out.sequences.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("kw", [dict(max_length=10, forced_bos_token_id=996), dict(max_length=12), dict(max_length=8, decoder_start_token_id=998),
+                                dict(max_length=10, num_beams=2, length_penalty=1.0, early_stopping=False)])
+def test_beam_ids_exact(dev, kw):
+    rc, p, model = make_pair(torch.float32, dev, gelu="tanh", decoder_ln_eps=1e-6)
+    B = 3
+    px, *_ = batch(rc, B, 12, seed=22)
+    kw = dict(kw)
+    kw.setdefault("num_beams", 4)
+    ref = _oracle_gen(rc, p, px, B, **kw)
+    out = model.generate(px.numpy(), **kw)
+    assert out["steps"] == ref.steps
+    assert np.array_equal(out.sequences.cpu().numpy(), ref.sequences), (out.sequences, ref.sequences)
+    assert np.allclose(out.scores.cpu().numpy(), ref.scores, rtol=1e-4, atol=1e-4)
+
+
+def test_beam_early_finish_eos_bias(dev):
+    """Push EOS up through final_logits_bias so beams finish early: exercises the finished-merge, the -1e7 arithmetic,
+    early_stopping termination and the improvement test (gen:798-820, 889-940)."""
+    from mic_amd.params import flatten_tree, unflatten_tree
+
+    rc, p, model = make_pair(torch.float32, dev, gelu="tanh", decoder_ln_eps=1e-6)
+    p = dict(p)
+    flb = p["final_logits_bias"].clone()
+    flb[0, rc.eos_token_id] = 6.0
+    p["final_logits_bias"] = flb
+    model.params = unflatten_tree({k: v.numpy() for k, v in p.items()})
+    B = 4
+    px, *_ = batch(rc, B, 12, seed=23)
+    for kw in (dict(max_length=12, num_beams=4, decoder_start_token_id=999), dict(max_length=12, num_beams=3, early_stopping=False, decoder_start_token_id=999)):
+        ref = _oracle_gen(rc, p, px, B, **kw)
+        out = model.generate(px.numpy(), **kw)
+        assert out["steps"] == ref.steps, (out["steps"], ref.steps)
+        assert np.array_equal(out.sequences.cpu().numpy(), ref.sequences)
+        assert np.allclose(out.scores.cpu().numpy(), ref.scores, rtol=1e-4, atol=1e-4)
+    assert (ref.sequences == rc.eos_token_id).any()  # finished hypotheses keep EOS (unlike greedy)
+
+
+def test_generate_bf16_runs_and_mostly_agrees(dev):
+    rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6)
+    B = 4
+    px, *_ = batch(rc, B, 12, seed=24)
+    kw = dict(max_length=10, num_beams=4, forced_bos_token_id=996)
+    ref = _oracle_gen(rc, p, px, B, **kw)
+    out = model.generate(px.numpy(), **kw)
+    got = out.sequences.cpu().numpy()
+    assert got.shape == ref.sequences.shape and (got[:, 0] == 2).all() and (got[:, 1] == 996).all()
+    print("bf16 beam-4 token agreement with the fp32 oracle:", float((got == ref.sequences).mean()))
+
+
+def test_generate_api_errors(dev):
+    rc, p, model = make_pair(torch.float32, dev)
+    px, *_ = batch(rc, 1, 12, seed=1)
+    with pytest.raises(NotImplementedError):
+        model.generate(px.numpy(), do_sample=True, num_beams=4, max_length=5)
+    model.config.mbart_config.decoder_start_token_id = None
+    with pytest.raises(ValueError):
+        model.generate(px.numpy(), max_length=5, num_beams=1)
