@@ -1,0 +1,191 @@
+"""CPU tests of the oracle itself: pinned against the committed golden vectors of the PyTorch twin
+(tests/golden/twin_small.npz, generator tests/golden/make_golden.py), plus self-consistency and the
+known-answer tests SURVEY §8(c) lists (the reference ships none)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util_small import ref_config
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "twin_small.npz")
+
+
+def test_oracle_matches_twin_golden():
+    from oracle import model_ref as M
+
+    g = np.load(GOLD)
+    rc = ref_config("erf", 1e-5)
+    p = M.init_params(rc, seed=int(g["seed"]), perturb_ln=True)
+    px, ids, mask = torch.from_numpy(g["pixels"]), torch.from_numpy(g["ids"]), torch.from_numpy(g["mask"])
+    with torch.no_grad():
+        last, pooled = M.vit_encoder(rc, p, px)
+        ehs = M.dense(last, p, "model/visual_projection")
+        h = M.decoder_forward(rc, p, ids, mask, torch.arange(ids.shape[1])[None].expand_as(ids), ehs)
+        logits = M.forward_logits(rc, p, px, ids, mask)
+    valid = mask.bool().numpy()
+    assert np.abs(last.numpy() - g["enc_last"]).max() < 2e-5
+    assert np.abs(pooled.numpy() - g["pooled"]).max() < 2e-5
+    assert np.abs(ehs.numpy() - g["ehs"]).max() < 2e-5
+    assert np.abs(h.numpy() - g["dec_hidden"])[valid].max() < 2e-5
+    assert np.abs(logits.numpy() - g["logits"])[valid].max() < 2e-5
+
+
+def test_cached_decode_equals_teacher_forced():
+    """The static max_length-slot cache path (modeling:249-282, App. B7) reproduces the full causal forward."""
+    from oracle import model_ref as M
+
+    rc = ref_config("tanh", 1e-6)
+    p = M.init_params(rc, seed=3, perturb_ln=True)
+    B, T = 2, 7
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(4, rc.vocab_size, (B, T), generator=g)
+    ehs = torch.randn(B, rc.v_seq, rc.d_model, generator=g)
+    with torch.no_grad():
+        full = M.lm_head(rc, p, M.decoder_forward(rc, p, ids, torch.ones_like(ids), torch.arange(T)[None].expand(B, T), ehs))
+        st = M.DecodeState(rc, B, 9)
+        for t in range(T):
+            step = M.decode_step(rc, p, st, ids[:, t:t + 1], torch.full((B, 1), t), ehs)
+            assert (step[:, 0] - full[:, t]).abs().max().item() < 1e-5
+
+
+def test_encode_truncates_pixels_toward_zero():
+    from oracle import model_ref as M
+
+    rc = ref_config()
+    p = M.init_params(rc, seed=1)
+    px = torch.tensor([-1.7, -0.3, 0.9, 2.1]).repeat(rc.image_size * rc.image_size * 3 // 4).reshape(1, rc.image_size, rc.image_size, 3)
+    with torch.no_grad():
+        a, _ = M.encode(rc, p, px, int32_cast=True)
+        b, _ = M.encode(rc, p, torch.trunc(px), int32_cast=False)
+        c, _ = M.encode(rc, p, px, int32_cast=False)
+    assert torch.equal(a, b) and not torch.allclose(a, c)
+
+
+def test_param_tree_size_full_model():
+    from oracle import model_ref as M
+
+    n = sum(int(np.prod(s)) for s in M.param_shapes(M.RefConfig()).values())
+    assert n == 547_163_590
+
+
+# ---------------------------------------------------------------- training pieces (main.py)
+def test_shift_tokens_right_kat():
+    from oracle import train_ref
+
+    out = train_ref.shift_tokens_right(np.array([[250004, 5, 6, 2, 1, 1]]), 1)
+    assert out.tolist() == [[1, 250004, 5, 6, 2, 1]] and out.dtype == np.int64
+
+
+def test_loss_fn_kat():
+    from oracle import train_ref
+
+    logits = torch.tensor([[[1.0, 2.0, 0.5, -1.0, 0.0], [0.0, 0.0, 0.0, 0.0, 0.0], [3.0, -2.0, 1.0, 0.5, 0.2]],
+                           [[0.1, 0.2, 0.3, 0.4, 0.5], [2.0, 1.0, 0.0, -1.0, -2.0], [1.0, 1.0, 1.0, 1.0, 1.0]]])
+    labels = torch.tensor([[1, 0, 2], [4, 0, 3]])
+    mask = torch.tensor([[1, 1, 0], [1, 1, 1]])
+    lp = torch.log_softmax(logits.double(), -1)
+    nll = -lp.gather(-1, labels[..., None])[..., 0]
+    expect0 = (nll * mask).sum() / mask.sum()
+    assert abs(train_ref.loss_fn(logits, labels, mask, 0.0).item() - expect0.item()) < 1e-6
+    V, ls = 5, 0.1
+    conf, low = 1 - ls, ls / (V - 1)
+    soft = torch.full_like(lp, low)
+    soft.scatter_(-1, labels[..., None], conf)
+    norm = -(conf * math.log(conf) + (V - 1) * low * math.log(low + 1e-20))
+    expect = (((-(soft * lp).sum(-1)) - norm) * mask).sum() / mask.sum()
+    assert abs(train_ref.loss_fn(logits, labels, mask, ls).item() - expect.item()) < 1e-6
+
+
+def test_lr_schedule_kat():
+    from oracle import train_ref
+
+    lr, W, N = 5e-5, 1000, 7000
+    f = lambda s: train_ref.linear_warmup_decay(s, lr, W, N)
+    assert f(0) == 0.0 and abs(f(500) - 2.5e-5) < 1e-12 and abs(f(1000) - lr) < 1e-12
+    assert abs(f(4000) - lr * 0.5) < 1e-12 and abs(f(6999) - lr / 6000) < 1e-12 and f(7000) == 0.0 and f(9000) == 0.0
+
+
+def test_adamw_one_step_kat():
+    from oracle import train_ref
+
+    p, g = torch.tensor([1.0, -2.0, 0.5]), torch.tensor([0.1, -0.2, 0.0])
+    m = v = torch.zeros(3)
+    np_, nm, nv = train_ref.adamw_update(p, g, m, v, count=0, lr_t=0.01, wd=0.1)
+    # first step: mhat = g, vhat = g^2 -> update = sign(g) (eps aside) + wd*p
+    exp = p - 0.01 * (torch.tensor([1.0, -1.0, 0.0]) + 0.1 * p)
+    assert torch.allclose(np_, exp, atol=1e-6) and torch.allclose(nm, 0.1 * g) and torch.allclose(nv, 0.001 * g * g)
+
+
+# ---------------------------------------------------------------- generation restatement KATs (scripted fake decoders)
+def _table(V, peak_fn):
+    def t(step, hist):
+        x = np.full(V, -4.0, dtype=np.float32)
+        for tok, val in peak_fn(step, hist).items():
+            x[tok] = val
+        return x
+    return t
+
+
+def test_greedy_replaces_eos_by_pad():
+    from oracle import generation_ref as G
+
+    seqs = G.greedy_search(G.ScriptedStepper(1, _table(6, lambda s, h: {5: 3.0} if s == 0 else {2: 3.0})), 1, 4, 6, 1, 2, [])
+    assert seqs.tolist() == [[4, 5, 1, 1, 1, 1]]  # EOS never appears: the EOS step itself writes PAD (gen:501-507)
+    seqs = G.greedy_search(G.ScriptedStepper(1, _table(6, lambda s, h: {3: 3.0})), 1, 4, 5, 1, 2, G.get_logits_processor(0, 5, 2, None, 2))
+    assert seqs.tolist() == [[4, 3, 3, 3, 1]]  # ForcedEOS at the last step -> finished -> PAD in the last column
+    seqs = G.greedy_search(G.ScriptedStepper(1, _table(6, lambda s, h: {2: 3.0, 3: 2.0})), 1, 4, 5, 1, 2, G.get_logits_processor(3, 5, 2, None, None))
+    assert seqs.tolist() == [[4, 3, 3, 1, 1]]  # MinLength suppresses EOS while cur_len < 3
+
+
+def test_top_k_is_index_stable_and_handles_neg_inf():
+    from oracle import generation_ref as G
+
+    x = np.array([[1.0, 3.0, 3.0, -np.inf, -np.inf, 3.0, 0.0]], dtype=np.float32)
+    v, i = G.top_k(x, 5)
+    assert i.tolist() == [[1, 2, 5, 0, 6]]
+    v, i = G.top_k(np.full((1, 6), -np.inf, dtype=np.float32), 3)
+    assert i.tolist() == [[0, 1, 2]]
+
+
+def test_beam_forced_bos_ties_and_no_finished_fallback():
+    from oracle import generation_ref as G
+
+    V = 7
+    tab = _table(V, lambda s, h: {3: 2.0, 4: 1.5, 5: 1.0, 2: -1e9})  # EOS can never enter the top-2K
+    procs = G.get_logits_processor(0, 5, 2, 6, None)  # forced BOS = 6, no forced EOS
+    r = G.beam_search(G.ScriptedStepper(2 * 3, tab), 2, 3, 0, 5, 1, 2, 1.0, True, procs)
+    assert r.steps == 4
+    assert r.sequences.tolist() == [[0, 6, 3, 3, 3]] * 2  # nothing finished -> running beams returned (gen:980-984)
+    lp = G.log_softmax(tab(0, None)[None])[0]
+    assert abs(r.scores[0] - 3 * lp[3]) < 1e-4  # forced step contributes 0
+
+
+def test_beam_early_finish_and_early_stopping():
+    from oracle import generation_ref as G
+
+    V = 6
+
+    def peaks(s, h):
+        if len(h) >= 2 and h[-1] == 3:
+            return {2: 5.0}  # after token 3 -> EOS strongly
+        return {3: 2.0, 4: 1.9}
+    r = G.beam_search(G.ScriptedStepper(2, _table(V, peaks)), 1, 2, 0, 8, 1, 2, 1.0, True, [])
+    assert r.steps < 7  # early_stopping ends the loop once both finished slots are filled
+    seq = r.sequences[0].tolist()
+    assert 2 in seq and seq[seq.index(2) + 1:] == [1] * (8 - seq.index(2) - 1)  # finished hypotheses keep EOS, PAD after it
+    assert r.scores[0] < -1e5  # finished scores carry the reference's -1e7 arithmetic: (lp - 1e7) / cur_len
+    r2 = G.beam_search(G.ScriptedStepper(2, _table(V, peaks)), 1, 2, 0, 8, 1, 2, 1.0, False, [])
+    assert r2.steps >= r.steps
+
+
+def test_generate_dispatch_errors():
+    from oracle import generation_ref as G
+
+    d = G.GenDefaults(decoder_start_token_id=None)
+    with pytest.raises(ValueError):
+        G.generate(lambda r: None, 1, d, max_length=4, num_beams=1)
+    with pytest.raises(NotImplementedError):
+        G.generate(lambda r: None, 1, G.GenDefaults(), max_length=4, num_beams=2, do_sample=True)
