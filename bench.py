@@ -150,10 +150,21 @@ def main():
             recs.append((2.0 * M * N * K, e0, e1))
             return r
 
+        orig_g = ops.gemm_grouped
+
+        def timed_grouped(arg_list):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig_g(arg_list)
+            e1.record()
+            recs.append((sum(2.0 * g.M * g.N * g.K for g in arg_list), e0, e1))
+            return r
+
         ops.gemm = timed_gemm
+        ops.gemm_grouped = timed_grouped
         tr.train_step(dbatches[0])
         torch.cuda.synchronize()
-        ops.gemm = orig
+        ops.gemm, ops.gemm_grouped = orig, orig_g
         flops = sum(r[0] for r in recs)
         ms = sum(r[1].elapsed_time(r[2]) for r in recs)
         ach = flops / (ms * 1e-3) / 1e12

@@ -52,8 +52,8 @@ const char* mic_last_error(void);
  *   v *= act'(Zin[m,n]) (activation backward);  v = dropout(v; seed, p, index m*N+n);
  *   v += R[m,n];  v += C_old[m,n] (accumulate);  C[m,n] = v  (c_dtype)
  * Requirements: K % 64 == 0 for MIC_BF16 (callers zero-pad the reduction dimension); lda/ldb % 8 == 0 (bf16).
- * bf16 path: LDS-staged 128x128x64 tiles (direct global->LDS DMA, XOR-swizzled), v_mfma_f32_32x32x16_bf16,
- * k-major operands through ds_read_b64_tr_b16.  f32 path: v_mfma_f32_32x32x2_f32 (exact fp32).
+ * bf16 path: LDS-staged 128x128x64 or 256x256x64 tiles (direct global->LDS DMA, XOR-swizzled),
+ * v_mfma_f32_32x32x16_bf16, k-major operands through ds_read_b64_tr_b16.  f32 path: v_mfma_f32_32x32x2_f32 (exact fp32).
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
   int dtype;         /* dtype of A, B, R, Zin, Zout */
@@ -71,8 +71,13 @@ typedef struct {
   int accumulate;          /* add existing C */
   float dropout_p; uint32_t dropout_seed; /* p = 0 disables */
   float alpha;             /* scale on acc before bias (0 means 1) */
+  int split_k;             /* > 1 (bf16 only): split the reduction over that many workgroups per tile; partial sums are
+                              atomically added (fp32) into a caller-zeroed C; no other epilogue allowed */
 } mic_gemm_args;
 int mic_gemm(const mic_gemm_args* a, void* stream);
+/* `count` GEMMs that share dtype and operand layouts in as few launches as possible (one launch per 8 problems):
+ * the weight-gradient GEMMs of a layer have 36..256 output tiles each — grouped they fill the 256 CUs. */
+int mic_gemm_grouped(const mic_gemm_args* args, int count, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm (flax nn.LayerNorm: biased variance, fp32 statistics; 3P).

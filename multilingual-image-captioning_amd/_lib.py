@@ -26,7 +26,7 @@ class GemmArgs(C.Structure):
         ("A", C.c_void_p), ("lda", C.c_int), ("B", C.c_void_p), ("ldb", C.c_int), ("C", C.c_void_p), ("ldc", C.c_int),
         ("bias", C.c_void_p), ("act", C.c_int), ("Zout", C.c_void_p), ("ldz", C.c_int), ("Zin", C.c_void_p),
         ("dact", C.c_int), ("R", C.c_void_p), ("ldr", C.c_int), ("accumulate", C.c_int), ("dropout_p", C.c_float),
-        ("dropout_seed", C.c_uint32), ("alpha", C.c_float),
+        ("dropout_seed", C.c_uint32), ("alpha", C.c_float), ("split_k", C.c_int),
     ]
 
 
@@ -45,6 +45,7 @@ _SIGS = {
     "mic_version": ([], C.c_int),
     "mic_last_error": ([], C.c_char_p),
     "mic_gemm": ([C.POINTER(GemmArgs), _p], C.c_int),
+    "mic_gemm_grouped": ([C.POINTER(GemmArgs), _i, _p], C.c_int),
     "mic_layernorm_fwd": ([_i, _i, _i, _p, _p, _p, _f, _p, _p, _p, _f, _u32, _p], C.c_int),
     "mic_layernorm_bwd": ([_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _u32, _f, _u32, _p], C.c_int),
     "mic_attn_fwd": ([_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p], C.c_int),

@@ -266,28 +266,50 @@ extern "C" int mic_ce_bwd(int dtype, int rows, int V, int Vpad, void* logits, in
 }
 
 // ------------------------------------------------------------------ column sums (bias gradients)
-// grid.x covers 64-column strips, grid.y splits rows; each thread sums a column over its row slice; fp32 atomics combine.
+// Each thread owns 8 consecutive columns (one 16-B load per row); a block = 32 column-chunks x 8 row lanes covers 256
+// columns and walks its row slice with stride 8; the 8 row lanes combine through LDS, one fp32 atomic per column.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(int rows, int cols, const T* __restrict__ x, int ld, float* __restrict__ out) {
-  __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int w = threadIdx.x >> 6;
+  __shared__ float red[8][256 + 8];
+  const int cc = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c0 = blockIdx.x * 256 + cc * 8;
   const int rows_per = (rows + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
-  float acc = 0.f;
-  if (c < cols)
-    for (int r = r0 + w; r < r1; r += 4) acc += ElemT<T>::ld(x + (size_t)r * ld + c);
-  red[w][threadIdx.x & 63] = acc;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c0 + 8 <= cols) {
+    for (int r = r0 + rl; r < r1; r += 8) {
+      float v[8];
+      ld8(x + (size_t)r * ld + c0, v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += v[i];
+    }
+  } else if (c0 < cols) {
+    for (int r = r0 + rl; r < r1; r += 8)
+      for (int i = 0; i < cols - c0; ++i) acc[i] += ElemT<T>::ld(x + (size_t)r * ld + c0 + i);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[rl][cc * 8 + i] = acc[i];
   __syncthreads();
-  if (w == 0 && c < cols) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < cols) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += red[j][threadIdx.x];
+    atomicAdd(out + c, s);
+  }
 }
 extern "C" int mic_colsum(int dtype, int rows, int cols, const void* x, int ld, float* out, int accumulate, void* stream) {
   MIC_CHECK(rows > 0 && cols > 0 && x && out, "mic_colsum: bad args");
+  MIC_CHECK(ld % 8 == 0 && ((uintptr_t)x & 15) == 0, "mic_colsum: rows must be 16-B aligned");
   if (!accumulate) hipMemsetAsync(out, 0, sizeof(float) * cols, (hipStream_t)stream);
   return dispatch_t(dtype, [&](auto* tag) {
     using T = TYPE_OF(tag);
-    int gy = (rows + 127) / 128; if (gy > 64) gy = 64;
-    hipLaunchKernelGGL(colsum_kernel<T>, dim3((cols + 63) / 64, gy), dim3(256), 0, (hipStream_t)stream, rows, cols, (const T*)x, ld, out);
+    const int gx = (cols + 255) / 256;
+    int gy = (rows + 63) / 64;
+    const int cap = (2048 + gx - 1) / gx;  // ~2k blocks in total
+    if (gy > cap) gy = cap;
+    if (gy < 1) gy = 1;
+    hipLaunchKernelGGL(colsum_kernel<T>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, rows, cols, (const T*)x, ld, out);
   });
 }
 

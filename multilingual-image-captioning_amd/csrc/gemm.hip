@@ -1,11 +1,18 @@
-// gemm.hip — MFMA GEMMs with fused epilogues (mic_gemm).
+// gemm.hip — MFMA GEMMs with fused epilogues (mic_gemm / mic_gemm_grouped).
 //
-// bf16 kernel: 128x128 output tile, BK = 64, 256 threads = 4 waves (2x2), each wave a 64x64 sub-tile as 2x2
-// v_mfma_f32_32x32x16_bf16 accumulators (64 accumulator registers).  Operand tiles go HBM -> LDS by direct DMA
-// (global_load_lds_dwordx4: destination = wave-uniform base + lane*16), double-buffered (2 x 32 KiB), one barrier per
-// K-tile.  LDS images are lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE address and the
-// matching XOR on the read side:
-//   k-contiguous operand  -> image [128 rows][64 k]  (128-B rows), 16-B chunk c of row r stored at c ^ (r & 7),
+// bf16 kernel (one template, two tile configurations, table-driven so one launch can carry several GEMMs):
+//   small: 128x128 tile, 4 waves (2x2), wave tile  64x64 = 2x2 v_mfma_f32_32x32x16_bf16 accumulators, 64 KiB LDS, 2 blocks/CU
+//   big  : 256x256 tile, 8 waves (2x4), wave tile 128x64 = 4x2 accumulators (128 acc registers), 128 KiB LDS, 1 block/CU
+// BK = 64.  Operand tiles go HBM/L2 -> LDS by direct DMA (global_load_lds_dwordx4: destination = wave-uniform base +
+// lane*16) in 16 KiB half-tiles (128 rows x 64 k, or 64 k x 128 x), double-buffered, one barrier per K-tile.  Measured on
+// MI355X the 128^2 structure saturates at ~20-25 B/clk/CU of operand delivery (0.85 PF/s at 4096^3, L2 hit 84 %, MFMA pipe
+// 43 % busy at the ~1.8 GHz the chip sustains under MFMA load) — arithmetic intensity per delivered byte is the lever,
+// hence the 256^2 configuration for every launch that has enough tiles to fill 256 CUs (LM head = half of all FLOPs),
+// grouped launches for the many small weight-gradient GEMMs, and split-K (fp32 atomics) for tiny-output/huge-K shapes.
+// LDS images are lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE address and the matching
+// XOR on the read side:
+//   k-contiguous operand  -> image [128 rows][64 k]  (128-B rows), 16-B chunk c of row r stored at c ^ ((r >> 1) & 7)
+//                            (conflict-free for ds_read_b128's lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31}),
 //                            fragments by ds_read_b128 (8 consecutive k of row lane&31);
 //   k-major operand       -> image [64 k][128 x]     (256-B rows), chunk c of row k stored at c ^ ((k & 3) << 2),
 //                            fragments by 2 x ds_read_b64_tr_b16 (hardware transpose; lane layouts verified on
@@ -13,29 +20,39 @@
 // So Linear forward (NT), dX (NN) and dW (TN) all run from the tensors as they lie in HBM — no transposed copies.
 // Block ids are remapped XCD-aware (block b runs on XCD b % 8): each XCD walks a contiguous run of tiles ordered in
 // GROUP_M-tall column panels so neighbouring tiles share A/B panels in that XCD's L2.
+// Epilogue: accumulators are restaged through LDS (free after the main loop) so every thread owns 8 consecutive columns
+// of a row: bias / activation / dropout / residual / Z / C all move as 16-B coalesced vectors.
 //
 // f32 kernel (the reference's default dtype; parity mode): 64x64x16 tiles, v_mfma_f32_32x32x2_f32 (bit-exact fp32
 // fma chain), generic strides.
 #include "common.h"
 
-#define BM 128
-#define BN 128
 #define BK 64
-#define TILE_BYTES (128 * 64 * 2)  // 16 KiB per operand tile
+#define HALF_BYTES (128 * 64 * 2)  // 16 KiB: one half-tile image
+#define MAX_PROBLEMS 8
 
-// --- DMA one 16 KiB operand tile into LDS.  KMAJOR=false: src is [rows][ld] k-contiguous, tile = 128 rows x 64 k.
-//     KMAJOR=true: src is [K][ld] x-contiguous, tile = 64 k x 128 x.  `lim` = number of valid rows (resp. x) in src;
+struct Problem {
+  const uint16_t* A; const uint16_t* B;
+  int lda, ldb, M, N, K;
+  int tiles_m, tiles_n, block_begin, nsplit;
+  EpiArgs epi;
+};
+struct LaunchTable { int count; int total_blocks; Problem p[MAX_PROBLEMS]; };
+
+// --- DMA one 16 KiB half-tile into LDS.  KMAJOR=false: src is [rows][ld] k-contiguous, image = 128 rows x 64 k.
+//     KMAJOR=true: src is [K][ld] x-contiguous, image = 64 k x 128 x.  `lim` = number of valid rows (resp. x) in src;
 //     out-of-range rows/chunks are redirected to a valid address (their products are masked at the store).
-template <bool KMAJOR>
-__device__ __forceinline__ void stage_tile(const uint16_t* __restrict__ src, int ld, int x0, int k0, int lim,
+template <bool KMAJOR, int NWAVES>
+__device__ __forceinline__ void stage_half(const uint16_t* __restrict__ src, int ld, int x0, int k0, int lim,
                                            char* lds_tile, int wave, int lane) {
+  constexpr int PER = 16 / NWAVES;  // 16 wave-instructions of 1 KiB cover the half-tile
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int q = wave * 4 + i;  // 16 wave-instructions of 1 KiB cover the tile
+  for (int i = 0; i < PER; ++i) {
+    const int q = wave * PER + i;
     const uint16_t* g;
     if (!KMAJOR) {
       const int row = q * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ (row & 7);
+      const int c = (lane & 7) ^ ((row >> 1) & 7);
       int gr = x0 + row;
       gr = gr < lim ? gr : lim - 1;
       g = src + (size_t)gr * ld + k0 + c * 8;
@@ -56,7 +73,7 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int xb, int kk
   if (!KMAJOR) {
     const int row = xb + (lane & 31);
     const int kc = kk * 2 + (lane >> 5);
-    return *reinterpret_cast<const bf16x8*>(lds_tile + row * 128 + ((kc ^ (row & 7)) << 4));
+    return *reinterpret_cast<const bf16x8*>(lds_tile + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
   } else {
     const int g = lane >> 4, p = lane & 15;
     const int x = xb + 16 * (g & 1) + (p & 3) * 4;
@@ -69,13 +86,8 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int xb, int kk
   }
 }
 
-__device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
-  const int nwg = tiles_m * tiles_n;
-  // bijective XCD remap: the blocks that land on XCD x (= bid % 8) get a contiguous run of logical tile ids
-  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  // GROUP_M-tall column panels
-  const int GROUP_M = 8;
+__device__ __forceinline__ void tile_coords(int lid, int tiles_m, int tiles_n, int& tm, int& tn) {
+  const int GROUP_M = 8;  // GROUP_M-tall column panels
   const int per_group = GROUP_M * tiles_n;
   const int gidx = lid / per_group;
   const int first_m = gidx * GROUP_M;
@@ -85,47 +97,78 @@ __device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, i
   tn = in_g / gsz;
 }
 
-template <bool AK, bool BKM>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t* __restrict__ A, int lda,
-                                                           const uint16_t* __restrict__ B, int ldb, int M, int N, int K,
-                                                           int tiles_m, int tiles_n, EpiArgs epi) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A tile | B tile]
+// WM: rows per wave (64 or 128); WNW: waves along N (2 or 4); 2 waves along M.  BM = 2*WM, BN = 64*WNW.
+template <int WM, int WNW, bool AK, bool BKM>
+__global__ __launch_bounds__(128 * WNW, 2) void gemm_bf16_kernel(LaunchTable tab) {
+  constexpr int BM = 2 * WM, BN = 64 * WNW, NWAVES = 2 * WNW, NTHREADS = 64 * NWAVES;
+  constexpr int NHA = BM / 128, NHB = BN / 128, STAGE = (NHA + NHB) * HALF_BYTES, AI = WM / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A halves | B halves]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int tm, tn;
-  tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int wr = wave >> 1, wc = wave & 1;
-
-  f32x16 acc[2][2];
+  // bijective XCD remap: the blocks that land on XCD x (= bid % 8) get a contiguous run of logical block ids
+  int lid;
+  {
+    const int bid = blockIdx.x, nwg = tab.total_blocks;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  int pi = 0;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 1; i < MAX_PROBLEMS; ++i)
+    if (i < tab.count && lid >= tab.p[i].block_begin) pi = i;
+  const Problem& P = tab.p[pi];
+  const int local = lid - P.block_begin;
+  const int tile = local / P.nsplit, split = local - tile * P.nsplit;
+  int tm, tn;
+  tile_coords(tile, P.tiles_m, P.tiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int M = P.M, N = P.N;
+  const uint16_t* __restrict__ A = P.A;
+  const uint16_t* __restrict__ B = P.B;
+  const int lda = P.lda, ldb = P.ldb;
+  const int wr = wave / WNW, wc = wave % WNW;
+
+  f32x16 acc[AI][2];
+#pragma unroll
+  for (int i = 0; i < AI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const int nk = K / BK;
-  stage_tile<AK>(A, lda, m0, 0, M, smem, wave, lane);
-  stage_tile<BKM>(B, ldb, n0, 0, N, smem + TILE_BYTES, wave, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  const int nk_total = P.K / BK;
+  const int nk_per = (nk_total + P.nsplit - 1) / P.nsplit;
+  const int kt0 = split * nk_per, kt1 = min(nk_total, kt0 + nk_per);
 
-  for (int t = 0; t < nk; ++t) {
-    char* cur = smem + (t & 1) * (2 * TILE_BYTES);
-    char* nxt = smem + ((t + 1) & 1) * (2 * TILE_BYTES);
-    if (t + 1 < nk) {
-      stage_tile<AK>(A, lda, m0, (t + 1) * BK, M, nxt, wave, lane);
-      stage_tile<BKM>(B, ldb, n0, (t + 1) * BK, N, nxt + TILE_BYTES, wave, lane);
-    }
+  auto stage = [&](int kt, char* buf) {
+#pragma unroll
+    for (int h = 0; h < NHA; ++h) stage_half<AK, NWAVES>(A, lda, m0 + h * 128, kt * BK, M, buf + h * HALF_BYTES, wave, lane);
+#pragma unroll
+    for (int h = 0; h < NHB; ++h) stage_half<BKM, NWAVES>(B, ldb, n0 + h * 128, kt * BK, N, buf + (NHA + h) * HALF_BYTES, wave, lane);
+  };
+  // this wave's operand sub-images
+  const int a_half = (wr * WM) / 128, a_off = (wr * WM) % 128;
+  const int b_half = (wc * 64) / 128, b_off = (wc * 64) % 128;
+
+  if (kt0 < kt1) {
+    stage(kt0, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  for (int t = kt0; t < kt1; ++t) {
+    char* cur = smem + ((t - kt0) & 1) * STAGE;
+    char* nxt = smem + ((t - kt0 + 1) & 1) * STAGE;
+    if (t + 1 < kt1) stage(t + 1, nxt);
+    const char* At = cur + a_half * HALF_BYTES;
+    const char* Bt = cur + (NHA + b_half) * HALF_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      bf16x8 af[2], bfr[2];
+      bf16x8 af[AI], bfr[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = read_frag<AK>(cur, wr * 64 + i * 32, kk, lane);
+      for (int i = 0; i < AI; ++i) af[i] = read_frag<AK>(At, a_off + i * 32, kk, lane);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bfr[j] = read_frag<BKM>(cur + TILE_BYTES, wc * 64 + j * 32, kk, lane);
+      for (int j = 0; j < 2; ++j) bfr[j] = read_frag<BKM>(Bt, b_off + j * 32, kk, lane);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < AI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
@@ -133,27 +176,39 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t* __res
     __syncthreads();
   }
 
-  // epilogue: restage the 128x128 fp32 tile through LDS (operand buffers are free now: 64 KiB = 128*128*4) so each
-  // thread owns 8 consecutive columns of a row -> 16-B coalesced loads/stores for bias / residual / Z / C.
-  float* Cs = reinterpret_cast<float*>(smem);
+  // epilogue: each wave restages 64x64 fp32 blocks of its accumulators through its own 16 KiB LDS region, then the
+  // whole block streams them out: every thread owns 8 consecutive columns of a row (16-B vectors).
+  float* Cw = reinterpret_cast<float*>(smem) + wave * (64 * 64);
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int p = 0; p < WM / 64; ++p) {
+    if (p > 0) __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        Cs[(wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 128 + wc * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
-  __syncthreads();
-  for (int it = 0; it < 8; ++it) {
-    const int id = it * 256 + tid;
-    const int row = id >> 4, c8 = (id & 15) * 8;
-    const int m = m0 + row, n = n0 + c8;
-    if (m >= M || n >= N) continue;
-    float v[8];
-    const float4 lo = *reinterpret_cast<const float4*>(Cs + row * 128 + c8);
-    const float4 hi = *reinterpret_cast<const float4*>(Cs + row * 128 + c8 + 4);
-    v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-    epilogue_store8<uint16_t>(epi, m, n, v, min(8, N - n));
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          Cw[(i2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 64 + j * 32 + (lane & 31)] = acc[2 * p + i2][j][r];
+    __syncthreads();
+    for (int it = 0; it < 8; ++it) {
+      const int id = it * NTHREADS + tid;
+      const int w = id >> 9, rem = id & 511;
+      const int row = rem >> 3, c8 = (rem & 7) * 8;
+      const int m = m0 + (w / WNW) * WM + p * 64 + row, n = n0 + (w % WNW) * 64 + c8;
+      if (m >= M || n >= N) continue;
+      const float* src = reinterpret_cast<const float*>(smem) + w * (64 * 64) + row * 64 + c8;
+      float v[8];
+      const float4 lo = *reinterpret_cast<const float4*>(src);
+      const float4 hi = *reinterpret_cast<const float4*>(src + 4);
+      v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+      const int cnt = min(8, N - n);
+      if (P.nsplit > 1) {  // split-K: fp32 atomic accumulation into a zero-initialised C
+        float* c = (float*)P.epi.C + (size_t)m * P.epi.ldc + n;
+        for (int i = 0; i < cnt; ++i) atomicAdd(c + i, v[i] * P.epi.alpha);
+      } else {
+        epilogue_store8<uint16_t>(P.epi, m, n, v, cnt);
+      }
+    }
   }
 }
 
@@ -205,44 +260,109 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   }
 }
 
-extern "C" int mic_gemm(const mic_gemm_args* a, void* stream) {
+static int fill_epi(const mic_gemm_args* a, EpiArgs& e) {
   MIC_CHECK(a && a->A && a->B && a->C, "mic_gemm: null pointer");
   MIC_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "mic_gemm: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
   MIC_CHECK(a->dtype == MIC_BF16 || a->dtype == MIC_F32, "mic_gemm: bad dtype %d", a->dtype);
   MIC_CHECK(a->c_dtype == a->dtype || a->c_dtype == MIC_F32, "mic_gemm: c_dtype must be dtype or f32");
   MIC_CHECK(!(a->dact && !a->Zin), "mic_gemm: dact needs Zin");
   MIC_CHECK(a->dropout_p >= 0.f && a->dropout_p < 1.f, "mic_gemm: dropout_p out of range");
-  EpiArgs e;
   e.C = a->C; e.ldc = a->ldc; e.c_f32 = (a->c_dtype == MIC_F32);
   e.bias = a->bias; e.act = a->act; e.Zout = a->Zout; e.ldz = a->ldz; e.Zin = a->Zin; e.dact = a->dact;
   e.R = a->R; e.ldr = a->ldr; e.accumulate = a->accumulate;
   e.drop_thr = a->dropout_p > 0.f ? (uint32_t)fminf(a->dropout_p * 4294967296.0f, 4294967295.0f) : 0u;
   e.drop_seed = a->dropout_seed; e.drop_scale = 1.0f / (1.0f - a->dropout_p);
   e.alpha = a->alpha == 0.f ? 1.0f : a->alpha; e.N = a->N;
-  hipStream_t s = (hipStream_t)stream;
   if (a->dtype == MIC_BF16) {
     MIC_CHECK(a->K % BK == 0, "mic_gemm(bf16): K=%d must be a multiple of 64 (zero-pad the reduction dim)", a->K);
     MIC_CHECK(a->lda % 8 == 0 && a->ldb % 8 == 0, "mic_gemm(bf16): lda/ldb must be multiples of 8");
     MIC_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->B & 15) == 0, "mic_gemm(bf16): A/B must be 16-B aligned");
     if (a->a_kmajor) MIC_CHECK(a->M % 8 == 0, "mic_gemm(bf16): k-major A needs M %% 8 == 0");
     if (a->b_kmajor) MIC_CHECK(a->N % 8 == 0, "mic_gemm(bf16): k-major B needs N %% 8 == 0");
-    const int tiles_m = (a->M + BM - 1) / BM, tiles_n = (a->N + BN - 1) / BN;
-    dim3 grid(tiles_m * tiles_n), block(256);
-    const size_t lds = 4 * TILE_BYTES;
-    const uint16_t* A = (const uint16_t*)a->A; const uint16_t* B = (const uint16_t*)a->B;
-#define LAUNCH(AKM, BKMM) hipLaunchKernelGGL((gemm_bf16_kernel<AKM, BKMM>), grid, block, lds, s, A, a->lda, B, a->ldb, a->M, a->N, a->K, tiles_m, tiles_n, e)
-    if (!a->a_kmajor && !a->b_kmajor) LAUNCH(false, false);
-    else if (!a->a_kmajor && a->b_kmajor) LAUNCH(false, true);
-    else if (a->a_kmajor && a->b_kmajor) LAUNCH(true, true);
-    else LAUNCH(true, false);
-#undef LAUNCH
-  } else {
-    dim3 grid((a->N + 63) / 64, (a->M + 63) / 64), block(256);
-    const long sam = a->a_kmajor ? 1 : a->lda, sak = a->a_kmajor ? a->lda : 1;
-    const long sbk = a->b_kmajor ? a->ldb : 1, sbn = a->b_kmajor ? 1 : a->ldb;
-    hipLaunchKernelGGL(gemm_f32_kernel, grid, block, 0, s, (const float*)a->A, sam, sak, (const float*)a->B, sbk, sbn,
-                       a->M, a->N, a->K, e);
+    if (a->split_k > 1)
+      MIC_CHECK(a->c_dtype == MIC_F32 && !a->bias && !a->act && !a->dact && !a->Zout && !a->R && !a->accumulate && a->dropout_p == 0.f,
+                "mic_gemm: split_k accumulates raw fp32 partial sums into a zeroed C (no other epilogue)");
   }
+  return MIC_OK;
+}
+
+template <int WM, int WNW>
+static void launch_cfg(const LaunchTable& tab, int akm, int bkm, hipStream_t s) {
+  constexpr int BM = 2 * WM, BN = 64 * WNW;
+  const size_t lds = 2 * (BM / 128 + BN / 128) * HALF_BYTES;
+  dim3 grid(tab.total_blocks), block(128 * WNW);
+#define LAUNCH(AKM, BKMM)                                                                                              \
+  do {                                                                                                                 \
+    if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WNW, AKM, BKMM>),         \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
+    hipLaunchKernelGGL((gemm_bf16_kernel<WM, WNW, AKM, BKMM>), grid, block, lds, s, tab);                              \
+  } while (0)
+  if (!akm && !bkm) LAUNCH(false, false);
+  else if (!akm && bkm) LAUNCH(false, true);
+  else if (akm && bkm) LAUNCH(true, true);
+  else LAUNCH(true, false);
+#undef LAUNCH
+}
+
+static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
+  LaunchTable tab;
+  tab.count = count;
+  long tiles_big = 0;
+  for (int i = 0; i < count; ++i) {
+    const int sp = args[i].split_k > 1 ? args[i].split_k : 1;
+    tiles_big += (long)((args[i].M + 255) / 256) * ((args[i].N + 255) / 256) * sp;
+  }
+  // 256x256 tiles deliver 2x the FLOPs per operand byte but need >= ~0.8 blocks per CU to pay
+  const bool big = tiles_big >= 200;
+  const int bm = big ? 256 : 128;
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    Problem& p = tab.p[i];
+    if (int rc = fill_epi(&args[i], p.epi)) return rc;
+    MIC_CHECK(args[i].a_kmajor == args[0].a_kmajor && args[i].b_kmajor == args[0].b_kmajor && args[i].dtype == MIC_BF16,
+              "mic_gemm_grouped: all problems of a group must share dtype (bf16) and operand layouts");
+    p.A = (const uint16_t*)args[i].A; p.B = (const uint16_t*)args[i].B;
+    p.lda = args[i].lda; p.ldb = args[i].ldb; p.M = args[i].M; p.N = args[i].N; p.K = args[i].K;
+    p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bm - 1) / bm;
+    p.nsplit = args[i].split_k > 1 ? args[i].split_k : 1;
+    if (p.nsplit > p.K / BK) p.nsplit = p.K / BK;
+    p.block_begin = blocks;
+    blocks += p.tiles_m * p.tiles_n * p.nsplit;
+  }
+  tab.total_blocks = blocks;
+  if (big) launch_cfg<128, 4>(tab, args[0].a_kmajor, args[0].b_kmajor, s);
+  else launch_cfg<64, 2>(tab, args[0].a_kmajor, args[0].b_kmajor, s);
   MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}
+
+extern "C" int mic_gemm(const mic_gemm_args* a, void* stream) {
+  MIC_CHECK(a, "mic_gemm: null args");
+  hipStream_t s = (hipStream_t)stream;
+  if (a->dtype == MIC_BF16) return launch_bf16(a, 1, s);
+  EpiArgs e;
+  if (int rc = fill_epi(a, e)) return rc;
+  MIC_CHECK(a->split_k <= 1, "mic_gemm(f32): split_k is a bf16-path feature");
+  dim3 grid((a->N + 63) / 64, (a->M + 63) / 64), block(256);
+  const long sam = a->a_kmajor ? 1 : a->lda, sak = a->a_kmajor ? a->lda : 1;
+  const long sbk = a->b_kmajor ? a->ldb : 1, sbn = a->b_kmajor ? 1 : a->ldb;
+  hipLaunchKernelGGL(gemm_f32_kernel, grid, block, 0, s, (const float*)a->A, sam, sak, (const float*)a->B, sbk, sbn,
+                     a->M, a->N, a->K, e);
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}
+
+extern "C" int mic_gemm_grouped(const mic_gemm_args* args, int count, void* stream) {
+  MIC_CHECK(args && count >= 1, "mic_gemm_grouped: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  if (args[0].dtype != MIC_BF16) {  // parity mode: plain sequence
+    for (int i = 0; i < count; ++i)
+      if (int rc = mic_gemm(&args[i], stream)) return rc;
+    return MIC_OK;
+  }
+  for (int i = 0; i < count; i += MAX_PROBLEMS) {
+    const int n = count - i < MAX_PROBLEMS ? count - i : MAX_PROBLEMS;
+    if (int rc = launch_bf16(args + i, n, s)) return rc;
+  }
   return MIC_OK;
 }

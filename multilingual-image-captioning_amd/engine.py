@@ -40,6 +40,7 @@ class Engine:
         self.vit_eps = float(store.cfg.clip_vision_config.layer_norm_eps)
         self.p_drop = float(mc.dropout)
         self.embed_scale = math.sqrt(store.d) if mc.scale_embedding else 1.0
+        self._dw_queue = []
         self.grad_progress = None  # callable(offset): every gradient with flat offset < offset is final (DDP overlap)
 
     def _done(self, seg_name: str):
@@ -79,19 +80,33 @@ class Engine:
         return ops.gemm(x, w, out, M, N, K, bias=P.f32(wname + ".b") if bias else None, act=act, zout=zout,
                         residual=residual, dropout_p=p, dropout_seed=drop_seed or 0)
 
-    def linear_bwd(self, wname, x, dy, M, *, dx=None, zin=None, dact=0, dx_accumulate=False, bias=True):
-        """dW = dy^T x (fp32, overwrite), db = colsum(dy), optionally dx = (dy W) [* act'(zin)]."""
+    def linear_bwd(self, wname, x, dy, M, *, dx=None, zin=None, dact=0, dx_accumulate=False, bias=True, defer=False):
+        """dW = dy^T x (fp32, overwrite), db = colsum(dy), optionally dx = (dy W) [* act'(zin)].
+        defer=True queues the weight-gradient GEMM (nothing but the optimizer depends on it): the caller keeps dy and x
+        intact until flush_dw() launches the layer's queue as ONE grouped GEMM (36..256-tile problems fill the chip
+        only together)."""
         P = self.P
         w = P.w(wname + ".w")
         N, K = w.shape
         Mp = _rup(M, ROWPAD)
-        ops.gemm(dy, x, P.g(wname + ".w"), N, K, Mp, a_kmajor=True, b_kmajor=True)
+        if defer:
+            self._dw_queue.append((ops.gemm_args(dy, x, P.g(wname + ".w"), N, K, Mp, a_kmajor=True, b_kmajor=True), wname, bias))
+        else:
+            ops.gemm(dy, x, P.g(wname + ".w"), N, K, Mp, a_kmajor=True, b_kmajor=True)
         if bias:
             ops.colsum(dy, P.g(wname + ".b"), M, N, dy.stride(0))
         if dx is not None:
             ops.gemm(dy, w, dx, M, K, N, b_kmajor=True, zin=zin, dact=dact, accumulate=dx_accumulate)
-        self._done(wname + (".b" if bias else ".w"))
+        if not defer:
+            self._done(wname + (".b" if bias else ".w"))
         return dx
+
+    def flush_dw(self):
+        if self._dw_queue:
+            ops.gemm_grouped([q[0] for q in self._dw_queue])
+            _, wname, bias = self._dw_queue[-1]
+            self._dw_queue = []
+            self._done(wname + (".b" if bias else ".w"))
 
     # ------------------------------------------------------------------ ViT
     def vit_forward(self, pixels: torch.Tensor, save: bool, trunc_int32: bool = False):
@@ -159,17 +174,18 @@ class Engine:
             lse = self.vec(tag + "lse", B * H * S)
             x_in = self.buf(f"v{l - 1}.xo", Mv, vd) if l > 0 else self.buf("v.x0", Mv, vd)
             dz = self.buf("vb.dz", Mv, vf)
-            self.linear_bwd(p + "fc2", u, dx, Mv, dx=dz, zin=z, dact=L.ACT_QUICK_GELU)
+            self.linear_bwd(p + "fc2", u, dx, Mv, dx=dz, zin=z, dact=L.ACT_QUICK_GELU, defer=True)
             da = self.buf("vb.da", Mv, vd)
-            self.linear_bwd(p + "fc1", a2, dz, Mv, dx=da)
+            self.linear_bwd(p + "fc1", a2, dz, Mv, dx=da, defer=True)
             dxm = self.buf("vb.dxm", Mv, vd)
             ops.layernorm_bwd(xm, P.f32(p + "ln2.g"), st2[0], st2[1], da, dxm, P.g(p + "ln2.g"), P.g(p + "ln2.b"), rows=Mv, dres=dx)
             dctx = self.buf("vb.dctx", Mv, vd)
-            self.linear_bwd(p + "o", ctx, dxm, Mv, dx=dctx)
+            self.linear_bwd(p + "o", ctx, dxm, Mv, dx=dctx, defer=True)
             dqkv = self.buf("vb.dqkv", Mv, 3 * vd)
             ops.attn_bwd(qkv, qkv[:, vd:], qkv[:, 2 * vd:], ctx, dctx, lse, dqkv, dqkv[:, vd:], dqkv[:, 2 * vd:], B, H, S, S,
                          ldq=3 * vd, ldk=3 * vd, ldv=3 * vd, ldo=vd, lddo=vd, lddq=3 * vd, lddk=3 * vd, lddv=3 * vd)
-            self.linear_bwd(p + "qkv", a1, dqkv, Mv, dx=da)
+            self.linear_bwd(p + "qkv", a1, dqkv, Mv, dx=da, defer=True)
+            self.flush_dw()  # before LN1 backward overwrites dx (the fc2 gradient operand)
             ops.layernorm_bwd(x_in, P.f32(p + "ln1.g"), st1[0], st1[1], da, dx, P.g(p + "ln1.g"), P.g(p + "ln1.b"), rows=Mv, dres=dxm)
         emb = self.buf("v.emb", Mv, vd)
         st = self.buf("v.pre.stats", 2, _rup(Mv, ROWPAD), torch.float32)
@@ -259,9 +275,18 @@ class Engine:
         ops.colsum(dlogits, P.g("flb"), M, P.Vpad, dlogits.stride(0))
         ops.gemm(dlogits, hf, P.g("shared"), P.Vpad, d, Mp, a_kmajor=True, b_kmajor=True)
         dhf = self.buf("db.dhf", M, d)
-        ops.gemm(dlogits, P.w("shared"), dhf, M, d, P.Vpad, b_kmajor=True)
+        if self.dt == torch.bfloat16:
+            # tiny output, K = Vpad: split the reduction over 8 workgroups per tile (fp32 atomics), then round once
+            dhf32 = self.buf("db.dhf32", M, d, torch.float32)
+            dhf32.zero_()
+            ops.gemm(dlogits, P.w("shared"), dhf32, M, d, P.Vpad, b_kmajor=True, split_k=8)
+            ops.cast2d(dhf32, dhf, M, d, d, d)
+        else:
+            ops.gemm(dlogits, P.w("shared"), dhf, M, d, P.Vpad, b_kmajor=True)
         dx = self.buf("db.dx", M, d)
-        dxm = self.buf("db.dxm", M, d)
+        dxm = self.buf("db.dxm_a", M, d)   # masked grad entering the FFN branch
+        dxm_b = self.buf("db.dxm_b", M, d)  # ... the cross-attention branch
+        dxm_c = self.buf("db.dxm_c", M, d)  # ... the self-attention branch (kept apart: deferred dW GEMMs read them)
         stf = self.buf("d.f.stats", 2, _rup(M, ROWPAD), torch.float32)
         x_last = self.buf(f"d{P.L - 1}.x3", M, d)
         ops.layernorm_bwd(x_last, P.f32("dec.ln_f.g"), stf[0], stf[1], dhf, dx, P.g("dec.ln_f.g"), P.g("dec.ln_f.b"), rows=M,
@@ -278,30 +303,31 @@ class Engine:
             x_in = self.buf(f"d{l - 1}.x3", M, d) if l > 0 else self.buf("d.x0", M, d)
             # --- FFN branch: x3 = x2 + drop(fc2(gelu(fc1(LN(x2)))));  dxm = dropout-masked dx3
             dz = self.buf("db.dz", M, f)
-            self.linear_bwd(p + "fc2", u, dxm, M, dx=dz, zin=z, dact=self.gelu)
+            self.linear_bwd(p + "fc2", u, dxm, M, dx=dz, zin=z, dact=self.gelu, defer=True)
             da = self.buf("db.da", M, d)
-            self.linear_bwd(p + "fc1", a_ff, dz, M, dx=da)
+            self.linear_bwd(p + "fc1", a_ff, dz, M, dx=da, defer=True)
             dx2 = self.buf("db.dx2", M, d)
             ops.layernorm_bwd(x2, P.f32(p + "ln_ff.g"), stats[4], stats[5], da, dx2, P.g(p + "ln_ff.g"), P.g(p + "ln_ff.b"), rows=M,
-                              dres=dx, dxm=dxm, dropout_p=pd, dropout_seed=sd(11 + 3 * l))
+                              dres=dx, dxm=dxm_b, dropout_p=pd, dropout_seed=sd(11 + 3 * l))
             # --- cross-attention branch
             dctx = self.buf("db.dctx", M, d)
-            self.linear_bwd(p + "co", cctx, dxm, M, dx=dctx)
+            self.linear_bwd(p + "co", cctx, dxm_b, M, dx=dctx, defer=True)
             dq = self.buf("db.dq", M, d)
             dkv = self.buf("db.dkv", Mv, 2 * d)
             ops.attn_bwd(cq, ckv, ckv[:, d:], cctx, dctx, clse, dq, dkv, dkv[:, d:], B, H, T, S, ldq=d, ldk=2 * d, ldv=2 * d, ldo=d,
                          lddo=d, lddq=d, lddk=2 * d, lddv=2 * d)
-            self.linear_bwd(p + "cq", a_ca, dq, M, dx=da)
-            self.linear_bwd(p + "ckv", ehs, dkv, Mv, dx=dehs, dx_accumulate=(l != P.L - 1))
+            self.linear_bwd(p + "cq", a_ca, dq, M, dx=da, defer=True)
+            self.linear_bwd(p + "ckv", ehs, dkv, Mv, dx=dehs, dx_accumulate=(l != P.L - 1), defer=True)
             dx1 = self.buf("db.dx1", M, d)
             ops.layernorm_bwd(x1, P.f32(p + "ln_ca.g"), stats[2], stats[3], da, dx1, P.g(p + "ln_ca.g"), P.g(p + "ln_ca.b"), rows=M,
-                              dres=dx2, dxm=dxm, dropout_p=pd, dropout_seed=sd(10 + 3 * l))
+                              dres=dx2, dxm=dxm_c, dropout_p=pd, dropout_seed=sd(10 + 3 * l))
             # --- self-attention branch
-            self.linear_bwd(p + "so", ctx, dxm, M, dx=dctx)
+            self.linear_bwd(p + "so", ctx, dxm_c, M, dx=dctx, defer=True)
             dqkv = self.buf("db.dqkv", M, 3 * d)
             ops.attn_bwd(qkv, qkv[:, d:], qkv[:, 2 * d:], ctx, dctx, lse, dqkv, dqkv[:, d:], dqkv[:, 2 * d:], B, H, T, T, ldq=3 * d,
                          ldk=3 * d, ldv=3 * d, ldo=d, lddo=d, lddq=3 * d, lddk=3 * d, lddv=3 * d, key_mask=key_mask, causal=True)
-            self.linear_bwd(p + "qkv", a_sa, dqkv, M, dx=da)
+            self.linear_bwd(p + "qkv", a_sa, dqkv, M, dx=da, defer=True)
+            self.flush_dw()  # the layer's 7 weight-gradient GEMMs as one grouped launch (before dxm_a is rewritten)
             if l > 0:
                 ops.layernorm_bwd(x_in, P.f32(p + "ln_sa.g"), stats[0], stats[1], da, dx, P.g(p + "ln_sa.g"), P.g(p + "ln_sa.b"), rows=M,
                                   dres=dx1, dxm=dxm, dropout_p=pd, dropout_seed=sd(12 + 3 * (l - 1)))

@@ -31,10 +31,9 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, *, a_kmajor=False, b_kmajor=False,
-         bias=None, act=0, zout=None, zin=None, dact=0, residual=None, accumulate=False, dropout_p=0.0, dropout_seed=0,
-         alpha=1.0, lda=None, ldb=None, ldc=None, ldz=None, ldr=None):
-    """out[M,N] = epi(op(a) @ op(b)); a: [M,K] (or [K,M] if a_kmajor); b: [N,K] (or [K,N] if b_kmajor)."""
+def gemm_args(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, *, a_kmajor=False, b_kmajor=False,
+              bias=None, act=0, zout=None, zin=None, dact=0, residual=None, accumulate=False, dropout_p=0.0, dropout_seed=0,
+              alpha=1.0, lda=None, ldb=None, ldc=None, ldz=None, ldr=None, split_k=0) -> "L.GemmArgs":
     g = L.GemmArgs()
     g.dtype, g.c_dtype = _dt(a), _dt(out)
     g.M, g.N, g.K = M, N, K
@@ -48,8 +47,21 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K:
     g.ldz = ldz if ldz is not None else (zz.stride(0) if zz is not None else 0)
     g.R, g.ldr = _p(residual), ldr if ldr is not None else (residual.stride(0) if residual is not None else 0)
     g.accumulate, g.dropout_p, g.dropout_seed, g.alpha = int(accumulate), float(dropout_p), int(dropout_seed) & 0xFFFFFFFF, float(alpha)
+    g.split_k = int(split_k)
+    return g
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, **kw):
+    """out[M,N] = epi(op(a) @ op(b)); a: [M,K] (or [K,M] if a_kmajor); b: [N,K] (or [K,N] if b_kmajor)."""
+    g = gemm_args(a, b, out, M, N, K, **kw)
     L.check(L.lib().mic_gemm(C.byref(g), _stream()), "mic_gemm")
     return out
+
+
+def gemm_grouped(arg_list):
+    """Several GEMMs (same dtype / operand layouts) in as few launches as possible."""
+    arr = (L.GemmArgs * len(arg_list))(*arg_list)
+    L.check(L.lib().mic_gemm_grouped(arr, len(arg_list), _stream()), "mic_gemm_grouped")
 
 
 def layernorm_fwd(x, gamma, beta, eps, y, mean=None, rstd=None, rows=None, dropout_p=0.0, dropout_seed=0):

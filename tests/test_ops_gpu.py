@@ -87,6 +87,49 @@ def test_gemm_epilogue_full(dev, dtype):
     assert relerr(dW, dYm.float().T @ A.float() + 1.0) < (2e-5 if dtype == torch.float32 else 2e-3)
 
 
+@pytest.mark.parametrize("akm,bkm", [(False, False), (False, True), (True, True)])
+def test_gemm_big_tiles_split_k_and_grouped(dev, akm, bkm):
+    """256x256 configuration (chosen when a launch has >= 200 big tiles), split-K via fp32 atomics, grouped launches."""
+    from mic_amd import ops
+
+    g = torch.Generator().manual_seed(11 + akm + 2 * bkm)
+    dt = torch.bfloat16
+
+    def mk(M, N, K):
+        A = rnd((K, M) if akm else (M, K), g, dt)
+        B = rnd((K, N) if bkm else (N, K), g, dt)
+        ref = (A.float().T if akm else A.float()) @ (B.float() if bkm else B.float().T)
+        return A.to(dev), B.to(dev), ref
+
+    # big tiles with ragged edges in both dims: 15 x 14 = 210 tiles of 256
+    M, N, K = 3720, 3400, 128
+    A, B, ref = mk(M, N, K)
+    bias = torch.randn(N, generator=g)
+    out = torch.full((M, N), float("nan"), dtype=dt, device=dev)
+    ops.gemm(A, B, out, M, N, K, a_kmajor=akm, b_kmajor=bkm, bias=bias.to(dev))
+    torch.cuda.synchronize()
+    assert relerr(out, ref + bias) < tol(dt)
+    # split-K: tiny output, long reduction, fp32 atomics into a zeroed C (small and big tile configs)
+    for (M, N, K, sk) in ((256, 136, 4096, 8), (1024, 1024, 8192, 16)):
+        A, B, ref = mk(M, N, K)
+        c = torch.zeros((M, N), dtype=torch.float32, device=dev)
+        ops.gemm(A, B, c, M, N, K, a_kmajor=akm, b_kmajor=bkm, split_k=sk)
+        torch.cuda.synchronize()
+        assert relerr(c, ref) < 2e-3
+    # grouped: 5 problems of different shapes in one launch
+    probs, refs, outs = [], [], []
+    for (M, N, K) in ((768, 768, 256), (1024, 264, 128), (136, 1024, 192), (2304, 768, 128), (384, 384, 64)):
+        A, B, ref = mk(M, N, K)
+        c = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev)
+        probs.append(ops.gemm_args(A, B, c, M, N, K, a_kmajor=akm, b_kmajor=bkm))
+        refs.append(ref)
+        outs.append((A, B, c))
+    ops.gemm_grouped(probs)
+    torch.cuda.synchronize()
+    for (A, B, c), ref in zip(outs, refs):
+        assert relerr(c, ref) < 2e-3
+
+
 def test_gemm_rejects_bad_args(dev):
     from mic_amd import _lib, ops
 
