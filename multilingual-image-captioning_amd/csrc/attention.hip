@@ -18,10 +18,11 @@ template <> struct Tile<uint16_t> {
   // element (row, col) -> byte offset; 16-B chunk index XOR-swizzled by row (conflict-free ds_read_b128 fragments)
   static __device__ __forceinline__ int off(int row, int col) { return row * 128 + ((((col >> 3) ^ (row & 7)) << 4) | ((col & 7) << 1)); }
   // stage rows [0,nrows) x 64 cols from src (row stride ld); rows >= nrows are zero
+  template <int NT = 64>
   static __device__ __forceinline__ void stage(char* t, const uint16_t* src, int ld, int nrows, int lane) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int idx = it * 64 + lane, row = idx >> 3, c = idx & 7;
+    for (int it = 0; it < 512 / NT; ++it) {
+      const int idx = it * NT + lane, row = idx >> 3, c = idx & 7;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (row < nrows) v = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + c * 8);
       *reinterpret_cast<uint4*>(t + row * 128 + ((c ^ (row & 7)) << 4)) = v;
@@ -60,11 +61,12 @@ template <> struct Tile<uint16_t> {
 
 template <> struct Tile<float> {
   static constexpr int BYTES = 64 * 64 * 4;
+  template <int NT = 64>
   static __device__ __forceinline__ void stage(char* t, const float* src, int ld, int nrows, int lane) {
     float* f = reinterpret_cast<float*>(t);
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const int idx = it * 64 + lane, row = idx >> 4, c = idx & 15;
+    for (int it = 0; it < 1024 / NT; ++it) {
+      const int idx = it * NT + lane, row = idx >> 4, c = idx & 15;
       float4 v = make_float4(0, 0, 0, 0);
       if (row < nrows) v = *reinterpret_cast<const float4*>(src + (size_t)row * ld + c * 4);
       *reinterpret_cast<float4*>(f + row * 64 + c * 4) = v;
@@ -174,13 +176,17 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(int H, int Tq, int Tk, con
 }
 
 // ------------------------------------------------------------------ backward
+// 256 threads = 4 waves (one per SIMD) share one (batch, head) problem: same LDS footprint as a single-wave design but
+// 4x the waves per CU and 1/4 of the serial MFMA/LDS chain per wave.  Phase 1: wave w owns the (ib, jb) = (w>>1, w&1)
+// quadrant of S^T / dP^T and writes its quadrant of the P and dS tiles.  Phase 2: wave w owns output block
+// (w>>1, w&1) of dQ, dK and dV.
 template <typename T>
-__global__ __launch_bounds__(64) void attn_bwd_kernel(int H, int Tq, int Tk, const T* __restrict__ q, int ldq,
-                                                      const T* __restrict__ k, int ldk, const T* __restrict__ v, int ldv,
-                                                      const T* __restrict__ out, int ldo, const T* __restrict__ dout, int lddo,
-                                                      const float* __restrict__ lse_in, const int32_t* __restrict__ key_mask,
-                                                      int causal, T* __restrict__ dq, int lddq, T* __restrict__ dk, int lddk,
-                                                      T* __restrict__ dv, int lddv) {
+__global__ __launch_bounds__(256) void attn_bwd_kernel(int H, int Tq, int Tk, const T* __restrict__ q, int ldq,
+                                                       const T* __restrict__ k, int ldk, const T* __restrict__ v, int ldv,
+                                                       const T* __restrict__ out, int ldo, const T* __restrict__ dout, int lddo,
+                                                       const float* __restrict__ lse_in, const int32_t* __restrict__ key_mask,
+                                                       int causal, T* __restrict__ dq, int lddq, T* __restrict__ dk, int lddk,
+                                                       T* __restrict__ dv, int lddv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TB = Tile<T>::BYTES;
   char* Qt = smem;
@@ -191,93 +197,93 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(int H, int Tq, int Tk, con
   char* dSt = smem + 5 * TB;
   float* lse_s = reinterpret_cast<float*>(smem + 6 * TB);
   float* delta_s = lse_s + 64;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / H, h = blockIdx.x % H;
-  Tile<T>::stage(Qt, q + (size_t)b * Tq * ldq + h * 64, ldq, Tq, lane);
-  Tile<T>::stage(Kt, k + (size_t)b * Tk * ldk + h * 64, ldk, Tk, lane);
-  Tile<T>::stage(Vt, v + (size_t)b * Tk * ldv + h * 64, ldv, Tk, lane);
-  Tile<T>::stage(dOt, dout + (size_t)b * Tq * lddo + h * 64, lddo, Tq, lane);
+  Tile<T>::template stage<256>(Qt, q + (size_t)b * Tq * ldq + h * 64, ldq, Tq, tid);
+  Tile<T>::template stage<256>(Kt, k + (size_t)b * Tk * ldk + h * 64, ldk, Tk, tid);
+  Tile<T>::template stage<256>(Vt, v + (size_t)b * Tk * ldv + h * 64, ldv, Tk, tid);
+  Tile<T>::template stage<256>(dOt, dout + (size_t)b * Tq * lddo + h * 64, lddo, Tq, tid);
   {
-    float dl = 0.f, ls = 0.f;
-    if (lane < Tq) {
-      const T* orow = out + ((size_t)b * Tq + lane) * ldo + h * 64;
-      const T* drow = dout + ((size_t)b * Tq + lane) * lddo + h * 64;
+    // delta_i = dO_i . O_i : thread t covers 16 of the 64 dims of row t>>2
+    const int row = tid >> 2, part = tid & 3;
+    float dl = 0.f;
+    if (row < Tq) {
+      const T* orow = out + ((size_t)b * Tq + row) * ldo + h * 64 + part * 16;
+      const T* drow = dout + ((size_t)b * Tq + row) * lddo + h * 64 + part * 16;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
+      for (int c = 0; c < 2; ++c) {
         float a[8], g[8];
         ld8(orow + c * 8, a);
         ld8(drow + c * 8, g);
 #pragma unroll
         for (int e = 0; e < 8; ++e) dl += a[e] * g[e];
       }
-      ls = lse_in[((size_t)b * H + h) * Tq + lane];
     }
-    lse_s[lane] = ls;
-    delta_s[lane] = dl;
+    dl += __shfl_xor(dl, 1, 64);
+    dl += __shfl_xor(dl, 2, 64);
+    if (part == 0) delta_s[row] = dl;
+    if (tid < 64) lse_s[tid] = tid < Tq ? lse_in[((size_t)b * H + h) * Tq + tid] : 0.f;
   }
   const unsigned long long km = load_key_mask(key_mask, b, Tk, lane);
   __syncthreads();
   const int nib = (Tq + 31) >> 5, njb = (Tk + 31) >> 5;
-  // P and dS tiles (rows = queries); rows >= Tq and keys >= Tk are exact zeros
-  for (int ib = 0; ib < 2; ++ib) {
+  {
+    // P and dS tiles (rows = queries); rows >= Tq and keys >= Tk are exact zeros
+    const int ib = wave >> 1, jb = wave & 1;
     const int i = ib * 32 + (lane & 31);
     const float lse_i = lse_s[i], delta_i = delta_s[i];
-    for (int jb = 0; jb < 2; ++jb) {
-      f32x16 s, dp;
-      zero16(s); zero16(dp);
-      const bool live = ib < nib && jb < njb;
-      if (live) {
-        Tile<T>::template mma<false, false>(s, Kt, jb * 32, Qt, ib * 32, lane);
-        Tile<T>::template mma<false, false>(dp, Vt, jb * 32, dOt, ib * 32, lane);
-      }
+    f32x16 sacc, dp;
+    zero16(sacc); zero16(dp);
+    const bool live = ib < nib && jb < njb;
+    if (live) {
+      Tile<T>::template mma<false, false>(sacc, Kt, jb * 32, Qt, ib * 32, lane);
+      Tile<T>::template mma<false, false>(dp, Vt, jb * 32, dOt, ib * 32, lane);
+    }
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        float pv[4], dsv[4];
+    for (int g4 = 0; g4 < 4; ++g4) {
+      float pv[4], dsv[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = g4 * 4 + e;
-          const int j = jb * 32 + acc_row(r, lane);
-          const bool ok = live && i < Tq && j < Tk && (!causal || j <= i) && ((km >> j) & 1ull);
-          const float p = ok ? __expf(s[r] * SCALE - lse_i) : 0.f;
-          pv[e] = p;
-          dsv[e] = p * (dp[r] - delta_i) * SCALE;
-        }
-        Tile<T>::store4(Pt, i, jb * 32 + 8 * g4 + 4 * (lane >> 5), pv);
-        Tile<T>::store4(dSt, i, jb * 32 + 8 * g4 + 4 * (lane >> 5), dsv);
+      for (int e = 0; e < 4; ++e) {
+        const int r = g4 * 4 + e;
+        const int j = jb * 32 + acc_row(r, lane);
+        const bool ok = live && i < Tq && j < Tk && (!causal || j <= i) && ((km >> j) & 1ull);
+        const float p = ok ? __expf(sacc[r] * SCALE - lse_i) : 0.f;
+        pv[e] = p;
+        dsv[e] = p * (dp[r] - delta_i) * SCALE;
       }
+      Tile<T>::store4(Pt, i, jb * 32 + 8 * g4 + 4 * (lane >> 5), pv);
+      Tile<T>::store4(dSt, i, jb * 32 + 8 * g4 + 4 * (lane >> 5), dsv);
     }
   }
   __syncthreads();
-  for (int ib = 0; ib < nib; ++ib)
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
+  {
+    const int xb = wave >> 1, db = wave & 1;
+    const int d = db * 32 + (lane & 31);
+    if (xb < nib) {
       f32x16 a;
       zero16(a);
-      Tile<T>::template mma<false, true>(a, dSt, ib * 32, Kt, db * 32, lane);  // dQ = dS K
-      const int d = db * 32 + (lane & 31);
+      Tile<T>::template mma<false, true>(a, dSt, xb * 32, Kt, db * 32, lane);  // dQ = dS K
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int i = ib * 32 + acc_row(r, lane);
+        const int i = xb * 32 + acc_row(r, lane);
         if (i < Tq) ElemT<T>::st(dq + ((size_t)b * Tq + i) * lddq + h * 64 + d, a[r]);
       }
     }
-  for (int jb = 0; jb < njb; ++jb)
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
+    if (xb < njb) {
       f32x16 a, c;
       zero16(a); zero16(c);
-      Tile<T>::template mma<true, true>(a, dSt, jb * 32, Qt, db * 32, lane);   // dK = dS^T Q
-      Tile<T>::template mma<true, true>(c, Pt, jb * 32, dOt, db * 32, lane);   // dV = P^T dO
-      const int d = db * 32 + (lane & 31);
+      Tile<T>::template mma<true, true>(a, dSt, xb * 32, Qt, db * 32, lane);   // dK = dS^T Q
+      Tile<T>::template mma<true, true>(c, Pt, xb * 32, dOt, db * 32, lane);   // dV = P^T dO
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int j = jb * 32 + acc_row(r, lane);
+        const int j = xb * 32 + acc_row(r, lane);
         if (j < Tk) {
           ElemT<T>::st(dk + ((size_t)b * Tk + j) * lddk + h * 64 + d, a[r]);
           ElemT<T>::st(dv + ((size_t)b * Tk + j) * lddv + h * 64 + d, c[r]);
         }
       }
     }
+  }
 }
 
 template <typename K>
@@ -316,7 +322,7 @@ extern "C" int mic_attn_bwd(int dtype, int B, int H, int Tq, int Tk, const void*
   MIC_CHECK(q && k && v && out && dout && lse && dq && dk && dv, "mic_attn_bwd: null pointer");
   const int align = dtype == MIC_BF16 ? 8 : 4;
   MIC_CHECK(ldq % align == 0 && ldk % align == 0 && ldv % align == 0 && ldo % align == 0 && lddo % align == 0, "mic_attn_bwd: row strides must keep 16-B alignment");
-  dim3 grid(B * H), block(64);
+  dim3 grid(B * H), block(256);
   if (dtype == MIC_BF16) {
     const size_t lds = 6 * Tile<uint16_t>::BYTES + 512;
     hipLaunchKernelGGL(attn_bwd_kernel<uint16_t>, grid, block, lds, (hipStream_t)stream, H, Tq, Tk, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk, (const uint16_t*)v, ldv, (const uint16_t*)out, ldo, (const uint16_t*)dout, lddo, lse, key_mask, causal, (uint16_t*)dq, lddq, (uint16_t*)dk, lddk, (uint16_t*)dv, lddv);

@@ -62,15 +62,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int width, const 
 // dx = (dres) + rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat));  dgamma += dy*xhat, dbeta += dy.
 // Each wave walks rows with a grid stride keeping per-column partial dgamma/dbeta in registers; the block combines
 // its 4 waves through LDS and issues one fp32 atomic per column.
+#define LNB_WAVES 8  // waves per backward block: atomics scale with the BLOCK count, latency hiding with the WAVE count
 template <typename T>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int width, const T* __restrict__ x,
+__global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(int rows, int width, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const T* __restrict__ dy,
                                                      const T* __restrict__ dres, T* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      T* __restrict__ dxm, uint32_t thr_m, uint32_t seed_m, float scale_m,
                                                      uint32_t thr_in, uint32_t seed_in, float scale_in) {
-  __shared__ float red[2][4][64 * 8 + 8];
+  __shared__ float red[2][LNB_WAVES][64 * 8 + 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = width >> 3;
   float dg[LN_MAXC][8], db[LN_MAXC][8];
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int width, const 
 #pragma unroll
     for (int i = 0; i < 8; ++i) { dg[c][i] = 0.f; db[c][i] = 0.f; }
 
-  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+  for (int row = blockIdx.x * LNB_WAVES + wave; row < rows; row += gridDim.x * LNB_WAVES) {
     const T* xr = x + (size_t)row * width;
     const T* dyr = dy + (size_t)row * width;
     const float mu = mean[row], rs = rstd[row];
@@ -142,12 +143,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int width, const 
       for (int i = 0; i < 8; ++i) { red[0][wave][lane * 8 + i] = dg[c][i]; red[1][wave][lane * 8 + i] = db[c][i]; }
     }
     __syncthreads();
-    // 512 columns of this chunk group; thread t handles columns t and t+256
-    for (int col = threadIdx.x; col < 512; col += 256) {
+    // 512 columns of this chunk group
+    for (int col = threadIdx.x; col < 512; col += 64 * LNB_WAVES) {
       const int gcol = c * 512 + col;  // = (lane' + c*64)*8 + i with lane'*8+i = col
       if (gcol < width) {
-        const float a = red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col];
-        const float b = red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col];
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < LNB_WAVES; ++w) { a += red[0][w][col]; b += red[1][w][col]; }
         if (dgamma) atomicAdd(dgamma + gcol, a);
         if (dbeta) atomicAdd(dbeta + gcol, b);
       }
@@ -180,9 +182,9 @@ extern "C" int mic_layernorm_bwd(int dtype, int rows, int width, const void* x, 
                                  uint32_t in_dropout_seed, void* stream) {
   MIC_CHECK(rows > 0 && width > 0 && width % 8 == 0 && width <= 64 * 8 * LN_MAXC, "mic_layernorm_bwd: bad shape rows=%d width=%d", rows, width);
   MIC_CHECK(x && gamma && mean && rstd && dy && dx, "mic_layernorm_bwd: null pointer");
-  int nblk = (rows + 3) / 4;
-  if (nblk > 1024) nblk = 1024;
-  dim3 grid(nblk), block(256);
+  int nblk = (rows + LNB_WAVES - 1) / LNB_WAVES;
+  if (nblk > 256) nblk = 256;  // each block ends with 2*width fp32 atomics: keep the block count low
+  dim3 grid(nblk), block(64 * LNB_WAVES);
   const uint32_t thr_m = dxm ? thr_of(dropout_p) : 0u, thr_in = thr_of(in_dropout_p);
   const float sm = 1.0f / (1.0f - dropout_p), si = 1.0f / (1.0f - in_dropout_p);
   if (dtype == MIC_BF16)

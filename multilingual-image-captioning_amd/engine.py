@@ -94,11 +94,11 @@ class Engine:
         else:
             ops.gemm(dy, x, P.g(wname + ".w"), N, K, Mp, a_kmajor=True, b_kmajor=True)
         if bias:
-            ops.colsum(dy, P.g(wname + ".b"), M, N, dy.stride(0))
+            ops.colsum(dy, P.g(wname + ".b"), M, N, dy.stride(0), accumulate=True)  # region pre-zeroed once per step
         if dx is not None:
             ops.gemm(dy, w, dx, M, K, N, b_kmajor=True, zin=zin, dact=dact, accumulate=dx_accumulate)
         if not defer:
-            self._done(wname + (".b" if bias else ".w"))
+            self._done(wname + ".w")
         return dx
 
     def flush_dw(self):
@@ -106,7 +106,7 @@ class Engine:
             ops.gemm_grouped([q[0] for q in self._dw_queue])
             _, wname, bias = self._dw_queue[-1]
             self._dw_queue = []
-            self._done(wname + (".b" if bias else ".w"))
+            self._done(wname + ".w")
 
     # ------------------------------------------------------------------ ViT
     def vit_forward(self, pixels: torch.Tensor, save: bool, trunc_int32: bool = False):

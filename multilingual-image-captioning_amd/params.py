@@ -9,7 +9,7 @@ Device layout (one flat fp32 master buffer; same offsets for the compute copy, g
   * Segments are ordered as backward produces their gradients (logits bias, decoder top->bottom, embedding,
     projection, ViT top->bottom) so gradient all-reduce buckets are contiguous slices that complete in order; every
     parameter whose gradient is accumulated with atomics (LayerNorm scale/bias, class/position embeddings) lives in one
-    trailing region that a single memset clears.
+    trailing region that a single memset clears (bias column sums included: no per-call memsets).
 """
 from __future__ import annotations
 
@@ -87,25 +87,29 @@ class ParamStore:
             off = _rup(off + self.segs[name].numel, ALIGN)
 
         d, f, vd, vf = self.d, self.ffn, self.vd, self.vffn
-        # ---- dense region, in backward-completion order
+        # ---- dense region (GEMM-written weight gradients), in backward-completion order
         add("flb", (self.Vpad,))
+        dec_lin = (("fc2", (d, f)), ("fc1", (f, d)), ("co", (d, d)), ("cq", (d, d)), ("ckv", (2 * d, d)), ("so", (d, d)), ("qkv", (3 * d, d)))
+        vit_lin = (("fc2", (vd, vf)), ("fc1", (vf, vd)), ("o", (vd, vd)), ("qkv", (3 * vd, vd)))
         for l in reversed(range(self.L)):
-            p = f"dec{l}."
-            for n, shp in (("fc2.w", (d, f)), ("fc2.b", (d,)), ("fc1.w", (f, d)), ("fc1.b", (f,)),
-                           ("co.w", (d, d)), ("co.b", (d,)), ("cq.w", (d, d)), ("cq.b", (d,)), ("ckv.w", (2 * d, d)), ("ckv.b", (2 * d,)),
-                           ("so.w", (d, d)), ("so.b", (d,)), ("qkv.w", (3 * d, d)), ("qkv.b", (3 * d,))):
-                add(p + n, shp)
+            for n, shp in dec_lin:
+                add(f"dec{l}.{n}.w", shp)
         add("shared", (self.Vpad, d))
         add("vp.w", (d, vd))
-        add("vp.b", (d,))
         for l in reversed(range(self.vL)):
-            p = f"vit{l}."
-            for n, shp in (("fc2.w", (vd, vf)), ("fc2.b", (vd,)), ("fc1.w", (vf, vd)), ("fc1.b", (vf,)),
-                           ("o.w", (vd, vd)), ("o.b", (vd,)), ("qkv.w", (3 * vd, vd)), ("qkv.b", (3 * vd,))):
-                add(p + n, shp)
+            for n, shp in vit_lin:
+                add(f"vit{l}.{n}.w", shp)
         add("patch.w", (vd, self.ps * self.ps * 3))
         self.atomic_begin = off
-        # ---- gradients accumulated with atomics: cleared by one memset
+        # ---- gradients accumulated with atomics (bias column sums, LayerNorm scale/bias, class/position embeddings):
+        #      one trailing region, cleared by one memset per step
+        for l in reversed(range(self.L)):
+            for n, shp in dec_lin:
+                add(f"dec{l}.{n}.b", (shp[0],))
+        add("vp.b", (d,))
+        for l in reversed(range(self.vL)):
+            for n, shp in vit_lin:
+                add(f"vit{l}.{n}.b", (shp[0],))
         add("dec.ln_f.g", (d,)); add("dec.ln_f.b", (d,))
         for l in range(self.L):
             for n in ("ln_sa", "ln_ca", "ln_ff"):
