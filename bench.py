@@ -71,6 +71,39 @@ def cpu_baseline(seconds_budget=25.0):
             "sample": f"oracle (torch-CPU fp32 restatement, not Flax) fwd+bwd, full-size model, B=8 x {n // 8} timed iters after 1 warm-up, no optimizer"}
 
 
+BEAM_GFLOP_PER_CAPTION = 230.0  # 4 rows x 63 steps x 868.5 MF + encoder/cross-KV once
+
+
+def bench_generate(model, cfg, dev, batch=256, langs=(250004,), max_length=64, seed=99):
+    """BASELINE configs[3]: beam-4 `.generate`, forced-BOS language, max_len 64, KV-cached, batch 256 on one GPU.
+    final_logits_bias[eos] = -1e9 keeps every run at exactly 63 decoder steps (ForcedEOS still fires at the last step)."""
+    import numpy as np
+    import torch
+
+    st = model.store
+    eos = cfg.mbart_config.eos_token_id
+    st.f32("flb")[eos] = -1e9
+    st.refresh_lp()
+    rng = np.random.default_rng(seed)
+    img = cfg.clip_vision_config.image_size
+    px = torch.from_numpy(np.clip(rng.standard_normal((batch, img, img, 3), dtype=np.float32), -1.8, 2.2)).to(dev)
+    V = cfg.mbart_config.vocab_size
+    langs = [l if l < V else V - 4 + i for i, l in enumerate(langs)]
+    out = model.generate(px, forced_bos_token_id=langs[0], num_beams=4, max_length=max_length)  # warm-up (allocations)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 0
+    for lang in langs:
+        out = model.generate(px, forced_bos_token_id=lang, num_beams=4, max_length=max_length)
+        assert out["steps"] == max_length - 1, out["steps"]
+        n += batch
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"metric": "beam-4 captions/sec (configs[3]: batch 256, 4 beams, max_len 64, forced BOS, KV-cached)",
+            "value": round(n / dt, 1), "unit": "captions/sec", "ms_per_decoder_step": round(dt / (len(langs) * (max_length - 1)) * 1e3, 3),
+            "langs": len(langs), "batch": batch, "model_tflops": round(n * BEAM_GFLOP_PER_CAPTION / dt / 1e3, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,6 +113,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-generate", action="store_true", help="skip the beam-4 captions/sec leg")
+    ap.add_argument("--gen-batch", type=int, default=256)
+    ap.add_argument("--generate-only", action="store_true", help="profiling aid: only the beam-4 leg")
     ap.add_argument("--small", action="store_true", help="reduced model (debug only; result is NOT the benchmark)")
     args = ap.parse_args()
 
@@ -119,6 +155,10 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.generate_only:
+        print(json.dumps(bench_generate(model, cfg, dev, batch=args.gen_batch)))
+        return
 
     for i in range(args.warmup):
         tr.train_step(dbatches[i % 2])
@@ -176,6 +216,16 @@ def main():
     if world > 1:
         dist.barrier()
 
+    gen = None
+    if not args.no_generate:
+        # generation is replicas-only (no collective): every rank decodes its own 256 images; report the sum
+        g = bench_generate(model, cfg, dev, batch=args.gen_batch if not args.small else 8)
+        if world > 1:
+            tv = torch.tensor([g["value"]], dtype=torch.float64, device=dev)
+            dist.all_reduce(tv, op=dist.ReduceOp.SUM)
+            g["value"] = round(float(tv.item()), 1)
+        g["n_gpus"] = world
+        gen = g
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.small:
         try:
@@ -195,7 +245,7 @@ def main():
                        "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}", "grad_allreduce": "fp32 flat buckets, RCCL, side stream"},
             "model_tflops_per_gpu": round(step_flops * args.steps / dt / 1e12, 1),
             "final_loss": round(loss, 4),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "beam4_generate": gen,
         }
         print(json.dumps(line))
     if world > 1:

@@ -336,8 +336,10 @@ extern "C" int mic_attn_bwd(int dtype, int B, int H, int Tq, int Tk, const void*
 }
 
 // ------------------------------------------------------------------ decode-time attention (K9d): one wave per (row, head)
-// scores: lane = cache slot (each lane reads its slot's 64 contiguous elements); softmax by wave reductions;
-// output: lane = head-dim element, loop over valid slots with coalesced 64-element rows.
+// HBM-bound.  8 lanes cover one cache slot's 64-element row (16 B per lane, a full 128-B line in bf16), so one wave
+// instruction streams 8 slots fully coalesced for both K and V.  Scores: 8-dim partial dots reduced over the 8 lanes of a
+// slot group; softmax: wave reductions over slots; PV: each lane accumulates its 8 dims over its slots, then the 8 slot
+// groups are summed by xor-shuffles.  Slot ownership (beam-parent indirection) is looked up per slot.
 template <typename T>
 __global__ __launch_bounds__(256) void attn_decode_kernel(int R, int H, int max_len, int cur, const T* __restrict__ q, int ldq,
                                                           const T* __restrict__ kc, const T* __restrict__ vc, int ldc,
@@ -347,39 +349,59 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(int R, int H, int max_
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wid >= R * H) return;
   const int r = wid / H, h = wid % H;
-  float qv[64];
-  {
-    const T* qr = q + (size_t)r * ldq + h * 64;
+  const int sub = lane & 7, grp = lane >> 3;  // 8 dims [sub*8, sub*8+8) of slot (it*8 + grp)
+  float qv[8];
+  ld8(q + (size_t)r * ldq + h * 64 + sub * 8, qv);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) ld8(qr + c * 8, qv + c * 8);
-  }
-  float s = -INFINITY;
-  int my_src = 0;
-  if (lane <= cur && lane < max_len) {
-    my_src = src_row ? src_row[(size_t)r * max_len + lane] : r / row_div;
-    const T* kr = kc + ((size_t)my_src * max_len + lane) * ldc + h * 64;
-    float acc = 0.f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      float kv[8];
-      ld8(kr + c * 8, kv);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc += (qv[c * 8 + e] * SCALE) * kv[e];
-    }
-    s = acc;
-  }
-  const float m = wave_max(s);
-  const float p = (lane <= cur && lane < max_len) ? __expf(s - m) : 0.f;
-  const float l = wave_sum(p);
-  const float pn = p / l;
-  float o = 0.f;
+  for (int e = 0; e < 8; ++e) qv[e] *= SCALE;
   const int n = min(cur + 1, max_len);
-  for (int t = 0; t < n; ++t) {
-    const float pt = __shfl(pn, t, 64);
-    const int sr = __shfl(my_src, t, 64);
-    o += pt * ElemT<T>::ld(vc + ((size_t)sr * max_len + t) * ldc + h * 64 + lane);
+  float sc[8];
+  int srow[8];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int slot = it * 8 + grp;
+    float acc = 0.f;
+    srow[it] = 0;
+    if (slot < n) {
+      srow[it] = src_row ? src_row[(size_t)r * max_len + slot] : r / row_div;
+      float kv[8];
+      ld8(kc + ((size_t)srow[it] * max_len + slot) * ldc + h * 64 + sub * 8, kv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += qv[e] * kv[e];
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    sc[it] = slot < n ? acc : -INFINITY;
   }
-  ElemT<T>::st(out + (size_t)r * ldo + h * 64 + lane, o);
+  float m = sc[0];
+#pragma unroll
+  for (int it = 1; it < 8; ++it) m = fmaxf(m, sc[it]);
+  m = wave_max(m);
+  float l = 0.f;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) { sc[it] = __expf(sc[it] - m); l += sc[it]; }
+  l = wave_sum(l) * 0.125f;  // every slot's probability is replicated on its 8 lanes
+  const float inv = 1.0f / l;
+  float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int slot = it * 8 + grp;
+    if (slot < n) {
+      float vv[8];
+      ld8(vc + ((size_t)srow[it] * max_len + slot) * ldc + h * 64 + sub * 8, vv);
+      const float p = sc[it] * inv;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += p * vv[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    o[e] += __shfl_xor(o[e], 8, 64);
+    o[e] += __shfl_xor(o[e], 16, 64);
+    o[e] += __shfl_xor(o[e], 32, 64);
+  }
+  if (grp == 0) st8(out + (size_t)r * ldo + h * 64 + sub * 8, o);
 }
 extern "C" int mic_attn_decode(int dtype, int R, int H, int max_len, int cur, const void* q, int ldq, const void* kc,
                                const void* vc, int ldc, const int32_t* src_row, int row_div, void* out, int ldo, void* stream) {
