@@ -9,6 +9,12 @@
 __device__ __forceinline__ bool better(float av, int ai, float bv, int bi) { return av > bv || (av == bv && ai < bi); }
 
 // ------------------------------------------------------------------ per-row lse + top-k
+// One 256-thread block per row of the [R][ld] logits.  Pass 1 streams the row once: online (max, sum-exp) and each
+// thread's own maximum.  The 8th largest of the 256 thread maxima is a provable lower bound tau on the row's k-th best
+// value (8 distinct elements are >= it), so pass 2 only has to run the (divergent, 8-deep) insertion on the rare
+// elements >= tau; everything else costs two subtractions and a compare.  Ordering is exactly lax.top_k's
+// (value desc, index asc) on the PROCESSED value (log-softmax, processors, + running score) — ties in the rounded fp32
+// value are broken by index, so thresholds are compared in that same processed domain.
 template <typename T>
 __global__ __launch_bounds__(256) void row_lse_topk_kernel(int V, const T* __restrict__ logits, int ld, int k, int forced,
                                                            int suppress_eos, int eos, int raw, const float* __restrict__ row_bias,
@@ -18,22 +24,60 @@ __global__ __launch_bounds__(256) void row_lse_topk_kernel(int V, const T* __res
   const int row = blockIdx.x, tid = threadIdx.x;
   const T* lr = logits + (size_t)row * ld;
   const int nchunk = (V + 7) >> 3;
-  float mx = 0.f, logsum = 0.f;
-  if (!raw) {
-    float m = -INFINITY, s = 0.f;
-    for (int ch = tid; ch < nchunk; ch += 256) {
-      float v[8];
-      ld8(lr + ch * 8, v);
-      float cm = -INFINITY;
+  const float bias = row_bias ? row_bias[row] : 0.f;
+  if (forced >= 0) {
+    // ForcedBOS / ForcedEOS: everything -inf except the forced token := 0 (+ running score); lax.top_k then lists the
+    // lowest indices among the -inf ties.  No scan needed.
+    if (tid < k) {
+      int idx = forced;
+      if (tid > 0) { idx = tid - 1; if (idx >= forced) ++idx; }
+      top_val[(size_t)row * k + tid] = tid == 0 ? 0.f + bias : -INFINITY;
+      top_idx[(size_t)row * k + tid] = idx;
+    }
+    return;
+  }
+  // ---- pass 1: online log-sum-exp + per-thread maximum (of the values that stay eligible)
+  float m = -INFINITY, s = 0.f, tmax = -INFINITY;
+  int targ = 0x7fffffff;
+  for (int ch0 = tid; ch0 < nchunk; ch0 += 4 * 256) {
+    float v[4][8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) if (ch * 8 + i < V) cm = fmaxf(cm, v[i]);
+    for (int u = 0; u < 4; ++u) {
+      const int ch = ch0 + u * 256;
+      if (ch < nchunk) ld8(lr + ch * 8, v[u]);
+    }
+    float cm = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ch = ch0 + u * 256;
+      if (ch < nchunk) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int c = ch * 8 + i;
+          if (c < V) {
+            cm = fmaxf(cm, v[u][i]);
+            if (!(suppress_eos && c == eos) && v[u][i] > tmax) { tmax = v[u][i]; targ = c; }
+          }
+        }
+      }
+    }
+    if (!raw) {
       const float mn = fmaxf(m, cm);
       float add = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) if (ch * 8 + i < V) add += __expf(v[i] - mn);
-      s = s * __expf(m - mn) + add;
+      for (int u = 0; u < 4; ++u) {
+        const int ch = ch0 + u * 256;
+        if (ch < nchunk) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) if (ch * 8 + i < V) add += __expf(v[u][i] - mn);
+        }
+      }
+      s = (mn == -INFINITY) ? 0.f : s * __expf(m - mn) + add;
       m = mn;
     }
+  }
+  float mx = 0.f, logsum = 0.f;
+  if (!raw) {
     sm[tid] = m; ss[tid] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -49,29 +93,66 @@ __global__ __launch_bounds__(256) void row_lse_topk_kernel(int V, const T* __res
     logsum = logf(ss[0]);
     __syncthreads();
   }
-  const float bias = row_bias ? row_bias[row] : 0.f;
+  if (raw && k == 1) {
+    // greedy: first-max argmax (gen:499)
+    sm[tid] = tmax; si[tid] = targ;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o && better(sm[tid + o], si[tid + o], sm[tid], si[tid])) { sm[tid] = sm[tid + o]; si[tid] = si[tid + o]; }
+      __syncthreads();
+    }
+    if (tid == 0) { top_val[row] = sm[0] + bias; top_idx[row] = si[0]; }
+    return;
+  }
+  // ---- tau: the 8th largest thread maximum (processed domain)
+  float tau;
+  {
+    float mine = tmax == -INFINITY ? -INFINITY : ((raw ? tmax : (tmax - mx) - logsum) + bias);
+    float last = INFINITY;
+    for (int round = 0; round < TOPK_MAX; ++round) {
+      sm[tid] = mine; si[tid] = tid;
+      __syncthreads();
+      for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o && better(sm[tid + o], si[tid + o], sm[tid], si[tid])) { sm[tid] = sm[tid + o]; si[tid] = si[tid + o]; }
+        __syncthreads();
+      }
+      last = sm[0];
+      if (tid == si[0]) mine = -INFINITY;
+      __syncthreads();
+    }
+    tau = last;  // -inf when fewer than 8 threads saw an eligible value: then everything is a candidate
+  }
+  // ---- pass 2: exact per-thread top-k of the candidates >= tau
   float bv[TOPK_MAX];
   int bi[TOPK_MAX];
 #pragma unroll
   for (int i = 0; i < TOPK_MAX; ++i) { bv[i] = -INFINITY; bi[i] = 0x7fffffff; }
-  for (int ch = tid; ch < nchunk; ch += 256) {
-    float v[8];
-    ld8(lr + ch * 8, v);
+  for (int ch0 = tid; ch0 < nchunk; ch0 += 4 * 256) {
+    float v[4][8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int c = ch * 8 + i;
-      if (c >= V) continue;
-      float x = raw ? v[i] : (v[i] - mx) - logsum;   // log_softmax (gen:850)
-      if (suppress_eos && c == eos) x = -INFINITY;     // MinLength
-      if (forced >= 0) x = (c == forced) ? 0.f : -INFINITY;  // ForcedBOS / ForcedEOS
-      x += bias;                                       // + running score (gen:857)
-      if (better(x, c, bv[TOPK_MAX - 1], bi[TOPK_MAX - 1])) {
-        bv[TOPK_MAX - 1] = x; bi[TOPK_MAX - 1] = c;
+    for (int u = 0; u < 4; ++u) {
+      const int ch = ch0 + u * 256;
+      if (ch < nchunk) ld8(lr + ch * 8, v[u]);
+    }
 #pragma unroll
-        for (int p = TOPK_MAX - 1; p > 0; --p) {
-          if (better(bv[p], bi[p], bv[p - 1], bi[p - 1])) {
-            const float tv = bv[p]; bv[p] = bv[p - 1]; bv[p - 1] = tv;
-            const int ti = bi[p]; bi[p] = bi[p - 1]; bi[p - 1] = ti;
+    for (int u = 0; u < 4; ++u) {
+      const int ch = ch0 + u * 256;
+      if (ch >= nchunk) continue;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = ch * 8 + i;
+        if (c >= V) continue;
+        float x = raw ? v[u][i] : (v[u][i] - mx) - logsum;   // log_softmax (gen:850)
+        if (suppress_eos && c == eos) x = -INFINITY;           // MinLength
+        x += bias;                                             // + running score (gen:857)
+        if (x >= tau && better(x, c, bv[TOPK_MAX - 1], bi[TOPK_MAX - 1])) {
+          bv[TOPK_MAX - 1] = x; bi[TOPK_MAX - 1] = c;
+#pragma unroll
+          for (int p = TOPK_MAX - 1; p > 0; --p) {
+            if (better(bv[p], bi[p], bv[p - 1], bi[p - 1])) {
+              const float tv = bv[p]; bv[p] = bv[p - 1]; bv[p - 1] = tv;
+              const int ti = bi[p]; bi[p] = bi[p - 1]; bi[p - 1] = ti;
+            }
           }
         }
       }
