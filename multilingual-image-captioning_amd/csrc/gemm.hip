@@ -27,9 +27,8 @@
 // fma chain), generic strides.
 #include "common.h"
 
-#define BK 64
-#define HALF_BYTES (128 * 64 * 2)  // 16 KiB: one half-tile image
 #define MAX_PROBLEMS 8
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in VGPRs across the loop back-edge
 
 struct Problem {
   const uint16_t* A; const uint16_t* B;
@@ -39,41 +38,66 @@ struct Problem {
 };
 struct LaunchTable { int count; int total_blocks; Problem p[MAX_PROBLEMS]; };
 
-// --- DMA one 16 KiB half-tile into LDS.  KMAJOR=false: src is [rows][ld] k-contiguous, image = 128 rows x 64 k.
-//     KMAJOR=true: src is [K][ld] x-contiguous, image = 64 k x 128 x.  `lim` = number of valid rows (resp. x) in src;
-//     out-of-range rows/chunks are redirected to a valid address (their products are masked at the store).
-template <bool KMAJOR, int NWAVES>
-__device__ __forceinline__ void stage_half(const uint16_t* __restrict__ src, int ld, int x0, int k0, int lim,
-                                           char* lds_tile, int wave, int lane) {
-  constexpr int PER = 16 / NWAVES;  // 16 wave-instructions of 1 KiB cover the half-tile
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int q = wave * PER + i;
-    const uint16_t* g;
+// --- stage one half-tile image (128 rows x BKT k, or BKT k x 128 x; 128*BKT*2 bytes) HBM/L2 -> registers -> LDS.
+//     Measured on gfx950: a global_load_lds (LDS-DMA) instruction costs ~100 cycles of issue time in the issuing wave's
+//     in-order stream; 8 of them per K-tile next to 16 MFMAs made every one-block-per-CU shape DMA-issue bound
+//     (1.3-1.4k cycles per K-tile against 512 MFMA cycles).  global_load_dwordx4 + ds_write_b128 issue in ~20 cycles a
+//     pair, cost 4 VGPRs per piece, and let the swizzle sit on the LDS destination.
+//     KMAJOR=false: src is [rows][ld] k-contiguous.  KMAJOR=true: src is [K][ld] x-contiguous.  `lim` = number of valid
+//     rows (resp. x) in src; out-of-range rows/chunks are redirected to a valid address (masked at the store).
+template <bool KMAJOR, int NWAVES, int BKT>
+struct HalfStager {
+  static constexpr int NINST = 128 * BKT * 2 / 1024;  // 1 KiB pieces per image
+  static constexpr int PER = NINST / NWAVES;
+  static_assert(PER >= 1, "too many waves for this image");
+  static __device__ __forceinline__ void coords(int q, int lane, int& row, int& c) {
     if (!KMAJOR) {
-      const int row = q * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ ((row >> 1) & 7);
-      int gr = x0 + row;
-      gr = gr < lim ? gr : lim - 1;
-      g = src + (size_t)gr * ld + k0 + c * 8;
-    } else {
-      const int k = q * 4 + (lane >> 4);
-      const int c = (lane & 15) ^ ((k & 3) << 2);
-      int gx = x0 + c * 8;
-      gx = gx < lim ? gx : 0;
-      g = src + (size_t)(k0 + k) * ld + gx;
-    }
-    __builtin_amdgcn_global_load_lds(GLB_PTR(g), (__attribute__((address_space(3))) void*)(lds_tile + q * 1024), 16, 0, 0);
+      if (BKT == 64) { row = q * 8 + (lane >> 3); c = lane & 7; }
+      else { row = q * 16 + (lane >> 2); c = lane & 3; }
+    } else { row = q * 4 + (lane >> 4); c = lane & 15; }
   }
-}
+  static __device__ __forceinline__ void load(u32x4 (&r)[PER], const uint16_t* __restrict__ src, int ld, int x0, int k0, int lim,
+                                              int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int row, c;
+      coords(wave * PER + i, lane, row, c);
+      const uint16_t* g;
+      if (!KMAJOR) {
+        int gr = x0 + row;
+        gr = gr < lim ? gr : lim - 1;
+        g = src + (size_t)gr * ld + k0 + c * 8;
+      } else {
+        int gx = x0 + c * 8;
+        gx = gx < lim ? gx : 0;
+        g = src + (size_t)(k0 + row) * ld + gx;
+      }
+      r[i] = *reinterpret_cast<const u32x4*>(g);
+    }
+  }
+  static __device__ __forceinline__ void store(const u32x4 (&r)[PER], char* lds_tile, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int row, c;
+      coords(wave * PER + i, lane, row, c);
+      int off;
+      if (!KMAJOR) off = BKT == 64 ? row * 128 + ((c ^ ((row >> 1) & 7)) << 4) : row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
+      else off = row * 256 + ((c ^ ((row & 3) << 2)) << 4);
+      *reinterpret_cast<u32x4*>(lds_tile + off) = r[i];
+    }
+  }
+};
 
 // --- read one 32(x) x 16(k) MFMA operand fragment: 8 consecutive k (kk*16 + 8*(lane>>5) ..) of x = xb + (lane&31)
-template <bool KMAJOR>
+//     k-contiguous images: BKT=64 -> 128-B rows, chunk ^ ((row>>1)&7); BKT=32 -> 64-B rows, chunk ^ ((row>>2)&3); both are
+//     conflict-free for ds_read_b128's 16-lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31}.
+template <bool KMAJOR, int BKT>
 __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int xb, int kk, int lane) {
   if (!KMAJOR) {
     const int row = xb + (lane & 31);
     const int kc = kk * 2 + (lane >> 5);
-    return *reinterpret_cast<const bf16x8*>(lds_tile + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+    if (BKT == 64) return *reinterpret_cast<const bf16x8*>(lds_tile + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+    return *reinterpret_cast<const bf16x8*>(lds_tile + row * 64 + ((kc ^ ((row >> 2) & 3)) << 4));
   } else {
     const int g = lane >> 4, p = lane & 15;
     const int x = xb + 16 * (g & 1) + (p & 3) * 4;
@@ -97,12 +121,21 @@ __device__ __forceinline__ void tile_coords(int lid, int tiles_m, int tiles_n, i
   tn = in_g / gsz;
 }
 
-// WM: rows per wave (64 or 128); WNW: waves along N (2 or 4); 2 waves along M.  BM = 2*WM, BN = 64*WNW.
-template <int WM, int WNW, bool AK, bool BKM>
+// Wave tile WM x WN (WM in {64,128}, WN in {32,64}); 2 waves along M, WNW along N.  BM = 2*WM, BN = WN*WNW.
+//   <64,32,4>  128x128, 8 waves : even one block per CU puts two waves on every SIMD, so one wave's staging / LDS waits
+//                                 hide under the other's MFMAs (the 4-wave 64x64 wave tile measured 26 % MFMA-busy at
+//                                 one block per CU: a single in-order stream cannot overlap its own waits)
+//   <128,64,4> 256x256, 8 waves : launches with >= 200 such tiles (2x the FLOPs per staged byte)
+// BKT: k-depth of one pipeline stage.  Two LDS buffers; tile t+1 travels through registers while tile t is multiplied
+// (loads issued a full iteration before their ds_write), one barrier per stage.
+template <int WM, int WN, int WNW, int BKT, bool AK, bool BKM>
 __global__ __launch_bounds__(128 * WNW, 2) void gemm_bf16_kernel(LaunchTable tab) {
-  constexpr int BM = 2 * WM, BN = 64 * WNW, NWAVES = 2 * WNW, NTHREADS = 64 * NWAVES;
-  constexpr int NHA = BM / 128, NHB = BN / 128, STAGE = (NHA + NHB) * HALF_BYTES, AI = WM / 32;
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A halves | B halves]
+  constexpr int BM = 2 * WM, BN = WN * WNW, NWAVES = 2 * WNW, NTHREADS = 64 * NWAVES;
+  constexpr int HALF = 128 * BKT * 2;
+  constexpr int NHA = BM / 128, NHB = BN / 128, STAGE = (NHA + NHB) * HALF, AI = WM / 32, NJ = WN / 32, KSTEPS = BKT / 16;
+  using SA = HalfStager<AK, NWAVES, BKT>;
+  using SB = HalfStager<BKM, NWAVES, BKT>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A halves | B halves]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // bijective XCD remap: the blocks that land on XCD x (= bid % 8) get a contiguous run of logical block ids
   int lid;
@@ -127,76 +160,88 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_bf16_kernel(LaunchTable tab
   const int lda = P.lda, ldb = P.ldb;
   const int wr = wave / WNW, wc = wave % WNW;
 
-  f32x16 acc[AI][2];
+  f32x16 acc[AI][NJ];
 #pragma unroll
   for (int i = 0; i < AI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const int nk_total = P.K / BK;
+  const int nk_total = P.K / BKT;
   const int nk_per = (nk_total + P.nsplit - 1) / P.nsplit;
   const int kt0 = split * nk_per, kt1 = min(nk_total, kt0 + nk_per);
+  const int nk = kt1 - kt0;
 
-  auto stage = [&](int kt, char* buf) {
+  u32x4 ra[NHA][SA::PER], rb[NHB][SB::PER];  // the tile in flight
+  auto load_regs = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
-    for (int h = 0; h < NHA; ++h) stage_half<AK, NWAVES>(A, lda, m0 + h * 128, kt * BK, M, buf + h * HALF_BYTES, wave, lane);
+    for (int h = 0; h < NHA; ++h) SA::load(ra[h], A, lda, m0 + h * 128, (kt0 + t) * BKT, M, wave, lane);
 #pragma unroll
-    for (int h = 0; h < NHB; ++h) stage_half<BKM, NWAVES>(B, ldb, n0 + h * 128, kt * BK, N, buf + (NHA + h) * HALF_BYTES, wave, lane);
+    for (int h = 0; h < NHB; ++h) SB::load(rb[h], B, ldb, n0 + h * 128, (kt0 + t) * BKT, N, wave, lane);
+  };
+  auto write_lds = [&](char* buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int h = 0; h < NHA; ++h) SA::store(ra[h], buf + h * HALF, wave, lane);
+#pragma unroll
+    for (int h = 0; h < NHB; ++h) SB::store(rb[h], buf + (NHA + h) * HALF, wave, lane);
   };
   // this wave's operand sub-images
   const int a_half = (wr * WM) / 128, a_off = (wr * WM) % 128;
-  const int b_half = (wc * 64) / 128, b_off = (wc * 64) % 128;
+  const int b_half = (wc * WN) / 128, b_off = (wc * WN) % 128;
 
-  if (kt0 < kt1) {
-    stage(kt0, smem);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (nk > 0) {
+    load_regs(0);
+    write_lds(smem);
+    if (nk > 1) load_regs(1);
     __syncthreads();
   }
-  for (int t = kt0; t < kt1; ++t) {
-    char* cur = smem + ((t - kt0) & 1) * STAGE;
-    char* nxt = smem + ((t - kt0 + 1) & 1) * STAGE;
-    if (t + 1 < kt1) stage(t + 1, nxt);
-    const char* At = cur + a_half * HALF_BYTES;
-    const char* Bt = cur + (NHA + b_half) * HALF_BYTES;
+  for (int t = 0; t < nk; ++t) {
+    if (t + 1 < nk) {
+      write_lds(smem + ((t + 1) & 1) * STAGE);  // its buffer was last read in iteration t-1 (barrier below)
+      if (t + 2 < nk) load_regs(t + 2);         // a full iteration of MFMAs to land
+    }
+    const char* cur = smem + (t & 1) * STAGE;
+    const char* At = cur + a_half * HALF;
+    const char* Bt = cur + (NHA + b_half) * HALF;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      bf16x8 af[AI], bfr[2];
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+      bf16x8 af[AI], bfr[NJ];
 #pragma unroll
-      for (int i = 0; i < AI; ++i) af[i] = read_frag<AK>(At, a_off + i * 32, kk, lane);
+      for (int i = 0; i < AI; ++i) af[i] = read_frag<AK, BKT>(At, a_off + i * 32, kk, lane);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bfr[j] = read_frag<BKM>(Bt, b_off + j * 32, kk, lane);
+      for (int j = 0; j < NJ; ++j) bfr[j] = read_frag<BKM, BKT>(Bt, b_off + j * 32, kk, lane);
 #pragma unroll
       for (int i = 0; i < AI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
-  // epilogue: each wave restages 64x64 fp32 blocks of its accumulators through its own 16 KiB LDS region, then the
-  // whole block streams them out: every thread owns 8 consecutive columns of a row (16-B vectors).
-  float* Cw = reinterpret_cast<float*>(smem) + wave * (64 * 64);
+  // epilogue: each wave restages a 64 x WN fp32 block of its accumulators through its own LDS region, then the whole
+  // block streams them out: every thread owns 8 consecutive columns of a row (16-B vectors).
+  constexpr int REGION = 64 * WN;       // floats per wave region
+  constexpr int CPR = WN / 8;           // 8-column chunks per region row
+  float* Cw = reinterpret_cast<float*>(smem) + wave * REGION;
 #pragma unroll
   for (int p = 0; p < WM / 64; ++p) {
     if (p > 0) __syncthreads();
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          Cw[(i2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 64 + j * 32 + (lane & 31)] = acc[2 * p + i2][j][r];
+          Cw[(i2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * WN + j * 32 + (lane & 31)] = acc[2 * p + i2][j][r];
     __syncthreads();
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < CPR; ++it) {
       const int id = it * NTHREADS + tid;
-      const int w = id >> 9, rem = id & 511;
-      const int row = rem >> 3, c8 = (rem & 7) * 8;
-      const int m = m0 + (w / WNW) * WM + p * 64 + row, n = n0 + (w % WNW) * 64 + c8;
+      const int w = id / (64 * CPR), rem = id % (64 * CPR);
+      const int row = rem / CPR, c8 = (rem % CPR) * 8;
+      const int m = m0 + (w / WNW) * WM + p * 64 + row, n = n0 + (w % WNW) * WN + c8;
       if (m >= M || n >= N) continue;
-      const float* src = reinterpret_cast<const float*>(smem) + w * (64 * 64) + row * 64 + c8;
+      const float* src = reinterpret_cast<const float*>(smem) + w * REGION + row * WN + c8;
       float v[8];
       const float4 lo = *reinterpret_cast<const float4*>(src);
       const float4 hi = *reinterpret_cast<const float4*>(src + 4);
@@ -274,7 +319,7 @@ static int fill_epi(const mic_gemm_args* a, EpiArgs& e) {
   e.drop_seed = a->dropout_seed; e.drop_scale = 1.0f / (1.0f - a->dropout_p);
   e.alpha = a->alpha == 0.f ? 1.0f : a->alpha; e.N = a->N;
   if (a->dtype == MIC_BF16) {
-    MIC_CHECK(a->K % BK == 0, "mic_gemm(bf16): K=%d must be a multiple of 64 (zero-pad the reduction dim)", a->K);
+    MIC_CHECK(a->K % 64 == 0, "mic_gemm(bf16): K=%d must be a multiple of 64 (zero-pad the reduction dim)", a->K);
     MIC_CHECK(a->lda % 8 == 0 && a->ldb % 8 == 0, "mic_gemm(bf16): lda/ldb must be multiples of 8");
     MIC_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->B & 15) == 0, "mic_gemm(bf16): A/B must be 16-B aligned");
     if (a->a_kmajor) MIC_CHECK(a->M % 8 == 0, "mic_gemm(bf16): k-major A needs M %% 8 == 0");
@@ -286,16 +331,18 @@ static int fill_epi(const mic_gemm_args* a, EpiArgs& e) {
   return MIC_OK;
 }
 
-template <int WM, int WNW>
+template <int WM, int WN, int WNW, int BKT>
 static void launch_cfg(const LaunchTable& tab, int akm, int bkm, hipStream_t s) {
-  constexpr int BM = 2 * WM, BN = 64 * WNW;
-  const size_t lds = 2 * (BM / 128 + BN / 128) * HALF_BYTES;
+  constexpr int BM = 2 * WM, BN = WN * WNW;
+  size_t lds = (size_t)2 * (BM / 128 + BN / 128) * (128 * BKT * 2);
+  const size_t epi = (size_t)2 * WNW * 64 * WN * 4;  // the epilogue restages 64 x WN floats per wave
+  if (epi > lds) lds = epi;
   dim3 grid(tab.total_blocks), block(128 * WNW);
 #define LAUNCH(AKM, BKMM)                                                                                              \
   do {                                                                                                                 \
-    if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WNW, AKM, BKMM>),         \
+    if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WN, WNW, BKT, AKM, BKMM>), \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
-    hipLaunchKernelGGL((gemm_bf16_kernel<WM, WNW, AKM, BKMM>), grid, block, lds, s, tab);                              \
+    hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, WNW, BKT, AKM, BKMM>), grid, block, lds, s, tab);                     \
   } while (0)
   if (!akm && !bkm) LAUNCH(false, false);
   else if (!akm && bkm) LAUNCH(false, true);
@@ -307,10 +354,11 @@ static void launch_cfg(const LaunchTable& tab, int akm, int bkm, hipStream_t s) 
 static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
   LaunchTable tab;
   tab.count = count;
-  long tiles_big = 0;
+  long tiles_big = 0, tiles_small = 0;
   for (int i = 0; i < count; ++i) {
     const int sp = args[i].split_k > 1 ? args[i].split_k : 1;
     tiles_big += (long)((args[i].M + 255) / 256) * ((args[i].N + 255) / 256) * sp;
+    tiles_small += (long)((args[i].M + 127) / 128) * ((args[i].N + 127) / 128) * sp;
   }
   // 256x256 tiles deliver 2x the FLOPs per operand byte but need >= ~0.8 blocks per CU to pay
   const bool big = tiles_big >= 200;
@@ -325,13 +373,15 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
     p.lda = args[i].lda; p.ldb = args[i].ldb; p.M = args[i].M; p.N = args[i].N; p.K = args[i].K;
     p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bm - 1) / bm;
     p.nsplit = args[i].split_k > 1 ? args[i].split_k : 1;
-    if (p.nsplit > p.K / BK) p.nsplit = p.K / BK;
+    if (p.nsplit > p.K / 64) p.nsplit = p.K / 64;
     p.block_begin = blocks;
     blocks += p.tiles_m * p.tiles_n * p.nsplit;
   }
   tab.total_blocks = blocks;
-  if (big) launch_cfg<128, 4>(tab, args[0].a_kmajor, args[0].b_kmajor, s);
-  else launch_cfg<64, 2>(tab, args[0].a_kmajor, args[0].b_kmajor, s);
+  (void)tiles_small;
+  if (big) launch_cfg<128, 64, 4, 64>(tab, args[0].a_kmajor, args[0].b_kmajor, s);  // 256x256x64, 8 waves
+  else launch_cfg<64, 32, 4, 64>(tab, args[0].a_kmajor, args[0].b_kmajor, s);       // 128x128x64, 8 waves (measured better than
+                                                                                    // the 4-wave 64x64 wave tile at every tile count)
   MIC_LAUNCH_CHECK();
   return MIC_OK;
 }

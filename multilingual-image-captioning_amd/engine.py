@@ -275,14 +275,7 @@ class Engine:
         ops.colsum(dlogits, P.g("flb"), M, P.Vpad, dlogits.stride(0))
         ops.gemm(dlogits, hf, P.g("shared"), P.Vpad, d, Mp, a_kmajor=True, b_kmajor=True)
         dhf = self.buf("db.dhf", M, d)
-        if self.dt == torch.bfloat16:
-            # tiny output, K = Vpad: split the reduction over 8 workgroups per tile (fp32 atomics), then round once
-            dhf32 = self.buf("db.dhf32", M, d, torch.float32)
-            dhf32.zero_()
-            ops.gemm(dlogits, P.w("shared"), dhf32, M, d, P.Vpad, b_kmajor=True, split_k=8)
-            ops.cast2d(dhf32, dhf, M, d, d, d)
-        else:
-            ops.gemm(dlogits, P.w("shared"), dhf, M, d, P.Vpad, b_kmajor=True)
+        ops.gemm(dlogits, P.w("shared"), dhf, M, d, P.Vpad, b_kmajor=True)
         dx = self.buf("db.dx", M, d)
         dxm = self.buf("db.dxm_a", M, d)   # masked grad entering the FFN branch
         dxm_b = self.buf("db.dxm_b", M, d)  # ... the cross-attention branch
