@@ -164,6 +164,9 @@ int mic_ce_bwd(int dtype, int rows, int V, int Vpad, void* logits, int ld, const
  * ------------------------------------------------------------------------------------------- */
 /* out[n] (+)= sum_m x[m,n]  (bias gradients).  accumulate=0 overwrites. */
 int mic_colsum(int dtype, int rows, int cols, const void* x, int ld, float* out, int accumulate, void* stream);
+/* several column sums (always accumulating into caller-zeroed outputs) in one launch per 8 items */
+typedef struct { const void* x; float* out; int rows, cols, ld; } mic_colsum_item;
+int mic_colsum_grouped(int dtype, const mic_colsum_item* items, int count, void* stream);
 /* keep-mask (uint8, 1 = keep) that the fused dropout epilogues use for (seed, p) over n elements */
 int mic_dropout_mask(uint8_t* out, int64_t n, float p, uint32_t seed, void* stream);
 int mic_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);

@@ -30,6 +30,10 @@ class GemmArgs(C.Structure):
     ]
 
 
+class ColsumItem(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("ld", C.c_int)]
+
+
 class BeamStepArgs(C.Structure):
     _fields_ = [
         ("B", C.c_int), ("K", C.c_int), ("max_len", C.c_int), ("V", C.c_int), ("cur_len", C.c_int),
@@ -61,6 +65,7 @@ _SIGS = {
     "mic_ce_reduce": ([_i, _p, _p, _p, _p, _p], C.c_int),
     "mic_ce_bwd": ([_i, _i, _i, _i, _p, _i, _p, _p, _f, _p, _p, _f, _p], C.c_int),
     "mic_colsum": ([_i, _i, _i, _p, _i, _p, _i, _p], C.c_int),
+    "mic_colsum_grouped": ([_i, C.POINTER(ColsumItem), _i, _p], C.c_int),
     "mic_dropout_mask": ([_p, _i64, _f, _u32, _p], C.c_int),
     "mic_cast": ([_i, _i, _p, _p, _i64, _p], C.c_int),
     "mic_cast2d": ([_i, _i, _i, _i, _p, _i, _p, _i, _p], C.c_int),

@@ -41,6 +41,7 @@ class Engine:
         self.p_drop = float(mc.dropout)
         self.embed_scale = math.sqrt(store.d) if mc.scale_embedding else 1.0
         self._dw_queue = []
+        self._cs_queue = []
         self.grad_progress = None  # callable(offset): every gradient with flat offset < offset is final (DDP overlap)
 
     def _done(self, seg_name: str):
@@ -94,7 +95,10 @@ class Engine:
         else:
             ops.gemm(dy, x, P.g(wname + ".w"), N, K, Mp, a_kmajor=True, b_kmajor=True)
         if bias:
-            ops.colsum(dy, P.g(wname + ".b"), M, N, dy.stride(0), accumulate=True)  # region pre-zeroed once per step
+            if defer:
+                self._cs_queue.append((dy, P.g(wname + ".b"), M, N, dy.stride(0)))
+            else:
+                ops.colsum(dy, P.g(wname + ".b"), M, N, dy.stride(0), accumulate=True)  # region pre-zeroed once per step
         if dx is not None:
             ops.gemm(dy, w, dx, M, K, N, b_kmajor=True, zin=zin, dact=dact, accumulate=dx_accumulate)
         if not defer:
@@ -102,6 +106,9 @@ class Engine:
         return dx
 
     def flush_dw(self):
+        if self._cs_queue:
+            ops.colsum_grouped(self._cs_queue)
+            self._cs_queue = []
         if self._dw_queue:
             ops.gemm_grouped([q[0] for q in self._dw_queue])
             _, wname, bias = self._dw_queue[-1]

@@ -140,6 +140,12 @@ def colsum(x, out, rows, cols, ld, accumulate=False):
     L.check(L.lib().mic_colsum(_dt(x), rows, cols, _p(x), ld, _p(out), int(accumulate), _stream()), "mic_colsum")
 
 
+def colsum_grouped(items):
+    """items: [(x, out, rows, cols, ld)]: all accumulate into pre-zeroed fp32 outputs, one launch per 8 items."""
+    arr = (L.ColsumItem * len(items))(*[L.ColsumItem(_p(x), _p(out), rows, cols, ld) for (x, out, rows, cols, ld) in items])
+    L.check(L.lib().mic_colsum_grouped(_dt(items[0][0]), arr, len(items), _stream()), "mic_colsum_grouped")
+
+
 def dropout_mask(n: int, p: float, seed: int, device) -> torch.Tensor:
     out = torch.empty(n, dtype=torch.uint8, device=device)
     L.check(L.lib().mic_dropout_mask(_p(out), n, float(p), int(seed) & 0xFFFFFFFF, _stream()), "mic_dropout_mask")
