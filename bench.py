@@ -155,6 +155,11 @@ def main():
     batches = [synth_batch(B, T, V, img, 1234 + rank * 100 + i) for i in range(2)]
     # inputs resident in HBM before the timed region
     dbatches = [{k: torch.from_numpy(v).to(dev) for k, v in b.items()} for b in batches]
+    from mic_amd import loss_rows
+
+    for b, db in zip(batches, dbatches):  # collate-side: positions that carry loss (the LM head runs only there)
+        idx, rl = loss_rows(b["attention_mask"], b["input_ids"])
+        db["loss_rows"] = (torch.from_numpy(idx).to(dev), torch.from_numpy(rl).to(dev))
 
     def barrier():
         if world > 1:
@@ -247,7 +252,8 @@ def main():
             "dtype": args.dtype, "data": "synthetic (random-init weights, N(0,1) pixels, ragged random captions)",
             "config": {"workload": "configs[1]: ViT-B/32 + mBART-large-50 train step (fwd+loss+bwd+all-reduce+AdamW), "
                                    f"per-GPU batch {B}, 224x224 NHWC fp32 pixels, seq_len {T}, dropout 0.1" + (" [SMALL DEBUG MODEL]" if args.small else ""),
-                       "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}", "grad_allreduce": "fp32 flat buckets, RCCL, side stream"},
+                       "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}", "grad_allreduce": "fp32 flat buckets, RCCL, side stream",
+                       "lm_head": "logits/CE on the label positions with loss mask 1 only (exact; ragged captions n~U{8..62})"},
             "model_tflops_per_gpu": round(step_flops * args.steps / dt / 1e12, 1),
             "final_loss": round(loss, 4),
             "roofline": roofline, "cpu_baseline": cpu, "beam4_generate": gen,

@@ -401,6 +401,34 @@ extern "C" int mic_cast(int src_dtype, int dst_dtype, const void* src, void* dst
   return MIC_OK;
 }
 
+// ------------------------------------------------------------------ row gather / scatter
+// dst[dst_idx ? dst_idx[i] : i][:] = src[src_idx ? src_idx[i] : i][:]  for i < n   (16-B vectors)
+template <typename T>
+__global__ void copy_rows_kernel(int n, int width, const T* __restrict__ src, int ld_src, const int32_t* __restrict__ src_idx,
+                                 T* __restrict__ dst, int ld_dst, const int32_t* __restrict__ dst_idx) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int nchunk = width / VEC;
+  const long total = (long)n * nchunk;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(e % nchunk);
+    const int i = (int)(e / nchunk);
+    const int rs = src_idx ? src_idx[i] : i, rd = dst_idx ? dst_idx[i] : i;
+    *reinterpret_cast<uint4*>(dst + (size_t)rd * ld_dst + ch * VEC) = *reinterpret_cast<const uint4*>(src + (size_t)rs * ld_src + ch * VEC);
+  }
+}
+extern "C" int mic_copy_rows(int dtype, int n, int width, const void* src, int ld_src, const int32_t* src_idx, void* dst, int ld_dst,
+                             const int32_t* dst_idx, void* stream) {
+  MIC_CHECK(n > 0 && width > 0 && src && dst, "mic_copy_rows: bad args");
+  const int vec = dtype == MIC_BF16 ? 8 : 4;
+  MIC_CHECK(width % vec == 0 && ld_src % vec == 0 && ld_dst % vec == 0, "mic_copy_rows: rows must be 16-B multiples");
+  return dispatch_t(dtype, [&](auto* tag) {
+    using T = TYPE_OF(tag);
+    const long total = (long)n * (width / vec);
+    int nb = (int)((total + 255) / 256); if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(copy_rows_kernel<T>, dim3(nb), dim3(256), 0, (hipStream_t)stream, n, width, (const T*)src, ld_src, src_idx, (T*)dst, ld_dst, dst_idx);
+  });
+}
+
 // ------------------------------------------------------------------ fused AdamW over the flat parameter buffer (K15)
 __global__ __launch_bounds__(256) void adamw_kernel(long n, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                     const float* __restrict__ g, uint16_t* __restrict__ p_lp,

@@ -266,23 +266,35 @@ class Engine:
         ops.gemm(hf, P.w("shared"), logits, M, P.Vpad, P.d, bias=P.f32("flb"))
         return logits
 
-    def decoder_backward(self, B: int, T: int, ids, pos_ids, key_mask, ehs, dlogits, seed: Optional[int]):
-        """Consumes dlogits [M,Vpad]; writes all decoder/embedding/head grads; returns dehs [B*S,d]."""
+    def decoder_backward(self, B: int, T: int, ids, pos_ids, key_mask, ehs, dlogits, seed: Optional[int], rows=None):
+        """Consumes dlogits [M,Vpad] (or [Mc,Vpad] for the compacted head: rows = (idx int32 [Mc], Mc)); writes all
+        decoder/embedding/head grads; returns dehs [B*S,d]."""
         P = self.P
         d, f, H, S = P.d, P.ffn, P.H, P.S
         M, Mv = B * T, B * S
-        Mp = _rup(M, ROWPAD)
         drop = seed is not None and self.p_drop > 0
         pd = self.p_drop if drop else 0.0
 
         def sd(site):
             return _mix(seed, site) if drop else 0
 
-        hf = self.buf("d.hf", M, d)
-        ops.colsum(dlogits, P.g("flb"), M, P.Vpad, dlogits.stride(0))
-        ops.gemm(dlogits, hf, P.g("shared"), P.Vpad, d, Mp, a_kmajor=True, b_kmajor=True)
         dhf = self.buf("db.dhf", M, d)
-        ops.gemm(dlogits, P.w("shared"), dhf, M, d, P.Vpad, b_kmajor=True)
+        if rows is None:
+            hf = self.buf("d.hf", M, d)
+            Mh = M
+        else:
+            hf = self.buf("d.hfc", M, d)  # compacted final hidden states (pad rows zero)
+            Mh = rows[1]
+        Mhp = _rup(Mh, 64)
+        ops.colsum(dlogits, P.g("flb"), Mh, P.Vpad, dlogits.stride(0))
+        ops.gemm(dlogits, hf, P.g("shared"), P.Vpad, d, Mhp, a_kmajor=True, b_kmajor=True)
+        if rows is None:
+            ops.gemm(dlogits, P.w("shared"), dhf, M, d, P.Vpad, b_kmajor=True)
+        else:
+            dhfc = self.buf("db.dhfc", M, d)
+            ops.gemm(dlogits, P.w("shared"), dhfc, Mh, d, P.Vpad, b_kmajor=True)
+            dhf[:M].zero_()  # masked-out positions receive exactly zero gradient from the loss
+            ops.copy_rows(dhfc, dhf, Mh, d, dst_idx=rows[0])
         dx = self.buf("db.dx", M, d)
         dxm = self.buf("db.dxm_a", M, d)   # masked grad entering the FFN branch
         dxm_b = self.buf("db.dxm_b", M, d)  # ... the cross-attention branch
@@ -361,13 +373,58 @@ class Engine:
         hf = self.decoder_forward(ids, pos_ids, key_mask, ehs, B, T, save, seed)
         return self.head_logits(hf, B * T), ehs
 
-    def loss_and_grads(self, pixels, ids, pos_ids, key_mask, labels, B, T, *, label_smoothing=0.0, seed=None):
-        """value_and_grad(compute_loss) of train_step (main.py:688-697): grads land in ParamStore.grad."""
+    def compact_head(self, hf, M: int, rows):
+        """LM head on the loss-relevant rows only: gather hf[idx] -> [Mc, d] (zero pad to a multiple of 64 rows) and
+        project.  Exact: loss_fn multiplies every other position by 0 (main.py:678)."""
+        P = self.P
+        idx, Mc = rows
+        Mcp = _rup(Mc, 64)
+        hfc = self.buf("d.hfc", M, P.d)
+        ops.copy_rows(hf, hfc, Mc, P.d, src_idx=idx)
+        if Mcp > Mc:
+            hfc[Mc:Mcp].zero_()
+        logits = self.buf("d.logits", M, P.Vpad)
+        ops.gemm(hfc, P.w("shared"), logits, Mc, P.Vpad, P.d, bias=P.f32("flb"))
+        if Mcp > Mc:
+            logits[Mc:Mcp].zero_()  # reduction padding of the dE GEMM (rows of an earlier, longer batch may linger here)
+        return logits
+
+    def loss_only(self, pixels, ids, pos_ids, key_mask, labels, B, T, *, label_smoothing=0.0, rows=None, row_labels=None):
+        """eval_step's forward + loss (main.py:710-716)."""
+        M = B * T
+        if rows is None:
+            logits, _ = self.forward_logits(pixels, ids, pos_ids, key_mask, B, T, save=False, seed=None)
+            return self.loss_and_dlogits(logits, labels, key_mask.reshape(-1), M, label_smoothing, backward=False)
+        _, ehs = self.vit_forward(pixels, False)
+        hf = self.decoder_forward(ids, pos_ids, key_mask, ehs, B, T, False, None)
+        logits = self.compact_head(hf, M, rows)
+        return self.loss_and_dlogits(logits, row_labels, self.ones_i32(rows[1]), rows[1], label_smoothing, backward=False)
+
+    def ones_i32(self, n: int):
+        key = f"ones_i32:{n}"
+        t = self._bufs.get(key)
+        if t is None:
+            t = torch.ones(max(n, 1), dtype=torch.int32, device=self.dev)
+            self._bufs[key] = t
+        return t
+
+    def loss_and_grads(self, pixels, ids, pos_ids, key_mask, labels, B, T, *, label_smoothing=0.0, seed=None, rows=None,
+                       row_labels=None):
+        """value_and_grad(compute_loss) of train_step (main.py:688-697): grads land in ParamStore.grad.
+        rows = (idx int32 [Mc] of the positions with loss mask 1, Mc) and row_labels = labels[idx] switch the LM head,
+        the cross-entropy and their backward to those rows only (identical loss and gradients, ~(1 - Mc/M) less head work)."""
         P = self.P
         P.ensure_grads()
         P.grad[P.atomic_begin:].zero_()
-        logits, ehs = self.forward_logits(pixels, ids, pos_ids, key_mask, B, T, save=True, seed=seed)
-        loss = self.loss_and_dlogits(logits, labels, key_mask.reshape(-1), B * T, label_smoothing, backward=True)
-        dehs = self.decoder_backward(B, T, ids, pos_ids, key_mask, ehs, logits, seed)
+        M = B * T
+        if rows is None:
+            logits, ehs = self.forward_logits(pixels, ids, pos_ids, key_mask, B, T, save=True, seed=seed)
+            loss = self.loss_and_dlogits(logits, labels, key_mask.reshape(-1), M, label_smoothing, backward=True)
+        else:
+            _, ehs = self.vit_forward(pixels, True)
+            hf = self.decoder_forward(ids, pos_ids, key_mask, ehs, B, T, True, seed)
+            logits = self.compact_head(hf, M, rows)
+            loss = self.loss_and_dlogits(logits, row_labels, self.ones_i32(rows[1]), rows[1], label_smoothing, backward=True)
+        dehs = self.decoder_backward(B, T, ids, pos_ids, key_mask, ehs, logits, seed, rows=rows)
         self.vit_backward(B, dehs)
         return loss

@@ -163,6 +163,11 @@ def cast2d(src, dst, rows, cols, ld_src, ld_dst):
     return dst
 
 
+def copy_rows(src, dst, n, width, *, src_idx=None, dst_idx=None):
+    L.check(L.lib().mic_copy_rows(_dt(src), n, width, _p(src), src.stride(0), _p(src_idx), _p(dst), dst.stride(0), _p(dst_idx), _stream()),
+            "mic_copy_rows")
+
+
 def adamw(p, m, v, g, p_lp, hyper, b1, b2, eps, wd, grad_scale=1.0, n=None):
     n = n if n is not None else p.numel()
     L.check(L.lib().mic_adamw(n, _p(p), _p(m), _p(v), _p(g), _p(p_lp), _p(hyper), float(b1), float(b2), float(eps), float(wd),

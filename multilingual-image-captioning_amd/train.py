@@ -45,6 +45,15 @@ def create_learning_rate_fn(train_ds_size: int, train_batch_size: int, num_train
     return schedule
 
 
+def loss_rows(attention_mask, labels):
+    """Collate-side helper: flat indices of the label positions whose loss mask is 1 (row-major over [B,T]) and the labels
+    at those positions.  `Trainer` runs the LM head / cross-entropy only there (exact: main.py:678 multiplies the rest by 0).
+    Returns (idx int32 [Mc], labels int32 [Mc]) as numpy arrays."""
+    m = np.asarray(attention_mask).reshape(-1)
+    idx = np.nonzero(m)[0].astype(np.int32)
+    return idx, np.asarray(labels).reshape(-1)[idx].astype(np.int32)
+
+
 def plan_buckets(numel: int, bucket_elems: int, boundaries: List[int]) -> List[Tuple[int, int]]:
     """Contiguous [begin, end) slices of the flat gradient buffer, cut at segment boundaries, each >= bucket_elems
     (except the last).  Pure host logic (tested on CPU)."""
@@ -106,11 +115,12 @@ class Trainer:
     """TrainState + train_step/eval_step of main.py, for one rank."""
 
     def __init__(self, model, learning_rate_fn: Callable[[int], float], b1=0.9, b2=0.999, eps=1e-8, weight_decay=0.0,
-                 label_smoothing_factor=0.0, seed: int = 42, bucket_mb: float = 64.0, group=None):
+                 label_smoothing_factor=0.0, seed: int = 42, bucket_mb: float = 64.0, group=None, compact_head: bool = True):
         import torch.distributed as dist
 
         self.model, self.lr_fn = model, learning_rate_fn
         self.b1, self.b2, self.eps, self.wd, self.ls = b1, b2, eps, weight_decay, label_smoothing_factor
+        self.compact_head = compact_head
         self.step = 0  # state.step
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -133,6 +143,21 @@ class Trainer:
         dec_in = m._dev(batch["decoder_input_ids"], torch.int32)
         B, T = labels.shape
         pos = torch.arange(T, dtype=torch.int32, device=m.device)[None].expand(B, T).contiguous()
+        rows = row_labels = None
+        if self.compact_head:
+            if "loss_rows" in batch:  # precomputed by the collate function (no device->host sync in the step)
+                idx, rl = batch["loss_rows"]
+                idx, rl = m._dev(idx, torch.int32), m._dev(rl, torch.int32)
+            else:
+                am = batch["attention_mask"]
+                am = am.cpu().numpy() if isinstance(am, torch.Tensor) else np.asarray(am)
+                lb = batch["input_ids"]
+                lb = lb.cpu().numpy() if isinstance(lb, torch.Tensor) else np.asarray(lb)
+                idx, rl = loss_rows(am, lb)
+                idx, rl = m._dev(idx, torch.int32), m._dev(rl, torch.int32)
+            if 0 < idx.numel() < B * T:
+                rows, row_labels = (idx, int(idx.numel())), rl
+        self._rows, self._row_labels = rows, row_labels
         return px, labels, mask, dec_in, pos, B, T
 
     def train_step(self, batch: Dict) -> Dict[str, float]:
@@ -143,7 +168,7 @@ class Trainer:
         self.reducer.start_step()
         eng.grad_progress = self.reducer.progress if self.world > 1 else None
         loss = eng.loss_and_grads(px, dec_in.reshape(-1), pos.reshape(-1), mask, labels.reshape(-1), B, T,
-                                  label_smoothing=self.ls, seed=seed)
+                                  label_smoothing=self.ls, seed=seed, rows=self._rows, row_labels=self._row_labels)
         self.reducer.finish()  # pmean(grad) (main.py:698): SUM here, 1/world folded into AdamW's grad_scale
         lr = float(self.lr_fn(self.step))
         self.hyper.copy_(torch.tensor([lr, float(self.step + 1)], dtype=torch.float32), non_blocking=True)
@@ -159,8 +184,8 @@ class Trainer:
         """main.py:710-721 (train=False, no dropout)."""
         m, eng = self.model, self.model.engine
         px, labels, mask, dec_in, pos, B, T = self._prep(batch)
-        logits, _ = eng.forward_logits(px, dec_in.reshape(-1), pos.reshape(-1), mask, B, T, save=False, seed=None)
-        loss = eng.loss_and_dlogits(logits, labels.reshape(-1), mask.reshape(-1), B * T, self.ls, backward=False)
+        loss = eng.loss_only(px, dec_in.reshape(-1), pos.reshape(-1), mask, labels.reshape(-1), B, T, label_smoothing=self.ls,
+                             rows=self._rows, row_labels=self._row_labels)
         self.metrics_buf[0:1].copy_(loss)
         self.metrics_buf[1] = 0.0
         out = self._pmean_metrics()

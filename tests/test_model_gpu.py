@@ -91,8 +91,8 @@ def _oracle_masks(model, rc, seed, B, T):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("train,ls", [(False, 0.0), (True, 0.0), (True, 0.1)])
-def test_loss_and_grads_match_oracle(dev, dtype, train, ls):
+@pytest.mark.parametrize("train,ls,compact", [(False, 0.0, False), (True, 0.0, False), (True, 0.1, False), (True, 0.1, True), (False, 0.0, True)])
+def test_loss_and_grads_match_oracle(dev, dtype, train, ls, compact):
     from mic_amd.params import flatten_tree, unflatten_tree
     from oracle import train_ref
 
@@ -104,8 +104,15 @@ def test_loss_and_grads_match_oracle(dev, dtype, train, ls):
     ref_loss, ref_g = train_ref.loss_and_grads(rc, p, px, labels, mask, dec_in, masks, ls)
     d = lambda x, t: model._dev(x, t)
     pos = torch.arange(T, dtype=torch.int32, device=dev)[None].expand(B, T).contiguous()
+    kw = {}
+    if compact:  # LM head + CE on the masked-in label positions only: must give the same loss and gradients
+        from mic_amd import loss_rows
+
+        idx, rl = loss_rows(mask.numpy(), labels.numpy())
+        assert 0 < len(idx) < B * T
+        kw = dict(rows=(d(idx, torch.int32), len(idx)), row_labels=d(rl, torch.int32))
     loss = model.engine.loss_and_grads(d(px, torch.float32), d(dec_in, torch.int32).reshape(-1), pos.reshape(-1), d(mask, torch.int32),
-                                       d(labels, torch.int32).reshape(-1), B, T, label_smoothing=ls, seed=seed)
+                                       d(labels, torch.int32).reshape(-1), B, T, label_smoothing=ls, seed=seed, **kw)
     torch.cuda.synchronize()
     tol_loss = 2e-5 if dtype == torch.float32 else 2e-2
     assert abs(loss.item() - ref_loss.item()) < tol_loss * max(1.0, abs(ref_loss.item())), (loss.item(), ref_loss.item())
