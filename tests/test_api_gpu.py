@@ -1,0 +1,95 @@
+"""Drop-in API surface of SURVEY §8(b) on the GPU: checkpoint round trips (config.json + flax_model.msgpack),
+`from_clip_vision_mbart_pretrained` grafting (modeling:703-773), the params property/setter contract (utils:99-117) and the
+`params=` keyword the reference's pmapped functions pass (main.py:692, 727; evaluation.py:81)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util_small import batch, make_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def test_save_and_from_pretrained_roundtrip(dev, tmp_path):
+    from mic_amd import FlaxCLIPVisionMBartForConditionalGeneration as Model
+
+    rc, p, model = make_pair(torch.float32, dev)
+    px, labels, mask, dec_in = batch(rc, 2, 12, seed=31)
+    ref = model(px.numpy(), dec_in.numpy(), mask.numpy())[0].cpu()
+    d = str(tmp_path / "ckpt")
+    model.save_pretrained(d)
+    assert sorted(os.listdir(d)) == ["config.json", "flax_model.msgpack"]  # main.py:307-312 layout
+    cfg = json.load(open(os.path.join(d, "config.json")))
+    assert cfg["model_type"] == "clip-vision-mbart" and cfg["mbart_config"]["d_model"] == rc.d_model
+    m2 = Model.from_pretrained(d, device=dev)
+    assert m2.config.mbart_config.decoder_ln_eps == model.config.mbart_config.decoder_ln_eps
+    got = m2(px.numpy(), dec_in.numpy(), mask.numpy())[0].cpu()
+    assert torch.equal(got, ref)
+    with pytest.raises(EnvironmentError):
+        Model.from_pretrained(str(tmp_path / "nope"))
+    with pytest.raises(NotImplementedError):
+        model.save_pretrained(d, push_to_hub=True)
+
+
+def test_from_clip_vision_mbart_pretrained_grafts_components(dev, tmp_path):
+    from mic_amd import FlaxCLIPVisionMBartForConditionalGeneration as Model
+    from mic_amd.checkpoint import save_flax_msgpack
+    from mic_amd.params import flatten_tree, unflatten_tree
+
+    rc, p, model = make_pair(torch.float32, dev)
+    tree = unflatten_tree({k: v.numpy() for k, v in p.items()})
+    clip_dir, mbart_dir = str(tmp_path / "clip"), str(tmp_path / "mbart")
+    os.makedirs(clip_dir), os.makedirs(mbart_dir)
+    save_flax_msgpack(os.path.join(clip_dir, "flax_model.msgpack"), tree["model"]["encoder"])  # FlaxCLIPVisionModel.params
+    json.dump(model.config.clip_vision_config.to_dict(), open(os.path.join(clip_dir, "config.json"), "w"))
+    save_flax_msgpack(os.path.join(mbart_dir, "flax_model.msgpack"),
+                      {"shared": tree["model"]["shared"], "decoder": tree["model"]["decoder"], "encoder": {"ignored": np.zeros(3, np.float32)}})
+    json.dump(model.config.mbart_config.to_dict(), open(os.path.join(mbart_dir, "config.json"), "w"))
+    m = Model.from_clip_vision_mbart_pretrained(clip_dir, mbart_dir, seed=3, dtype="float32", mbart_from_pt=True, device=dev)  # main.py:421-427
+    got = flatten_tree(m.params)
+    for k, v in p.items():
+        if k.startswith("model/encoder/") or k.startswith("model/decoder/") or k.startswith("model/shared/"):
+            assert np.array_equal(got[k], v.numpy()), k  # modeling:768-770
+    # visual_projection / final_logits_bias are NOT loaded: random / zero init (modeling:766-770)
+    assert not np.array_equal(got["model/visual_projection/kernel"], p["model/visual_projection/kernel"].numpy())
+    assert np.count_nonzero(got["final_logits_bias"]) == 0 and got["final_logits_bias"].shape == (1, rc.vocab_size)
+    with pytest.raises(AssertionError):
+        Model.from_clip_vision_mbart_pretrained(None, mbart_dir, device=dev)
+
+
+def test_params_property_contract_and_params_kwarg(dev):
+    from mic_amd.params import flatten_tree, unflatten_tree
+
+    rc, p, model = make_pair(torch.float32, dev)
+    tree = model.params
+    assert set(tree) == {"model", "final_logits_bias"} and set(tree["model"]) == {"encoder", "decoder", "shared", "visual_projection"}
+    assert tree["model"]["encoder"]["vision_model"]["pre_layrnorm"]["scale"].shape == (rc.v_hidden,)  # upstream typo is part of the key
+    assert tree["model"]["decoder"]["layers"]["0"]["self_attn"]["q_proj"]["kernel"].shape == (rc.d_model, rc.d_model)  # [in,out]
+    bad = unflatten_tree({k: v for k, v in flatten_tree(tree).items() if "visual_projection" not in k})
+    with pytest.raises(ValueError, match="Some parameters are missing"):
+        model.params = bad  # utils:107-117
+    # `params=` kwarg: generate_step / eval_step pass the (replicated) pytree explicitly (main.py:714, 727)
+    px, labels, mask, dec_in = batch(rc, 2, 12, seed=33)
+    base = model(px.numpy(), dec_in.numpy(), mask.numpy())[0].cpu()
+    flat = dict(flatten_tree(tree))
+    flat["final_logits_bias"] = flat["final_logits_bias"] + 1.5
+    shifted = model(px.numpy(), dec_in.numpy(), mask.numpy(), params=unflatten_tree(flat))[0].cpu()
+    assert torch.allclose(shifted, base + 1.5, atol=1e-5)
+    out = model(px.numpy(), dec_in.numpy(), mask.numpy(), return_dict=False)
+    assert isinstance(out, tuple) and out[0].shape == (2, 12, rc.vocab_size)
+
+
+def test_prepare_and_update_inputs_for_generation(dev):
+    rc, p, model = make_pair(torch.float32, dev)
+    px, *_ = batch(rc, 2, 12, seed=34)
+    enc = model.encode(px.numpy())
+    kw = model.prepare_inputs_for_generation(np.full((2, 1), 2, np.int32), 9, encoder_outputs=enc)
+    assert set(kw) == {"past_key_values", "encoder_outputs", "encoder_attention_mask", "decoder_attention_mask", "decoder_position_ids"}
+    assert kw["decoder_attention_mask"].shape == (2, 9) and int(kw["decoder_attention_mask"].sum()) == 18  # modeling:669
+    assert kw["decoder_position_ids"].tolist() == [[0], [0]]
+    out = model.decode(np.full((2, 1), 2, np.int32), enc, decoder_position_ids=kw["decoder_position_ids"], past_key_values=kw["past_key_values"])
+    kw = model.update_inputs_for_generation(out, kw)
+    assert kw["decoder_position_ids"].tolist() == [[1], [1]] and kw["past_key_values"]["cache_index"] == 1  # modeling:688-693
