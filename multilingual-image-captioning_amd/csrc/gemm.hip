@@ -23,6 +23,11 @@
 // Epilogue: accumulators are restaged through LDS (free after the main loop) so every thread owns 8 consecutive columns
 // of a row: bias / activation / dropout / residual / Z / C all move as 16-B coalesced vectors.
 //
+// Cost model measured on MI355X (tools/bench_gemm_k.py): 256^2 tile = 19.6 us fixed + 1.73 us per K-tile (1.24 PF/s
+// asymptotically), 128^2 launch = 9.6 us fixed + 0.57 us per K-tile (0.94 PF/s).  Of the fixed part ~4 us per 256^2 tile is
+// the output store burst (~15 B/clk/CU store path) which nothing overlaps at one block per CU — the next structural step is
+// a persistent tile loop that drains tile i's stores inside tile i+1's K-loop.
+//
 // f32 kernel (the reference's default dtype; parity mode): 64x64x16 tiles, v_mfma_f32_32x32x2_f32 (bit-exact fp32
 // fma chain), generic strides.
 #include "common.h"
@@ -133,6 +138,10 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_bf16_kernel(LaunchTable tab
   constexpr int BM = 2 * WM, BN = WN * WNW, NWAVES = 2 * WNW, NTHREADS = 64 * NWAVES;
   constexpr int HALF = 128 * BKT * 2;
   constexpr int NHA = BM / 128, NHB = BN / 128, STAGE = (NHA + NHB) * HALF, AI = WM / 32, NJ = WN / 32, KSTEPS = BKT / 16;
+#ifndef MIC_STAGE_AT
+#define MIC_STAGE_AT 0
+#endif
+  constexpr int STAGE_AT = MIC_STAGE_AT;  // k-step in front of which the next tile's LDS writes / global loads are issued
   using SA = HalfStager<AK, NWAVES, BKT>;
   using SB = HalfStager<BKM, NWAVES, BKT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A halves | B halves]
@@ -197,15 +206,15 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_bf16_kernel(LaunchTable tab
     __syncthreads();
   }
   for (int t = 0; t < nk; ++t) {
-    if (t + 1 < nk) {
-      write_lds(smem + ((t + 1) & 1) * STAGE);  // its buffer was last read in iteration t-1 (barrier below)
-      if (t + 2 < nk) load_regs(t + 2);         // a full iteration of MFMAs to land
-    }
     const char* cur = smem + (t & 1) * STAGE;
     const char* At = cur + a_half * HALF;
     const char* Bt = cur + (NHA + b_half) * HALF;
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; ++kk) {
+      if (kk == STAGE_AT && t + 1 < nk) {
+        write_lds(smem + ((t + 1) & 1) * STAGE);  // its buffer was last read in iteration t-1 (barrier below)
+        if (t + 2 < nk) load_regs(t + 2);         // a full iteration of MFMAs to land
+      }
       bf16x8 af[AI], bfr[NJ];
 #pragma unroll
       for (int i = 0; i < AI; ++i) af[i] = read_frag<AK, BKT>(At, a_off + i * 32, kk, lane);

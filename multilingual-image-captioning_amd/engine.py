@@ -292,7 +292,7 @@ class Engine:
             ops.gemm(dlogits, P.w("shared"), dhf, M, d, P.Vpad, b_kmajor=True)
         else:
             dhfc = self.buf("db.dhfc", M, d)
-            ops.gemm(dlogits, P.w("shared"), dhfc, Mh, d, P.Vpad, b_kmajor=True)  # (split-K measured no gain here)
+            ops.gemm(dlogits, P.w("shared"), dhfc, Mh, d, P.Vpad, b_kmajor=True)  # split-K (128^2 or 256^2 tiles) measured no gain
             dhf[:M].zero_()  # masked-out positions receive exactly zero gradient from the loss
             ops.copy_rows(dhfc, dhf, Mh, d, dst_idx=rows[0])
         dx = self.buf("db.dx", M, d)

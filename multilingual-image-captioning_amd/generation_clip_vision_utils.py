@@ -130,12 +130,13 @@ class FlaxCLIPVisionMBartGenerationMixin:
         cur_len = 1
         steps = 0
         while True:
-            logits = self._decode_step(cache, next_token, pos)  # gen:830-840
-            forced, suppress = self._proc_args(procs, cur_len, max_length, eos_token_id)
-            ops.row_lse_topk(logits, logits.stride(0), st.V, 2 * K, cand_val, cand_idx, R, forced_token=forced, suppress_eos=suppress,
-                             eos_token_id=eos_token_id, row_bias=running_scores.reshape(-1))  # gen:850-873 (per row)
-            ops.beam_step(B, K, max_length, st.V, cur_len, eos_token_id, pad_token_id, length_penalty, early_stopping, cand_val,
-                          cand_idx, running_seq, running_scores, seq, scores, finished, src_row, next_token, flags)  # gen:872-966
+            with ops.pinned_stream():
+                logits = self._decode_step(cache, next_token, pos)  # gen:830-840
+                forced, suppress = self._proc_args(procs, cur_len, max_length, eos_token_id)
+                ops.row_lse_topk(logits, logits.stride(0), st.V, 2 * K, cand_val, cand_idx, R, forced_token=forced, suppress_eos=suppress,
+                                 eos_token_id=eos_token_id, row_bias=running_scores.reshape(-1))  # gen:850-873 (per row)
+                ops.beam_step(B, K, max_length, st.V, cur_len, eos_token_id, pad_token_id, length_penalty, early_stopping, cand_val,
+                              cand_idx, running_seq, running_scores, seq, scores, finished, src_row, next_token, flags)  # gen:872-966
             pos += 1
             cur_len += 1
             steps += 1

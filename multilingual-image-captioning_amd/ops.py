@@ -27,8 +27,29 @@ def _p(t: Optional[torch.Tensor]):
     return t.data_ptr()
 
 
+_STREAM_OVERRIDE = None
+
+
 def _stream():
+    """HIP stream every kernel is launched on: torch's current stream (looked up per call: ~8 us), or the handle pinned by
+    `pinned_stream()` for the duration of a step."""
+    if _STREAM_OVERRIDE is not None:
+        return _STREAM_OVERRIDE
     return torch.cuda.current_stream().cuda_stream
+
+
+class pinned_stream:
+    """Context manager: resolve torch's current stream once and reuse the raw handle for every launch inside."""
+
+    def __enter__(self):
+        global _STREAM_OVERRIDE
+        self.prev = _STREAM_OVERRIDE
+        _STREAM_OVERRIDE = torch.cuda.current_stream().cuda_stream
+        return self
+
+    def __exit__(self, *a):
+        global _STREAM_OVERRIDE
+        _STREAM_OVERRIDE = self.prev
 
 
 def gemm_args(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, *, a_kmajor=False, b_kmajor=False,

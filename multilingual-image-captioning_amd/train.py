@@ -67,9 +67,11 @@ def plan_buckets(numel: int, bucket_elems: int, boundaries: List[int]) -> List[T
 
 
 class GradReducer:
-    """Bucketed all-reduce(mean) of the flat gradient buffer on a side stream (C1 of SURVEY §2.3)."""
+    """Bucketed all-reduce(mean) of the flat gradient buffer on a side stream (C1 of SURVEY §2.3), optionally followed —
+    still on the side stream — by a per-bucket callback (the fused AdamW of that slice): HBM-bound optimizer traffic then
+    overlaps the MFMA-bound remainder of backward instead of trailing it."""
 
-    def __init__(self, flat_grad: torch.Tensor, buckets: List[Tuple[int, int]], group=None):
+    def __init__(self, flat_grad: torch.Tensor, buckets: List[Tuple[int, int]], group=None, on_ready=None):
         import torch.distributed as dist
 
         self.dist, self.group = dist, group
@@ -77,8 +79,13 @@ class GradReducer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.cuda = flat_grad.is_cuda
         self.stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
+        self.on_ready = on_ready if self.cuda else None
         self.next = 0
         self.handles = []
+
+    @property
+    def active(self) -> bool:
+        return self.world > 1 or self.on_ready is not None
 
     def start_step(self):
         self.next = 0
@@ -86,7 +93,7 @@ class GradReducer:
 
     def progress(self, offset_done: int):
         """Backward reports that every gradient with flat offset < offset_done is final."""
-        if self.world == 1:
+        if not self.active:
             return
         while self.next < len(self.buckets) and self.buckets[self.next][1] <= offset_done:
             b, e = self.buckets[self.next]
@@ -95,14 +102,18 @@ class GradReducer:
                 ev.record(torch.cuda.current_stream())
                 with torch.cuda.stream(self.stream):
                     self.stream.wait_event(ev)
-                    self.dist.all_reduce(self.grad[b:e], op=self.dist.ReduceOp.SUM, group=self.group)
+                    if self.world > 1:
+                        self.dist.all_reduce(self.grad[b:e], op=self.dist.ReduceOp.SUM, group=self.group)
+                    if self.on_ready is not None:
+                        with ops.pinned_stream():  # launch on the side stream, not on the step's pinned main stream
+                            self.on_ready(b, e)
             else:
                 self.handles.append(self.dist.all_reduce(self.grad[b:e], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.next += 1
 
     def finish(self):
         self.progress(self.grad.numel())
-        if self.world == 1:
+        if not self.active:
             return
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.stream)
@@ -115,7 +126,8 @@ class Trainer:
     """TrainState + train_step/eval_step of main.py, for one rank."""
 
     def __init__(self, model, learning_rate_fn: Callable[[int], float], b1=0.9, b2=0.999, eps=1e-8, weight_decay=0.0,
-                 label_smoothing_factor=0.0, seed: int = 42, bucket_mb: float = 64.0, group=None, compact_head: bool = True):
+                 label_smoothing_factor=0.0, seed: int = 42, bucket_mb: float = 64.0, group=None, compact_head: bool = True,
+                 overlap_optimizer: bool = True):
         import torch.distributed as dist
 
         self.model, self.lr_fn = model, learning_rate_fn
@@ -132,8 +144,15 @@ class Trainer:
         self.hyper = torch.zeros(2, dtype=torch.float32, device=model.device)
         bounds = [s.offset for s in st.segs.values()]
         self.buckets = plan_buckets(st.numel, int(bucket_mb * 1024 * 1024 / 4), bounds)
-        self.reducer = GradReducer(st.grad, self.buckets, group)
+        self.overlap_optimizer = overlap_optimizer
+        self.reducer = GradReducer(st.grad, self.buckets, group, on_ready=self._adamw_slice if overlap_optimizer else None)
         self.metrics_buf = torch.zeros(2, dtype=torch.float32, device=model.device)
+
+    def _adamw_slice(self, b: int, e: int):
+        """AdamW on flat slice [b, e) — runs on the reducer's side stream right after that bucket's all-reduce."""
+        st = self.model.store
+        ops.adamw(st.master[b:e], st.m[b:e], st.v[b:e], st.grad[b:e], None if st.lp is st.master else st.lp[b:e], self.hyper,
+                  self.b1, self.b2, self.eps, self.wd, grad_scale=1.0 / self.world, n=e - b)
 
     def _prep(self, batch):
         m = self.model
@@ -165,15 +184,17 @@ class Trainer:
         m, st, eng = self.model, self.model.store, self.model.engine
         px, labels, mask, dec_in, pos, B, T = self._prep(batch)
         seed = (self.dropout_seed + self.step * 0x9E3779B1) & 0xFFFFFFFF  # split(dropout_rng) per step (main.py:686)
-        self.reducer.start_step()
-        eng.grad_progress = self.reducer.progress if self.world > 1 else None
-        loss = eng.loss_and_grads(px, dec_in.reshape(-1), pos.reshape(-1), mask, labels.reshape(-1), B, T,
-                                  label_smoothing=self.ls, seed=seed, rows=self._rows, row_labels=self._row_labels)
-        self.reducer.finish()  # pmean(grad) (main.py:698): SUM here, 1/world folded into AdamW's grad_scale
-        lr = float(self.lr_fn(self.step))
+        lr = float(self.lr_fn(self.step))  # schedule at the pre-increment count, bias correction with count+1
         self.hyper.copy_(torch.tensor([lr, float(self.step + 1)], dtype=torch.float32), non_blocking=True)
-        ops.adamw(st.master, st.m, st.v, st.grad, None if st.lp is st.master else st.lp, self.hyper, self.b1, self.b2, self.eps,
-                  self.wd, grad_scale=1.0 / self.world)
+        self.reducer.start_step()
+        eng.grad_progress = self.reducer.progress if self.reducer.active else None
+        with ops.pinned_stream():
+            loss = eng.loss_and_grads(px, dec_in.reshape(-1), pos.reshape(-1), mask, labels.reshape(-1), B, T,
+                                      label_smoothing=self.ls, seed=seed, rows=self._rows, row_labels=self._row_labels)
+        self.reducer.finish()  # pmean(grad) (main.py:698): SUM here, 1/world folded into AdamW's grad_scale
+        if not self.overlap_optimizer:
+            ops.adamw(st.master, st.m, st.v, st.grad, None if st.lp is st.master else st.lp, self.hyper, self.b1, self.b2, self.eps,
+                      self.wd, grad_scale=1.0 / self.world)
         m.invalidate_params_cache()
         self.step += 1
         self.metrics_buf[0:1].copy_(loss)
