@@ -104,75 +104,79 @@ __device__ __forceinline__ unsigned long long load_key_mask(const int32_t* key_m
 }
 
 // ------------------------------------------------------------------ forward
+// 256 threads = 4 waves share one (batch, head) problem.  Phase 1: wave w owns the (ib, jb) = (w>>1, w&1) quadrant of
+// S^T = K Q^T (lane <-> query): quadrant max -> LDS, barrier, p = exp(s - rowmax) written UNnormalised to the P tile,
+// quadrant row sums -> LDS.  Phase 2: wave w owns output block (ib, db) of O = P V and scales each row by 1/rowsum.
 template <typename T>
-__global__ __launch_bounds__(64) void attn_fwd_kernel(int H, int Tq, int Tk, const T* __restrict__ q, int ldq,
-                                                      const T* __restrict__ k, int ldk, const T* __restrict__ v, int ldv,
-                                                      T* __restrict__ out, int ldo, const int32_t* __restrict__ key_mask,
-                                                      int causal, float* __restrict__ lse_out) {
+__global__ __launch_bounds__(256) void attn_fwd_kernel(int H, int Tq, int Tk, const T* __restrict__ q, int ldq,
+                                                       const T* __restrict__ k, int ldk, const T* __restrict__ v, int ldv,
+                                                       T* __restrict__ out, int ldo, const int32_t* __restrict__ key_mask,
+                                                       int causal, float* __restrict__ lse_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TB = Tile<T>::BYTES;
   char* Qt = smem;
-  char* Kt = smem + Tile<T>::BYTES;
-  char* Vt = smem + 2 * Tile<T>::BYTES;
-  char* Pt = smem + 3 * Tile<T>::BYTES;
-  const int lane = threadIdx.x;
+  char* Kt = smem + TB;
+  char* Vt = smem + 2 * TB;
+  char* Pt = smem + 3 * TB;
+  float* pmax = reinterpret_cast<float*>(smem + 4 * TB);  // [2 jb][64 queries]
+  float* psum = pmax + 128;                               // [2 jb][64 queries]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / H, h = blockIdx.x % H;
-  Tile<T>::stage(Qt, q + (size_t)b * Tq * ldq + h * 64, ldq, Tq, lane);
-  Tile<T>::stage(Kt, k + (size_t)b * Tk * ldk + h * 64, ldk, Tk, lane);
-  Tile<T>::stage(Vt, v + (size_t)b * Tk * ldv + h * 64, ldv, Tk, lane);
+  Tile<T>::template stage<256>(Qt, q + (size_t)b * Tq * ldq + h * 64, ldq, Tq, tid);
+  Tile<T>::template stage<256>(Kt, k + (size_t)b * Tk * ldk + h * 64, ldk, Tk, tid);
+  Tile<T>::template stage<256>(Vt, v + (size_t)b * Tk * ldv + h * 64, ldv, Tk, tid);
   const unsigned long long km = load_key_mask(key_mask, b, Tk, lane);
   __syncthreads();
   const int nib = (Tq + 31) >> 5, njb = (Tk + 31) >> 5;
-  for (int ib = 0; ib < nib; ++ib) {
-    f32x16 s[2];
-    zero16(s[0]); zero16(s[1]);
+  const int ib = wave >> 1, jb = wave & 1;
+  const int i = ib * 32 + (lane & 31);
+  f32x16 s;
+  zero16(s);
+  const bool live = ib < nib && jb < njb;
+  if (live) Tile<T>::template mma<false, false>(s, Kt, jb * 32, Qt, ib * 32, lane);
+  float m = -INFINITY;
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
-      if (jb < njb) Tile<T>::template mma<false, false>(s[jb], Kt, jb * 32, Qt, ib * 32, lane);
-    const int i = ib * 32 + (lane & 31);
-    float m = -INFINITY;
-#pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = jb * 32 + acc_row(r, lane);
-        const bool ok = jb < njb && j < Tk && (!causal || j <= i) && ((km >> j) & 1ull);
-        const float x = ok ? s[jb][r] * SCALE : -INFINITY;
-        s[jb][r] = x;
-        m = fmaxf(m, x);
-      }
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float l = 0.f;
-#pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { const float p = __expf(s[jb][r] - m); s[jb][r] = p; l += p; }
-    l += __shfl_xor(l, 32, 64);
-    const float inv = 1.0f / l;
-    if (lse_out && lane < 32 && i < Tq) lse_out[((size_t)b * H + h) * Tq + i] = m + logf(l);
-#pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        float pv[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) pv[e] = s[jb][g4 * 4 + e] * inv;
-        Tile<T>::store4(Pt, i, jb * 32 + 8 * g4 + 4 * (lane >> 5), pv);
-      }
+  for (int r = 0; r < 16; ++r) {
+    const int j = jb * 32 + acc_row(r, lane);
+    const bool ok = live && j < Tk && (!causal || j <= i) && ((km >> j) & 1ull);
+    const float x = ok ? s[r] * SCALE : -INFINITY;
+    s[r] = x;
+    m = fmaxf(m, x);
   }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  if (lane < 32) pmax[jb * 64 + i] = m;
   __syncthreads();
-  for (int ib = 0; ib < nib; ++ib)
+  const float mrow = fmaxf(pmax[i], pmax[64 + i]);
+  float l = 0.f;
 #pragma unroll
-    for (int db = 0; db < 2; ++db) {
+  for (int g4 = 0; g4 < 4; ++g4) {
+    float pv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float p = __expf(s[g4 * 4 + e] - mrow);
+      pv[e] = p;
+      l += p;
+    }
+    Tile<T>::store4(Pt, i, jb * 32 + 8 * g4 + 4 * (lane >> 5), pv);
+  }
+  l += __shfl_xor(l, 32, 64);
+  if (lane < 32) psum[jb * 64 + i] = l;
+  __syncthreads();
+  if (jb == 0 && lane < 32 && i < Tq && lse_out) lse_out[((size_t)b * H + h) * Tq + i] = mrow + logf(psum[i] + psum[64 + i]);
+  {
+    const int db = wave & 1;  // output block (ib, db)
+    if (ib < nib) {
       f32x16 o;
       zero16(o);
       Tile<T>::template mma<false, true>(o, Pt, ib * 32, Vt, db * 32, lane);
       const int d = db * 32 + (lane & 31);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int i = ib * 32 + acc_row(r, lane);
-        if (i < Tq) ElemT<T>::st(out + ((size_t)b * Tq + i) * ldo + h * 64 + d, o[r]);
+        const int qi = ib * 32 + acc_row(r, lane);
+        if (qi < Tq) ElemT<T>::st(out + ((size_t)b * Tq + qi) * ldo + h * 64 + d, o[r] / (psum[qi] + psum[64 + qi]));
       }
     }
+  }
 }
 
 // ------------------------------------------------------------------ backward
@@ -302,11 +306,11 @@ extern "C" int mic_attn_fwd(int dtype, int B, int H, int Tq, int Tk, const void*
   MIC_CHECK(q && k && v && out, "mic_attn_fwd: null pointer");
   const int align = dtype == MIC_BF16 ? 8 : 4;
   MIC_CHECK(ldq % align == 0 && ldk % align == 0 && ldv % align == 0, "mic_attn_fwd: row strides must keep 16-B alignment");
-  dim3 grid(B * H), block(64);
+  dim3 grid(B * H), block(256);
   if (dtype == MIC_BF16) {
-    hipLaunchKernelGGL(attn_fwd_kernel<uint16_t>, grid, block, 4 * Tile<uint16_t>::BYTES, (hipStream_t)stream, H, Tq, Tk, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk, (const uint16_t*)v, ldv, (uint16_t*)out, ldo, key_mask, causal, lse);
+    hipLaunchKernelGGL(attn_fwd_kernel<uint16_t>, grid, block, 4 * Tile<uint16_t>::BYTES + 1024, (hipStream_t)stream, H, Tq, Tk, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk, (const uint16_t*)v, ldv, (uint16_t*)out, ldo, key_mask, causal, lse);
   } else if (dtype == MIC_F32) {
-    const size_t lds = 4 * Tile<float>::BYTES;
+    const size_t lds = 4 * Tile<float>::BYTES + 1024;
     if (int rc = set_lds(attn_fwd_kernel<float>, lds)) return rc;
     hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, block, lds, (hipStream_t)stream, H, Tq, Tk, (const float*)q, ldq, (const float*)k, ldk, (const float*)v, ldv, (float*)out, ldo, key_mask, causal, lse);
   } else MIC_CHECK(false, "mic_attn_fwd: bad dtype");
