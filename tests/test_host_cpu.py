@@ -16,7 +16,7 @@ def test_abi_exports_every_declared_symbol():
     from mic_amd import _lib
 
     hdr = open(os.path.join(ROOT, "include", "mic_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(mic_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|const char\*)\s+(mic_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
     assert declared, "no declarations parsed"
     l = _lib.lib()  # loads without a GPU
     for name in declared:
