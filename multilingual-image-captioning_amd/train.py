@@ -78,7 +78,8 @@ class GradReducer:
         self.grad, self.buckets = flat_grad, buckets
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.cuda = flat_grad.is_cuda
-        self.stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
+        self.stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None       # collectives
+        self.opt_stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None   # per-bucket optimizer work
         self.on_ready = on_ready if self.cuda else None
         self.next = 0
         self.handles = []
@@ -100,12 +101,17 @@ class GradReducer:
             if self.cuda:
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream())
-                with torch.cuda.stream(self.stream):
-                    self.stream.wait_event(ev)
-                    if self.world > 1:
+                if self.world > 1:
+                    with torch.cuda.stream(self.stream):
+                        self.stream.wait_event(ev)
                         self.dist.all_reduce(self.grad[b:e], op=self.dist.ReduceOp.SUM, group=self.group)
-                    if self.on_ready is not None:
-                        with ops.pinned_stream():  # launch on the side stream, not on the step's pinned main stream
+                        ev = torch.cuda.Event()
+                        ev.record(self.stream)
+                if self.on_ready is not None:
+                    # the optimizer slice runs on its own stream: it must not sit between two collectives
+                    with torch.cuda.stream(self.opt_stream):
+                        self.opt_stream.wait_event(ev)
+                        with ops.pinned_stream():  # launch on that stream, not on the step's pinned main stream
                             self.on_ready(b, e)
             else:
                 self.handles.append(self.dist.all_reduce(self.grad[b:e], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -117,6 +123,7 @@ class GradReducer:
             return
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.stream)
+            torch.cuda.current_stream().wait_stream(self.opt_stream)
         else:
             for h in self.handles:
                 h.wait()
