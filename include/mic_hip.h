@@ -138,7 +138,8 @@ int mic_vit_assemble_bwd(int dtype, int B, int S, int width, const void* dx, voi
 /* ---------------------------------------------------------------------------------------------
  * Decoder token embedding (3P FlaxMBartDecoder):
  *   h[r] = table[ids[r]] * scale + pos_table[pos_ids[r] + 2]        (table in `dtype`, pos_table fp32)
- *   bwd: dtable[ids[r]] += dh[r]*scale ; dpos_table[pos+2] += dh[r]  (fp32 atomics into the grad buffers)
+ *   bwd: dtable[ids[r]] += dh[r]*scale ; dpos_table[pos+2] += dh[r]  (fp32 atomics into the grad buffers); either output
+ *        may be NULL (data-parallel runs all-gather the (ids, dh) rows and scatter them after the dense all-reduce)
  * ------------------------------------------------------------------------------------------- */
 int mic_embed_fwd(int dtype, int rows, int width, const int32_t* ids, const int32_t* pos_ids, const void* table,
                   const float* pos_table, float scale, void* h, void* stream);

@@ -136,13 +136,13 @@ __global__ void embed_bwd_kernel(int rows, int width, const int32_t* __restrict_
     const int c = (int)(e % width);
     const int r = (int)(e / width);
     const float g = ElemT<T>::ld(dh + e);
-    atomicAdd(dtable + (size_t)ids[r] * width + c, g * scale);
-    atomicAdd(dpos + (size_t)(pos_ids[r] + 2) * width + c, g);
+    if (dtable) atomicAdd(dtable + (size_t)ids[r] * width + c, g * scale);
+    if (dpos) atomicAdd(dpos + (size_t)(pos_ids[r] + 2) * width + c, g);
   }
 }
 extern "C" int mic_embed_bwd(int dtype, int rows, int width, const int32_t* ids, const int32_t* pos_ids, const void* dh,
                              float scale, float* dtable, float* dpos_table, void* stream) {
-  MIC_CHECK(rows > 0 && width > 0 && ids && pos_ids && dh && dtable && dpos_table, "mic_embed_bwd: bad args");
+  MIC_CHECK(rows > 0 && width > 0 && dh && (dtable || dpos_table) && (!dtable || ids) && (!dpos_table || pos_ids), "mic_embed_bwd: bad args");
   return dispatch_t(dtype, [&](auto* tag) {
     using T = TYPE_OF(tag);
     const long total = (long)rows * width;

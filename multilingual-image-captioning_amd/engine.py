@@ -40,6 +40,8 @@ class Engine:
         self.vit_eps = float(store.cfg.clip_vision_config.layer_norm_eps)
         self.p_drop = float(mc.dropout)
         self.embed_scale = math.sqrt(store.d) if mc.scale_embedding else 1.0
+        self.defer_embed = False  # True: leave the sparse tied-embedding rows (ids, dh0) to the caller (data parallel)
+        self.embed_rows = None     # (ids, dh0 buffer, M) of the last backward when deferred
         self._dw_queue = []
         self._cs_queue = []
         self.grad_progress = None  # callable(offset): every gradient with flat offset < offset is final (DDP overlap)
@@ -288,6 +290,7 @@ class Engine:
         Mhp = _rup(Mh, 64)
         ops.colsum(dlogits, P.g("flb"), Mh, P.Vpad, dlogits.stride(0))
         ops.gemm(dlogits, hf, P.g("shared"), P.Vpad, d, Mhp, a_kmajor=True, b_kmajor=True)
+        self._done("shared")  # dense (LM head) part of the tied embedding gradient: first thing backward completes
         if rows is None:
             ops.gemm(dlogits, P.w("shared"), dhf, M, d, P.Vpad, b_kmajor=True)
         else:
@@ -352,8 +355,12 @@ class Engine:
         dh0 = self.buf("db.dh0", M, d)
         ops.layernorm_bwd(h0, P.f32("dec.ln_emb.g"), ste[0], ste[1], dx, dh0, P.g("dec.ln_emb.g"), P.g("dec.ln_emb.b"), rows=M,
                           in_dropout_p=pd, in_dropout_seed=sd(1))
-        ops.embed_bwd(ids, pos_ids, dh0, self.embed_scale, P.g("shared"), P.g("dec.pos"), M, d)
-        self._done("shared")
+        if self.defer_embed:
+            ops.embed_bwd(ids, pos_ids, dh0, self.embed_scale, None, P.g("dec.pos"), M, d)
+            self.embed_rows = (ids, dh0, M)
+        else:
+            # single process: the scatter lands before the optimizer touches the segment (Trainer holds that bucket)
+            ops.embed_bwd(ids, pos_ids, dh0, self.embed_scale, P.g("shared"), P.g("dec.pos"), M, d)
         return dehs
 
     # ------------------------------------------------------------------ loss (main.py:658-680) on materialised logits

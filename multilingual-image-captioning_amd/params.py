@@ -89,12 +89,13 @@ class ParamStore:
         d, f, vd, vf = self.d, self.ffn, self.vd, self.vffn
         # ---- dense region (GEMM-written weight gradients), in backward-completion order
         add("flb", (self.Vpad,))
+        add("shared", (self.Vpad, d))  # LM-head part is final right after the head dW GEMM; the sparse input-embedding rows are
+        #                                added after the dense all-reduce (see Trainer / Engine.defer_embed)
         dec_lin = (("fc2", (d, f)), ("fc1", (f, d)), ("co", (d, d)), ("cq", (d, d)), ("ckv", (2 * d, d)), ("so", (d, d)), ("qkv", (3 * d, d)))
         vit_lin = (("fc2", (vd, vf)), ("fc1", (vf, vd)), ("o", (vd, vd)), ("qkv", (3 * vd, vd)))
         for l in reversed(range(self.L)):
             for n, shp in dec_lin:
                 add(f"dec{l}.{n}.w", shp)
-        add("shared", (self.Vpad, d))
         add("vp.w", (d, vd))
         for l in reversed(range(self.vL)):
             for n, shp in vit_lin:

@@ -71,7 +71,7 @@ class GradReducer:
     still on the side stream — by a per-bucket callback (the fused AdamW of that slice): HBM-bound optimizer traffic then
     overlaps the MFMA-bound remainder of backward instead of trailing it."""
 
-    def __init__(self, flat_grad: torch.Tensor, buckets: List[Tuple[int, int]], group=None, on_ready=None):
+    def __init__(self, flat_grad: torch.Tensor, buckets: List[Tuple[int, int]], group=None, on_ready=None, hold=None):
         import torch.distributed as dist
 
         self.dist, self.group = dist, group
@@ -83,6 +83,9 @@ class GradReducer:
         self.on_ready = on_ready if self.cuda else None
         self.next = 0
         self.handles = []
+        self.hold = hold  # (begin, end): buckets touching this range are reduced as usual but their on_ready is postponed
+        self.held: List[Tuple[int, int]] = []
+        self.last_comm_event = None
 
     @property
     def active(self) -> bool:
@@ -91,6 +94,8 @@ class GradReducer:
     def start_step(self):
         self.next = 0
         self.handles = []
+        self.held = []
+        self.last_comm_event = None
 
     def progress(self, offset_done: int):
         """Backward reports that every gradient with flat offset < offset_done is final."""
@@ -107,7 +112,10 @@ class GradReducer:
                         self.dist.all_reduce(self.grad[b:e], op=self.dist.ReduceOp.SUM, group=self.group)
                         ev = torch.cuda.Event()
                         ev.record(self.stream)
-                if self.on_ready is not None:
+                self.last_comm_event = ev
+                if self.hold is not None and b < self.hold[1] and e > self.hold[0]:
+                    self.held.append((b, e))
+                elif self.on_ready is not None:
                     # the optimizer slice runs on its own stream: it must not sit between two collectives
                     with torch.cuda.stream(self.opt_stream):
                         self.opt_stream.wait_event(ev)
@@ -116,6 +124,25 @@ class GradReducer:
             else:
                 self.handles.append(self.dist.all_reduce(self.grad[b:e], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.next += 1
+
+    def release_held(self, before=None):
+        """Run `before()` (e.g. the sparse embedding scatter) and then the postponed on_ready calls, on the optimizer stream,
+        after every collective issued so far."""
+        if not self.cuda or (not self.held and before is None):
+            return
+        ev = torch.cuda.Event()
+        ev.record(self.stream if self.world > 1 else torch.cuda.current_stream())
+        with torch.cuda.stream(self.opt_stream):
+            self.opt_stream.wait_event(ev)
+            if self.world == 1:
+                self.opt_stream.wait_stream(torch.cuda.current_stream())
+            with ops.pinned_stream():
+                if before is not None:
+                    before()
+                if self.on_ready is not None:
+                    for (b, e) in self.held:
+                        self.on_ready(b, e)
+        self.held = []
 
     def finish(self):
         self.progress(self.grad.numel())
@@ -152,7 +179,9 @@ class Trainer:
         bounds = [s.offset for s in st.segs.values()]
         self.buckets = plan_buckets(st.numel, int(bucket_mb * 1024 * 1024 / 4), bounds)
         self.overlap_optimizer = overlap_optimizer
-        self.reducer = GradReducer(st.grad, self.buckets, group, on_ready=self._adamw_slice if overlap_optimizer else None)
+        sh = st.segs["shared"]
+        self.reducer = GradReducer(st.grad, self.buckets, group, on_ready=self._adamw_slice if overlap_optimizer else None,
+                                   hold=(sh.offset, sh.offset + sh.numel))
         self.metrics_buf = torch.zeros(2, dtype=torch.float32, device=model.device)
 
     def _adamw_slice(self, b: int, e: int):
@@ -160,6 +189,20 @@ class Trainer:
         st = self.model.store
         ops.adamw(st.master[b:e], st.m[b:e], st.v[b:e], st.grad[b:e], None if st.lp is st.master else st.lp[b:e], self.hyper,
                   self.b1, self.b2, self.eps, self.wd, grad_scale=1.0 / self.world, n=e - b)
+
+    def _scatter_embedding_rows(self):
+        """Data parallel: the sparse half of the tied-embedding gradient.  Every rank all-gathers (ids, dh0) — <= B*T rows
+        per rank — and scatter-adds ALL ranks' rows into its already all-reduced dense half (sum over ranks, like the
+        all-reduce; 1/world is applied by AdamW).  Runs on the optimizer stream after the last collective."""
+        import torch.distributed as dist
+
+        eng, st = self.model.engine, self.model.store
+        ids, dh0, M = eng.embed_rows
+        all_ids = torch.empty((self.world * M,), dtype=ids.dtype, device=ids.device)
+        all_dh = torch.empty((self.world * M, st.d), dtype=dh0.dtype, device=dh0.device)
+        dist.all_gather_into_tensor(all_ids, ids[:M].contiguous(), group=self.group)
+        dist.all_gather_into_tensor(all_dh, dh0[:M].contiguous(), group=self.group)
+        ops.embed_bwd(all_ids, None, all_dh, eng.embed_scale, st.g("shared"), None, self.world * M, st.d)
 
     def _prep(self, batch):
         m = self.model
@@ -195,9 +238,12 @@ class Trainer:
         self.hyper.copy_(torch.tensor([lr, float(self.step + 1)], dtype=torch.float32), non_blocking=True)
         self.reducer.start_step()
         eng.grad_progress = self.reducer.progress if self.reducer.active else None
+        eng.defer_embed = self.world > 1
         with ops.pinned_stream():
             loss = eng.loss_and_grads(px, dec_in.reshape(-1), pos.reshape(-1), mask, labels.reshape(-1), B, T,
                                       label_smoothing=self.ls, seed=seed, rows=self._rows, row_labels=self._row_labels)
+        self.reducer.progress(st.numel)  # everything is final now: remaining buckets go out
+        self.reducer.release_held(self._scatter_embedding_rows if self.world > 1 else None)
         self.reducer.finish()  # pmean(grad) (main.py:698): SUM here, 1/world folded into AdamW's grad_scale
         if not self.overlap_optimizer:
             ops.adamw(st.master, st.m, st.v, st.grad, None if st.lp is st.master else st.lp, self.hyper, self.b1, self.b2, self.eps,
