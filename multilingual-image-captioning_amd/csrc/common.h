@@ -90,11 +90,14 @@ __device__ __forceinline__ uint32_t dropout_threshold(float p) { return (uint32_
 __device__ __forceinline__ bool dropout_keep(uint32_t seed, uint32_t idx, uint32_t thr) { return mic_hash(seed, idx) >= thr; }
 
 // ---- activations
+// tanh through one v_exp_f32 + one v_rcp_f32 (abs error ~1e-7; saturates correctly at +-inf) — ocml's tanhf costs ~10x more
+// and the GEMM epilogue evaluates it once per FFN element.
+__device__ __forceinline__ float fast_tanh(float u) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * u)); }
 __device__ __forceinline__ float act_fwd(int act, float x) {
   switch (act) {
     case MIC_ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
-    case MIC_ACT_GELU_TANH: { float u = 0.7978845608028654f * (x + 0.044715f * x * x * x); return 0.5f * x * (1.0f + tanhf(u)); }
-    case MIC_ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
+    case MIC_ACT_GELU_TANH: { float u = 0.7978845608028654f * (x + 0.044715f * x * x * x); return 0.5f * x * (1.0f + fast_tanh(u)); }
+    case MIC_ACT_QUICK_GELU: return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
     default: return x;
   }
 }
@@ -106,10 +109,10 @@ __device__ __forceinline__ float act_bwd(int act, float x) {
     }
     case MIC_ACT_GELU_TANH: {
       float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-      float t = tanhf(u);
+      float t = fast_tanh(u);
       return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
     }
-    case MIC_ACT_QUICK_GELU: { float s = 1.0f / (1.0f + __expf(-1.702f * x)); return s + 1.702f * x * s * (1.0f - s); }
+    case MIC_ACT_QUICK_GELU: { float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); return s + 1.702f * x * s * (1.0f - s); }
     default: return 1.0f;
   }
 }
@@ -143,6 +146,76 @@ __device__ __forceinline__ void epilogue_store(const EpiArgs& e, int m, int n, f
     T* c = (T*)e.C + (size_t)m * e.ldc + n;
     if (e.accumulate) v += ElemT<T>::ld(c);
     ElemT<T>::st(c, v);
+  }
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in VGPRs (HIP's uint4 class may not)
+__device__ __forceinline__ void unpack8(u32x4 u, float* o) {
+  o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xffff0000u);
+  o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xffff0000u);
+  o[4] = __uint_as_float(u.z << 16); o[5] = __uint_as_float(u.z & 0xffff0000u);
+  o[6] = __uint_as_float(u.w << 16); o[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ bool epilogue_vec_ok(const EpiArgs& e, int cnt) {
+  return cnt == 8 && (e.ldc & 7) == 0 && (!e.Zout || (e.ldz & 7) == 0) && (!e.Zin || (e.ldz & 7) == 0) && (!e.R || (e.ldr & 7) == 0);
+}
+// bf16 epilogue split in two so a thread can issue the side loads (Zin / residual / accumulate-into-C) of ALL its 8-column
+// groups before it starts computing and storing: inside the store loop every such load would cost a full memory latency.
+// Two register slots per group: zc = Zin (dact) or the old C (bf16 accumulate) — a launch using both takes the plain path.
+__device__ __forceinline__ bool epilogue_pre_ok(const EpiArgs& e) { return !(e.dact && e.accumulate && !e.c_f32); }
+__device__ __forceinline__ void epilogue_prefetch8(const EpiArgs& e, int m, int n, u32x4& zc, u32x4& r) {
+  if (e.dact) zc = *reinterpret_cast<const u32x4*>((const uint16_t*)e.Zin + (size_t)m * e.ldz + n);
+  else if (e.accumulate && !e.c_f32) zc = *reinterpret_cast<const u32x4*>((const uint16_t*)e.C + (size_t)m * e.ldc + n);
+  if (e.R) r = *reinterpret_cast<const u32x4*>((const uint16_t*)e.R + (size_t)m * e.ldr + n);
+}
+__device__ __forceinline__ void epilogue_store8_pre(const EpiArgs& e, int m, int n, float* v, u32x4 zc, u32x4 rq) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] *= e.alpha;
+  if (e.bias) {
+    float b[8];
+    ld8(e.bias + n, b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += b[i];
+  }
+  if (e.Zout) st8((uint16_t*)e.Zout + (size_t)m * e.ldz + n, v);
+  if (e.act) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = act_fwd(e.act, round_to<uint16_t>(v[i]));
+  }
+  if (e.dact) {
+    float z[8];
+    unpack8(zc, z);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] *= act_bwd(e.dact, z[i]);
+  }
+  if (e.drop_thr) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      v[i] = dropout_keep(e.drop_seed, (uint32_t)m * (uint32_t)e.N + (uint32_t)(n + i), e.drop_thr) ? v[i] * e.drop_scale : 0.0f;
+  }
+  if (e.R) {
+    float r[8];
+    unpack8(rq, r);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += r[i];
+  }
+  if (e.c_f32) {
+    float* c = (float*)e.C + (size_t)m * e.ldc + n;
+    if (e.accumulate) {
+      float o[8];
+      ld8(c, o);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += o[i];
+    }
+    st8(c, v);
+  } else {
+    if (e.accumulate) {
+      float o[8];
+      unpack8(zc, o);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += o[i];
+    }
+    st8((uint16_t*)e.C + (size_t)m * e.ldc + n, v);
   }
 }
 

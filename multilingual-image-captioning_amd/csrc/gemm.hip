@@ -33,7 +33,6 @@
 #include "common.h"
 
 #define MAX_PROBLEMS 8
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in VGPRs across the loop back-edge
 
 struct Problem {
   const uint16_t* A; const uint16_t* B;
@@ -159,7 +158,15 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_bf16_kernel(LaunchTable tab
     if (i < tab.count && lid >= tab.p[i].block_begin) pi = i;
   const Problem& P = tab.p[pi];
   const int local = lid - P.block_begin;
-  const int tile = local / P.nsplit, split = local - tile * P.nsplit;
+  int tile = local / P.nsplit, split = local - tile * P.nsplit;
+  if (tab.count == 1 && P.nsplit > 1 && (P.nsplit & 7) == 0) {
+    // split-K with K-range <-> XCD affinity: XCD x owns the K-chunks [x*S, (x+1)*S) and walks them chunk by chunk over ALL
+    // output tiles, so the ~32 blocks resident on an XCD read the same K-range of A and B at the same time (one HBM read
+    // per operand byte; tile-major order made every block stream private panels: fabric-bound, no gain over no split)
+    const int T = P.tiles_m * P.tiles_n, S = P.nsplit >> 3, j = blockIdx.x >> 3;
+    split = (blockIdx.x & 7) * S + j / T;
+    tile = j % T;
+  }
   int tm, tn;
   tile_coords(tile, P.tiles_m, P.tiles_n, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
@@ -243,7 +250,19 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_bf16_kernel(LaunchTable tab
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           Cw[(i2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * WN + j * 32 + (lane & 31)] = acc[2 * p + i2][j][r];
+    // side loads of all this thread's groups go out before the barrier (their latency hides behind it and each other)
+    u32x4 zq[CPR], rq[CPR];
+    const bool split = P.nsplit > 1, pre = !split && epilogue_pre_ok(P.epi) && epilogue_vec_ok(P.epi, 8);
+#pragma unroll
+    for (int it = 0; it < CPR; ++it) {
+      const int id = it * NTHREADS + tid;
+      const int w = id / (64 * CPR), rem = id % (64 * CPR);
+      const int m = m0 + (w / WNW) * WM + p * 64 + rem / CPR, n = n0 + (w % WNW) * WN + (rem % CPR) * 8;
+      zq[it] = rq[it] = u32x4{0u, 0u, 0u, 0u};
+      if (pre && m < M && n + 8 <= N) epilogue_prefetch8(P.epi, m, n, zq[it], rq[it]);
+    }
     __syncthreads();
+#pragma unroll
     for (int it = 0; it < CPR; ++it) {
       const int id = it * NTHREADS + tid;
       const int w = id / (64 * CPR), rem = id % (64 * CPR);
@@ -256,9 +275,11 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_bf16_kernel(LaunchTable tab
       const float4 hi = *reinterpret_cast<const float4*>(src + 4);
       v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
       const int cnt = min(8, N - n);
-      if (P.nsplit > 1) {  // split-K: fp32 atomic accumulation into a zero-initialised C
+      if (split) {  // split-K: fp32 atomic accumulation into a zero-initialised C
         float* c = (float*)P.epi.C + (size_t)m * P.epi.ldc + n;
         for (int i = 0; i < cnt; ++i) atomicAdd(c + i, v[i] * P.epi.alpha);
+      } else if (pre && cnt == 8) {
+        epilogue_store8_pre(P.epi, m, n, v, zq[it], rq[it]);
       } else {
         epilogue_store8<uint16_t>(P.epi, m, n, v, cnt);
       }

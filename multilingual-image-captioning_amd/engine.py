@@ -291,13 +291,19 @@ class Engine:
         ops.colsum(dlogits, P.g("flb"), Mh, P.Vpad, dlogits.stride(0))
         ops.gemm(dlogits, hf, P.g("shared"), P.Vpad, d, Mhp, a_kmajor=True, b_kmajor=True)
         self._done("shared")  # dense (LM head) part of the tied embedding gradient: first thing backward completes
-        if rows is None:
-            ops.gemm(dlogits, P.w("shared"), dhf, M, d, P.Vpad, b_kmajor=True)
+        dhc = dhf if rows is None else self.buf("db.dhfc", M, d)
+        if self.dt == torch.bfloat16 and P.Vpad >= 16384:
+            # [Mh, d] output, reduction over the whole vocabulary: far too few tiles to fill 256 CUs.  Split-K 16 with K-range
+            # <-> XCD affinity (gemm.hip) into an fp32 buffer, one rounding to bf16 afterwards.
+            d32 = self.buf("db.dhf32", M, d, torch.float32)
+            d32[:Mh].zero_()
+            ops.gemm(dlogits, P.w("shared"), d32, Mh, d, P.Vpad, b_kmajor=True, split_k=16)
+            ops.cast2d(d32, dhc, Mh, d, d32.stride(0), dhc.stride(0))
         else:
-            dhfc = self.buf("db.dhfc", M, d)
-            ops.gemm(dlogits, P.w("shared"), dhfc, Mh, d, P.Vpad, b_kmajor=True)  # split-K (128^2 or 256^2 tiles) measured no gain
+            ops.gemm(dlogits, P.w("shared"), dhc, Mh, d, P.Vpad, b_kmajor=True)
+        if rows is not None:
             dhf[:M].zero_()  # masked-out positions receive exactly zero gradient from the loss
-            ops.copy_rows(dhfc, dhf, Mh, d, dst_idx=rows[0])
+            ops.copy_rows(dhc, dhf, Mh, d, dst_idx=rows[0])
         dx = self.buf("db.dx", M, d)
         dxm = self.buf("db.dxm_a", M, d)   # masked grad entering the FFN branch
         dxm_b = self.buf("db.dxm_b", M, d)  # ... the cross-attention branch

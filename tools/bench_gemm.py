@@ -19,6 +19,9 @@ shapes = [  # (name, M, N, K, a_kmajor, b_kmajor)
     ("vit qkv dW", 2304, 768, 3200, 1, 1), ("vit o dW", 768, 768, 3200, 1, 1), ("vit fc1 dW", 3072, 768, 3200, 1, 1),
     ("head dW", 250112, 1024, 4096, 1, 1),
     ("head dX splitK8", 4096, 1024, 250112, 0, 1),
+    ("cmp head dX", 2176, 1024, 250112, 0, 1), ("cmp head dX splitK8", 2176, 1024, 250112, 0, 1), ("cmp head dX splitK16", 2176, 1024, 250112, 0, 1),
+    ("cmp head dX splitK24", 2176, 1024, 250112, 0, 1), ("cmp head dX splitK32", 2176, 1024, 250112, 0, 1), ("cmp head dX splitK64", 2176, 1024, 250112, 0, 1),
+    ("cmp2 head dX", 2640, 1024, 250112, 0, 1), ("cmp2 head dX splitK16", 2640, 1024, 250112, 0, 1), ("cmp2 head dX splitK32", 2640, 1024, 250112, 0, 1),
 ]
 only = sys.argv[1] if len(sys.argv) > 1 else None
 tot_f, tot_t = 0.0, 0.0
@@ -27,7 +30,7 @@ for name, M, N, K, akm, bkm in shapes:
         continue
     A = (torch.randn((K, M) if akm else (M, K), device=dev) * 0.5).to(torch.bfloat16)
     B = (torch.randn((K, N) if bkm else (N, K), device=dev) * 0.5).to(torch.bfloat16)
-    sk = 8 if "splitK" in name else 0
+    sk = int(name.split("splitK")[1]) if "splitK" in name else 0
     out = torch.empty((M, N), dtype=torch.float32 if (akm or sk) else torch.bfloat16, device=dev)
     reps = 3 if M * N * K > 5e11 else 20
     for _ in range(2):
