@@ -223,6 +223,14 @@ def main():
                     "frac": round(ach / (PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else 157.3), 4), "traffic": None,
                     "launches_per_step": len(recs), "gemm_ms_per_step": round(ms, 3),
                     "gemm_gflop_per_step": round(flops / 1e9, 1)}
+        # HBM bytes per launch come from separate rocprofv3 --pmc passes (a profiler cannot run inside this process); the
+        # committed summary of the last such pass over this same command is reported, with its provenance.
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_train_pmc_hbm_traffic.json")
+        if dtype == torch.bfloat16 and B == 64 and not args.small and os.path.exists(pmc):
+            t = json.load(open(pmc))
+            roofline["traffic"] = t["bytes_per_launch"]
+            roofline["traffic_unit"] = "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, avg over the step's GEMM launches)"
+            roofline["traffic_source"] = t["summary"]
     if world > 1:
         dist.barrier()
 
