@@ -1,7 +1,9 @@
 """Checkpoint wire format of the reference: `flax_model.msgpack` (flax.serialization.to_bytes/from_bytes:
 msgpack with ndarray ext-type 1 = (shape, dtype name, raw bytes)) + `config.json`
 (`modeling_clip_vision_utils.py:323-333, 441-445`).  flax is not installed here; the format is restated from its
-published serializer and round-trip tested (tests/test_checkpoint.py)."""
+published serializer and round-trip tested (tests/test_host_cpu.py).  Also here: PyTorch-checkpoint ingestion for
+`mbart_from_pt=True` (`modeling_clip_vision_utils.py:318-321`, `main.py:426`) and the optimizer/step files of
+`save_model_checkpoint(with_opt=True)` / `restore_model_checkpoint` (`main.py:299-345`)."""
 from __future__ import annotations
 
 import json
@@ -48,13 +50,102 @@ def load_flax_msgpack(path: str):
         return msgpack.unpackb(f.read(), ext_hook=_decode, raw=False, strict_map_key=False)
 
 
+# ---------------------------------------------------------------------------------------------- PyTorch checkpoints
+def load_pt_state_dict(path: str):
+    """`pytorch_model.bin` (torch pickle, weights only) or `model.safetensors` in directory `path` -> {name: np.ndarray}."""
+    st = os.path.join(path, "model.safetensors")
+    if os.path.isfile(st):
+        from safetensors.numpy import load_file
+
+        return dict(load_file(st))
+    pt = os.path.join(path, "pytorch_model.bin")
+    if os.path.isfile(pt):
+        import torch
+
+        sd = torch.load(pt, map_location="cpu", weights_only=True)
+        return {k: v.to(torch.float32).numpy() for k, v in sd.items()}
+    raise EnvironmentError(f"Error no file named flax_model.msgpack, model.safetensors or pytorch_model.bin found in directory {path}")
+
+
+def convert_pt_state_dict(sd, expected, strip=("model.",), add=("", "vision_model.")):
+    """PyTorch state dict -> flat Flax leaves ('/'-joined), restating transformers'
+    `load_pytorch_checkpoint_in_flax_state_dict` (imported at `modeling_clip_vision_utils.py:26-28`) [UNVERIFIED-3P: the
+    pinned commit is not in the image]: the target leaf name decides the rule —
+      X.weight 4-D  -> X/kernel, OIHW -> HWIO (transpose 2,3,1,0)          (nn.Conv)
+      X.weight 2-D  -> X/kernel transposed                                  (nn.Dense stores [in,out])
+      X.weight      -> X/embedding as is (nn.Embed) or X/scale (nn.LayerNorm)
+      X.bias / bare parameters (class_embedding, final_logits_bias) -> same name.
+    `expected` = set of leaves the Flax module owns; keys that map to none of them are dropped like the reference drops
+    unexpected keys (`modeling_clip_vision_utils.py:355-364`); `strip` = base-model prefixes removed first; `add` =
+    prefixes tried in front of the name (recent PyTorch CLIPVisionModel files dropped the `vision_model.` level the Flax
+    tree keeps)."""
+    out = {}
+    for k0, v in sd.items():
+        for pre in strip:
+            if k0.startswith(pre):
+                k0 = k0[len(pre):]
+                break
+        for a in add:
+            _convert_one(a + k0, v, expected, out)
+    return out
+
+
+def _convert_one(k, v, expected, out):
+    parts = k.split(".")
+    base, last = "/".join(parts[:-1]), parts[-1]
+    a = np.asarray(v)
+    if last == "weight":
+        if a.ndim == 4 and base + "/kernel" in expected:
+            out[base + "/kernel"] = np.ascontiguousarray(a.transpose(2, 3, 1, 0))
+        elif a.ndim == 2 and base + "/kernel" in expected:
+            out[base + "/kernel"] = np.ascontiguousarray(a.T)
+        elif base + "/embedding" in expected:
+            out[base + "/embedding"] = a
+        elif base + "/scale" in expected:
+            out[base + "/scale"] = a
+    elif "/".join(parts) in expected:
+        out["/".join(parts)] = a
+
+
 def load_component(path: str, config=None):
-    """A CLIP-vision or mBART checkpoint directory (`config.json` + `flax_model.msgpack`) -> object with `.config`
-    (dict) and `.params` (nested numpy tree), the two things `from_clip_vision_mbart_pretrained` reads (modeling:740-770)."""
+    """A CLIP-vision or mBART checkpoint directory -> object with `.config` (dict) and either `.params` (nested numpy
+    tree from `flax_model.msgpack`) or `.pt_state` (PyTorch state dict, for `from_pt=True` checkpoints) — what
+    `from_clip_vision_mbart_pretrained` reads (modeling:740-770)."""
     if not os.path.isdir(path):
         raise EnvironmentError(f"{path}: only local checkpoint directories can be loaded (no network in this build)")
     if config is None:
         with open(os.path.join(path, "config.json")) as f:
             config = json.load(f)
             config = config.get("vision_config", config) if "vision_config" in config and "hidden_size" not in config else config
-    return SimpleNamespace(config=config, params=load_flax_msgpack(os.path.join(path, "flax_model.msgpack")))
+    fx = os.path.join(path, "flax_model.msgpack")
+    if os.path.isfile(fx):
+        return SimpleNamespace(config=config, params=load_flax_msgpack(fx), pt_state=None)
+    return SimpleNamespace(config=config, params=None, pt_state=load_pt_state_dict(path))
+
+
+# ---------------------------------------------------------------------------------------------- optimizer state
+def save_train_state(ckpt_dir: str, store, step: int) -> None:
+    """`opt_state.msgpack` + `training_state.json` (main.py:313-317).  Wire layout = flax `to_bytes` of the optax 0.0.9
+    `adamw` chain state [UNVERIFIED-3P]: tuples become {"0","1","2"}, NamedTuples dicts of their fields:
+      "0": ScaleByAdamState(count, mu, nu)   "1": AddDecayedWeightsState() = {}   "2": ScaleByScheduleState(count)."""
+    from .params import unflatten_tree
+
+    cnt = np.asarray(step, dtype=np.int32)
+    tree = {"0": {"count": cnt, "mu": unflatten_tree(store.export_flat("m")), "nu": unflatten_tree(store.export_flat("v"))},
+            "1": {}, "2": {"count": cnt}}
+    save_flax_msgpack(os.path.join(ckpt_dir, "opt_state.msgpack"), tree)
+    with open(os.path.join(ckpt_dir, "training_state.json"), "w") as f:
+        json.dump({"step": int(step)}, f)
+
+
+def load_train_state(ckpt_dir: str, store) -> int:
+    """main.py:330-343: params, AdamW moments and the step counter back into the device buffers; returns step."""
+    from .params import flatten_tree
+
+    store.load_flat(flatten_tree(load_flax_msgpack(os.path.join(ckpt_dir, "flax_model.msgpack"))), "master")
+    opt = load_flax_msgpack(os.path.join(ckpt_dir, "opt_state.msgpack"))
+    store.ensure_opt_state()
+    store.load_flat(flatten_tree(opt["0"]["mu"]), "m")
+    store.load_flat(flatten_tree(opt["0"]["nu"]), "v")
+    with open(os.path.join(ckpt_dir, "training_state.json")) as f:
+        return int(json.load(f)["step"])

@@ -356,13 +356,21 @@ class FlaxCLIPVisionMBartForConditionalGeneration(FlaxCLIPVisionMBartPreTrainedM
         config = CLIPVisionMBartConfig.from_clip_vision_mbart_configs(clip_model.config, mbart_model.config, **kwargs)
         model = cls(config, *model_args, seed=seed, dtype=dtype, device=device)
         flat = model.store.export_flat("master")
-        for k, v in flatten_tree(clip_model.params).items():
+        from .checkpoint import convert_pt_state_dict
+
+        def leaves(comp, prefix):
+            """component's Flax leaves (relative names); PyTorch checkpoints (`from_pt=True`, main.py:426) are converted
+            against the leaf names this model owns under `prefix`."""
+            if getattr(comp, "pt_state", None) is not None:
+                expected = {k[len(prefix):] for k in flat if k.startswith(prefix)}
+                return convert_pt_state_dict(comp.pt_state, expected)
+            return flatten_tree(comp.params)
+
+        for k, v in leaves(clip_model, "model/encoder/").items():
             flat["model/encoder/" + k] = np.asarray(v)  # modeling:768
-        mp = mbart_model.params
-        for k, v in flatten_tree(mp["decoder"]).items():
-            flat["model/decoder/" + k] = np.asarray(v)  # modeling:769
-        for k, v in flatten_tree(mp["shared"]).items():
-            flat["model/shared/" + k] = np.asarray(v)  # modeling:770
+        for k, v in leaves(mbart_model, "model/").items():  # FlaxMBartModel tree: shared / encoder / decoder
+            if k.startswith("decoder/") or k.startswith("shared/"):
+                flat["model/" + k] = np.asarray(v)  # modeling:769-770 (the mBART text encoder is not used)
         model.store.load_flat(flat)
         model._params_cache = None
         return model

@@ -236,10 +236,21 @@ class ParamStore:
                 m.append((p + n + ".w", [(Lp + f"{n}/kernel", "T")])); m.append((p + n + ".b", [(Lp + f"{n}/bias", "id")]))
         return m
 
-    def load_flat(self, flat: Dict[str, np.ndarray]) -> None:
-        """flat: {'/'-joined flax leaf: array-like} in the reference layout -> device buffers."""
+    def _buffer(self, which: str) -> torch.Tensor:
+        buf = {"master": self.master, "grad": self.grad, "m": self.m, "v": self.v}[which]
+        if buf is None:
+            raise ValueError(f"ParamStore: the '{which}' buffer has not been allocated")
+        return buf
+
+    def _seg_view(self, which: str, name: str) -> torch.Tensor:
+        s = self.segs[name]
+        return self._buffer(which)[s.offset: s.offset + s.numel].view(s.shape)
+
+    def load_flat(self, flat: Dict[str, np.ndarray], target: str = "master") -> None:
+        """flat: {'/'-joined flax leaf: array-like} in the reference layout -> device buffers
+        (target: master | m | v — the AdamW moments share the parameter layout)."""
         for seg_name, parts in self._mapping():
-            dst = self.f32(seg_name)
+            dst = self._seg_view(target, seg_name)
             r0 = 0
             for leaf, tr in parts:
                 a = flat[leaf]
@@ -254,14 +265,15 @@ class ParamStore:
                 n = t.shape[0]
                 dst[r0: r0 + n].copy_(t.to(self.device), non_blocking=False)
                 r0 += n
-        self.refresh_lp()
+        if target == "master":
+            self.refresh_lp()
 
     def export_flat(self, source: str = "master") -> Dict[str, np.ndarray]:
-        """device buffers -> {'/'-joined flax leaf: np.ndarray} in the reference layout (source: master | grad)."""
+        """device buffers -> {'/'-joined flax leaf: np.ndarray} in the reference layout (source: master | grad | m | v)."""
         out: Dict[str, np.ndarray] = {}
         shapes = self.flax_shapes()
         for seg_name, parts in self._mapping():
-            src = (self.f32(seg_name) if source == "master" else self.g(seg_name)).detach().cpu()
+            src = self._seg_view(source, seg_name).detach().cpu()
             r0 = 0
             for leaf, tr in parts:
                 shp = shapes[leaf]

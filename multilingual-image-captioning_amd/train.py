@@ -266,6 +266,32 @@ class Trainer:
         out.pop("learning_rate")
         return out
 
+    # ------------------------------------------------------------------ checkpoints (main.py:299-345)
+    def save_checkpoint(self, save_dir: str, with_opt: bool = False, overwrite: bool = False) -> str:
+        """`save_model_checkpoint`: `<save_dir>/ckpt-<step-1>/` with config.json + flax_model.msgpack, and with
+        `with_opt` also opt_state.msgpack + training_state.json.  Rank 0 writes (state is replicated, main.py:300)."""
+        import os
+
+        from .checkpoint import save_train_state
+
+        ckpt = os.path.join(save_dir, f"ckpt-{self.step - 1}")
+        if self.rank != 0 or (os.path.exists(ckpt) and not overwrite):  # main.py:304-305
+            return ckpt
+        torch.cuda.synchronize(self.model.device) if self.model.device.type == "cuda" else None
+        self.model.save_pretrained(ckpt)
+        if with_opt:
+            save_train_state(ckpt, self.model.store, self.step)
+        return ckpt
+
+    def restore_checkpoint(self, ckpt_dir: str) -> int:
+        """`restore_model_checkpoint` (main.py:330-345) — applied to this trainer (the reference's `state.replace` line is
+        commented out, 345): parameters, AdamW moments, step counter.  Returns the restored step."""
+        from .checkpoint import load_train_state
+
+        self.step = load_train_state(ckpt_dir, self.model.store)
+        self.model.invalidate_params_cache()
+        return self.step
+
     def _pmean_metrics(self) -> Dict[str, torch.Tensor]:
         """pmean of the 2 scalars (main.py:703-704, 719).  Returned as device tensors (no host sync in the step)."""
         if self.world > 1:

@@ -93,3 +93,73 @@ def test_prepare_and_update_inputs_for_generation(dev):
     out = model.decode(np.full((2, 1), 2, np.int32), enc, decoder_position_ids=kw["decoder_position_ids"], past_key_values=kw["past_key_values"])
     kw = model.update_inputs_for_generation(out, kw)
     assert kw["decoder_position_ids"].tolist() == [[1], [1]] and kw["past_key_values"]["cache_index"] == 1  # modeling:688-693
+
+
+def test_from_pt_directories(dev, tmp_path):
+    """main.py:421-427 with `mbart_from_pt=True`: component directories holding PyTorch weights (pytorch_model.bin /
+    model.safetensors in PyTorch layouts and names) graft to the same parameters as the Flax files."""
+    from safetensors.numpy import save_file
+
+    from mic_amd import FlaxCLIPVisionMBartForConditionalGeneration as Model
+    from mic_amd.params import flatten_tree
+
+    rc, p, model = make_pair(torch.float32, dev)
+
+    def to_pt(prefix, strip):
+        out = {}
+        for k, v in p.items():
+            if not k.startswith(prefix):
+                continue
+            a, parts = v.numpy(), k[len(strip):].split("/")
+            if parts[-1] == "kernel":
+                a, parts[-1] = (a.transpose(3, 2, 0, 1) if a.ndim == 4 else a.T), "weight"
+            elif parts[-1] in ("scale", "embedding"):
+                parts[-1] = "weight"
+            out[".".join(parts)] = np.ascontiguousarray(a)
+        return out
+
+    clip_dir, mbart_dir = str(tmp_path / "clip"), str(tmp_path / "mbart")
+    os.makedirs(clip_dir), os.makedirs(mbart_dir)
+    torch.save({k: torch.from_numpy(v) for k, v in to_pt("model/encoder/", "model/encoder/").items()}, os.path.join(clip_dir, "pytorch_model.bin"))
+    sd = {"model." + k: v for k, v in to_pt("model/decoder/", "model/").items()}
+    sd["model.shared.weight"] = p["model/shared/embedding"].numpy()
+    sd["lm_head.weight"] = p["model/shared/embedding"].numpy().copy()  # ForConditionalGeneration extras are dropped
+    sd["final_logits_bias"] = np.ones((1, rc.vocab_size), np.float32)
+    save_file(sd, os.path.join(mbart_dir, "model.safetensors"))
+    json.dump(model.config.clip_vision_config.to_dict(), open(os.path.join(clip_dir, "config.json"), "w"))
+    json.dump(model.config.mbart_config.to_dict(), open(os.path.join(mbart_dir, "config.json"), "w"))
+    m = Model.from_clip_vision_mbart_pretrained(clip_dir, mbart_dir, seed=3, dtype="float32", mbart_from_pt=True, device=dev)
+    got = flatten_tree(m.params)
+    for k, v in p.items():
+        if k.startswith(("model/encoder/", "model/decoder/", "model/shared/")):
+            assert np.array_equal(got[k], v.numpy()), k
+    assert np.count_nonzero(got["final_logits_bias"]) == 0
+
+
+def test_trainer_checkpoint_resume(dev, tmp_path):
+    """save_model_checkpoint(with_opt=True) / restore_model_checkpoint (main.py:299-345): a restored trainer continues
+    where the saved one would have (parameters, both AdamW moments, step counter -> LR schedule, bias correction and dropout stream)."""
+    from mic_amd import Trainer, create_learning_rate_fn
+
+    lr_fn = create_learning_rate_fn(640, 2, 5, 3, 1e-3)
+    rc, p, model = make_pair(torch.float32, dev, dropout=0.1)
+    b0, b1 = (dict(zip(("pixel_values", "input_ids", "attention_mask", "decoder_input_ids"), (x.numpy() for x in batch(rc, 2, 10, seed=s))))
+              for s in (5, 6))
+    tr = Trainer(model, lr_fn, weight_decay=0.01, seed=7)
+    tr.train_step(b0)
+    tr.train_step(b1)
+    ck = tr.save_checkpoint(str(tmp_path), with_opt=True)
+    assert os.path.basename(ck) == "ckpt-1" and sorted(os.listdir(ck)) == ["config.json", "flax_model.msgpack", "opt_state.msgpack", "training_state.json"]
+    assert json.load(open(os.path.join(ck, "training_state.json"))) == {"step": 2}
+    ref = tr.train_step(b0)
+    ref_loss, ref_params = float(ref["loss"]), model.store.master.clone()
+    _, _, model2 = make_pair(torch.float32, dev, seed=99, dropout=0.1)  # different weights until restored
+    tr2 = Trainer(model2, lr_fn, weight_decay=0.01, seed=7)
+    assert tr2.restore_checkpoint(ck) == 2
+    got = tr2.train_step(b0)
+    assert float(got["loss"]) == ref_loss and float(got["learning_rate"]) == float(ref["learning_rate"])
+    # the forward is bit-identical; backward sums biases / LayerNorm / embedding rows with fp32 atomics (order varies run to run)
+    assert (model2.store.master - ref_params).abs().max().item() < 1e-4
+    assert (model2.store.m - model.store.m).abs().max().item() < 1e-5 and (model2.store.v - model.store.v).abs().max().item() < 1e-6
+    assert tr.save_checkpoint(str(tmp_path / "x"), with_opt=False).endswith("ckpt-2")
+    assert sorted(os.listdir(tmp_path / "x" / "ckpt-2")) == ["config.json", "flax_model.msgpack"]

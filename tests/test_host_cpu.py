@@ -173,3 +173,85 @@ def test_grad_reducer_gloo_world2():
         p.join(timeout=60)
     assert [r[1] for r in res] == [True, True]
     assert all(abs(r[2] - 1.5) < 1e-9 for r in res)
+
+
+def test_optimizer_state_files_roundtrip(tmp_path):
+    """opt_state.msgpack / training_state.json (main.py:313-317, 330-343): wire layout of the optax adamw chain state and a
+    bit-exact round trip of parameters + both moments through the Flax layouts."""
+    import msgpack
+
+    from mic_amd.checkpoint import load_flax_msgpack, load_train_state, save_flax_msgpack, save_train_state
+    from mic_amd.params import ParamStore, unflatten_tree
+
+    st = ParamStore(_small_cfg(), torch.float32, "cpu")
+    st.init_random(seed=3)
+    st.ensure_opt_state()
+    g = torch.Generator().manual_seed(1)
+    st.m.copy_(torch.randn(st.numel, generator=g))
+    st.v.copy_(torch.rand(st.numel, generator=g))
+    ref = {k: st.export_flat(k) for k in ("master", "m", "v")}
+    d = str(tmp_path)
+    save_flax_msgpack(os.path.join(d, "flax_model.msgpack"), unflatten_tree(ref["master"]))
+    save_train_state(d, st, step=17)
+    opt = load_flax_msgpack(os.path.join(d, "opt_state.msgpack"))
+    assert set(opt) == {"0", "1", "2"} and set(opt["0"]) == {"count", "mu", "nu"} and opt["1"] == {} and set(opt["2"]) == {"count"}
+    assert int(opt["0"]["count"]) == 17 and opt["0"]["count"].dtype == np.int32
+    assert set(opt["0"]["mu"]["model"]) == {"encoder", "decoder", "shared", "visual_projection"}
+    st2 = ParamStore(_small_cfg(), torch.float32, "cpu")
+    assert load_train_state(d, st2) == 17
+    for k in ("master", "m", "v"):
+        back = st2.export_flat(k)
+        assert all(np.array_equal(back[n], ref[k][n]) for n in ref[k]), k
+
+
+def test_pt_checkpoint_ingestion_matches_twin(tmp_path):
+    """`mbart_from_pt=True` (main.py:426): PyTorch state dicts of the PT twins -> Flax leaves; the oracle run on the converted
+    leaves reproduces the twin's own forward (names, Dense/conv transposes, LayerNorm/Embed renames)."""
+    transformers = pytest.importorskip("transformers")
+    from mic_amd.checkpoint import convert_pt_state_dict, load_pt_state_dict
+    from oracle import model_ref as M
+
+    from util_small import ref_config
+
+    rc = ref_config("erf", 1e-5)
+    torch.manual_seed(0)
+    vcfg = transformers.CLIPVisionConfig(hidden_size=rc.v_hidden, intermediate_size=rc.v_ffn, num_hidden_layers=rc.v_layers,
+                                         num_attention_heads=rc.v_heads, image_size=rc.image_size, patch_size=rc.patch_size)
+    mcfg = transformers.MBartConfig(vocab_size=rc.vocab_size, d_model=rc.d_model, decoder_layers=rc.d_layers, encoder_layers=1,
+                                    decoder_attention_heads=rc.d_heads, encoder_attention_heads=rc.d_heads, decoder_ffn_dim=rc.d_ffn,
+                                    encoder_ffn_dim=rc.d_ffn, max_position_embeddings=rc.max_position_embeddings, scale_embedding=True, dropout=0.0)
+    clip = transformers.CLIPVisionModel(vcfg).eval()
+    mbart = transformers.MBartForConditionalGeneration(mcfg).eval()
+    cdir, mdir = tmp_path / "clip", tmp_path / "mbart"
+    cdir.mkdir()
+    mdir.mkdir()
+    torch.save(clip.state_dict(), cdir / "pytorch_model.bin")
+    from safetensors.torch import save_file
+
+    save_file({k: v.contiguous() for k, v in mbart.state_dict().items() if k != "lm_head.weight" and "embed_tokens" not in k}, str(mdir / "model.safetensors"))
+    shapes = M.param_shapes(rc)
+    p = M.init_params(rc, seed=9, perturb_ln=True)
+    enc = convert_pt_state_dict(load_pt_state_dict(str(cdir)), {k[len("model/encoder/"):] for k in shapes if k.startswith("model/encoder/")})
+    dec = convert_pt_state_dict(load_pt_state_dict(str(mdir)), {k[len("model/"):] for k in shapes if k.startswith("model/")})
+    n = 0
+    for k, v in enc.items():
+        assert tuple(v.shape) == tuple(shapes["model/encoder/" + k]), k
+        p["model/encoder/" + k] = torch.from_numpy(np.array(v))
+        n += 1
+    for k, v in dec.items():
+        if k.startswith("decoder/") or k.startswith("shared/"):
+            assert tuple(v.shape) == tuple(shapes["model/" + k]), k
+            p["model/" + k] = torch.from_numpy(np.array(v))
+            n += 1
+    assert n == sum(1 for k in shapes if k.startswith(("model/encoder/", "model/decoder/", "model/shared/")))  # every leaf was found
+    g = torch.Generator().manual_seed(2)
+    px = torch.randn(2, rc.image_size, rc.image_size, 3, generator=g)
+    ids = torch.randint(4, rc.vocab_size, (2, 6), generator=g)
+    with torch.no_grad():
+        last, _ = M.vit_encoder(rc, p, px)
+        twin_last = clip(pixel_values=px.permute(0, 3, 1, 2)).last_hidden_state
+        assert (last - twin_last).abs().max().item() < 2e-5
+        ehs = torch.randn(2, rc.v_seq, rc.d_model, generator=g)
+        h = M.decoder_forward(rc, p, ids, torch.ones_like(ids), torch.arange(6)[None].expand(2, 6), ehs)
+        twin_h = mbart.model.decoder(input_ids=ids, encoder_hidden_states=ehs).last_hidden_state
+        assert (h - twin_h).abs().max().item() < 2e-5
