@@ -223,6 +223,18 @@ int mic_beam_step(const mic_beam_step_args* a, void* stream);
 int mic_greedy_step(int B, int max_len, int cur_len, int eos_token_id, int pad_token_id, const int32_t* top_idx,
                     int ld_top, int32_t* sequences, int32_t* finished, int32_t* next_token, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Input pipeline: the reference's image Transform (main.py:165-179; evaluation.py:35-60) + the
+ * NCHW->NHWC permute of collate_fn (main.py:494) for a batch of uint8 images of arbitrary sizes:
+ * Resize([S], bicubic, shorter side) -> CenterCrop(S) -> /255 -> (x - mean) / std.  `items` is a HOST array (the
+ * per-image sizes are host data); `src` pointers are device pointers to CHW (hwc = 0, what read_image yields) or HWC
+ * (hwc = 1) bytes.  dst: float32 [n][S][S][3] (dst_chw = 0, what the model consumes) or [n][3][S][S] (dst_chw = 1,
+ * what Transform.forward returns).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct { const void* src; int H, W, hwc; } mic_image_item;
+int mic_image_transform(const mic_image_item* items, int n, int out_size, const float* mean, const float* std,
+                        float* dst, int dst_chw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

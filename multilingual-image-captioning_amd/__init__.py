@@ -7,7 +7,8 @@ Importable as `mic_amd` (see the `mic_amd.py` shim at the repo root: the directo
 from . import _lib  # noqa: F401
 from .configuration_clip_vision_mbart import CLIPVisionMBartConfig  # noqa: F401
 from .modeling_clip_vision_mbart import FlaxCLIPVisionMBartForConditionalGeneration  # noqa: F401
+from .image_transform import Transform  # noqa: F401
 from .train import Trainer, create_learning_rate_fn, loss_rows, shift_tokens_right  # noqa: F401
 
-__all__ = ["CLIPVisionMBartConfig", "FlaxCLIPVisionMBartForConditionalGeneration", "Trainer", "create_learning_rate_fn",
+__all__ = ["CLIPVisionMBartConfig", "FlaxCLIPVisionMBartForConditionalGeneration", "Trainer", "Transform", "create_learning_rate_fn",
            "loss_rows", "shift_tokens_right"]

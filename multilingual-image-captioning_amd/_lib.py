@@ -44,6 +44,10 @@ class BeamStepArgs(C.Structure):
     ]
 
 
+class ImageItem(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("H", C.c_int), ("W", C.c_int), ("hwc", C.c_int)]
+
+
 _i, _f, _p, _u32, _i64 = C.c_int, C.c_float, C.c_void_p, C.c_uint32, C.c_int64
 _SIGS = {
     "mic_version": ([], C.c_int),
@@ -74,6 +78,7 @@ _SIGS = {
     "mic_row_lse_topk": ([_i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p], C.c_int),
     "mic_beam_step": ([C.POINTER(BeamStepArgs), _p], C.c_int),
     "mic_greedy_step": ([_i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p], C.c_int),
+    "mic_image_transform": ([C.POINTER(ImageItem), _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _p, _i, _p], C.c_int),
 }
 EXPORTS = tuple(_SIGS)
 

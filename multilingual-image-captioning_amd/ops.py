@@ -215,3 +215,20 @@ def beam_step(B, K, max_len, V, cur_len, eos, pad, length_penalty, early_stoppin
 def greedy_step(B, max_len, cur_len, eos, pad, top_idx, ld_top, sequences, finished, next_token):
     L.check(L.lib().mic_greedy_step(B, max_len, cur_len, eos, pad, _p(top_idx), ld_top, _p(sequences), _p(finished), _p(next_token),
                                     _stream()), "mic_greedy_step")
+
+
+def image_transform(images, out_size, mean, std, dst, *, chw_out=False):
+    """images: list of uint8 device tensors, each [3,H,W] (CHW) or [H,W,3] (HWC); dst float32 [n,S,S,3] (or [n,3,S,S])."""
+    import ctypes as C
+
+    n = len(images)
+    items = (L.ImageItem * n)()
+    for i, im in enumerate(images):
+        if im.dtype != torch.uint8 or im.dim() != 3 or not im.is_contiguous():
+            raise L.MicError("image_transform: images must be contiguous uint8 [3,H,W] or [H,W,3] tensors")
+        hwc = im.shape[-1] == 3 and im.shape[0] != 3
+        H, W = (im.shape[0], im.shape[1]) if hwc else (im.shape[1], im.shape[2])
+        items[i].src, items[i].H, items[i].W, items[i].hwc = _p(im), H, W, int(hwc)
+    m, s = (C.c_float * 3)(*[float(x) for x in mean]), (C.c_float * 3)(*[float(x) for x in std])
+    L.check(L.lib().mic_image_transform(items, n, out_size, m, s, _p(dst), int(chw_out), _stream()), "mic_image_transform")
+    return dst

@@ -189,3 +189,44 @@ def test_generate_dispatch_errors():
         G.generate(lambda r: None, 1, d, max_length=4, num_beams=1)
     with pytest.raises(NotImplementedError):
         G.generate(lambda r: None, 1, G.GenDefaults(), max_length=4, num_beams=2, do_sample=True)
+
+
+# ---------------------------------------------------------------- image Transform restatement (main.py:165-179)
+def test_image_transform_matches_torch_interpolate():
+    """Pins oracle/image_ref.py on torch's own bicubic kernel: the committed golden (made by tests/golden/make_golden_image.py)
+    and a fresh run here.  After rounding to uint8 the two may differ only where the fp32 sum lands on an exact .5 tie."""
+    import torch.nn.functional as F
+
+    from oracle import image_ref as I
+
+    g = np.load(os.path.join(os.path.dirname(GOLD), "image_small.npz"))
+    for i in range(4):
+        img, S = g[f"img{i}"], int(g[f"S{i}"])
+        u8 = I.transform(img, S, return_u8=True)
+        d = np.abs(u8.astype(np.int32) - g[f"u8_{i}"].astype(np.int32))
+        assert d.max() <= 1 and (d != 0).mean() < 2e-3, (i, d.max(), (d != 0).mean())
+        out = I.transform(img, S)
+        ok = d == 0
+        assert np.abs(out - g[f"out{i}"])[ok].max() < 1e-6
+    # identity resize (H = W = S): taps collapse onto the source pixel
+    img = g["img2"]
+    assert np.array_equal(I.transform(img, 24, return_u8=True), img)
+    # fresh comparison at the real size, portrait and landscape
+    rng = np.random.default_rng(0)
+    for (H, W) in ((300, 451), (512, 333)):
+        img = rng.integers(0, 256, size=(3, H, W), dtype=np.uint8)
+        nh, nw = I.resize_dims(H, W, 224)
+        r = F.interpolate(torch.from_numpy(img)[None].float(), size=[nh, nw], mode="bicubic", align_corners=False)[0]
+        r = torch.round(r).clamp(0, 255).to(torch.uint8)
+        top, left = int(round((nh - 224) / 2.0)), int(round((nw - 224) / 2.0))
+        ref = r[:, top: top + 224, left: left + 224].numpy()
+        d = np.abs(I.transform(img, 224, return_u8=True).astype(np.int32) - ref.astype(np.int32))
+        assert d.max() <= 1 and (d != 0).mean() < 2e-3
+
+
+def test_image_resize_dims_and_crop_rule():
+    from oracle import image_ref as I
+
+    assert I.resize_dims(480, 640, 224) == (224, 298) and I.resize_dims(640, 480, 224) == (298, 224)
+    assert I.resize_dims(224, 224, 224) == (224, 224) and I.resize_dims(333, 500, 224) == (224, 336)
+    assert int(round((249 - 224) / 2.0)) == 12 and int(round((251 - 224) / 2.0)) == 14  # CenterCrop: half to even
