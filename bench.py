@@ -74,8 +74,9 @@ def cpu_baseline(seconds_budget=25.0):
 BEAM_GFLOP_PER_CAPTION = 230.0  # 4 rows x 63 steps x 868.5 MF + encoder/cross-KV once
 
 
-def bench_generate(model, cfg, dev, batch=256, langs=(250004,), max_length=64, seed=99):
-    """BASELINE configs[3]: beam-4 `.generate`, forced-BOS language, max_len 64, KV-cached, batch 256 on one GPU.
+def bench_generate(model, cfg, dev, batch=256, langs=(250004, 250008, 250003, 250005), max_length=64, seed=99):
+    """BASELINE configs[3]: beam-4 `.generate`, 4 forced-BOS languages (en/fr/de/es, one call each like evaluation.py:80-94),
+    max_len 64, KV-cached, batch 256 on one GPU.
     final_logits_bias[eos] = -1e9 keeps every run at exactly 63 decoder steps (ForcedEOS still fires at the last step)."""
     import numpy as np
     import torch

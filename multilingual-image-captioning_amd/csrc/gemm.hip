@@ -33,6 +33,9 @@
 #include "common.h"
 
 #define MAX_PROBLEMS 8
+#ifndef MIC_TINY_BELOW
+#define MIC_TINY_BELOW 128  // 128x128-tile count under which a launch uses 64x64 tiles (tools/bench_tile_cfg.py)
+#endif
 
 struct Problem {
   const uint16_t* A; const uint16_t* B;
@@ -49,16 +52,18 @@ struct LaunchTable { int count; int total_blocks; Problem p[MAX_PROBLEMS]; };
 //     pair, cost 4 VGPRs per piece, and let the swizzle sit on the LDS destination.
 //     KMAJOR=false: src is [rows][ld] k-contiguous.  KMAJOR=true: src is [K][ld] x-contiguous.  `lim` = number of valid
 //     rows (resp. x) in src; out-of-range rows/chunks are redirected to a valid address (masked at the store).
-template <bool KMAJOR, int NWAVES, int BKT>
+template <bool KMAJOR, int NWAVES, int BKT, int ROWS>
 struct HalfStager {
-  static constexpr int NINST = 128 * BKT * 2 / 1024;  // 1 KiB pieces per image
+  static_assert(ROWS == 128 || (ROWS == 64 && BKT == 64), "image = 128 rows (x) of BKT k, or 64 rows of 64 k");
+  static constexpr int NINST = ROWS * BKT * 2 / 1024;  // 1 KiB pieces per image
   static constexpr int PER = NINST / NWAVES;
   static_assert(PER >= 1, "too many waves for this image");
   static __device__ __forceinline__ void coords(int q, int lane, int& row, int& c) {
     if (!KMAJOR) {
       if (BKT == 64) { row = q * 8 + (lane >> 3); c = lane & 7; }
       else { row = q * 16 + (lane >> 2); c = lane & 3; }
-    } else { row = q * 4 + (lane >> 4); c = lane & 15; }
+    } else if (ROWS == 128) { row = q * 4 + (lane >> 4); c = lane & 15; }   // [BKT k][128 x]: 256-B rows
+    else { row = q * 8 + (lane >> 3); c = lane & 7; }                       // [64 k][64 x]: 128-B rows
   }
   static __device__ __forceinline__ void load(u32x4 (&r)[PER], const uint16_t* __restrict__ src, int ld, int x0, int k0, int lim,
                                               int wave, int lane) {
@@ -86,7 +91,8 @@ struct HalfStager {
       coords(wave * PER + i, lane, row, c);
       int off;
       if (!KMAJOR) off = BKT == 64 ? row * 128 + ((c ^ ((row >> 1) & 7)) << 4) : row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
-      else off = row * 256 + ((c ^ ((row & 3) << 2)) << 4);
+      else if (ROWS == 128) off = row * 256 + ((c ^ ((row & 3) << 2)) << 4);
+      else off = row * 128 + ((c ^ (((row >> 1) & 1) << 2)) << 4);
       *reinterpret_cast<u32x4*>(lds_tile + off) = r[i];
     }
   }
@@ -95,7 +101,9 @@ struct HalfStager {
 // --- read one 32(x) x 16(k) MFMA operand fragment: 8 consecutive k (kk*16 + 8*(lane>>5) ..) of x = xb + (lane&31)
 //     k-contiguous images: BKT=64 -> 128-B rows, chunk ^ ((row>>1)&7); BKT=32 -> 64-B rows, chunk ^ ((row>>2)&3); both are
 //     conflict-free for ds_read_b128's 16-lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31}.
-template <bool KMAJOR, int BKT>
+//     k-major images: [k][128 x] 256-B rows, chunk ^ ((k&3)<<2): the 4 k-rows one ds_read_b64_tr_b16 half-wave touches land
+//     on 4 different 64-B bank groups; [k][64 x] 128-B rows, chunk ^ (((k>>1)&1)<<2): rows k and k+2 would share a bank half.
+template <bool KMAJOR, int BKT, int ROWS>
 __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int xb, int kk, int lane) {
   if (!KMAJOR) {
     const int row = xb + (lane & 31);
@@ -105,10 +113,12 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int xb, int kk
   } else {
     const int g = lane >> 4, p = lane & 15;
     const int x = xb + 16 * (g & 1) + (p & 3) * 4;
-    const int k = kk * 16 + 8 * (g >> 1) + (p >> 2);  // k & 3 == p >> 2 for both halves (k+4 keeps k&3)
-    const int off = k * 256 + ((((x >> 3) ^ ((k & 3) << 2)) << 4) | ((x & 7) << 1));
+    const int k = kk * 16 + 8 * (g >> 1) + (p >> 2);  // k & 3 == p >> 2 for both halves (k+4 keeps k&3 and (k>>1)&1)
+    constexpr int RB = ROWS * 2;
+    const int off = ROWS == 128 ? k * 256 + ((((x >> 3) ^ ((k & 3) << 2)) << 4) | ((x & 7) << 1))
+                                : k * 128 + ((((x >> 3) ^ (((k >> 1) & 1) << 2)) << 4) | ((x & 7) << 1));
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, lds_tile + off));
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, lds_tile + off + 4 * 256));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, lds_tile + off + 4 * RB));
     s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, r);
   }
@@ -125,7 +135,8 @@ __device__ __forceinline__ void tile_coords(int lid, int tiles_m, int tiles_n, i
   tn = in_g / gsz;
 }
 
-// Wave tile WM x WN (WM in {64,128}, WN in {32,64}); 2 waves along M, WNW along N.  BM = 2*WM, BN = WN*WNW.
+// Wave tile WM x WN (WM in {32,64,128}, WN in {32,64}); 2 waves along M, WNW along N.  BM = 2*WM, BN = WN*WNW.
+//   <32,32,2>  64x64,   4 waves : launches too small to give every CU a 128x128 tile; 32 KiB LDS, several blocks per CU
 //   <64,32,4>  128x128, 8 waves : even one block per CU puts two waves on every SIMD, so one wave's staging / LDS waits
 //                                 hide under the other's MFMAs (the 4-wave 64x64 wave tile measured 26 % MFMA-busy at
 //                                 one block per CU: a single in-order stream cannot overlap its own waits)
@@ -135,14 +146,15 @@ __device__ __forceinline__ void tile_coords(int lid, int tiles_m, int tiles_n, i
 template <int WM, int WN, int WNW, int BKT, bool AK, bool BKM>
 __global__ __launch_bounds__(128 * WNW, 2) void gemm_bf16_kernel(LaunchTable tab) {
   constexpr int BM = 2 * WM, BN = WN * WNW, NWAVES = 2 * WNW, NTHREADS = 64 * NWAVES;
-  constexpr int HALF = 128 * BKT * 2;
-  constexpr int NHA = BM / 128, NHB = BN / 128, STAGE = (NHA + NHB) * HALF, AI = WM / 32, NJ = WN / 32, KSTEPS = BKT / 16;
+  constexpr int UA = BM < 128 ? BM : 128, UB = BN < 128 ? BN : 128;  // rows per staged image (128, or 64 for the 64-wide tiles)
+  constexpr int HALF_A = UA * BKT * 2, HALF_B = UB * BKT * 2;
+  constexpr int NHA = BM / UA, NHB = BN / UB, STAGE = NHA * HALF_A + NHB * HALF_B, AI = WM / 32, NJ = WN / 32, KSTEPS = BKT / 16;
 #ifndef MIC_STAGE_AT
 #define MIC_STAGE_AT 0
 #endif
   constexpr int STAGE_AT = MIC_STAGE_AT;  // k-step in front of which the next tile's LDS writes / global loads are issued
-  using SA = HalfStager<AK, NWAVES, BKT>;
-  using SB = HalfStager<BKM, NWAVES, BKT>;
+  using SA = HalfStager<AK, NWAVES, BKT, UA>;
+  using SB = HalfStager<BKM, NWAVES, BKT, UB>;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A halves | B halves]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // bijective XCD remap: the blocks that land on XCD x (= bid % 8) get a contiguous run of logical block ids
@@ -192,19 +204,19 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_bf16_kernel(LaunchTable tab
   u32x4 ra[NHA][SA::PER], rb[NHB][SB::PER];  // the tile in flight
   auto load_regs = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
-    for (int h = 0; h < NHA; ++h) SA::load(ra[h], A, lda, m0 + h * 128, (kt0 + t) * BKT, M, wave, lane);
+    for (int h = 0; h < NHA; ++h) SA::load(ra[h], A, lda, m0 + h * UA, (kt0 + t) * BKT, M, wave, lane);
 #pragma unroll
-    for (int h = 0; h < NHB; ++h) SB::load(rb[h], B, ldb, n0 + h * 128, (kt0 + t) * BKT, N, wave, lane);
+    for (int h = 0; h < NHB; ++h) SB::load(rb[h], B, ldb, n0 + h * UB, (kt0 + t) * BKT, N, wave, lane);
   };
   auto write_lds = [&](char* buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int h = 0; h < NHA; ++h) SA::store(ra[h], buf + h * HALF, wave, lane);
+    for (int h = 0; h < NHA; ++h) SA::store(ra[h], buf + h * HALF_A, wave, lane);
 #pragma unroll
-    for (int h = 0; h < NHB; ++h) SB::store(rb[h], buf + (NHA + h) * HALF, wave, lane);
+    for (int h = 0; h < NHB; ++h) SB::store(rb[h], buf + NHA * HALF_A + h * HALF_B, wave, lane);
   };
   // this wave's operand sub-images
-  const int a_half = (wr * WM) / 128, a_off = (wr * WM) % 128;
-  const int b_half = (wc * WN) / 128, b_off = (wc * WN) % 128;
+  const int a_half = (wr * WM) / UA, a_off = (wr * WM) % UA;
+  const int b_half = (wc * WN) / UB, b_off = (wc * WN) % UB;
 
   if (nk > 0) {
     load_regs(0);
@@ -214,8 +226,8 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_bf16_kernel(LaunchTable tab
   }
   for (int t = 0; t < nk; ++t) {
     const char* cur = smem + (t & 1) * STAGE;
-    const char* At = cur + a_half * HALF;
-    const char* Bt = cur + (NHA + b_half) * HALF;
+    const char* At = cur + a_half * HALF_A;
+    const char* Bt = cur + NHA * HALF_A + b_half * HALF_B;
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; ++kk) {
       if (kk == STAGE_AT && t + 1 < nk) {
@@ -224,9 +236,9 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_bf16_kernel(LaunchTable tab
       }
       bf16x8 af[AI], bfr[NJ];
 #pragma unroll
-      for (int i = 0; i < AI; ++i) af[i] = read_frag<AK, BKT>(At, a_off + i * 32, kk, lane);
+      for (int i = 0; i < AI; ++i) af[i] = read_frag<AK, BKT, UA>(At, a_off + i * 32, kk, lane);
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) bfr[j] = read_frag<BKM, BKT>(Bt, b_off + j * 32, kk, lane);
+      for (int j = 0; j < NJ; ++j) bfr[j] = read_frag<BKM, BKT, UB>(Bt, b_off + j * 32, kk, lane);
 #pragma unroll
       for (int i = 0; i < AI; ++i)
 #pragma unroll
@@ -235,39 +247,41 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_bf16_kernel(LaunchTable tab
     __syncthreads();
   }
 
-  // epilogue: each wave restages a 64 x WN fp32 block of its accumulators through its own LDS region, then the whole
+  // epilogue: each wave restages an RP x WN fp32 block of its accumulators through its own LDS region, then the whole
   // block streams them out: every thread owns 8 consecutive columns of a row (16-B vectors).
-  constexpr int REGION = 64 * WN;       // floats per wave region
-  constexpr int CPR = WN / 8;           // 8-column chunks per region row
+  constexpr int RP = WM < 64 ? WM : 64;  // rows per pass
+  constexpr int REGION = RP * WN;        // floats per wave region
+  constexpr int CPR = WN / 8;            // 8-column chunks per region row
+  constexpr int NIT = RP * CPR / 64;     // 8-column groups per thread per pass
   float* Cw = reinterpret_cast<float*>(smem) + wave * REGION;
 #pragma unroll
-  for (int p = 0; p < WM / 64; ++p) {
+  for (int p = 0; p < WM / RP; ++p) {
     if (p > 0) __syncthreads();
 #pragma unroll
-    for (int i2 = 0; i2 < 2; ++i2)
+    for (int i2 = 0; i2 < RP / 32; ++i2)
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          Cw[(i2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * WN + j * 32 + (lane & 31)] = acc[2 * p + i2][j][r];
+          Cw[(i2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * WN + j * 32 + (lane & 31)] = acc[(RP / 32) * p + i2][j][r];
     // side loads of all this thread's groups go out before the barrier (their latency hides behind it and each other)
-    u32x4 zq[CPR], rq[CPR];
+    u32x4 zq[NIT], rq[NIT];
     const bool split = P.nsplit > 1, pre = !split && epilogue_pre_ok(P.epi) && epilogue_vec_ok(P.epi, 8);
 #pragma unroll
-    for (int it = 0; it < CPR; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       const int id = it * NTHREADS + tid;
-      const int w = id / (64 * CPR), rem = id % (64 * CPR);
-      const int m = m0 + (w / WNW) * WM + p * 64 + rem / CPR, n = n0 + (w % WNW) * WN + (rem % CPR) * 8;
+      const int w = id / (RP * CPR), rem = id % (RP * CPR);
+      const int m = m0 + (w / WNW) * WM + p * RP + rem / CPR, n = n0 + (w % WNW) * WN + (rem % CPR) * 8;
       zq[it] = rq[it] = u32x4{0u, 0u, 0u, 0u};
       if (pre && m < M && n + 8 <= N) epilogue_prefetch8(P.epi, m, n, zq[it], rq[it]);
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < CPR; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       const int id = it * NTHREADS + tid;
-      const int w = id / (64 * CPR), rem = id % (64 * CPR);
+      const int w = id / (RP * CPR), rem = id % (RP * CPR);
       const int row = rem / CPR, c8 = (rem % CPR) * 8;
-      const int m = m0 + (w / WNW) * WM + p * 64 + row, n = n0 + (w % WNW) * WN + c8;
+      const int m = m0 + (w / WNW) * WM + p * RP + row, n = n0 + (w % WNW) * WN + c8;
       if (m >= M || n >= N) continue;
       const float* src = reinterpret_cast<const float*>(smem) + w * REGION + row * WN + c8;
       float v[8];
@@ -364,8 +378,8 @@ static int fill_epi(const mic_gemm_args* a, EpiArgs& e) {
 template <int WM, int WN, int WNW, int BKT>
 static void launch_cfg(const LaunchTable& tab, int akm, int bkm, hipStream_t s) {
   constexpr int BM = 2 * WM, BN = WN * WNW;
-  size_t lds = (size_t)2 * (BM / 128 + BN / 128) * (128 * BKT * 2);
-  const size_t epi = (size_t)2 * WNW * 64 * WN * 4;  // the epilogue restages 64 x WN floats per wave
+  size_t lds = (size_t)2 * (BM + BN) * BKT * 2;
+  const size_t epi = (size_t)2 * WNW * (WM < 64 ? WM : 64) * WN * 4;  // the epilogue restages min(WM,64) x WN floats per wave
   if (epi > lds) lds = epi;
   dim3 grid(tab.total_blocks), block(128 * WNW);
 #define LAUNCH(AKM, BKMM)                                                                                              \
@@ -390,9 +404,13 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
     tiles_big += (long)((args[i].M + 255) / 256) * ((args[i].N + 255) / 256) * sp;
     tiles_small += (long)((args[i].M + 127) / 128) * ((args[i].N + 127) / 128) * sp;
   }
-  // 256x256 tiles deliver 2x the FLOPs per operand byte but need >= ~0.8 blocks per CU to pay
-  const bool big = tiles_big >= 200;
-  const int bm = big ? 256 : 128;
+  // 256x256 tiles deliver 2x the FLOPs per operand byte but need >= ~0.8 blocks per CU to pay; launches that cannot even
+  // give every CU one 128x128 tile (decode-time GEMMs on ~1k rows, the N = 768/1024 projections) run 64x64 tiles, 4 waves,
+  // several blocks per CU.  MIC_GEMM_TILE=256|128|64 forces a configuration (benchmarking).
+  static const int force = [] { const char* e = getenv("MIC_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  static const int tiny_below = [] { const char* e = getenv("MIC_TINY_BELOW"); return e ? atoi(e) : MIC_TINY_BELOW; }();
+  int bm = tiles_big >= 200 ? 256 : (tiles_small < tiny_below ? 64 : 128);
+  if (force == 256 || force == 128 || force == 64) bm = force;
   int blocks = 0;
   for (int i = 0; i < count; ++i) {
     Problem& p = tab.p[i];
@@ -408,10 +426,10 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
     blocks += p.tiles_m * p.tiles_n * p.nsplit;
   }
   tab.total_blocks = blocks;
-  (void)tiles_small;
-  if (big) launch_cfg<128, 64, 4, 64>(tab, args[0].a_kmajor, args[0].b_kmajor, s);  // 256x256x64, 8 waves
-  else launch_cfg<64, 32, 4, 64>(tab, args[0].a_kmajor, args[0].b_kmajor, s);       // 128x128x64, 8 waves (measured better than
-                                                                                    // the 4-wave 64x64 wave tile at every tile count)
+  if (bm == 256) launch_cfg<128, 64, 4, 64>(tab, args[0].a_kmajor, args[0].b_kmajor, s);     // 256x256x64, 8 waves
+  else if (bm == 128) launch_cfg<64, 32, 4, 64>(tab, args[0].a_kmajor, args[0].b_kmajor, s);  // 128x128x64, 8 waves (measured better than
+                                                                                              // the 4-wave 64x64 wave tile at every tile count)
+  else launch_cfg<32, 32, 2, 64>(tab, args[0].a_kmajor, args[0].b_kmajor, s);                 // 64x64x64, 4 waves
   MIC_LAUNCH_CHECK();
   return MIC_OK;
 }
