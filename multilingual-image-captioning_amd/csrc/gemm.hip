@@ -143,9 +143,13 @@ __device__ __forceinline__ void tile_coords(int lid, int tiles_m, int tiles_n, i
 //   <128,64,4> 256x256, 8 waves : launches with >= 200 such tiles (2x the FLOPs per staged byte)
 // BKT: k-depth of one pipeline stage.  Two LDS buffers; tile t+1 travels through registers while tile t is multiplied
 // (loads issued a full iteration before their ds_write), one barrier per stage.
-template <int WM, int WN, int WNW, int BKT, bool AK, bool BKM>
-__global__ __launch_bounds__(128 * WNW, 2) void gemm_bf16_kernel(LaunchTable tab) {
-  constexpr int BM = 2 * WM, BN = WN * WNW, NWAVES = 2 * WNW, NTHREADS = 64 * NWAVES;
+// KG > 1: KG groups of 2*WNW waves share one output tile and split its K range (each with its own pair of LDS stages);
+//   the partial accumulators meet in LDS before the epilogue.  For launches whose tile count cannot fill the chip the
+//   K loop is a latency chain (load -> ds_write -> barrier -> ds_read -> MFMA, ~0.5 us per 64-k step at one block per CU);
+//   KG groups cut the chain KG-fold without atomics or extra launches.
+template <int WM, int WN, int WNW, int BKT, bool AK, bool BKM, int KG = 1>
+__global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kernel(LaunchTable tab) {
+  constexpr int BM = 2 * WM, BN = WN * WNW, NWAVES = 2 * WNW, NTHREADS = 64 * NWAVES * KG;
   constexpr int UA = BM < 128 ? BM : 128, UB = BN < 128 ? BN : 128;  // rows per staged image (128, or 64 for the 64-wide tiles)
   constexpr int HALF_A = UA * BKT * 2, HALF_B = UB * BKT * 2;
   constexpr int NHA = BM / UA, NHB = BN / UB, STAGE = NHA * HALF_A + NHB * HALF_B, AI = WM / 32, NJ = WN / 32, KSTEPS = BKT / 16;
@@ -156,7 +160,8 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_bf16_kernel(LaunchTable tab
   using SA = HalfStager<AK, NWAVES, BKT, UA>;
   using SB = HalfStager<BKM, NWAVES, BKT, UB>;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A halves | B halves]
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = threadIdx.x, lane = tid & 63, wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = wave_all / NWAVES, wave = wave_all % NWAVES;  // K-group, wave within the group
   // bijective XCD remap: the blocks that land on XCD x (= bid % 8) get a contiguous run of logical block ids
   int lid;
   {
@@ -198,8 +203,11 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_bf16_kernel(LaunchTable tab
 
   const int nk_total = P.K / BKT;
   const int nk_per = (nk_total + P.nsplit - 1) / P.nsplit;
-  const int kt0 = split * nk_per, kt1 = min(nk_total, kt0 + nk_per);
-  const int nk = kt1 - kt0;
+  const int bt0 = split * nk_per, bt1 = min(nk_total, bt0 + nk_per);   // this block's K-tiles
+  const int g_per = (max(bt1 - bt0, 0) + KG - 1) / KG;                   // ... dealt to the K-groups
+  const int kt0 = bt0 + kg * g_per, kt1 = min(bt1, kt0 + g_per);
+  const int nk = max(kt1 - kt0, 0), nk_loop = KG > 1 ? g_per : nk;      // every group runs nk_loop barriers
+  char* const gsm = smem + kg * 2 * STAGE;                               // this group's two stages
 
   u32x4 ra[NHA][SA::PER], rb[NHB][SB::PER];  // the tile in flight
   auto load_regs = [&](int t) __attribute__((always_inline)) {
@@ -220,29 +228,59 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_bf16_kernel(LaunchTable tab
 
   if (nk > 0) {
     load_regs(0);
-    write_lds(smem);
+    write_lds(gsm);
     if (nk > 1) load_regs(1);
+  }
+  if (nk_loop > 0) __syncthreads();
+  for (int t = 0; t < nk_loop; ++t) {
+    if (t < nk) {
+      const char* cur = gsm + (t & 1) * STAGE;
+      const char* At = cur + a_half * HALF_A;
+      const char* Bt = cur + NHA * HALF_A + b_half * HALF_B;
+#pragma unroll
+      for (int kk = 0; kk < KSTEPS; ++kk) {
+        if (kk == STAGE_AT && t + 1 < nk) {
+          write_lds(gsm + ((t + 1) & 1) * STAGE);  // its buffer was last read in iteration t-1 (barrier below)
+          if (t + 2 < nk) load_regs(t + 2);        // a full iteration of MFMAs to land
+        }
+        bf16x8 af[AI], bfr[NJ];
+#pragma unroll
+        for (int i = 0; i < AI; ++i) af[i] = read_frag<AK, BKT, UA>(At, a_off + i * 32, kk, lane);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bfr[j] = read_frag<BKM, BKT, UB>(Bt, b_off + j * 32, kk, lane);
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+    }
     __syncthreads();
   }
-  for (int t = 0; t < nk; ++t) {
-    const char* cur = smem + (t & 1) * STAGE;
-    const char* At = cur + a_half * HALF_A;
-    const char* Bt = cur + NHA * HALF_A + b_half * HALF_B;
-#pragma unroll
-    for (int kk = 0; kk < KSTEPS; ++kk) {
-      if (kk == STAGE_AT && t + 1 < nk) {
-        write_lds(smem + ((t + 1) & 1) * STAGE);  // its buffer was last read in iteration t-1 (barrier below)
-        if (t + 2 < nk) load_regs(t + 2);         // a full iteration of MFMAs to land
-      }
-      bf16x8 af[AI], bfr[NJ];
-#pragma unroll
-      for (int i = 0; i < AI; ++i) af[i] = read_frag<AK, BKT, UA>(At, a_off + i * 32, kk, lane);
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) bfr[j] = read_frag<BKM, BKT, UB>(Bt, b_off + j * 32, kk, lane);
+
+  if constexpr (KG > 1) {  // groups 1.. hand their partial sums to group 0 through LDS (register-image layout, lane-linear)
+    float* red = reinterpret_cast<float*>(smem);
+    constexpr int PER_WAVE = AI * NJ * 16 * 64;
+    if (kg > 0) {
+      float* dst = red + ((kg - 1) * NWAVES + wave) * PER_WAVE;
 #pragma unroll
       for (int i = 0; i < AI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[((i * NJ + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int g = 1; g < KG; ++g) {
+        const float* src = red + ((g - 1) * NWAVES + wave) * PER_WAVE;
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += src[((i * NJ + j) * 16 + r) * 64 + lane];
+      }
     }
     __syncthreads();
   }
@@ -252,18 +290,21 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_bf16_kernel(LaunchTable tab
   constexpr int RP = WM < 64 ? WM : 64;  // rows per pass
   constexpr int REGION = RP * WN;        // floats per wave region
   constexpr int CPR = WN / 8;            // 8-column chunks per region row
-  constexpr int NIT = RP * CPR / 64;     // 8-column groups per thread per pass
+  constexpr int NGRP = NWAVES * RP * CPR;                 // 8-column groups per pass (whole tile)
+  constexpr int NIT = (NGRP + NTHREADS - 1) / NTHREADS;   // ... per thread
   float* Cw = reinterpret_cast<float*>(smem) + wave * REGION;
 #pragma unroll
   for (int p = 0; p < WM / RP; ++p) {
     if (p > 0) __syncthreads();
+    if (kg == 0) {
 #pragma unroll
-    for (int i2 = 0; i2 < RP / 32; ++i2)
+      for (int i2 = 0; i2 < RP / 32; ++i2)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          Cw[(i2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * WN + j * 32 + (lane & 31)] = acc[(RP / 32) * p + i2][j][r];
+          for (int r = 0; r < 16; ++r)
+            Cw[(i2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * WN + j * 32 + (lane & 31)] = acc[(RP / 32) * p + i2][j][r];
+    }
     // side loads of all this thread's groups go out before the barrier (their latency hides behind it and each other)
     u32x4 zq[NIT], rq[NIT];
     const bool split = P.nsplit > 1, pre = !split && epilogue_pre_ok(P.epi) && epilogue_vec_ok(P.epi, 8);
@@ -273,7 +314,7 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_bf16_kernel(LaunchTable tab
       const int w = id / (RP * CPR), rem = id % (RP * CPR);
       const int m = m0 + (w / WNW) * WM + p * RP + rem / CPR, n = n0 + (w % WNW) * WN + (rem % CPR) * 8;
       zq[it] = rq[it] = u32x4{0u, 0u, 0u, 0u};
-      if (pre && m < M && n + 8 <= N) epilogue_prefetch8(P.epi, m, n, zq[it], rq[it]);
+      if (pre && id < NGRP && m < M && n + 8 <= N) epilogue_prefetch8(P.epi, m, n, zq[it], rq[it]);
     }
     __syncthreads();
 #pragma unroll
@@ -282,7 +323,7 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_bf16_kernel(LaunchTable tab
       const int w = id / (RP * CPR), rem = id % (RP * CPR);
       const int row = rem / CPR, c8 = (rem % CPR) * 8;
       const int m = m0 + (w / WNW) * WM + p * RP + row, n = n0 + (w % WNW) * WN + c8;
-      if (m >= M || n >= N) continue;
+      if (id >= NGRP || m >= M || n >= N) continue;
       const float* src = reinterpret_cast<const float*>(smem) + w * REGION + row * WN + c8;
       float v[8];
       const float4 lo = *reinterpret_cast<const float4*>(src);
@@ -375,18 +416,20 @@ static int fill_epi(const mic_gemm_args* a, EpiArgs& e) {
   return MIC_OK;
 }
 
-template <int WM, int WN, int WNW, int BKT>
+template <int WM, int WN, int WNW, int BKT, int KG = 1>
 static void launch_cfg(const LaunchTable& tab, int akm, int bkm, hipStream_t s) {
   constexpr int BM = 2 * WM, BN = WN * WNW;
-  size_t lds = (size_t)2 * (BM + BN) * BKT * 2;
+  size_t lds = (size_t)KG * 2 * (BM + BN) * BKT * 2;
   const size_t epi = (size_t)2 * WNW * (WM < 64 ? WM : 64) * WN * 4;  // the epilogue restages min(WM,64) x WN floats per wave
+  const size_t red = (size_t)(KG - 1) * 2 * WNW * (WM / 32) * (WN / 32) * 16 * 64 * 4;  // K-group partial sums
   if (epi > lds) lds = epi;
-  dim3 grid(tab.total_blocks), block(128 * WNW);
-#define LAUNCH(AKM, BKMM)                                                                                              \
-  do {                                                                                                                 \
-    if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WN, WNW, BKT, AKM, BKMM>), \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
-    hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, WNW, BKT, AKM, BKMM>), grid, block, lds, s, tab);                     \
+  if (red > lds) lds = red;
+  dim3 grid(tab.total_blocks), block(128 * WNW * KG);
+#define LAUNCH(AKM, BKMM)                                                                                                  \
+  do {                                                                                                                     \
+    if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WN, WNW, BKT, AKM, BKMM, KG>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+    hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, WNW, BKT, AKM, BKMM, KG>), grid, block, lds, s, tab);                     \
   } while (0)
   if (!akm && !bkm) LAUNCH(false, false);
   else if (!akm && bkm) LAUNCH(false, true);
@@ -427,9 +470,25 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
   }
   tab.total_blocks = blocks;
   if (bm == 256) launch_cfg<128, 64, 4, 64>(tab, args[0].a_kmajor, args[0].b_kmajor, s);     // 256x256x64, 8 waves
-  else if (bm == 128) launch_cfg<64, 32, 4, 64>(tab, args[0].a_kmajor, args[0].b_kmajor, s);  // 128x128x64, 8 waves (measured better than
-                                                                                              // the 4-wave 64x64 wave tile at every tile count)
-  else launch_cfg<32, 32, 2, 64>(tab, args[0].a_kmajor, args[0].b_kmajor, s);                 // 64x64x64, 4 waves
+  else if (bm == 128) {  // 128x128x64, 8 waves (measured better than the 4-wave 64x64 wave tile at every tile count);
+                         // two K-groups (16 waves) when the launch is a single round of at most one block per CU
+    static const int kg128 = [] { const char* e = getenv("MIC_GEMM_KG128"); return e ? atoi(e) : -1; }();
+    int kmin = 1 << 30;
+    for (int i = 0; i < count; ++i) kmin = tab.p[i].K / 64 / tab.p[i].nsplit < kmin ? tab.p[i].K / 64 / tab.p[i].nsplit : kmin;
+    const bool two = kg128 >= 0 ? kg128 == 2 : (blocks <= 256 && kmin >= 8);
+    if (two) launch_cfg<64, 32, 4, 64, 2>(tab, args[0].a_kmajor, args[0].b_kmajor, s);
+    else launch_cfg<64, 32, 4, 64>(tab, args[0].a_kmajor, args[0].b_kmajor, s);
+  }
+  else {  // 64x64x64 tiles, 4 waves per K-group; K-groups while the grid leaves CUs under-occupied
+    static const int kg_force = [] { const char* e = getenv("MIC_GEMM_KG"); return e ? atoi(e) : 0; }();
+    int kmin = 1 << 30;
+    for (int i = 0; i < count; ++i) kmin = tab.p[i].K / 64 / tab.p[i].nsplit < kmin ? tab.p[i].K / 64 / tab.p[i].nsplit : kmin;
+    int kgs = blocks <= 256 && kmin >= 16 ? 4 : (blocks <= 512 && kmin >= 8 ? 2 : 1);
+    if (kg_force == 1 || kg_force == 2 || kg_force == 4) kgs = kg_force;
+    if (kgs == 4) launch_cfg<32, 32, 2, 64, 4>(tab, args[0].a_kmajor, args[0].b_kmajor, s);
+    else if (kgs == 2) launch_cfg<32, 32, 2, 64, 2>(tab, args[0].a_kmajor, args[0].b_kmajor, s);
+    else launch_cfg<32, 32, 2, 64>(tab, args[0].a_kmajor, args[0].b_kmajor, s);
+  }
   MIC_LAUNCH_CHECK();
   return MIC_OK;
 }
