@@ -163,3 +163,25 @@ def test_trainer_checkpoint_resume(dev, tmp_path):
     assert (model2.store.m - model.store.m).abs().max().item() < 1e-5 and (model2.store.v - model.store.v).abs().max().item() < 1e-6
     assert tr.save_checkpoint(str(tmp_path / "x"), with_opt=False).endswith("ckpt-2")
     assert sorted(os.listdir(tmp_path / "x" / "ckpt-2")) == ["config.json", "flax_model.msgpack"]
+
+
+def test_evaluate_loop(dev):
+    """The evaluation block of main.py:791-846: per-language eval loss + generate(decoder_start_token_id=lang) + BLEU-1..4."""
+    from mic_amd import Trainer, create_learning_rate_fn
+    from mic_amd.evaluation import evaluate
+
+    rc, p, model = make_pair(torch.float32, dev)
+    tr = Trainer(model, create_learning_rate_fn(640, 2, 5, 3, 1e-3))
+    keys = ("pixel_values", "input_ids", "attention_mask", "decoder_input_ids")
+    loaders = {"en_XX": [dict(zip(keys, (x.numpy() for x in batch(rc, 2, 10, seed=s)))) for s in (1, 2)],
+               "fr_XX": [dict(zip(keys, (x.numpy() for x in batch(rc, 2, 10, seed=3))))]}
+    codes = {"en_XX": rc.vocab_size - 10, "fr_XX": rc.vocab_size - 9}
+    dec = lambda rows: [" ".join(f"w{int(t)}" for t in row if int(t) > 3 and int(t) < rc.vocab_size - 20) for row in rows]
+    res = evaluate(tr, loaders, codes, dec, max_length=10, num_beams=2)
+    assert set(res) == {"en_XX", "fr_XX", "loss"} and set(res["en_XX"]) == {"BLEU-1", "BLEU-2", "BLEU-3", "BLEU-4"}
+    losses = [float(tr.eval_step(b)["loss"]) for l in loaders.values() for b in l]
+    assert abs(res["loss"] - float(np.mean(losses))) < 1e-6
+    assert all(0.0 <= v <= 1.0 for v in res["fr_XX"].values())
+    # generation really starts from the language code (main.py:820)
+    g = model.generate(loaders["fr_XX"][0]["pixel_values"], max_length=10, num_beams=2, decoder_start_token_id=codes["fr_XX"])
+    assert (g.sequences[:, 0] == codes["fr_XX"]).all()

@@ -255,3 +255,35 @@ def test_pt_checkpoint_ingestion_matches_twin(tmp_path):
         h = M.decoder_forward(rc, p, ids, torch.ones_like(ids), torch.arange(6)[None].expand(2, 6), ehs)
         twin_h = mbart.model.decoder(input_ids=ids, encoder_hidden_states=ehs).last_hidden_state
         assert (h - twin_h).abs().max().item() < 2e-5
+
+
+def test_bleu_known_answers():
+    """compute_bleu (main.py:573, 596-598) against hand-computed corpus BLEU values."""
+    import math
+
+    from mic_amd.evaluation import compute_bleu, compute_metrics, simple_word_tokenize
+
+    ref = "the cat is on the mat".split()
+    # identical -> 1; disjoint -> 0
+    assert compute_bleu([ref], [[ref]], 4)["bleu"] == 1.0
+    assert compute_bleu(["a b c d".split()], [[ref]], 4)["bleu"] == 0.0
+    # clipping: "the the the the the the the" vs reference with 2 x "the": p1 = 2/7
+    r = compute_bleu(["the the the the the the the".split()], [[ref]], 1)
+    assert abs(r["precisions"][0] - 2 / 7) < 1e-12 and r["brevity_penalty"] == 1.0 and abs(r["bleu"] - 2 / 7) < 1e-12
+    # hyp "the cat sat on the mat": p1 = 5/6, p2 = 3/5, p3 = 1/4, p4 = 0/3 -> BLEU-4 = 0 (no smoothing), BLEU-2 = sqrt(5/6*3/5)
+    hyp = "the cat sat on the mat".split()
+    r = compute_bleu([hyp], [[ref]], 4)
+    assert r["precisions"] == [5 / 6, 3 / 5, 1 / 4, 0.0] and r["bleu"] == 0.0
+    assert abs(compute_bleu([hyp], [[ref]], 2)["bleu"] - math.sqrt(5 / 6 * 3 / 5)) < 1e-12
+    # brevity penalty with the shortest reference: hyp len 4, refs len 6 and 5 -> bp = exp(1 - 5/4)
+    r = compute_bleu(["the cat is on".split()], [[ref, "the cat is on mat".split()]], 1)
+    assert abs(r["brevity_penalty"] - math.exp(1 - 5 / 4)) < 1e-12 and r["precisions"][0] == 1.0
+    # corpus-level pooling (not a mean of sentence scores)
+    r = compute_bleu([hyp, ref], [[ref], [ref]], 4)
+    p = [(5 + 6) / 12, (3 + 5) / 10, (1 + 4) / 8, (0 + 3) / 6]
+    assert abs(r["bleu"] - math.exp(sum(math.log(x) for x in p) / 4)) < 1e-12
+    assert simple_word_tokenize("Ein Hund, der läuft!") == ["Ein", "Hund", ",", "der", "läuft", "!"]
+    vocab = {5: "a", 6: "dog", 7: "runs", 8: "."}
+    dec = lambda rows: [" ".join(vocab[t] for t in row if t in vocab) for row in rows]
+    m = compute_metrics([[2, 5, 6, 7, 8, 2, 1]], [[250004, 5, 6, 7, 8, 2, 1]], dec)
+    assert m == {"BLEU-1": 1.0, "BLEU-2": 1.0, "BLEU-3": 1.0, "BLEU-4": 1.0}
