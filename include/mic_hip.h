@@ -223,6 +223,15 @@ int mic_beam_step(const mic_beam_step_args* a, void* stream);
 int mic_greedy_step(int B, int max_len, int cur_len, int eos_token_id, int pad_token_id, const int32_t* top_idx,
                     int ld_top, int32_t* sequences, int32_t* finished, int32_t* next_token, void* stream);
 
+/* mic_sample_rows: one draw per row of `jax.random.categorical(key, logits[R][V])` (gen:625-627 inside `_sample`,
+ *   gen:537-663) = argmax(logits / temperature + Gumbel noise) with the noise bit-compatible with jax 0.2.16's
+ *   threefry2x32 stream for key = (key0, key1) over the whole [R, V] array (counter layout in csrc/decode.hip).
+ *   forced_token >= 0: every row draws that token (ForcedBOS/ForcedEOS); suppress_eos: logit[eos] := -inf (MinLength);
+ *   min_keep (optional, [R]): values below min_keep[row] are masked (top-k / top-p thresholds). */
+int mic_sample_rows(int dtype, int R, int V, const void* logits, int ld, uint32_t key0, uint32_t key1,
+                    float temperature, int forced_token, int suppress_eos, int eos_token_id, const float* min_keep,
+                    int32_t* out_idx, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Input pipeline: the reference's image Transform (main.py:165-179; evaluation.py:35-60) + the
  * NCHW->NHWC permute of collate_fn (main.py:494) for a batch of uint8 images of arbitrary sizes:

@@ -342,3 +342,96 @@ extern "C" int mic_greedy_step(int B, int max_len, int cur_len, int eos_token_id
   MIC_LAUNCH_CHECK();
   return MIC_OK;
 }
+
+__global__ void fill_i32_kernel(int32_t* p, int n, int v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// ------------------------------------------------------------------ sampling (gen:537-663)
+// next_token = jax.random.categorical(prng_key, logits) (gen:625-627) = argmax(logits + Gumbel noise), with the noise
+// generated exactly like jax 0.2.16 does it [restated from the published algorithm; pinned on the Random123 / JAX
+// known-answer vectors in tests/test_oracle_cpu.py]:
+//   bits    = threefry2x32(key, counters): the [R*V] counter array (padded to even) is split in halves x0 | x1, the two
+//             output words are concatenated -> element e < h uses word 0 of (e, e+h), element e >= h word 1 of (e-h, e);
+//   uniform = max(tiny, (bitcast(bits >> 9 | 0x3f800000) - 1) * (1 - tiny) + tiny)        (random.uniform, minval=tiny)
+//   gumbel  = -log(-log(uniform)).
+// One block per row; ties resolve to the lowest index (jnp.argmax).
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+__device__ __forceinline__ void threefry2x32(uint32_t k0, uint32_t k1, uint32_t& x0, uint32_t& x1) {
+  const uint32_t ks[3] = {k0, k1, k0 ^ k1 ^ 0x1BD11BDAu};
+  const int R[2][4] = {{13, 15, 26, 6}, {17, 29, 16, 24}};
+  x0 += ks[0]; x1 += ks[1];
+#pragma unroll
+  for (int g = 0; g < 5; ++g) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { x0 += x1; x1 = rotl32(x1, R[g & 1][i]); x1 ^= x0; }
+    x0 += ks[(g + 1) % 3];
+    x1 += ks[(g + 2) % 3] + (uint32_t)(g + 1);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void sample_rows_kernel(int R, int V, const T* __restrict__ logits, int ld, uint32_t k0,
+                                                           uint32_t k1, float temperature, int suppress_eos, int eos,
+                                                           const float* __restrict__ min_keep, int32_t* __restrict__ out) {
+  const int row = blockIdx.x;
+  const uint32_t n = (uint32_t)R * (uint32_t)V, h = (n + 1u) >> 1;
+  const T* x = logits + (size_t)row * ld;
+  const float thr = min_keep ? min_keep[row] : -INFINITY;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < V; i += blockDim.x) {
+    const uint32_t e = (uint32_t)row * (uint32_t)V + (uint32_t)i;
+    uint32_t c0, c1;
+    if (e < h) { c0 = e; c1 = e + h < n ? e + h : 0u; } else { c0 = e - h; c1 = e; }
+    threefry2x32(k0, k1, c0, c1);
+    const uint32_t bits = e < h ? c0 : c1;
+    const float f = __uint_as_float((bits >> 9) | 0x3f800000u) - 1.0f;
+    const float tiny = 1.17549435e-38f;
+    const float u = fmaxf(tiny, f * (1.0f - tiny) + tiny);
+    const float g = -logf(-logf(u));
+    float v = ElemT<T>::ld(x + i);
+    if (temperature != 1.0f) v = v / temperature;
+    if ((suppress_eos && i == eos) || v < thr) v = -INFINITY;
+    v += g;
+    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+  }
+  // block argmax, lowest index on ties
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  __shared__ float sv[16];
+  __shared__ int si[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { sv[wave] = best; si[wave] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+      if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+    out[row] = bi;
+  }
+}
+
+extern "C" int mic_sample_rows(int dtype, int R, int V, const void* logits, int ld, uint32_t key0, uint32_t key1,
+                               float temperature, int forced_token, int suppress_eos, int eos_token_id,
+                               const float* min_keep, int32_t* out_idx, void* stream) {
+  MIC_CHECK(R > 0 && V > 0 && logits && out_idx && temperature > 0.f, "mic_sample_rows: bad args");
+  MIC_CHECK((uint64_t)R * (uint64_t)V < (1ull << 32), "mic_sample_rows: R*V must fit the 32-bit threefry counter");
+  if (forced_token >= 0) {  // ForcedBOS / ForcedEOS leave one finite logit: the categorical draw is that token
+    hipLaunchKernelGGL(fill_i32_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, out_idx, R, forced_token);
+    MIC_LAUNCH_CHECK();
+    return MIC_OK;
+  }
+  dim3 grid(R), block(1024);
+  if (dtype == MIC_BF16)
+    hipLaunchKernelGGL(sample_rows_kernel<uint16_t>, grid, block, 0, (hipStream_t)stream, R, V, (const uint16_t*)logits, ld, key0, key1, temperature, suppress_eos, eos_token_id, min_keep, out_idx);
+  else if (dtype == MIC_F32)
+    hipLaunchKernelGGL(sample_rows_kernel<float>, grid, block, 0, (hipStream_t)stream, R, V, (const float*)logits, ld, key0, key1, temperature, suppress_eos, eos_token_id, min_keep, out_idx);
+  else MIC_CHECK(false, "mic_sample_rows: bad dtype");
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}

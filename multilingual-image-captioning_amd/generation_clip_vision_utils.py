@@ -7,7 +7,9 @@ host as a fixed sequence of HIP launches per step:
 
 Differences in mechanism, not in results: cross-attention K/V are projected once (the reference re-projects every
 step), and the self-attention cache is never gathered by beam (gen:945-953) — a slot-ownership table is updated
-instead.  `_sample` / warpers are outside the hot-path scope.
+instead.  `_sample` (gen:537-663): the categorical draw is `mic_sample_rows` (Gumbel-argmax with jax's
+threefry2x32 stream); by default it draws from the RAW logits exactly like the reference does (its processed/warped logits
+are computed and dropped, gen:620-627); `sample_from_processed_logits=True` applies processors and temperature.
 """
 from __future__ import annotations
 
@@ -31,6 +33,7 @@ class FlaxCLIPVisionMBartGenerationMixin:
                  length_penalty: Optional[float] = None, early_stopping: Optional[bool] = None, trace: bool = True,
                  params=None, **model_kwargs):
         mc = self.config.mbart_config
+        from_processed = bool(model_kwargs.pop("sample_from_processed_logits", False))  # build-only switch, see _sample
         max_length = max_length if max_length is not None else mc.max_length  # gen:205-209
         bos_token_id = bos_token_id if bos_token_id is not None else mc.bos_token_id
         pad_token_id = pad_token_id if pad_token_id is not None else mc.pad_token_id
@@ -55,7 +58,13 @@ class FlaxCLIPVisionMBartGenerationMixin:
         if not do_sample and num_beams == 1:
             return self._greedy_search(ehs, B, decoder_start_token_id, max_length, pad_token_id, eos_token_id, procs)
         elif do_sample and num_beams == 1:
-            raise NotImplementedError("sampling (`_sample`, gen:537-663) is outside the hot-path scope")
+            mcfg = mc
+            top_k = top_k if top_k is not None else getattr(mcfg, "top_k", 50)  # gen:349-356
+            top_p = top_p if top_p is not None else getattr(mcfg, "top_p", 1.0)
+            temperature = temperature if temperature is not None else getattr(mcfg, "temperature", 1.0)
+            return self._sample(ehs, B, decoder_start_token_id, max_length, pad_token_id, eos_token_id, prng_key, procs,
+                                dict(top_k=top_k, top_p=top_p, temperature=temperature),
+                                from_processed)
         elif not do_sample and num_beams > 1:
             length_penalty = length_penalty if length_penalty is not None else mc.length_penalty  # gen:733-742
             early_stopping = early_stopping if early_stopping is not None else mc.early_stopping
@@ -98,6 +107,41 @@ class FlaxCLIPVisionMBartGenerationMixin:
             ops.row_lse_topk(logits, logits.stride(0), st.V, 1, top_val, top_idx, B, forced_token=forced, suppress_eos=suppress,
                              eos_token_id=eos_token_id, raw_logits=True)
             ops.greedy_step(B, max_length, cur_len, eos_token_id, pad_token_id, top_idx, 1, sequences, finished, next_token)
+            pos += 1
+            cur_len += 1
+        return ModelOutput(sequences=sequences)
+
+    # ------------------------------------------------------------------ gen:537-663
+    def _sample(self, ehs, B, start_token, max_length, pad_token_id, eos_token_id, prng_key, procs, warp, from_processed: bool):
+        from . import prng
+        from .modeling_clip_vision_mbart import ModelOutput
+
+        dev, st = self.device, self.store
+        if from_processed and ((warp["top_k"] not in (None, 0)) or (warp["top_p"] is not None and warp["top_p"] < 1.0)):
+            raise NotImplementedError("top-k / top-p warpers are not built yet; the reference never applies them either "
+                                      "(gen:620-627) — pass top_k=0, top_p=1.0 with sample_from_processed_logits=True")
+        key = prng.prng_key(0 if prng_key is None else prng_key)  # gen:561
+        sequences = torch.full((B, max_length), pad_token_id, dtype=torch.int32, device=dev)
+        sequences[:, 0] = start_token
+        finished = torch.zeros(B, dtype=torch.int32, device=dev)
+        next_token = torch.full((B,), start_token, dtype=torch.int32, device=dev)
+        cache = self.init_cache(B, max_length)
+        self._decode_set_encoder(cache, ehs.reshape(B * st.S, st.d), B, 1)
+        drawn = torch.empty((B, 1), dtype=torch.int32, device=dev)
+        pos = torch.zeros(B, dtype=torch.int32, device=dev)
+        cur_len = 1
+        while True:
+            if cur_len == max_length or bool(finished.all().item()):  # gen:596-603
+                break
+            k, key = prng.split(key)  # gen:610
+            logits = self._decode_step(cache, next_token, pos)
+            if from_processed:
+                forced, suppress = self._proc_args(procs, cur_len, max_length, eos_token_id)
+                ops.sample_rows(logits, logits.stride(0), st.V, k, drawn, B, temperature=warp["temperature"] or 1.0,
+                                forced_token=forced, suppress_eos=suppress, eos_token_id=eos_token_id)
+            else:  # the reference's behaviour: jax.random.categorical(prng_key, model_outputs.logits[:, -1]) (gen:625-627)
+                ops.sample_rows(logits, logits.stride(0), st.V, k, drawn, B)
+            ops.greedy_step(B, max_length, cur_len, eos_token_id, pad_token_id, drawn, 1, sequences, finished, next_token)  # gen:629-642
             pos += 1
             cur_len += 1
         return ModelOutput(sequences=sequences)

@@ -217,6 +217,12 @@ def greedy_step(B, max_len, cur_len, eos, pad, top_idx, ld_top, sequences, finis
                                     _stream()), "mic_greedy_step")
 
 
+def sample_rows(logits, ld, V, key, out_idx, R, *, temperature=1.0, forced_token=-1, suppress_eos=False, eos_token_id=2, min_keep=None):
+    L.check(L.lib().mic_sample_rows(_dt(logits), R, V, _p(logits), ld, int(key[0]) & 0xFFFFFFFF, int(key[1]) & 0xFFFFFFFF,
+                                    float(temperature), int(forced_token), int(suppress_eos), eos_token_id, _p(min_keep), _p(out_idx),
+                                    _stream()), "mic_sample_rows")
+
+
 def image_transform(images, out_size, mean, std, dst, *, chw_out=False):
     """images: list of uint8 device tensors, each [3,H,W] (CHW) or [H,W,3] (HWC); dst float32 [n,S,S,3] (or [n,3,S,S])."""
     import ctypes as C

@@ -227,8 +227,139 @@ def generate(make_stepper: Callable[[int], object], batch_size: int, defaults: G
         return beam_search(make_stepper(batch_size * num_beams), batch_size, num_beams, decoder_start_token_id,
                            max_length, pad_token_id, eos_token_id, length_penalty, early_stopping, procs)
     if do_sample and num_beams == 1:
-        raise NotImplementedError("sampling is outside the hot-path scope (SURVEY §2 row 2)")
+        raise NotImplementedError("use generation_ref.sample() directly (it needs a PRNG key and the warpers)")
     raise NotImplementedError("`Beam sampling is currently not implemented.")  # gen:336
+
+
+# ------------------------------------------------------------------ sampling (gen:338-366, 537-663)
+# jax 0.2.16 PRNG (threefry2x32) restated from the published algorithm [3P]; pinned in tests/test_oracle_cpu.py on the
+# Random123 known-answer vectors, `split(PRNGKey(0))` and `uniform(PRNGKey(0))` as printed in the JAX documentation.
+_U = np.uint32
+_ROT = ((13, 15, 26, 6), (17, 29, 16, 24))
+
+
+def threefry2x32(key, x0, x1):
+    x0, x1 = np.array(x0, dtype=_U), np.array(x1, dtype=_U)
+    k0, k1 = _U(key[0]), _U(key[1])
+    ks = (k0, k1, _U(k0 ^ k1 ^ _U(0x1BD11BDA)))
+    with np.errstate(over="ignore"):
+        x0, x1 = (x0 + ks[0]).astype(_U), (x1 + ks[1]).astype(_U)
+        for g in range(5):
+            for r in _ROT[g % 2]:
+                x0 = (x0 + x1).astype(_U)
+                x1 = ((x1 << _U(r)) | (x1 >> _U(32 - r))).astype(_U)
+                x1 = (x1 ^ x0).astype(_U)
+            x0 = (x0 + ks[(g + 1) % 3]).astype(_U)
+            x1 = (x1 + ks[(g + 2) % 3] + _U(g + 1)).astype(_U)
+    return x0, x1
+
+
+def prng_key(seed: int) -> np.ndarray:
+    return np.array([(int(seed) >> 32) & 0xFFFFFFFF, int(seed) & 0xFFFFFFFF], dtype=_U)
+
+
+def random_bits(key, n: int) -> np.ndarray:
+    cnt = np.arange(n, dtype=_U)
+    if n % 2:
+        cnt = np.concatenate([cnt, np.zeros(1, _U)])
+    h = len(cnt) // 2
+    a, b = threefry2x32(key, cnt[:h], cnt[h:])
+    return np.concatenate([a, b])[:n]
+
+
+def prng_split(key, num: int = 2) -> np.ndarray:
+    return random_bits(key, 2 * num).reshape(num, 2)
+
+
+def uniform(key, shape, minval=0.0, maxval=1.0) -> np.ndarray:
+    n = int(np.prod(shape)) if len(shape) else 1
+    bits = random_bits(key, n)
+    f = ((bits >> _U(9)) | _U(0x3F800000)).view(np.float32) - np.float32(1.0)
+    lo, hi = np.float32(minval), np.float32(maxval)
+    return np.maximum(lo, (f * (hi - lo) + lo).astype(np.float32)).reshape(shape)
+
+
+def gumbel(key, shape) -> np.ndarray:
+    u = uniform(key, shape, minval=np.finfo(np.float32).tiny, maxval=1.0)
+    return (-np.log(-np.log(u))).astype(np.float32)
+
+
+def categorical(key, logits: np.ndarray) -> np.ndarray:
+    return np.argmax(gumbel(key, logits.shape) + logits.astype(np.float32), axis=-1).astype(np.int32)
+
+
+class TemperatureWarper:
+    def __init__(self, temperature: float):
+        self.t = np.float32(temperature)
+
+    def __call__(self, input_ids, scores, cur_len):
+        return (scores / self.t).astype(np.float32)
+
+
+class TopKWarper:
+    def __init__(self, k: int, min_tokens_to_keep: int = 1):
+        self.k = max(int(k), min_tokens_to_keep)
+
+    def __call__(self, input_ids, scores, cur_len):
+        k = min(self.k, scores.shape[-1])
+        v, i = top_k(scores, k)  # index-stable, like lax.top_k
+        out = np.full_like(scores, -np.inf)
+        np.put_along_axis(out, i, v, axis=-1)
+        return out
+
+
+class TopPWarper:
+    def __init__(self, p: float, min_tokens_to_keep: int = 1):
+        self.p, self.keep = np.float32(p), min_tokens_to_keep
+
+    def __call__(self, input_ids, scores, cur_len):
+        v, i = top_k(scores, scores.shape[-1])
+        e = np.exp(v - v[:, :1])
+        cum = np.cumsum((e / e.sum(-1, keepdims=True)).astype(np.float32), axis=-1, dtype=np.float32)
+        mask = cum < self.p
+        mask[:, 1:] |= mask[:, :-1].copy()  # "include the token that is higher than top_p as well"
+        mask[:, 0] = True
+        mask[:, : self.keep] = True
+        out = np.full_like(scores, -np.inf)
+        np.put_along_axis(out, i, np.where(mask, v, -np.inf).astype(scores.dtype), axis=-1)
+        return out
+
+
+def get_logits_warper(top_k_=None, top_p=None, temperature=None) -> List[Callable]:
+    """gen:338-366."""
+    w: List[Callable] = []
+    if temperature is not None and temperature != 1.0:
+        w.append(TemperatureWarper(temperature))
+    if top_k_ is not None and top_k_ != 0:
+        w.append(TopKWarper(top_k_, 1))
+    if top_p is not None and top_p < 1.0:
+        w.append(TopPWarper(top_p, 1))
+    return w
+
+
+def sample(stepper, batch_size: int, start_token: int, max_length: int, pad_token_id: int, eos_token_id: int, key,
+           procs: List[Callable], warpers: List[Callable], sample_from_processed_logits: bool = False) -> np.ndarray:
+    """gen:537-663.  The reference computes the processed + warped logits and then draws from the RAW model logits
+    (gen:620-627): `sample_from_processed_logits=False` reproduces that; True is the evidently intended behaviour."""
+    sequences = np.full((batch_size, max_length), pad_token_id, dtype=np.int32)
+    sequences[:, 0] = start_token
+    finished = np.zeros(batch_size, dtype=bool)
+    running = sequences[:, 0].copy()
+    cur_len = 1
+    key = np.asarray(key, dtype=_U)
+    while not (cur_len == max_length or finished.all()):  # gen:596-603
+        k, key = prng_split(key)  # gen:610
+        raw = stepper.step(running).astype(np.float32)
+        logits = _apply(procs, sequences, raw, cur_len)  # gen:620
+        for w in warpers:  # gen:622
+            logits = w(sequences, logits, cur_len)
+        nxt = categorical(k, logits if sample_from_processed_logits else raw)  # gen:625-627
+        finished = finished | (nxt == eos_token_id)
+        nxt = np.where(finished, pad_token_id, nxt).astype(np.int32)
+        sequences[:, cur_len] = nxt
+        running = nxt
+        cur_len += 1
+    return sequences
 
 
 # ------------------------------------------------------------------ steppers

@@ -123,3 +123,61 @@ def test_generate_api_errors(dev):
     model.config.mbart_config.decoder_start_token_id = None
     with pytest.raises(ValueError):
         model.generate(px.numpy(), max_length=5, num_beams=1)
+
+
+# ---------------------------------------------------------------- sampling (gen:537-663)
+def test_sample_rows_matches_jax_threefry_oracle(dev):
+    """mic_sample_rows = argmax(logits + Gumbel(threefry2x32 stream)) against the oracle's restatement of
+    jax.random.categorical: odd and even R*V (counter padding), bf16 and fp32 logits, temperature, EOS suppression."""
+    from mic_amd import ops
+    from oracle import generation_ref as G
+
+    for (R, V, dt) in ((3, 1003, torch.float32), (4, 1000, torch.float32), (2, 5003, torch.bfloat16), (1, 7, torch.float32)):
+        g = torch.Generator().manual_seed(R * V)
+        x = (torch.randn(R, V, generator=g) * 3).to(dt)
+        xd = x.to(dev)
+        out = torch.empty(R, dtype=torch.int32, device=dev)
+        key = G.prng_split(G.prng_key(R + V))[0]
+        ops.sample_rows(xd, xd.stride(0), V, key, out, R)
+        noisy = G.gumbel(key, (R, V)) + x.float().numpy()
+        ref = noisy.argmax(-1)
+        got = out.cpu().numpy()
+        for r in range(R):  # identical draw, or an fp32 log-rounding near-tie
+            assert got[r] == ref[r] or noisy[r, got[r]] >= noisy[r, ref[r]] - 1e-5, (R, V, r)
+        assert (got == ref).all()
+        ops.sample_rows(xd, xd.stride(0), V, key, out, R, temperature=0.7, suppress_eos=True, eos_token_id=2)
+        y = (x.float().numpy() / np.float32(0.7)).astype(np.float32)
+        y[:, 2] = -np.inf
+        assert (out.cpu().numpy() == (G.gumbel(key, (R, V)) + y).argmax(-1)).all()
+        ops.sample_rows(xd, xd.stride(0), V, key, out, R, forced_token=5)
+        assert (out.cpu().numpy() == 5).all()
+
+
+def test_generate_do_sample_matches_oracle(dev):
+    """generate(do_sample=True): same PRNG key -> same token ids as the oracle's `sample` loop, in the reference's
+    (raw-logits) mode and in the processed-logits mode; different keys differ; beam-sample is refused (gen:336)."""
+    from oracle import generation_ref as G
+    from oracle import model_ref as M
+
+    rc, p, model = make_pair(torch.float32, dev)
+    B, L = 3, 9
+    px = batch(rc, B, 8, seed=4)[0]
+    with torch.no_grad():
+        ehs, _ = M.encode(rc, p, px, int32_cast=True)
+
+    def stepper():
+        return G.ModelStepper(rc, p, ehs, L)
+
+    procs = G.get_logits_processor(0, L, rc.eos_token_id, rc.vocab_size - 7, rc.eos_token_id)
+    for mode in (False, True):
+        ref = G.sample(stepper(), B, 2, L, rc.pad_token_id, rc.eos_token_id, G.prng_key(123), procs,
+                       G.get_logits_warper(0, 1.0, 0.8) if mode else [], sample_from_processed_logits=mode)
+        out = model.generate(px, max_length=L, do_sample=True, num_beams=1, prng_key=123, top_k=0, top_p=1.0, temperature=0.8,
+                             forced_bos_token_id=rc.vocab_size - 7, sample_from_processed_logits=mode)
+        assert np.array_equal(out.sequences.cpu().numpy(), ref), mode
+    o2 = model.generate(px, max_length=L, do_sample=True, num_beams=1, prng_key=124, top_k=0, top_p=1.0)
+    assert not np.array_equal(o2.sequences.cpu().numpy(), ref)
+    o3 = model.generate(px, max_length=L, do_sample=True, num_beams=1, prng_key=np.array([0, 124], dtype=np.uint32), top_k=0, top_p=1.0)
+    assert torch.equal(o2.sequences, o3.sequences)  # PRNGKey(124) == [0, 124]
+    with pytest.raises(NotImplementedError):
+        model.generate(px, max_length=L, do_sample=True, num_beams=2)

@@ -230,3 +230,79 @@ def test_image_resize_dims_and_crop_rule():
     assert I.resize_dims(480, 640, 224) == (224, 298) and I.resize_dims(640, 480, 224) == (298, 224)
     assert I.resize_dims(224, 224, 224) == (224, 224) and I.resize_dims(333, 500, 224) == (224, 336)
     assert int(round((249 - 224) / 2.0)) == 12 and int(round((251 - 224) / 2.0)) == 14  # CenterCrop: half to even
+
+
+# ---------------------------------------------------------------- sampling restatement (gen:338-366, 537-663)
+def test_threefry_and_jax_prng_known_answers():
+    """Published vectors: Random123 threefry2x32 (the three cases of JAX's own testThreefry2x32), `split(PRNGKey(0))` and
+    `uniform(PRNGKey(0))` as printed in the JAX documentation."""
+    from oracle import generation_ref as G
+
+    for key, ctr, exp in (((0, 0), (0, 0), (0x6B200159, 0x99BA4EFE)),
+                          ((0xFFFFFFFF, 0xFFFFFFFF), (0xFFFFFFFF, 0xFFFFFFFF), (0x1CB996FC, 0xBB002BE7)),
+                          ((0x13198A2E, 0x03707344), (0x243F6A88, 0x85A308D3), (0xC4923A9C, 0x483DF7A0))):
+        a, b = G.threefry2x32(key, [ctr[0]], [ctr[1]])
+        assert (int(a[0]), int(b[0])) == exp
+    assert G.prng_split(G.prng_key(0)).tolist() == [[4146024105, 967050713], [2718843009, 1272950319]]
+    assert abs(float(G.uniform(G.prng_key(0), ())) - 0.41845703) < 1e-8
+    assert G.prng_key(42).tolist() == [0, 42]
+    # odd sizes pad the counter array; every shape draws from the same stream layout
+    u5 = G.uniform(G.prng_key(7), (5,))
+    assert u5.shape == (5,) and (u5 >= 0).all() and (u5 < 1).all()
+    g = G.gumbel(G.prng_key(3), (4, 1001))
+    assert np.isfinite(g).all() and abs(float(g.mean()) - 0.5772) < 0.05  # Euler-Mascheroni
+    # product host module walks the same key sequence
+    from mic_amd import prng
+
+    k = prng.prng_key(0)
+    for _ in range(3):
+        a, k = prng.split(k)
+    ko = G.prng_key(0)
+    for _ in range(3):
+        ao, ko = G.prng_split(ko)
+    assert a.tolist() == ao.tolist() and k.tolist() == ko.tolist()
+
+
+def test_logits_warpers_kat():
+    from oracle import generation_ref as G
+
+    x = np.array([[1.0, 3.0, 2.0, 3.0, -1.0, 0.5]], dtype=np.float32)
+    assert G.get_logits_warper(0, 1.0, 1.0) == [] and len(G.get_logits_warper(50, 0.9, 0.7)) == 3
+    out = G.TopKWarper(2)(None, x, 1)
+    assert np.isneginf(out[0, [0, 2, 4, 5]]).all() and out[0, 1] == 3.0 and out[0, 3] == 3.0
+    out = G.TopKWarper(1)(None, x, 1)  # tie: the lower index survives (lax.top_k)
+    assert out[0, 1] == 3.0 and np.isneginf(out[0, 3])
+    # top-p: probs sorted = softmax([3,3,2,1,.5,-1]); cumulative < p plus the first token crossing p
+    p = np.exp(np.array([3, 3, 2, 1, 0.5, -1.0]))
+    p /= p.sum()
+    out = G.TopPWarper(0.8)(None, x, 1)
+    kept = np.isfinite(out[0])
+    cum = np.cumsum(p)
+    n_keep = int((cum < 0.8).sum()) + 1
+    assert kept.sum() == n_keep and kept[[1, 3]].all()
+    assert np.isfinite(G.TopPWarper(1e-6)(None, x, 1)[0]).sum() == 1  # min_tokens_to_keep
+    assert np.allclose(G.TemperatureWarper(0.5)(None, x, 1), x * 2)
+
+
+def test_sample_loop_reference_bug_and_fixed_mode():
+    """gen:620-627: by default the draw ignores processors and warpers (the reference's behaviour); with
+    sample_from_processed_logits the forced tokens and MinLength take effect.  Same key -> same sequence."""
+    from oracle import generation_ref as G
+
+    V = 9
+    tab = _table(V, lambda s, h: {3: 1.0, 4: 0.5, 5: 0.0})
+    procs = G.get_logits_processor(0, 6, 2, 7, 2)  # forced BOS = 7, forced EOS = 2 at the last step
+    a = G.sample(G.ScriptedStepper(3, tab), 3, 4, 6, 1, 2, G.prng_key(5), procs, [], sample_from_processed_logits=True)
+    assert (a[:, 1] == 7).all() and (a[:, 5] == 1).all()  # forced BOS; forced EOS at the last step -> finished -> PAD
+    b = G.sample(G.ScriptedStepper(3, tab), 3, 4, 6, 1, 2, G.prng_key(5), procs, [], sample_from_processed_logits=False)
+    assert not (b[:, 1] == 7).all()  # the reference's draw never sees the processors
+    c = G.sample(G.ScriptedStepper(3, tab), 3, 4, 6, 1, 2, G.prng_key(5), procs, [], sample_from_processed_logits=False)
+    assert np.array_equal(b, c)
+    d = G.sample(G.ScriptedStepper(3, tab), 3, 4, 6, 1, 2, G.prng_key(6), procs, [], sample_from_processed_logits=False)
+    assert not np.array_equal(b, d)
+    # empirical frequencies of one categorical draw follow softmax
+    logits = np.tile(np.array([[2.0, 1.0, 0.0, -1.0]], dtype=np.float32), (20000, 1))
+    idx = G.categorical(G.prng_key(11), logits)
+    freq = np.bincount(idx, minlength=4) / 20000
+    sm = np.exp(logits[0]) / np.exp(logits[0]).sum()
+    assert np.abs(freq - sm).max() < 0.012
