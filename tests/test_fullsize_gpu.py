@@ -97,3 +97,95 @@ def test_fullsize_greedy_ids_exact_f32(full):
     out = models[torch.float32].generate(px.numpy(), **kw)
     assert np.array_equal(out.sequences.cpu().numpy(), ref.sequences)
     assert np.allclose(out.scores.cpu().numpy(), ref.scores, rtol=1e-4, atol=1e-4)
+
+
+# ---------------------------------------------------------------- BASELINE.json sizes: size-independent properties
+def _train_batch(B, T, seed):
+    g = torch.Generator().manual_seed(seed)
+    px = torch.randn(B, 224, 224, 3, generator=g).clamp(-1.8, 2.2)
+    labels = torch.full((B, T), 1, dtype=torch.int64)
+    mask = torch.zeros((B, T), dtype=torch.int64)
+    for b in range(B):
+        n = int(torch.randint(8, 63, (1,), generator=g))
+        labels[b, 0] = 250003 + (b % 4)
+        labels[b, 1:1 + n] = torch.randint(4, 250000, (n,), generator=g)
+        labels[b, 1 + n] = 2
+        mask[b, :n + 2] = 1
+    dec_in = torch.full_like(labels, 1)
+    dec_in[:, 1:] = labels[:, :-1]
+    return px, labels, mask, dec_in
+
+
+def _grads(model, px, labels, mask, dec_in, compact):
+    from mic_amd import loss_rows
+
+    d = model._dev
+    B, T = labels.shape
+    pos = torch.arange(T, dtype=torch.int32, device=model.device)[None].expand(B, T).contiguous()
+    kw = {}
+    if compact:
+        idx, rl = loss_rows(mask.numpy(), labels.numpy())
+        kw = dict(rows=(d(idx, torch.int32), len(idx)), row_labels=d(rl, torch.int32))
+    loss = model.engine.loss_and_grads(d(px, torch.float32), d(dec_in, torch.int32).reshape(-1), pos.reshape(-1), d(mask, torch.int32),
+                                       d(labels, torch.int32).reshape(-1), B, T, **kw)
+    torch.cuda.synchronize()
+    return float(loss), model.store.grad.clone()
+
+
+def test_baseline_train_batch64_properties_bf16(full):
+    """configs[1] (bf16, batch 64, seq 64, full model): (a) the compacted LM head (only rows with loss mask 1) gives the same
+    loss and gradients as the dense head; (b) data-parallel linearity — the batch gradient is the token-weighted mean of the
+    two half-batch gradients (what the per-rank masked mean + gradient mean of main.py:679, 698 relies on, up to the
+    per-rank normalisation)."""
+    rc, p, models, _, _ = full
+    model = models[torch.bfloat16]
+    px, labels, mask, dec_in = _train_batch(64, 64, seed=11)
+    l_c, g_c = _grads(model, px, labels, mask, dec_in, compact=True)
+    l_d, g_d = _grads(model, px, labels, mask, dec_in, compact=False)
+    assert abs(l_c - l_d) < 2e-6 * abs(l_d)
+    st = model.store
+    for name in ("shared", "flb", "dec11.fc2.w", "dec0.qkv.w", "vit0.fc1.w", "patch.w", "dec.ln_f.g"):
+        s = st.segs[name]
+        a, b = g_c[s.offset: s.offset + s.numel], g_d[s.offset: s.offset + s.numel]
+        assert ((a - b).abs().max() / b.abs().max()).item() < 1e-2, name  # bf16 activation gradients (one rounding of dh differs), dW row order
+    h = 32
+    la, ga = _grads(model, px[:h], labels[:h], mask[:h], dec_in[:h], compact=True)
+    lb, gb = _grads(model, px[h:], labels[h:], mask[h:], dec_in[h:], compact=True)
+    na, nb = int(mask[:h].sum()), int(mask[h:].sum())
+    assert abs((na * la + nb * lb) / (na + nb) - l_c) < 2e-4 * abs(l_c)  # bf16: tile configuration (summation order) varies with the row count
+    gm = (na * ga + nb * gb) / (na + nb)
+    for name in ("shared", "dec11.fc2.w", "dec0.qkv.w", "vit0.fc1.w", "vp.w"):
+        s = st.segs[name]
+        a, b = gm[s.offset: s.offset + s.numel], g_c[s.offset: s.offset + s.numel]
+        # bf16 dlogits are scaled by 1/n_half vs 1/n_batch before rounding and flow back through bf16 activations gradients:
+        # percent-level noise relative to the largest entry; a normalisation or reduction bug would be O(1)
+        assert ((a - b).abs().max() / b.abs().max()).item() < 5e-2, name
+        assert (torch.nn.functional.cosine_similarity(a, b, dim=0)).item() > 0.9995, name
+
+
+def test_baseline_beam4_batch256_properties_bf16(full):
+    """configs[3] (beam 4, batch 256, max_len 64, forced BOS, KV-cached): run-to-run determinism, permutation equivariance
+    over the batch (every row is computed independently of its neighbours), and the structure gen:665-990 guarantees."""
+    rc, p, models, _, _ = full
+    model = models[torch.bfloat16]
+    st = model.store
+    st.f32("flb")[rc.eos_token_id] = -1e9  # as bench.py: exactly 63 decoder steps
+    st.refresh_lp()
+    try:
+        g = torch.Generator().manual_seed(21)
+        px = torch.randn(256, 224, 224, 3, generator=g).clamp(-1.8, 2.2)
+        kw = dict(max_length=64, num_beams=4, forced_bos_token_id=250008)
+        a = model.generate(px, **kw)
+        b = model.generate(px, **kw)
+        assert a["steps"] == 63 and torch.equal(a.sequences, b.sequences) and torch.equal(a.scores, b.scores)
+        perm = torch.randperm(256, generator=g)
+        c = model.generate(px[perm], **kw)
+        assert torch.equal(c.sequences.cpu(), a.sequences.cpu()[perm]) and torch.equal(c.scores.cpu(), a.scores.cpu()[perm])
+        seq = a.sequences.cpu()
+        assert tuple(seq.shape) == (256, 64) and (seq[:, 0] == 2).all() and (seq[:, 1] == 250008).all()
+        assert (seq[:, 63] == rc.eos_token_id).all()           # ForcedEOS at the last step overrides the -1e9 bias
+        assert ((seq[:, 2:63] != rc.eos_token_id) & (seq[:, 2:63] != rc.pad_token_id)).all()
+        assert (a.scores.cpu() < 0).all() and torch.isfinite(a.scores.cpu()).all()
+    finally:
+        st.f32("flb")[rc.eos_token_id] = 0.0
+        st.refresh_lp()
