@@ -227,10 +227,15 @@ int mic_greedy_step(int B, int max_len, int cur_len, int eos_token_id, int pad_t
  *   gen:537-663) = argmax(logits / temperature + Gumbel noise) with the noise bit-compatible with jax 0.2.16's
  *   threefry2x32 stream for key = (key0, key1) over the whole [R, V] array (counter layout in csrc/decode.hip).
  *   forced_token >= 0: every row draws that token (ForcedBOS/ForcedEOS); suppress_eos: logit[eos] := -inf (MinLength);
- *   min_keep (optional, [R]): values below min_keep[row] are masked (top-k / top-p thresholds). */
+ *   min_keep / tie_limit (optional, [R], from mic_warp_thresholds): keep v > min_keep[row], or v == min_keep[row] and
+ *   index < tie_limit[row]; everything else is masked.
+ * mic_warp_thresholds: FlaxTopKLogitsWarper / FlaxTopPLogitsWarper (gen:338-366; temperature and MinLength applied first)
+ *   as a per-row (threshold value, tie index limit) pair: top_k <= 0 disables top-k, top_p >= 1 disables top-p. */
 int mic_sample_rows(int dtype, int R, int V, const void* logits, int ld, uint32_t key0, uint32_t key1,
                     float temperature, int forced_token, int suppress_eos, int eos_token_id, const float* min_keep,
-                    int32_t* out_idx, void* stream);
+                    const int32_t* tie_limit, int32_t* out_idx, void* stream);
+int mic_warp_thresholds(int dtype, int R, int V, const void* logits, int ld, float temperature, int suppress_eos,
+                        int eos_token_id, int top_k, float top_p, float* thr, int32_t* tie_limit, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Input pipeline: the reference's image Transform (main.py:165-179; evaluation.py:35-60) + the

@@ -78,7 +78,8 @@ _SIGS = {
     "mic_row_lse_topk": ([_i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p], C.c_int),
     "mic_beam_step": ([C.POINTER(BeamStepArgs), _p], C.c_int),
     "mic_greedy_step": ([_i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p], C.c_int),
-    "mic_sample_rows": ([_i, _i, _i, _p, _i, _u32, _u32, _f, _i, _i, _i, _p, _p, _p], C.c_int),
+    "mic_sample_rows": ([_i, _i, _i, _p, _i, _u32, _u32, _f, _i, _i, _i, _p, _p, _p, _p], C.c_int),
+    "mic_warp_thresholds": ([_i, _i, _i, _p, _i, _f, _i, _i, _i, _f, _p, _p, _p], C.c_int),
     "mic_image_transform": ([C.POINTER(ImageItem), _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _p, _i, _p], C.c_int),
 }
 EXPORTS = tuple(_SIGS)

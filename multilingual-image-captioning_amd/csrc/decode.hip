@@ -374,11 +374,13 @@ __device__ __forceinline__ void threefry2x32(uint32_t k0, uint32_t k1, uint32_t&
 template <typename T>
 __global__ __launch_bounds__(1024) void sample_rows_kernel(int R, int V, const T* __restrict__ logits, int ld, uint32_t k0,
                                                            uint32_t k1, float temperature, int suppress_eos, int eos,
-                                                           const float* __restrict__ min_keep, int32_t* __restrict__ out) {
+                                                           const float* __restrict__ min_keep,
+                                                           const int32_t* __restrict__ tie_limit, int32_t* __restrict__ out) {
   const int row = blockIdx.x;
   const uint32_t n = (uint32_t)R * (uint32_t)V, h = (n + 1u) >> 1;
   const T* x = logits + (size_t)row * ld;
   const float thr = min_keep ? min_keep[row] : -INFINITY;
+  const int lim = tie_limit ? tie_limit[row] : 0x7fffffff;
   float best = -INFINITY;
   int bi = 0x7fffffff;
   for (int i = threadIdx.x; i < V; i += blockDim.x) {
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(1024) void sample_rows_kernel(int R, int V, const T
     const float g = -logf(-logf(u));
     float v = ElemT<T>::ld(x + i);
     if (temperature != 1.0f) v = v / temperature;
-    if ((suppress_eos && i == eos) || v < thr) v = -INFINITY;
+    if ((suppress_eos && i == eos) || v < thr || (v == thr && i >= lim)) v = -INFINITY;
     v += g;
     if (v > best || (v == best && i < bi)) { best = v; bi = i; }
   }
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(1024) void sample_rows_kernel(int R, int V, const T
 
 extern "C" int mic_sample_rows(int dtype, int R, int V, const void* logits, int ld, uint32_t key0, uint32_t key1,
                                float temperature, int forced_token, int suppress_eos, int eos_token_id,
-                               const float* min_keep, int32_t* out_idx, void* stream) {
+                               const float* min_keep, const int32_t* tie_limit, int32_t* out_idx, void* stream) {
   MIC_CHECK(R > 0 && V > 0 && logits && out_idx && temperature > 0.f, "mic_sample_rows: bad args");
   MIC_CHECK((uint64_t)R * (uint64_t)V < (1ull << 32), "mic_sample_rows: R*V must fit the 32-bit threefry counter");
   if (forced_token >= 0) {  // ForcedBOS / ForcedEOS leave one finite logit: the categorical draw is that token
@@ -428,10 +430,179 @@ extern "C" int mic_sample_rows(int dtype, int R, int V, const void* logits, int 
   }
   dim3 grid(R), block(1024);
   if (dtype == MIC_BF16)
-    hipLaunchKernelGGL(sample_rows_kernel<uint16_t>, grid, block, 0, (hipStream_t)stream, R, V, (const uint16_t*)logits, ld, key0, key1, temperature, suppress_eos, eos_token_id, min_keep, out_idx);
+    hipLaunchKernelGGL(sample_rows_kernel<uint16_t>, grid, block, 0, (hipStream_t)stream, R, V, (const uint16_t*)logits, ld, key0, key1, temperature, suppress_eos, eos_token_id, min_keep, tie_limit, out_idx);
   else if (dtype == MIC_F32)
-    hipLaunchKernelGGL(sample_rows_kernel<float>, grid, block, 0, (hipStream_t)stream, R, V, (const float*)logits, ld, key0, key1, temperature, suppress_eos, eos_token_id, min_keep, out_idx);
+    hipLaunchKernelGGL(sample_rows_kernel<float>, grid, block, 0, (hipStream_t)stream, R, V, (const float*)logits, ld, key0, key1, temperature, suppress_eos, eos_token_id, min_keep, tie_limit, out_idx);
   else MIC_CHECK(false, "mic_sample_rows: bad dtype");
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}
+
+// ------------------------------------------------------------------ top-k / top-p warpers (gen:338-366)
+// FlaxTopKLogitsWarper keeps the k largest scores (lax.top_k: ties go to the lower index); FlaxTopPLogitsWarper sorts the
+// (already top-k-filtered) scores in descending order and keeps position j iff j == 0 or the softmax mass of the
+// positions before it is < top_p.  Neither needs a sort: both are "everything above a threshold value, plus the first
+// few (by index) of the entries equal to it" — found per row by a 3-pass radix descent over order-preserving 32-bit keys
+// (11 + 11 + 10 bits; LDS histograms of counts for top-k, of fixed-point masses for top-p so the sums are exact and
+// order-independent).  Output per row: thr (fp32 value) and tie_limit: keep v > thr, or v == thr and index < tie_limit.
+__device__ __forceinline__ uint32_t okey(float v) {  // ascending order-preserving key
+  const uint32_t u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float okey_inv(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+#define WARP_T 1024
+template <typename T>
+struct RowView {
+  const T* x; int V; float temperature; int suppress_eos, eos;
+  float thr_k; int lim_k;  // result of the top-k stage (thr_k = -inf: no filter yet)
+  __device__ __forceinline__ float at(int i) const {
+    float v = ElemT<T>::ld(x + i);
+    if (temperature != 1.0f) v = v / temperature;
+    if (suppress_eos && i == eos) v = -INFINITY;
+    if (v < thr_k || (v == thr_k && i >= lim_k)) v = -INFINITY;
+    return v;
+  }
+};
+
+// block-wide inclusive scan over WARP_T threads of a 64-bit value (wave shuffles + one LDS hop); returns inclusive sum
+__device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long v, unsigned long long* wsum /*[16]*/) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long n = __shfl_up(v, o, 64);
+    if (lane >= o) v += n;
+  }
+  __syncthreads();
+  if (lane == 63) wsum[wave] = v;
+  __syncthreads();
+  unsigned long long base = 0;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  return v + base;
+}
+
+// One radix-descent stage: hist[2048] (64-bit) holds the weight of every bin among the entries matching (key & pmask) ==
+// prefix; walking bins from the highest key down, finds the bin where the running weight first reaches `target`
+// (running_before < target <= running_before + hist[bin]); returns bin and the weight still needed inside it.
+__device__ __forceinline__ void pick_bin(const unsigned long long* hist, int nbins, unsigned long long target,
+                                         unsigned long long* wsum, int* out_bin, unsigned long long* out_need) {
+  // thread t covers descending bins nbins-1-2t and nbins-2-2t
+  const int b0 = nbins - 1 - 2 * (int)threadIdx.x, b1 = b0 - 1;
+  const unsigned long long h0 = b0 >= 0 ? hist[b0] : 0ull, h1 = b1 >= 0 ? hist[b1] : 0ull;
+  const unsigned long long incl = block_scan_u64(h0 + h1, wsum);
+  const unsigned long long before = incl - (h0 + h1);
+  if (before < target && target <= incl) {
+    if (target <= before + h0) { *out_bin = b0; *out_need = target - before; }
+    else { *out_bin = b1; *out_need = target - before - h0; }
+  }
+  __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(WARP_T) void warp_threshold_kernel(int V, const T* __restrict__ logits, int ld, float temperature,
+                                                                int suppress_eos, int eos, int top_k, float top_p,
+                                                                float* __restrict__ thr_out, int32_t* __restrict__ lim_out) {
+  __shared__ unsigned long long hist[2048];
+  __shared__ unsigned long long wsum[16];
+  __shared__ int s_bin;
+  __shared__ unsigned long long s_need;
+  __shared__ float s_red[16];
+  __shared__ int s_lim;
+  const int row = blockIdx.x, tid = threadIdx.x;
+  RowView<T> rv{logits + (size_t)row * ld, V, temperature, suppress_eos, eos, -INFINITY, 0x7fffffff};
+  const int shifts[3] = {21, 10, 0}, nb[3] = {2048, 2048, 1024};
+
+  for (int stage = 0; stage < 2; ++stage) {  // 0: top-k (weights = counts), 1: top-p (weights = fixed-point masses)
+    if (stage == 0 && (top_k <= 0 || top_k >= V)) continue;
+    if (stage == 1 && !(top_p < 1.0f)) continue;
+    float mx = -INFINITY;
+    unsigned long long target;
+    if (stage == 0) {
+      target = (unsigned long long)top_k;
+    } else {
+      // max and partition function over the surviving entries
+      for (int i = tid; i < V; i += WARP_T) mx = fmaxf(mx, rv.at(i));
+      mx = wave_max(mx);
+      if ((tid & 63) == 0) s_red[tid >> 6] = mx;
+      __syncthreads();
+      mx = s_red[0];
+      for (int w = 1; w < WARP_T / 64; ++w) mx = fmaxf(mx, s_red[w]);
+      unsigned long long z = 0;
+      for (int i = tid; i < V; i += WARP_T) z += (unsigned long long)(expf(rv.at(i) - mx) * 1099511627776.0f);  // 2^40
+      const unsigned long long tot = block_scan_u64(z, wsum);
+      __syncthreads();
+      if (tid == WARP_T - 1) s_need = tot;
+      __syncthreads();
+      const double t = (double)top_p * (double)s_need;
+      target = (unsigned long long)t;
+      if ((double)target < t) target += 1;   // keep position j iff mass_before(j) < top_p * Z  <=>  first reach of ceil(target)
+      if (target == 0) target = 1;           // min_tokens_to_keep = 1
+      __syncthreads();
+    }
+    uint32_t prefix = 0, pmask = 0;
+    unsigned long long need = target;
+    for (int ps = 0; ps < 3; ++ps) {
+      for (int b = tid; b < 2048; b += WARP_T) hist[b] = 0ull;
+      __syncthreads();
+      const uint32_t bm = (uint32_t)nb[ps] - 1u;
+      for (int i = tid; i < V; i += WARP_T) {
+        const float v = rv.at(i);
+        const uint32_t k = okey(v);
+        if ((k & pmask) == prefix && v > -INFINITY) {
+          const unsigned long long w = stage == 0 ? 1ull : (unsigned long long)(expf(v - mx) * 1099511627776.0f);
+          atomicAdd(&hist[(k >> shifts[ps]) & bm], w);
+        }
+      }
+      __syncthreads();
+      if (tid == 0) { s_bin = -1; s_need = 0; }
+      __syncthreads();
+      pick_bin(hist, nb[ps], need, wsum, &s_bin, &s_need);
+      const int bin = s_bin;
+      if (bin < 0) break;  // fewer surviving entries than requested: keep them all
+      need = s_need;
+      prefix |= (uint32_t)bin << shifts[ps];
+      pmask |= bm << shifts[ps];
+      __syncthreads();
+    }
+    if (pmask != 0xffffffffu) continue;  // nothing to cut
+    const float thr = okey_inv(prefix);
+    // entries equal to thr: keep the first n_keep by index
+    unsigned long long n_keep;
+    if (stage == 0) n_keep = need;
+    else {
+      const unsigned long long m_eq = (unsigned long long)(expf(thr - mx) * 1099511627776.0f);
+      n_keep = m_eq ? (need + m_eq - 1) / m_eq : 0x7fffffffull;
+    }
+    // index of the n_keep-th equal entry: per-thread contiguous segments, block scan of the counts, then a local walk
+    const int S = (V + WARP_T - 1) / WARP_T, i0 = tid * S, i1 = min(V, i0 + S);
+    unsigned long long cnt = 0;
+    for (int i = i0; i < i1; ++i) cnt += rv.at(i) == thr ? 1ull : 0ull;
+    const unsigned long long incl = block_scan_u64(cnt, wsum);
+    if (tid == 0) s_lim = 0x7fffffff;
+    __syncthreads();
+    const unsigned long long before = incl - cnt;
+    if (before < n_keep && n_keep <= incl) {
+      unsigned long long c = before;
+      for (int i = i0; i < i1; ++i)
+        if (rv.at(i) == thr && ++c == n_keep) { s_lim = i + 1; break; }
+    }
+    __syncthreads();
+    rv.thr_k = thr;
+    rv.lim_k = s_lim;
+    __syncthreads();
+  }
+  if (tid == 0) { thr_out[row] = rv.thr_k; lim_out[row] = rv.lim_k; }
+}
+
+extern "C" int mic_warp_thresholds(int dtype, int R, int V, const void* logits, int ld, float temperature, int suppress_eos,
+                                   int eos_token_id, int top_k, float top_p, float* thr, int32_t* tie_limit, void* stream) {
+  MIC_CHECK(R > 0 && V > 0 && logits && thr && tie_limit && temperature > 0.f && top_p > 0.f, "mic_warp_thresholds: bad args");
+  dim3 grid(R), block(WARP_T);
+  if (dtype == MIC_BF16)
+    hipLaunchKernelGGL(warp_threshold_kernel<uint16_t>, grid, block, 0, (hipStream_t)stream, V, (const uint16_t*)logits, ld, temperature, suppress_eos, eos_token_id, top_k, top_p, thr, tie_limit);
+  else if (dtype == MIC_F32)
+    hipLaunchKernelGGL(warp_threshold_kernel<float>, grid, block, 0, (hipStream_t)stream, V, (const float*)logits, ld, temperature, suppress_eos, eos_token_id, top_k, top_p, thr, tie_limit);
+  else MIC_CHECK(false, "mic_warp_thresholds: bad dtype");
   MIC_LAUNCH_CHECK();
   return MIC_OK;
 }

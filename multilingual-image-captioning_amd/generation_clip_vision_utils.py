@@ -9,7 +9,8 @@ Differences in mechanism, not in results: cross-attention K/V are projected once
 step), and the self-attention cache is never gathered by beam (gen:945-953) — a slot-ownership table is updated
 instead.  `_sample` (gen:537-663): the categorical draw is `mic_sample_rows` (Gumbel-argmax with jax's
 threefry2x32 stream); by default it draws from the RAW logits exactly like the reference does (its processed/warped logits
-are computed and dropped, gen:620-627); `sample_from_processed_logits=True` applies processors and temperature.
+are computed and dropped, gen:620-627); `sample_from_processed_logits=True` applies processors, temperature, top-k and
+top-p (`mic_warp_thresholds`).
 """
 from __future__ import annotations
 
@@ -117,9 +118,10 @@ class FlaxCLIPVisionMBartGenerationMixin:
         from .modeling_clip_vision_mbart import ModelOutput
 
         dev, st = self.device, self.store
-        if from_processed and ((warp["top_k"] not in (None, 0)) or (warp["top_p"] is not None and warp["top_p"] < 1.0)):
-            raise NotImplementedError("top-k / top-p warpers are not built yet; the reference never applies them either "
-                                      "(gen:620-627) — pass top_k=0, top_p=1.0 with sample_from_processed_logits=True")
+        use_k = from_processed and warp["top_k"] not in (None, 0)
+        use_p = from_processed and warp["top_p"] is not None and warp["top_p"] < 1.0
+        thr = torch.empty(B, dtype=torch.float32, device=dev) if (use_k or use_p) else None
+        lim = torch.empty(B, dtype=torch.int32, device=dev) if (use_k or use_p) else None
         key = prng.prng_key(0 if prng_key is None else prng_key)  # gen:561
         sequences = torch.full((B, max_length), pad_token_id, dtype=torch.int32, device=dev)
         sequences[:, 0] = start_token
@@ -137,8 +139,13 @@ class FlaxCLIPVisionMBartGenerationMixin:
             logits = self._decode_step(cache, next_token, pos)
             if from_processed:
                 forced, suppress = self._proc_args(procs, cur_len, max_length, eos_token_id)
-                ops.sample_rows(logits, logits.stride(0), st.V, k, drawn, B, temperature=warp["temperature"] or 1.0,
-                                forced_token=forced, suppress_eos=suppress, eos_token_id=eos_token_id)
+                temp = warp["temperature"] or 1.0
+                if thr is not None and forced < 0:  # gen:338-366: temperature -> top-k -> top-p, as (threshold, tie limit) per row
+                    ops.warp_thresholds(logits, logits.stride(0), st.V, thr, lim, B, temperature=temp, suppress_eos=suppress,
+                                        eos_token_id=eos_token_id, top_k=warp["top_k"] if use_k else 0,
+                                        top_p=warp["top_p"] if use_p else 1.0)
+                ops.sample_rows(logits, logits.stride(0), st.V, k, drawn, B, temperature=temp, forced_token=forced,
+                                suppress_eos=suppress, eos_token_id=eos_token_id, min_keep=thr, tie_limit=lim)
             else:  # the reference's behaviour: jax.random.categorical(prng_key, model_outputs.logits[:, -1]) (gen:625-627)
                 ops.sample_rows(logits, logits.stride(0), st.V, k, drawn, B)
             ops.greedy_step(B, max_length, cur_len, eos_token_id, pad_token_id, drawn, 1, sequences, finished, next_token)  # gen:629-642

@@ -217,10 +217,17 @@ def greedy_step(B, max_len, cur_len, eos, pad, top_idx, ld_top, sequences, finis
                                     _stream()), "mic_greedy_step")
 
 
-def sample_rows(logits, ld, V, key, out_idx, R, *, temperature=1.0, forced_token=-1, suppress_eos=False, eos_token_id=2, min_keep=None):
+def sample_rows(logits, ld, V, key, out_idx, R, *, temperature=1.0, forced_token=-1, suppress_eos=False, eos_token_id=2, min_keep=None,
+                tie_limit=None):
     L.check(L.lib().mic_sample_rows(_dt(logits), R, V, _p(logits), ld, int(key[0]) & 0xFFFFFFFF, int(key[1]) & 0xFFFFFFFF,
-                                    float(temperature), int(forced_token), int(suppress_eos), eos_token_id, _p(min_keep), _p(out_idx),
-                                    _stream()), "mic_sample_rows")
+                                    float(temperature), int(forced_token), int(suppress_eos), eos_token_id, _p(min_keep), _p(tie_limit),
+                                    _p(out_idx), _stream()), "mic_sample_rows")
+
+
+def warp_thresholds(logits, ld, V, thr, tie_limit, R, *, temperature=1.0, suppress_eos=False, eos_token_id=2, top_k=0, top_p=1.0):
+    L.check(L.lib().mic_warp_thresholds(_dt(logits), R, V, _p(logits), ld, float(temperature), int(suppress_eos), eos_token_id,
+                                        int(top_k or 0), float(top_p if top_p is not None else 1.0), _p(thr), _p(tie_limit), _stream()),
+            "mic_warp_thresholds")
 
 
 def image_transform(images, out_size, mean, std, dst, *, chw_out=False):

@@ -181,3 +181,59 @@ def test_generate_do_sample_matches_oracle(dev):
     assert torch.equal(o2.sequences, o3.sequences)  # PRNGKey(124) == [0, 124]
     with pytest.raises(NotImplementedError):
         model.generate(px, max_length=L, do_sample=True, num_beams=2)
+
+
+def test_warp_thresholds_match_oracle_warpers(dev):
+    """mic_warp_thresholds (threshold value + tie index limit) reproduces the keep-mask of FlaxTopK/TopP warpers as the oracle
+    restates them (sort-based), including ties at the cut (bf16-valued logits tie heavily) and temperature / MinLength first."""
+    from mic_amd import ops
+    from oracle import generation_ref as G
+
+    cases = [(3, 1003, 50, 1.0, 1.0, torch.float32), (3, 1003, 0, 0.9, 1.0, torch.float32), (2, 5003, 7, 0.5, 0.7, torch.bfloat16),
+             (4, 2000, 1, 1.0, 1.0, torch.bfloat16), (2, 1003, 2000, 0.3, 1.3, torch.float32), (2, 4096, 100, 0.95, 2.0, torch.bfloat16),
+             (1, 300, 5, 1e-4, 1.0, torch.float32)]
+    for (R, V, k, p, temp, dt) in cases:
+        g = torch.Generator().manual_seed(R * V + k)
+        x = (torch.randn(R, V, generator=g) * 2).to(dt)
+        xd = x.to(dev)
+        thr = torch.empty(R, dtype=torch.float32, device=dev)
+        lim = torch.empty(R, dtype=torch.int32, device=dev)
+        ops.warp_thresholds(xd, xd.stride(0), V, thr, lim, R, temperature=temp, suppress_eos=True, eos_token_id=2, top_k=k, top_p=p)
+        y = x.float().numpy()
+        y[:, 2] = -np.inf                                     # MinLength processor
+        ref = y
+        for w in G.get_logits_warper(k, p, temp):
+            ref = w(None, ref, 1)
+        yt = (y / np.float32(temp)).astype(np.float32) if temp != 1.0 else y
+        t, l = thr.cpu().numpy(), lim.cpu().numpy()
+        idx = np.arange(V)[None, :]
+        keep = (yt > t[:, None]) | ((yt == t[:, None]) & (idx < l[:, None]))
+        keep &= np.isfinite(yt)
+        ref_keep = np.isfinite(ref)
+        diff = (keep != ref_keep).sum(-1)
+        if p < 1.0:  # the nucleus boundary is decided by an fp32 cumulative sum in the oracle, fixed-point masses here
+            assert (diff <= 1).all(), (R, V, k, p, diff)
+        else:
+            assert (diff == 0).all(), (R, V, k, p, diff)
+        assert (keep.sum(-1) >= 1).all()
+
+
+def test_generate_sample_with_topk_topp(dev):
+    from oracle import generation_ref as G
+    from oracle import model_ref as M
+
+    rc, p, model = make_pair(torch.float32, dev)
+    B, L = 3, 8
+    px = batch(rc, B, 8, seed=9)[0]
+    with torch.no_grad():
+        ehs, _ = M.encode(rc, p, px, int32_cast=True)
+    procs = G.get_logits_processor(3, L, rc.eos_token_id, None, rc.eos_token_id)
+    ref = G.sample(G.ModelStepper(rc, p, ehs, L), B, 2, L, rc.pad_token_id, rc.eos_token_id, G.prng_key(77), procs,
+                   G.get_logits_warper(20, 0.9, 0.7), sample_from_processed_logits=True)
+    out = model.generate(px, max_length=L, do_sample=True, num_beams=1, prng_key=77, top_k=20, top_p=0.9, temperature=0.7,
+                         min_length=3, sample_from_processed_logits=True)
+    assert np.array_equal(out.sequences.cpu().numpy(), ref)
+    # top_k = 1 is greedy on the processed logits whatever the key
+    o1 = model.generate(px, max_length=L, do_sample=True, num_beams=1, prng_key=5, top_k=1, top_p=1.0, sample_from_processed_logits=True)
+    og = model.generate(px, max_length=L, num_beams=1)
+    assert torch.equal(o1.sequences, og.sequences)
