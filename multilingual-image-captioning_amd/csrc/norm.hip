@@ -63,31 +63,33 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int width, const 
 // Each wave walks rows with a grid stride keeping per-column partial dgamma/dbeta in registers; the block combines
 // its 4 waves through LDS and issues one fp32 atomic per column.
 #define LNB_WAVES 8  // waves per backward block: atomics scale with the BLOCK count, latency hiding with the WAVE count
-template <typename T>
-__global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(int rows, int width, const T* __restrict__ x,
+// NCH = 16-B chunks per lane (width <= 512*NCH): width <= 1024 runs with NCH = 2, half the registers of the generic
+// NCH = 4 build, so twice the waves fit a SIMD — this kernel lives on memory-level parallelism.
+template <typename T, int NCH, int NW>
+__global__ __launch_bounds__(64 * NW, NCH <= 2 ? 4 : 2) void ln_bwd_kernel(int rows, int width, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const T* __restrict__ dy,
                                                      const T* __restrict__ dres, T* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      T* __restrict__ dxm, uint32_t thr_m, uint32_t seed_m, float scale_m,
                                                      uint32_t thr_in, uint32_t seed_in, float scale_in) {
-  __shared__ float red[2][LNB_WAVES][64 * 8 + 8];
+  __shared__ float red[NW][64 * 8 + 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = width >> 3;
-  float dg[LN_MAXC][8], db[LN_MAXC][8];
+  float dg[NCH][8], db[NCH][8];
 #pragma unroll
-  for (int c = 0; c < LN_MAXC; ++c)
+  for (int c = 0; c < NCH; ++c)
 #pragma unroll
     for (int i = 0; i < 8; ++i) { dg[c][i] = 0.f; db[c][i] = 0.f; }
 
-  for (int row = blockIdx.x * LNB_WAVES + wave; row < rows; row += gridDim.x * LNB_WAVES) {
+  for (int row = blockIdx.x * NW + wave; row < rows; row += gridDim.x * NW) {
     const T* xr = x + (size_t)row * width;
     const T* dyr = dy + (size_t)row * width;
     const float mu = mean[row], rs = rstd[row];
-    float xh[LN_MAXC][8], gdy[LN_MAXC][8];
+    float xh[NCH][8], gdy[NCH][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
+    for (int c = 0; c < NCH; ++c) {
       const int ch = lane + c * 64;
       if (ch < nchunk) {
         float xv[8], dv[8], g[8];
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(int rows, int wi
     }
     const float c1 = wave_sum(s1) / (float)width, c2 = wave_sum(s2) / (float)width;
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
+    for (int c = 0; c < NCH; ++c) {
       const int ch = lane + c * 64;
       if (ch < nchunk) {
         float o[8], r[8];
@@ -133,25 +135,27 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(int rows, int wi
       }
     }
   }
-  // combine the 4 waves' column partials
+  // combine the waves' column partials (dgamma, then dbeta, through the same LDS buffer)
 #pragma unroll
-  for (int c = 0; c < LN_MAXC; ++c) {
+  for (int c = 0; c < NCH; ++c) {
     const int ch = lane + c * 64;
-    __syncthreads();
-    if (ch < nchunk) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { red[0][wave][lane * 8 + i] = dg[c][i]; red[1][wave][lane * 8 + i] = db[c][i]; }
-    }
-    __syncthreads();
-    // 512 columns of this chunk group
-    for (int col = threadIdx.x; col < 512; col += 64 * LNB_WAVES) {
-      const int gcol = c * 512 + col;  // = (lane' + c*64)*8 + i with lane'*8+i = col
-      if (gcol < width) {
-        float a = 0.f, b = 0.f;
+    for (int which = 0; which < 2; ++which) {
+      __syncthreads();
+      if (ch < nchunk) {
 #pragma unroll
-        for (int w = 0; w < LNB_WAVES; ++w) { a += red[0][w][col]; b += red[1][w][col]; }
-        if (dgamma) atomicAdd(dgamma + gcol, a);
-        if (dbeta) atomicAdd(dbeta + gcol, b);
+        for (int i = 0; i < 8; ++i) red[wave][lane * 8 + i] = which ? db[c][i] : dg[c][i];
+      }
+      __syncthreads();
+      float* dst = which ? dbeta : dgamma;
+      for (int col = threadIdx.x; col < 512; col += 64 * NW) {
+        const int gcol = c * 512 + col;  // = (lane' + c*64)*8 + i with lane'*8+i = col
+        if (gcol < width && dst) {
+          float a = 0.f;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) a += red[w][col];
+          atomicAdd(dst + gcol, a);
+        }
       }
     }
   }
@@ -182,15 +186,20 @@ extern "C" int mic_layernorm_bwd(int dtype, int rows, int width, const void* x, 
                                  uint32_t in_dropout_seed, void* stream) {
   MIC_CHECK(rows > 0 && width > 0 && width % 8 == 0 && width <= 64 * 8 * LN_MAXC, "mic_layernorm_bwd: bad shape rows=%d width=%d", rows, width);
   MIC_CHECK(x && gamma && mean && rstd && dy && dx, "mic_layernorm_bwd: null pointer");
-  int nblk = (rows + LNB_WAVES - 1) / LNB_WAVES;
-  if (nblk > 256) nblk = 256;  // each block ends with 2*width fp32 atomics: keep the block count low
-  dim3 grid(nblk), block(64 * LNB_WAVES);
+  // measured: 16-wave blocks 21.9 -> 20.9 us, more than 256 blocks slower (each block ends with 2*width fp32 atomics,
+  // ~4 us of the ~20 us at 4096x1024) -- the kernel is latency-bound at two rows per wave, not bandwidth-bound
+  const int NWS = LNB_WAVES;
+  int nblk = (rows + NWS - 1) / NWS;
+  if (nblk > 256) nblk = 256;
+  dim3 grid(nblk), block(64 * NWS);
   const uint32_t thr_m = dxm ? thr_of(dropout_p) : 0u, thr_in = thr_of(in_dropout_p);
   const float sm = 1.0f / (1.0f - dropout_p), si = 1.0f / (1.0f - in_dropout_p);
-  if (dtype == MIC_BF16)
-    hipLaunchKernelGGL(ln_bwd_kernel<uint16_t>, grid, block, 0, (hipStream_t)stream, rows, width, (const uint16_t*)x, gamma, mean, rstd, (const uint16_t*)dy, (const uint16_t*)dres, (uint16_t*)dx, dgamma, dbeta, (uint16_t*)dxm, thr_m, dropout_seed, sm, thr_in, in_dropout_seed, si);
-  else if (dtype == MIC_F32)
-    hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, 0, (hipStream_t)stream, rows, width, (const float*)x, gamma, mean, rstd, (const float*)dy, (const float*)dres, (float*)dx, dgamma, dbeta, (float*)dxm, thr_m, dropout_seed, sm, thr_in, in_dropout_seed, si);
+#define LNB_LAUNCH(TT, NC) LNB_LAUNCH2(TT, NC, LNB_WAVES)
+#define LNB_LAUNCH2(TT, NC, NWW) hipLaunchKernelGGL((ln_bwd_kernel<TT, NC, NWW>), grid, block, 0, (hipStream_t)stream, rows, width, (const TT*)x, gamma, mean, rstd, (const TT*)dy, (const TT*)dres, (TT*)dx, dgamma, dbeta, (TT*)dxm, thr_m, dropout_seed, sm, thr_in, in_dropout_seed, si)
+  if (dtype == MIC_BF16) { if (width <= 1024) LNB_LAUNCH(uint16_t, 2); else LNB_LAUNCH(uint16_t, LN_MAXC); }
+  else if (dtype == MIC_F32) { if (width <= 1024) LNB_LAUNCH(float, 2); else LNB_LAUNCH(float, LN_MAXC); }
+#undef LNB_LAUNCH
+#undef LNB_LAUNCH2
   else MIC_CHECK(false, "mic_layernorm_bwd: bad dtype");
   MIC_LAUNCH_CHECK();
   return MIC_OK;
