@@ -73,6 +73,11 @@ typedef struct {
   float alpha;             /* scale on acc before bias (0 means 1) */
   int split_k;             /* > 1 (bf16 only): split the reduction over that many workgroups per tile; partial sums are
                               atomically added (fp32) into a caller-zeroed C; no other epilogue allowed */
+  float* a_rowsum;         /* optional (bf16 only): a_rowsum[m] += sum over k < rowsum_k of A(m,k), fp32 atomics into a
+                              caller-zeroed vector.  With A = dy^T (a_kmajor, the weight-gradient GEMM dW = dy^T x) this is
+                              the bias gradient colsum(dy) (nn.Dense bias; main.py:696 grads) from operand fragments the
+                              kernel holds anyway — no extra pass over dy */
+  int rowsum_k;            /* valid reduction rows for a_rowsum (0 = K) */
 } mic_gemm_args;
 int mic_gemm(const mic_gemm_args* a, void* stream);
 /* `count` GEMMs that share dtype and operand layouts in as few launches as possible (one launch per 8 problems):

@@ -27,6 +27,7 @@ class GemmArgs(C.Structure):
         ("bias", C.c_void_p), ("act", C.c_int), ("Zout", C.c_void_p), ("ldz", C.c_int), ("Zin", C.c_void_p),
         ("dact", C.c_int), ("R", C.c_void_p), ("ldr", C.c_int), ("accumulate", C.c_int), ("dropout_p", C.c_float),
         ("dropout_seed", C.c_uint32), ("alpha", C.c_float), ("split_k", C.c_int),
+        ("a_rowsum", C.c_void_p), ("rowsum_k", C.c_int),
     ]
 
 

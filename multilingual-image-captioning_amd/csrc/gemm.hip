@@ -41,6 +41,7 @@ struct Problem {
   const uint16_t* A; const uint16_t* B;
   int lda, ldb, M, N, K;
   int tiles_m, tiles_n, block_begin, nsplit;
+  float* a_rowsum; int rowsum_k;
   EpiArgs epi;
 };
 struct LaunchTable { int count; int total_blocks; Problem p[MAX_PROBLEMS]; };
@@ -201,6 +202,13 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+  // optional row sums of A (bias gradient when A = dy^T): the K-tiles are dealt round-robin to the tile columns tn and the
+  // k-steps to the wave columns wc, so every wave adds 8 fragment values on 1/(tiles_n*WNW) of its k-steps
+  float bsum[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) bsum[i] = 0.0f;
+  const bool do_rowsum = P.a_rowsum != nullptr;
+
   const int nk_total = P.K / BKT;
   const int nk_per = (nk_total + P.nsplit - 1) / P.nsplit;
   const int bt0 = split * nk_per, bt1 = min(nk_total, bt0 + nk_per);   // this block's K-tiles
@@ -248,6 +256,21 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
         for (int i = 0; i < AI; ++i) af[i] = read_frag<AK, BKT, UA>(At, a_off + i * 32, kk, lane);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) bfr[j] = read_frag<BKM, BKT, UB>(Bt, b_off + j * 32, kk, lane);
+        if (do_rowsum && (kk % WNW) == wc && ((kt0 + t) % P.tiles_n) == tn) {
+          const int kb = (kt0 + t) * BKT + kk * 16 + 8 * (lane >> 5);  // this lane's 8 consecutive k
+#pragma unroll
+          for (int i = 0; i < AI; ++i) {
+            const u32x4 u = __builtin_bit_cast(u32x4, af[i]);
+            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+            float sacc = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float lo = __uint_as_float(w[q] << 16), hi = __uint_as_float(w[q] & 0xffff0000u);
+              sacc += (kb + 2 * q < P.rowsum_k ? lo : 0.0f) + (kb + 2 * q + 1 < P.rowsum_k ? hi : 0.0f);
+            }
+            bsum[i] += sacc;
+          }
+        }
 #pragma unroll
         for (int i = 0; i < AI; ++i)
 #pragma unroll
@@ -283,6 +306,15 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
       }
     }
     __syncthreads();
+  }
+
+  if (do_rowsum) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const float v = bsum[i] + __shfl_xor(bsum[i], 32, 64);  // the two k-halves of the fragment
+      const int m = m0 + wr * WM + i * 32 + lane;
+      if (lane < 32 && m < M) atomicAdd(P.a_rowsum + m, v);
+    }
   }
 
   // epilogue: each wave restages an RP x WN fp32 block of its accumulators through its own LDS region, then the whole
@@ -465,6 +497,8 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
     p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bm - 1) / bm;
     p.nsplit = args[i].split_k > 1 ? args[i].split_k : 1;
     if (p.nsplit > p.K / 64) p.nsplit = p.K / 64;
+    p.a_rowsum = args[i].a_rowsum;
+    p.rowsum_k = args[i].rowsum_k > 0 ? args[i].rowsum_k : p.K;
     p.block_begin = blocks;
     blocks += p.tiles_m * p.tiles_n * p.nsplit;
   }
@@ -500,6 +534,7 @@ extern "C" int mic_gemm(const mic_gemm_args* a, void* stream) {
   EpiArgs e;
   if (int rc = fill_epi(a, e)) return rc;
   MIC_CHECK(a->split_k <= 1, "mic_gemm(f32): split_k is a bf16-path feature");
+  MIC_CHECK(!a->a_rowsum, "mic_gemm(f32): a_rowsum is a bf16-path feature (use mic_colsum)");
   dim3 grid((a->N + 63) / 64, (a->M + 63) / 64), block(256);
   const long sam = a->a_kmajor ? 1 : a->lda, sak = a->a_kmajor ? a->lda : 1;
   const long sbk = a->b_kmajor ? a->ldb : 1, sbn = a->b_kmajor ? 1 : a->ldb;

@@ -92,11 +92,15 @@ class Engine:
         w = P.w(wname + ".w")
         N, K = w.shape
         Mp = _rup(M, ROWPAD)
+        # bf16: the bias gradient colsum(dy) rides on the dW GEMM (row sums of its A operand dy^T, from the fragments the
+        # kernel already holds; fp32 atomics into the pre-zeroed atomic region).  fp32 mode keeps the separate column sum.
+        fuse = bias and self.dt == torch.bfloat16
+        rs = dict(a_rowsum=P.g(wname + ".b"), rowsum_k=M) if fuse else {}
         if defer:
-            self._dw_queue.append((ops.gemm_args(dy, x, P.g(wname + ".w"), N, K, Mp, a_kmajor=True, b_kmajor=True), wname, bias))
+            self._dw_queue.append((ops.gemm_args(dy, x, P.g(wname + ".w"), N, K, Mp, a_kmajor=True, b_kmajor=True, **rs), wname, bias))
         else:
-            ops.gemm(dy, x, P.g(wname + ".w"), N, K, Mp, a_kmajor=True, b_kmajor=True)
-        if bias:
+            ops.gemm(dy, x, P.g(wname + ".w"), N, K, Mp, a_kmajor=True, b_kmajor=True, **rs)
+        if bias and not fuse:
             if defer:
                 self._cs_queue.append((dy, P.g(wname + ".b"), M, N, dy.stride(0)))
             else:
@@ -288,8 +292,12 @@ class Engine:
             hf = self.buf("d.hfc", M, d)  # compacted final hidden states (pad rows zero)
             Mh = rows[1]
         Mhp = _rup(Mh, 64)
-        ops.colsum(dlogits, P.g("flb"), Mh, P.Vpad, dlogits.stride(0))
-        ops.gemm(dlogits, hf, P.g("shared"), P.Vpad, d, Mhp, a_kmajor=True, b_kmajor=True)
+        if self.dt == torch.bfloat16:  # final_logits_bias gradient = row sums of dlogits^T, fused into the dE GEMM
+            P.g("flb").zero_()         # (atomics; this segment sits in front of the pre-zeroed atomic region)
+            ops.gemm(dlogits, hf, P.g("shared"), P.Vpad, d, Mhp, a_kmajor=True, b_kmajor=True, a_rowsum=P.g("flb"), rowsum_k=Mh)
+        else:
+            ops.colsum(dlogits, P.g("flb"), Mh, P.Vpad, dlogits.stride(0))
+            ops.gemm(dlogits, hf, P.g("shared"), P.Vpad, d, Mhp, a_kmajor=True, b_kmajor=True)
         self._done("shared")  # dense (LM head) part of the tied embedding gradient: first thing backward completes
         dhc = dhf if rows is None else self.buf("db.dhfc", M, d)
         if self.dt == torch.bfloat16 and P.Vpad >= 16384:

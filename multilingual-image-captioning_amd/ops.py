@@ -54,7 +54,7 @@ class pinned_stream:
 
 def gemm_args(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, *, a_kmajor=False, b_kmajor=False,
               bias=None, act=0, zout=None, zin=None, dact=0, residual=None, accumulate=False, dropout_p=0.0, dropout_seed=0,
-              alpha=1.0, lda=None, ldb=None, ldc=None, ldz=None, ldr=None, split_k=0) -> "L.GemmArgs":
+              alpha=1.0, lda=None, ldb=None, ldc=None, ldz=None, ldr=None, split_k=0, a_rowsum=None, rowsum_k=0) -> "L.GemmArgs":
     g = L.GemmArgs()
     g.dtype, g.c_dtype = _dt(a), _dt(out)
     g.M, g.N, g.K = M, N, K
@@ -69,6 +69,7 @@ def gemm_args(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: in
     g.R, g.ldr = _p(residual), ldr if ldr is not None else (residual.stride(0) if residual is not None else 0)
     g.accumulate, g.dropout_p, g.dropout_seed, g.alpha = int(accumulate), float(dropout_p), int(dropout_seed) & 0xFFFFFFFF, float(alpha)
     g.split_k = int(split_k)
+    g.a_rowsum, g.rowsum_k = _p(a_rowsum), int(rowsum_k)
     return g
 
 

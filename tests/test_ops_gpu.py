@@ -430,3 +430,31 @@ def test_row_lse_topk(dev, dtype, V, Vpad):
     ops.row_lse_topk(logits.to(dev), Vpad, V, 1, tv1, ti1, R, raw_logits=True)
     torch.cuda.synchronize()
     assert np.array_equal(ti1.cpu().numpy()[:, 0], np.argmax(x, axis=-1))
+
+
+@pytest.mark.parametrize("Mo,No,K,kvalid", [(3072, 1024, 4096, 4096), (768, 768, 3200, 3137), (1024, 768, 3200, 3200), (248, 136, 256, 200),
+                                           (5003 // 8 * 8, 256, 192, 130)])
+def test_gemm_a_rowsum_is_the_bias_gradient(dev, Mo, No, K, kvalid):
+    """mic_gemm a_rowsum: with A = dy^T (k-major) the weight-gradient GEMM dW = dy^T x also yields colsum(dy[:kvalid]) — every
+    tile configuration (256/128/64 tiles, K-groups) and a partially valid last K-tile; C itself is unchanged."""
+    from mic_amd import ops
+
+    g = torch.Generator().manual_seed(Mo + K)
+    dy = (torch.randn(K, Mo, generator=g)).to(torch.bfloat16).to(dev)
+    x = (torch.randn(K, No, generator=g) * 0.1).to(torch.bfloat16).to(dev)
+    x[kvalid:] = 0  # reduction padding rows of x are zero (dW unaffected), dy's may hold anything
+    dW = torch.empty(Mo, No, dtype=torch.float32, device=dev)
+    db = torch.zeros(Mo, dtype=torch.float32, device=dev)
+    ops.gemm(dy, x, dW, Mo, No, K, a_kmajor=True, b_kmajor=True, a_rowsum=db, rowsum_k=kvalid)
+    ref_db = dy[:kvalid].float().sum(0)
+    ref_dW = dy.float().T @ x.float()
+    assert (db - ref_db).abs().max().item() < 2e-3 * max(1.0, ref_db.abs().max().item())
+    assert (dW - ref_dW).abs().max().item() < 2e-3 * ref_dW.abs().max().item()
+    # grouped launch: each problem carries its own vector
+    db2 = torch.zeros(Mo, dtype=torch.float32, device=dev)
+    db3 = torch.zeros(Mo, dtype=torch.float32, device=dev)
+    dW2 = torch.empty_like(dW)
+    ops.gemm_grouped([ops.gemm_args(dy, x, dW, Mo, No, K, a_kmajor=True, b_kmajor=True, a_rowsum=db2, rowsum_k=kvalid),
+                      ops.gemm_args(dy, x, dW2, Mo, No, K, a_kmajor=True, b_kmajor=True, a_rowsum=db3)])
+    assert (db2 - ref_db).abs().max().item() < 2e-3 * max(1.0, ref_db.abs().max().item())
+    assert (db3 - dy.float().sum(0)).abs().max().item() < 2e-3 * max(1.0, dy.float().sum(0).abs().max().item())
