@@ -187,6 +187,9 @@ def main():
     images_per_sec = world * B * args.steps / dt
 
     roofline = None
+    if not args.no_roofline and rank != 0:
+        tr.train_step(dbatches[0])  # the instrumented extra step below contains collectives: every rank takes part
+        torch.cuda.synchronize()
     if not args.no_roofline and rank == 0:
         # dominant kernel = the bf16 MFMA GEMM (gemm_bf16_kernel): every launch of one extra, untimed step is bracketed
         # by HIP events on the launch stream; achieved = sum(2MNK) / sum(duration).
