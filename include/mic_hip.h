@@ -73,6 +73,9 @@ typedef struct {
   float alpha;             /* scale on acc before bias (0 means 1) */
   int split_k;             /* > 1 (bf16 only): split the reduction over that many workgroups per tile; partial sums are
                               atomically added (fp32) into a caller-zeroed C; no other epilogue allowed */
+  long long split_stride;  /* split_k > 1 only.  0: partial sums are atomically added into C (above).  > 0: split s stores its
+                              partial tile plainly at C + s * split_stride (elements; C = fp32 workspace of split_k slabs),
+                              to be summed by mic_sum_slabs — no atomics, no zero-fill, deterministic */
   float* a_rowsum;         /* optional (bf16 only): a_rowsum[m] += sum over k < rowsum_k of A(m,k), fp32 atomics into a
                               caller-zeroed vector.  With A = dy^T (a_kmajor, the weight-gradient GEMM dW = dy^T x) this is
                               the bias gradient colsum(dy) (nn.Dense bias; main.py:696 grads) from operand fragments the
@@ -80,6 +83,10 @@ typedef struct {
   int rowsum_k;            /* valid reduction rows for a_rowsum (0 = K) */
 } mic_gemm_args;
 int mic_gemm(const mic_gemm_args* a, void* stream);
+/* dst[r][c] (dst_dtype) = sum over s < n_slabs of src[s * slab_stride + r * ld_src + c] (fp32): the second half of a
+ * workspace split-K GEMM. */
+int mic_sum_slabs(int dst_dtype, int n_slabs, long long slab_stride, int rows, int cols, const float* src, int ld_src,
+                  void* dst, int ld_dst, void* stream);
 /* `count` GEMMs that share dtype and operand layouts in as few launches as possible (one launch per 8 problems):
  * the weight-gradient GEMMs of a layer have 36..256 output tiles each — grouped they fill the 256 CUs. */
 int mic_gemm_grouped(const mic_gemm_args* args, int count, void* stream);

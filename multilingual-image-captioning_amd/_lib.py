@@ -27,7 +27,7 @@ class GemmArgs(C.Structure):
         ("bias", C.c_void_p), ("act", C.c_int), ("Zout", C.c_void_p), ("ldz", C.c_int), ("Zin", C.c_void_p),
         ("dact", C.c_int), ("R", C.c_void_p), ("ldr", C.c_int), ("accumulate", C.c_int), ("dropout_p", C.c_float),
         ("dropout_seed", C.c_uint32), ("alpha", C.c_float), ("split_k", C.c_int),
-        ("a_rowsum", C.c_void_p), ("rowsum_k", C.c_int),
+        ("split_stride", C.c_longlong), ("a_rowsum", C.c_void_p), ("rowsum_k", C.c_int),
     ]
 
 
@@ -55,6 +55,7 @@ _SIGS = {
     "mic_last_error": ([], C.c_char_p),
     "mic_gemm": ([C.POINTER(GemmArgs), _p], C.c_int),
     "mic_gemm_grouped": ([C.POINTER(GemmArgs), _i, _p], C.c_int),
+    "mic_sum_slabs": ([_i, _i, C.c_longlong, _i, _i, _p, _i, _p, _i, _p], C.c_int),
     "mic_layernorm_fwd": ([_i, _i, _i, _p, _p, _p, _f, _p, _p, _p, _f, _u32, _p], C.c_int),
     "mic_layernorm_bwd": ([_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _u32, _f, _u32, _p], C.c_int),
     "mic_attn_fwd": ([_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p], C.c_int),

@@ -386,6 +386,40 @@ extern "C" int mic_cast2d(int src_dtype, int dst_dtype, int rows, int cols, cons
   MIC_LAUNCH_CHECK();
   return MIC_OK;
 }
+// ------------------------------------------------------------------ split-K second half: sum fp32 slabs
+template <typename D>
+__global__ __launch_bounds__(256) void sum_slabs_kernel(int n_slabs, long slab_stride, int rows, int cols, const float* __restrict__ src,
+                                                        long ld_src, D* __restrict__ dst, long ld_dst) {
+  const int cv = cols >> 3;  // 8-column groups (cols % 8 == 0)
+  const long total = (long)rows * cv;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long r = e / cv, c = (e % cv) * 8;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float* p = src + r * ld_src + c;
+    for (int s = 0; s < n_slabs; ++s) {
+      float v[8];
+      ld8(p + (long)s * slab_stride, v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += v[i];
+    }
+    st8(dst + r * ld_dst + c, acc);
+  }
+}
+extern "C" int mic_sum_slabs(int dst_dtype, int n_slabs, long long slab_stride, int rows, int cols, const float* src, int ld_src,
+                             void* dst, int ld_dst, void* stream) {
+  MIC_CHECK(n_slabs > 0 && rows > 0 && cols > 0 && cols % 8 == 0 && ld_src % 4 == 0 && ld_dst % 8 == 0 && slab_stride % 4 == 0 && src && dst,
+            "mic_sum_slabs: bad args");
+  const long total = (long)rows * (cols >> 3);
+  int nb = (int)((total + 255) / 256); if (nb > 2048) nb = 2048;
+  if (dst_dtype == MIC_BF16)
+    hipLaunchKernelGGL(sum_slabs_kernel<uint16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, n_slabs, (long)slab_stride, rows, cols, src, (long)ld_src, (uint16_t*)dst, (long)ld_dst);
+  else if (dst_dtype == MIC_F32)
+    hipLaunchKernelGGL(sum_slabs_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, n_slabs, (long)slab_stride, rows, cols, src, (long)ld_src, (float*)dst, (long)ld_dst);
+  else MIC_CHECK(false, "mic_sum_slabs: bad dtype");
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}
+
 extern "C" int mic_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream) {
   MIC_CHECK(n > 0 && n < (1LL << 40), "mic_cast: bad n");
   // split into rows of <= 2^20 so the 2-D kernel's int shape holds

@@ -42,6 +42,7 @@ struct Problem {
   int lda, ldb, M, N, K;
   int tiles_m, tiles_n, block_begin, nsplit;
   float* a_rowsum; int rowsum_k;
+  long long split_stride;
   EpiArgs epi;
 };
 struct LaunchTable { int count; int total_blocks; Problem p[MAX_PROBLEMS]; };
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
     }
     // side loads of all this thread's groups go out before the barrier (their latency hides behind it and each other)
     u32x4 zq[NIT], rq[NIT];
-    const bool split = P.nsplit > 1, pre = !split && epilogue_pre_ok(P.epi) && epilogue_vec_ok(P.epi, 8);
+    const bool is_split = P.nsplit > 1, pre = !is_split && epilogue_pre_ok(P.epi) && epilogue_vec_ok(P.epi, 8);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int id = it * NTHREADS + tid;
@@ -362,9 +363,20 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
       const float4 hi = *reinterpret_cast<const float4*>(src + 4);
       v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
       const int cnt = min(8, N - n);
-      if (split) {  // split-K: fp32 atomic accumulation into a zero-initialised C
+      if (is_split) {  // split-K: fp32 atomic accumulation into a zero-initialised C, or a plain store into this split's slab
         float* c = (float*)P.epi.C + (size_t)m * P.epi.ldc + n;
-        for (int i = 0; i < cnt; ++i) atomicAdd(c + i, v[i] * P.epi.alpha);
+        if (P.split_stride > 0) {
+          c += (size_t)split * (size_t)P.split_stride;
+          if (cnt == 8 && (P.epi.ldc & 3) == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] *= P.epi.alpha;
+            st8(c, v);
+          } else {
+            for (int i = 0; i < cnt; ++i) c[i] = v[i] * P.epi.alpha;
+          }
+        } else {
+          for (int i = 0; i < cnt; ++i) atomicAdd(c + i, v[i] * P.epi.alpha);
+        }
       } else if (pre && cnt == 8) {
         epilogue_store8_pre(P.epi, m, n, v, zq[it], rq[it]);
       } else {
@@ -497,6 +509,10 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
     p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bm - 1) / bm;
     p.nsplit = args[i].split_k > 1 ? args[i].split_k : 1;
     if (p.nsplit > p.K / 64) p.nsplit = p.K / 64;
+    p.split_stride = p.nsplit > 1 ? args[i].split_stride : 0;
+    MIC_CHECK(args[i].split_stride >= 0 && (args[i].split_stride == 0 || args[i].split_stride >= (long long)(p.M - 1) * args[i].ldc + p.N),
+              "mic_gemm: split_stride must cover one M x N slab");
+    MIC_CHECK(p.split_stride == 0 || p.nsplit == args[i].split_k, "mic_gemm: split_k exceeds K/64 with a slab workspace");
     p.a_rowsum = args[i].a_rowsum;
     p.rowsum_k = args[i].rowsum_k > 0 ? args[i].rowsum_k : p.K;
     p.block_begin = blocks;

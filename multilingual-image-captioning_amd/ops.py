@@ -54,7 +54,7 @@ class pinned_stream:
 
 def gemm_args(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, *, a_kmajor=False, b_kmajor=False,
               bias=None, act=0, zout=None, zin=None, dact=0, residual=None, accumulate=False, dropout_p=0.0, dropout_seed=0,
-              alpha=1.0, lda=None, ldb=None, ldc=None, ldz=None, ldr=None, split_k=0, a_rowsum=None, rowsum_k=0) -> "L.GemmArgs":
+              alpha=1.0, lda=None, ldb=None, ldc=None, ldz=None, ldr=None, split_k=0, split_stride=0, a_rowsum=None, rowsum_k=0) -> "L.GemmArgs":
     g = L.GemmArgs()
     g.dtype, g.c_dtype = _dt(a), _dt(out)
     g.M, g.N, g.K = M, N, K
@@ -68,7 +68,7 @@ def gemm_args(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: in
     g.ldz = ldz if ldz is not None else (zz.stride(0) if zz is not None else 0)
     g.R, g.ldr = _p(residual), ldr if ldr is not None else (residual.stride(0) if residual is not None else 0)
     g.accumulate, g.dropout_p, g.dropout_seed, g.alpha = int(accumulate), float(dropout_p), int(dropout_seed) & 0xFFFFFFFF, float(alpha)
-    g.split_k = int(split_k)
+    g.split_k, g.split_stride = int(split_k), int(split_stride)
     g.a_rowsum, g.rowsum_k = _p(a_rowsum), int(rowsum_k)
     return g
 
@@ -177,6 +177,11 @@ def dropout_mask(n: int, p: float, seed: int, device) -> torch.Tensor:
 def cast(src, dst, n=None):
     n = n if n is not None else src.numel()
     L.check(L.lib().mic_cast(_dt(src), _dt(dst), _p(src), _p(dst), n, _stream()), "mic_cast")
+    return dst
+
+
+def sum_slabs(src, n_slabs, slab_stride, dst, rows, cols, ld_src, ld_dst):
+    L.check(L.lib().mic_sum_slabs(_dt(dst), n_slabs, int(slab_stride), rows, cols, _p(src), ld_src, _p(dst), ld_dst, _stream()), "mic_sum_slabs")
     return dst
 
 

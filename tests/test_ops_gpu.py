@@ -458,3 +458,34 @@ def test_gemm_a_rowsum_is_the_bias_gradient(dev, Mo, No, K, kvalid):
                       ops.gemm_args(dy, x, dW2, Mo, No, K, a_kmajor=True, b_kmajor=True, a_rowsum=db3)])
     assert (db2 - ref_db).abs().max().item() < 2e-3 * max(1.0, ref_db.abs().max().item())
     assert (db3 - dy.float().sum(0)).abs().max().item() < 2e-3 * max(1.0, dy.float().sum(0).abs().max().item())
+
+
+def test_gemm_split_k_slabs_and_sum(dev):
+    """split_k with split_stride: every split stores its partial tile into its own fp32 slab (no atomics, no zero-fill);
+    mic_sum_slabs adds the slabs and rounds once.  Same result as the un-split GEMM; deterministic run to run."""
+    from mic_amd import ops
+
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 520, 1024, 64 * 96
+    a = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    w = (torch.randn(K, N, generator=g) * 0.05).to(torch.bfloat16).to(dev)  # k-major B, like the tied embedding in the head dX
+    ref = a.float() @ w.float()
+    for nsp in (8, 16, 6):
+        slab = 576 * N
+        ws = torch.full((nsp * 576, N), float("nan"), dtype=torch.float32, device=dev)  # garbage in: slabs are fully overwritten
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        ops.gemm(a, w, ws, M, N, K, b_kmajor=True, split_k=nsp, split_stride=slab)
+        ops.sum_slabs(ws, nsp, slab, out, M, N, ws.stride(0), out.stride(0))
+        assert torch.isfinite(out.float()).all()
+        assert (out.float() - ref).abs().max().item() < 2e-2 * ref.abs().max().item()
+        out2 = torch.empty_like(out)
+        ops.gemm(a, w, ws, M, N, K, b_kmajor=True, split_k=nsp, split_stride=slab)
+        ops.sum_slabs(ws, nsp, slab, out2, M, N, ws.stride(0), out2.stride(0))
+        assert torch.equal(out, out2)
+    o32 = torch.empty(M, N, dtype=torch.float32, device=dev)
+    ops.sum_slabs(ws, 6, slab, o32, M, N, ws.stride(0), o32.stride(0))
+    assert (o32 - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
+    from mic_amd._lib import MicError
+
+    with pytest.raises(MicError):
+        ops.gemm(a, w, ws, M, N, K, b_kmajor=True, split_k=8, split_stride=100)
