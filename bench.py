@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"],
+                    help="gradient exchange precision for --gpus > 1 (fp32 = the reference's pmean; bf16 = opt-in, halves xGMI bytes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-generate", action="store_true", help="skip the beam-4 captions/sec leg")
@@ -123,6 +125,7 @@ def main():
     import torch
     import torch.distributed as dist
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL; must be set before the HIP runtime starts
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -151,7 +154,7 @@ def main():
     model = FlaxCLIPVisionMBartForConditionalGeneration(cfg, seed=0, dtype=dtype, device=dev)
     B, T = args.batch, 64
     lr_fn = create_learning_rate_fn(train_ds_size=10_000_000, train_batch_size=B * world, num_train_epochs=7, num_warmup_steps=1000, learning_rate=5e-5)
-    tr = Trainer(model, lr_fn, seed=42)
+    tr = Trainer(model, lr_fn, seed=42, grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else None)
     V, img = cfg.mbart_config.vocab_size, cfg.clip_vision_config.image_size
     batches = [synth_batch(B, T, V, img, 1234 + rank * 100 + i) for i in range(2)]
     # inputs resident in HBM before the timed region
@@ -264,7 +267,7 @@ def main():
             "dtype": args.dtype, "data": "synthetic (random-init weights, N(0,1) pixels, ragged random captions)",
             "config": {"workload": "configs[1]: ViT-B/32 + mBART-large-50 train step (fwd+loss+bwd+all-reduce+AdamW), "
                                    f"per-GPU batch {B}, 224x224 NHWC fp32 pixels, seq_len {T}, dropout 0.1" + (" [SMALL DEBUG MODEL]" if args.small else ""),
-                       "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}", "grad_allreduce": "fp32 flat buckets, RCCL, side stream",
+                       "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}", "grad_allreduce": f"{args.grad_comm} flat buckets, RCCL, side stream",
                        "lm_head": "logits/CE on the label positions with loss mask 1 only (exact; ragged captions n~U{8..62})"},
             "model_tflops_per_gpu": round(step_flops * args.steps / dt / 1e12, 1),
             "final_loss": round(loss, 4),

@@ -71,7 +71,8 @@ class GradReducer:
     still on the side stream — by a per-bucket callback (the fused AdamW of that slice): HBM-bound optimizer traffic then
     overlaps the MFMA-bound remainder of backward instead of trailing it."""
 
-    def __init__(self, flat_grad: torch.Tensor, buckets: List[Tuple[int, int]], group=None, on_ready=None, hold=None):
+    def __init__(self, flat_grad: torch.Tensor, buckets: List[Tuple[int, int]], group=None, on_ready=None, hold=None,
+                 comm_dtype: Optional[torch.dtype] = None):
         import torch.distributed as dist
 
         self.dist, self.group = dist, group
@@ -86,6 +87,20 @@ class GradReducer:
         self.hold = hold  # (begin, end): buckets touching this range are reduced as usual but their on_ready is postponed
         self.held: List[Tuple[int, int]] = []
         self.last_comm_event = None
+        # opt-in reduced-precision exchange (e.g. torch.bfloat16): every rank rounds its bucket, the collective sums in that
+        # dtype, the result is widened back into the fp32 buffer.  Halves the xGMI bytes; NOT the reference's fp32 pmean.
+        self.comm_dtype = comm_dtype if (comm_dtype is not None and comm_dtype != flat_grad.dtype) else None
+        self.stage = (torch.empty(max(e - b for b, e in buckets), dtype=self.comm_dtype, device=flat_grad.device)
+                      if self.comm_dtype is not None and self.world > 1 else None)
+
+    def _all_reduce(self, b: int, e: int, async_op: bool = False):
+        if self.stage is None:
+            return self.dist.all_reduce(self.grad[b:e], op=self.dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        st = self.stage[: e - b]
+        st.copy_(self.grad[b:e])
+        self.dist.all_reduce(st, op=self.dist.ReduceOp.SUM, group=self.group)
+        self.grad[b:e].copy_(st)
+        return None
 
     @property
     def active(self) -> bool:
@@ -109,7 +124,7 @@ class GradReducer:
                 if self.world > 1:
                     with torch.cuda.stream(self.stream):
                         self.stream.wait_event(ev)
-                        self.dist.all_reduce(self.grad[b:e], op=self.dist.ReduceOp.SUM, group=self.group)
+                        self._all_reduce(b, e)
                         ev = torch.cuda.Event()
                         ev.record(self.stream)
                 self.last_comm_event = ev
@@ -122,7 +137,9 @@ class GradReducer:
                         with ops.pinned_stream():  # launch on that stream, not on the step's pinned main stream
                             self.on_ready(b, e)
             else:
-                self.handles.append(self.dist.all_reduce(self.grad[b:e], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+                h = self._all_reduce(b, e, async_op=True)
+                if h is not None:
+                    self.handles.append(h)
             self.next += 1
 
     def release_held(self, before=None):
@@ -161,7 +178,7 @@ class Trainer:
 
     def __init__(self, model, learning_rate_fn: Callable[[int], float], b1=0.9, b2=0.999, eps=1e-8, weight_decay=0.0,
                  label_smoothing_factor=0.0, seed: int = 42, bucket_mb: float = 64.0, group=None, compact_head: bool = True,
-                 overlap_optimizer: bool = True):
+                 overlap_optimizer: bool = True, grad_comm_dtype: Optional[torch.dtype] = None):
         import torch.distributed as dist
 
         self.model, self.lr_fn = model, learning_rate_fn
@@ -181,7 +198,7 @@ class Trainer:
         self.overlap_optimizer = overlap_optimizer
         sh = st.segs["shared"]
         self.reducer = GradReducer(st.grad, self.buckets, group, on_ready=self._adamw_slice if overlap_optimizer else None,
-                                   hold=(sh.offset, sh.offset + sh.numel))
+                                   hold=(sh.offset, sh.offset + sh.numel), comm_dtype=grad_comm_dtype)
         self.metrics_buf = torch.zeros(2, dtype=torch.float32, device=model.device)
 
     def _adamw_slice(self, b: int, e: int):

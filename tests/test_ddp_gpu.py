@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, comm=None):
     import torch.distributed as dist
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -30,7 +30,9 @@ def _worker(rank, world, port, q):
         dev = torch.device("cuda:0")
         rc, p, model = make_pair(torch.float32, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.0)
         lr_fn = create_learning_rate_fn(40, 4, 1, 0, 1e-3)
-        tr = Trainer(model, lr_fn, weight_decay=0.01, seed=42, bucket_mb=0.25)  # small buckets: several fire mid-backward
+        tr = Trainer(model, lr_fn, weight_decay=0.01, seed=42, bucket_mb=0.25,  # small buckets: several fire mid-backward
+                     grad_comm_dtype=torch.bfloat16 if comm == "bf16" else None)
+        gtol = 1e-2 if comm == "bf16" else 5e-4  # opt-in bf16 exchange: each rank's bucket is rounded to bf16 before the sum
         assert len(tr.buckets) > 3
         B, T = 2, 12
         shards = [batch(rc, B, T, seed=500 + r) for r in range(world)]
@@ -54,12 +56,12 @@ def _worker(rank, world, port, q):
                 sc = gm[k].abs().max().item()
                 if sc > 1e-6:
                     e = ((torch.from_numpy(gsum[k]) / world - gm[k]).abs().max() / sc).item()
-                    if e > 5e-4:
+                    if e > gtol:
                         ok, msg = False, f"grad {k}: {e}"
                         break
                 newp, _, _ = train_ref.adamw_update(p[k], gm[k], torch.zeros_like(p[k]), torch.zeros_like(p[k]), 0, 1e-3, wd=0.01)
                 d = (torch.from_numpy(got[k]) - newp).abs().max().item()
-                if d > 1e-4:  # first Adam step = lr * g/(|g|+eps): 10 % of one step, dominated by near-zero gradients
+                if comm is None and d > 1e-4:  # first Adam step = lr * g/(|g|+eps): 10 % of one step, dominated by near-zero gradients
                     ok, msg = False, f"param {k}: {d}"
                     break
         q.put((rank, ok, msg))
@@ -74,6 +76,22 @@ def test_two_rank_train_step_matches_oracle(dev):
     q = ctx.Queue()
     port = 29600 + (os.getpid() % 2000)
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for pr in procs:
+        pr.join(timeout=60)
+    assert all(r[1] for r in res), res
+
+
+def test_two_rank_bf16_gradient_exchange(dev):
+    """Trainer(grad_comm_dtype=torch.bfloat16): same step, gradients within bf16 rounding of the fp32 mean (opt-in mode)."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, "bf16")) for r in range(2)]
     for pr in procs:
         pr.start()
     res = sorted(q.get(timeout=300) for _ in range(2))

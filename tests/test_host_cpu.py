@@ -142,6 +142,14 @@ def _ddp_worker(rank, world, port, q):
     g = torch.arange(n, dtype=torch.float32) * (rank + 1)
     buckets = plan_buckets(n, 1200, list(range(0, n, 500)))
     red = GradReducer(g, buckets)
+    # opt-in bf16 exchange: sum of the ranks' bf16-rounded buckets, widened back to fp32
+    g16 = torch.arange(n, dtype=torch.float32) * 0.37 * (rank + 1)
+    r16 = GradReducer(g16, buckets, comm_dtype=torch.bfloat16)
+    r16.start_step()
+    r16.progress(n)
+    r16.finish()
+    exp16 = sum((torch.arange(n, dtype=torch.float32) * 0.37 * (r + 1)).to(torch.bfloat16) for r in range(world)).float()
+    ok16 = torch.equal(g16, exp16)
     red.start_step()
     fired = []
     for off in range(500, n + 1, 500):  # backward reports progress segment by segment
@@ -150,7 +158,7 @@ def _ddp_worker(rank, world, port, q):
         fired.append(red.next - before)
     red.finish()
     expect = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
-    ok = torch.equal(g, expect) and red.next == len(buckets) and sum(fired) == len(buckets)
+    ok = torch.equal(g, expect) and red.next == len(buckets) and sum(fired) == len(buckets) and ok16
     # pmean of per-rank masked means (main.py:679, 698): mean of means, not a token-weighted global mean
     m = torch.tensor([float(rank + 1), 0.0])
     dist.all_reduce(m)
