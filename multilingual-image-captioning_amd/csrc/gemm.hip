@@ -1,32 +1,33 @@
 // gemm.hip — MFMA GEMMs with fused epilogues (mic_gemm / mic_gemm_grouped).
 //
-// bf16 kernel (one template, two tile configurations, table-driven so one launch can carry several GEMMs):
-//   small: 128x128 tile, 4 waves (2x2), wave tile  64x64 = 2x2 v_mfma_f32_32x32x16_bf16 accumulators, 64 KiB LDS, 2 blocks/CU
-//   big  : 256x256 tile, 8 waves (2x4), wave tile 128x64 = 4x2 accumulators (128 acc registers), 128 KiB LDS, 1 block/CU
-// BK = 64.  Operand tiles go HBM/L2 -> LDS by direct DMA (global_load_lds_dwordx4: destination = wave-uniform base +
-// lane*16) in 16 KiB half-tiles (128 rows x 64 k, or 64 k x 128 x), double-buffered, one barrier per K-tile.  Measured on
-// MI355X the 128^2 structure saturates at ~20-25 B/clk/CU of operand delivery (0.85 PF/s at 4096^3, L2 hit 84 %, MFMA pipe
-// 43 % busy at the ~1.8 GHz the chip sustains under MFMA load) — arithmetic intensity per delivered byte is the lever,
-// hence the 256^2 configuration for every launch that has enough tiles to fill 256 CUs (LM head = half of all FLOPs),
-// grouped launches for the many small weight-gradient GEMMs, and split-K (fp32 atomics) for tiny-output/huge-K shapes.
-// LDS images are lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE address and the matching
-// XOR on the read side:
-//   k-contiguous operand  -> image [128 rows][64 k]  (128-B rows), 16-B chunk c of row r stored at c ^ ((r >> 1) & 7)
-//                            (conflict-free for ds_read_b128's lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31}),
-//                            fragments by ds_read_b128 (8 consecutive k of row lane&31);
-//   k-major operand       -> image [64 k][128 x]     (256-B rows), chunk c of row k stored at c ^ ((k & 3) << 2),
-//                            fragments by 2 x ds_read_b64_tr_b16 (hardware transpose; lane layouts verified on
-//                            gfx950 by tools/probe_layouts.hip).
+// bf16 kernel: ONE template, table-driven (a launch carries up to 8 problems), three tile configurations chosen per launch:
+//   256x256 tile, 8 waves (2x4), wave tile 128x64 (4x2 v_mfma_f32_32x32x16_bf16 accumulators), 128 KiB LDS, 1 block/CU
+//                 — launches with >= 200 such tiles (LM head, grouped dW, FFN): 2x the FLOPs per staged byte;
+//   128x128 tile, 8 waves (2x4), wave tile 64x32, 64 KiB LDS, 2 blocks/CU — the default;
+//   64x64 tile,   4 waves (2x2), wave tile 32x32, 32 KiB LDS — launches with fewer than 128 tiles of 128x128 (decode-time
+//                 GEMMs on ~1k rows, ViT dW);
+//   plus K-groups (template KG): 2 (128x128) or 2/4 (64x64) groups of waves share one output tile and split its K range
+//   when the grid leaves CUs under-occupied (the K loop is then a latency chain), partial sums meet in LDS.
+// BK = 64, two LDS stages, one barrier per K-tile.  Operands travel HBM/L2 -> registers (global_load_dwordx4, issued a full
+// iteration ahead) -> swizzled ds_write_b128 -> LDS; LDS-DMA (global_load_lds) was tried three times and lost every time
+// (~100 cycles of issue per 1 KiB piece in the issuing wave's in-order stream).  LDS images:
+//   k-contiguous operand -> [128|64 rows][64 k] (128-B rows), 16-B chunk c of row r at c ^ ((r >> 1) & 7): conflict-free for
+//                           ds_read_b128's lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31}; fragments by ds_read_b128;
+//   k-major operand      -> [64 k][128 x] (256-B rows), chunk c of row k at c ^ ((k & 3) << 2), or [64 k][64 x] (128-B rows),
+//                           c ^ (((k >> 1) & 1) << 2); fragments by 2 x ds_read_b64_tr_b16 (hardware transpose; lane
+//                           layouts verified on gfx950 by tools/probe_layouts.hip).
 // So Linear forward (NT), dX (NN) and dW (TN) all run from the tensors as they lie in HBM — no transposed copies.
 // Block ids are remapped XCD-aware (block b runs on XCD b % 8): each XCD walks a contiguous run of tiles ordered in
-// GROUP_M-tall column panels so neighbouring tiles share A/B panels in that XCD's L2.
+// GROUP_M-tall column panels so neighbouring tiles share A/B panels in that XCD's L2; split-K launches instead give each XCD
+// its own K-chunks over all tiles.  Split-K results go to fp32 atomics or, better, to one fp32 slab per split (mic_sum_slabs).
 // Epilogue: accumulators are restaged through LDS (free after the main loop) so every thread owns 8 consecutive columns
-// of a row: bias / activation / dropout / residual / Z / C all move as 16-B coalesced vectors.
+// of a row: bias / activation / dropout / residual / Z / C all move as 16-B coalesced vectors; side operands (Zin, residual,
+// old C) are prefetched for all of a thread's groups before the restage barrier.  Optional by-product: row sums of A (the
+// bias gradient when A = dy^T) from the A fragments the waves already hold.
 //
-// Cost model measured on MI355X (tools/bench_gemm_k.py): 256^2 tile = 19.6 us fixed + 1.73 us per K-tile (1.24 PF/s
-// asymptotically), 128^2 launch = 9.6 us fixed + 0.57 us per K-tile (0.94 PF/s).  Of the fixed part ~4 us per 256^2 tile is
-// the output store burst (~15 B/clk/CU store path) which nothing overlaps at one block per CU — the next structural step is
-// a persistent tile loop that drains tile i's stores inside tile i+1's K-loop.
+// Measured on MI355X: 256^2 tile = ~20 us fixed + 1.7-2.0 us per K-tile (0.95-1.06 PF/s at large K; the loop
+// is bound by operand delivery, ~17-20 B/clk/CU through TA/L2, not by MFMA issue), one-round 128^2 launch = 5.2k cycles
+// prologue + 2.25k per K-tile pair + 5.4k epilogue (28 B/clk/CU).  MFMA pipe ~45 % busy at the ~1.8 GHz the chip sustains.
 //
 // f32 kernel (the reference's default dtype; parity mode): 64x64x16 tiles, v_mfma_f32_32x32x2_f32 (bit-exact fp32
 // fma chain), generic strides.
@@ -47,7 +48,7 @@ struct Problem {
 };
 struct LaunchTable { int count; int total_blocks; Problem p[MAX_PROBLEMS]; };
 
-// --- stage one half-tile image (128 rows x BKT k, or BKT k x 128 x; 128*BKT*2 bytes) HBM/L2 -> registers -> LDS.
+// --- stage one operand image (ROWS x BKT k, or BKT k x ROWS x; ROWS = 128 or 64) HBM/L2 -> registers -> LDS.
 //     Measured on gfx950: a global_load_lds (LDS-DMA) instruction costs ~100 cycles of issue time in the issuing wave's
 //     in-order stream; 8 of them per K-tile next to 16 MFMAs made every one-block-per-CU shape DMA-issue bound
 //     (1.3-1.4k cycles per K-tile against 512 MFMA cycles).  global_load_dwordx4 + ds_write_b128 issue in ~20 cycles a
@@ -155,10 +156,7 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
   constexpr int UA = BM < 128 ? BM : 128, UB = BN < 128 ? BN : 128;  // rows per staged image (128, or 64 for the 64-wide tiles)
   constexpr int HALF_A = UA * BKT * 2, HALF_B = UB * BKT * 2;
   constexpr int NHA = BM / UA, NHB = BN / UB, STAGE = NHA * HALF_A + NHB * HALF_B, AI = WM / 32, NJ = WN / 32, KSTEPS = BKT / 16;
-#ifndef MIC_STAGE_AT
-#define MIC_STAGE_AT 0
-#endif
-  constexpr int STAGE_AT = MIC_STAGE_AT;  // k-step in front of which the next tile's LDS writes / global loads are issued
+  constexpr int STAGE_AT = 0;  // k-step in front of which the next tile's LDS writes / global loads are issued (1..3 measured equal)
   using SA = HalfStager<AK, NWAVES, BKT, UA>;
   using SB = HalfStager<BKM, NWAVES, BKT, UB>;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A halves | B halves]
