@@ -3,7 +3,7 @@
 // (K18) — a [rows][max_len] slot-ownership table is updated instead (see attention.hip / mic_attn_decode).
 #include "common.h"
 
-#define TOPK_MAX 8
+#define TOPK_MAX 16  // widest per-row top-k (= 2 * num_beams): num_beams <= 8; k <= 8 runs the 8-wide build
 #define NEG_BIG (-1.0e7f)
 
 __device__ __forceinline__ bool better(float av, int ai, float bv, int bi) { return av > bv || (av == bv && ai < bi); }
@@ -15,7 +15,7 @@ __device__ __forceinline__ bool better(float av, int ai, float bv, int bi) { ret
 // elements >= tau; everything else costs two subtractions and a compare.  Ordering is exactly lax.top_k's
 // (value desc, index asc) on the PROCESSED value (log-softmax, processors, + running score) — ties in the rounded fp32
 // value are broken by index, so thresholds are compared in that same processed domain.
-template <typename T>
+template <typename T, int KMAX>
 __global__ __launch_bounds__(256) void row_lse_topk_kernel(int V, const T* __restrict__ logits, int ld, int k, int forced,
                                                            int suppress_eos, int eos, int raw, const float* __restrict__ row_bias,
                                                            float* __restrict__ top_val, int32_t* __restrict__ top_idx) {
@@ -104,12 +104,12 @@ __global__ __launch_bounds__(256) void row_lse_topk_kernel(int V, const T* __res
     if (tid == 0) { top_val[row] = sm[0] + bias; top_idx[row] = si[0]; }
     return;
   }
-  // ---- tau: the 8th largest thread maximum (processed domain)
+  // ---- tau: the KMAX-th largest thread maximum (processed domain): at least KMAX >= k distinct elements are >= tau
   float tau;
   {
     float mine = tmax == -INFINITY ? -INFINITY : ((raw ? tmax : (tmax - mx) - logsum) + bias);
     float last = INFINITY;
-    for (int round = 0; round < TOPK_MAX; ++round) {
+    for (int round = 0; round < KMAX; ++round) {
       sm[tid] = mine; si[tid] = tid;
       __syncthreads();
       for (int o = 128; o > 0; o >>= 1) {
@@ -123,10 +123,10 @@ __global__ __launch_bounds__(256) void row_lse_topk_kernel(int V, const T* __res
     tau = last;  // -inf when fewer than 8 threads saw an eligible value: then everything is a candidate
   }
   // ---- pass 2: exact per-thread top-k of the candidates >= tau
-  float bv[TOPK_MAX];
-  int bi[TOPK_MAX];
+  float bv[KMAX];
+  int bi[KMAX];
 #pragma unroll
-  for (int i = 0; i < TOPK_MAX; ++i) { bv[i] = -INFINITY; bi[i] = 0x7fffffff; }
+  for (int i = 0; i < KMAX; ++i) { bv[i] = -INFINITY; bi[i] = 0x7fffffff; }
   for (int ch0 = tid; ch0 < nchunk; ch0 += 4 * 256) {
     float v[4][8];
 #pragma unroll
@@ -145,10 +145,10 @@ __global__ __launch_bounds__(256) void row_lse_topk_kernel(int V, const T* __res
         float x = raw ? v[u][i] : (v[u][i] - mx) - logsum;   // log_softmax (gen:850)
         if (suppress_eos && c == eos) x = -INFINITY;           // MinLength
         x += bias;                                             // + running score (gen:857)
-        if (x >= tau && better(x, c, bv[TOPK_MAX - 1], bi[TOPK_MAX - 1])) {
-          bv[TOPK_MAX - 1] = x; bi[TOPK_MAX - 1] = c;
+        if (x >= tau && better(x, c, bv[KMAX - 1], bi[KMAX - 1])) {
+          bv[KMAX - 1] = x; bi[KMAX - 1] = c;
 #pragma unroll
-          for (int p = TOPK_MAX - 1; p > 0; --p) {
+          for (int p = KMAX - 1; p > 0; --p) {
             if (better(bv[p], bi[p], bv[p - 1], bi[p - 1])) {
               const float tv = bv[p]; bv[p] = bv[p - 1]; bv[p - 1] = tv;
               const int ti = bi[p]; bi[p] = bi[p - 1]; bi[p - 1] = ti;
@@ -170,8 +170,8 @@ __global__ __launch_bounds__(256) void row_lse_topk_kernel(int V, const T* __res
     if (tid == 0) { top_val[(size_t)row * k + round] = sm[0]; top_idx[(size_t)row * k + round] = si[0]; }
     if (tid == winner) {
 #pragma unroll
-      for (int p = 0; p < TOPK_MAX - 1; ++p) { bv[p] = bv[p + 1]; bi[p] = bi[p + 1]; }
-      bv[TOPK_MAX - 1] = -INFINITY; bi[TOPK_MAX - 1] = 0x7fffffff;
+      for (int p = 0; p < KMAX - 1; ++p) { bv[p] = bv[p + 1]; bi[p] = bi[p + 1]; }
+      bv[KMAX - 1] = -INFINITY; bi[KMAX - 1] = 0x7fffffff;
     }
     __syncthreads();
   }
@@ -181,17 +181,17 @@ extern "C" int mic_row_lse_topk(int dtype, int R, int V, const void* logits, int
                                 int32_t* top_idx, void* stream) {
   MIC_CHECK(R > 0 && V > 0 && ld >= V && ld % 8 == 0 && k >= 1 && k <= TOPK_MAX && logits && top_val && top_idx, "mic_row_lse_topk: bad args");
   dim3 grid(R), block(256);
-  if (dtype == MIC_BF16)
-    hipLaunchKernelGGL(row_lse_topk_kernel<uint16_t>, grid, block, 0, (hipStream_t)stream, V, (const uint16_t*)logits, ld, k, forced_token, suppress_eos, eos_token_id, raw_logits, row_bias, top_val, top_idx);
-  else if (dtype == MIC_F32)
-    hipLaunchKernelGGL(row_lse_topk_kernel<float>, grid, block, 0, (hipStream_t)stream, V, (const float*)logits, ld, k, forced_token, suppress_eos, eos_token_id, raw_logits, row_bias, top_val, top_idx);
+#define TOPK_LAUNCH(TT, KM) hipLaunchKernelGGL((row_lse_topk_kernel<TT, KM>), grid, block, 0, (hipStream_t)stream, V, (const TT*)logits, ld, k, forced_token, suppress_eos, eos_token_id, raw_logits, row_bias, top_val, top_idx)
+  if (dtype == MIC_BF16) { if (k <= 8) TOPK_LAUNCH(uint16_t, 8); else TOPK_LAUNCH(uint16_t, 16); }
+  else if (dtype == MIC_F32) { if (k <= 8) TOPK_LAUNCH(float, 8); else TOPK_LAUNCH(float, 16); }
   else MIC_CHECK(false, "mic_row_lse_topk: bad dtype");
+#undef TOPK_LAUNCH
   MIC_LAUNCH_CHECK();
   return MIC_OK;
 }
 
 // ------------------------------------------------------------------ one beam_search_body_fn iteration (gen:857-966)
-// One 128-thread block per batch item; K <= 4 beams... (K <= 8: 2K*K <= 128 candidates).  All arithmetic is fp32 in
+// One 128-thread block per batch item; K <= 8 beams (2K*K <= 128 candidates).  All arithmetic is fp32 in
 // the reference's operation order so scores are bit-identical to the oracle.
 __global__ __launch_bounds__(128) void beam_step_kernel(mic_beam_step_args a) {
   extern __shared__ int32_t lds_i[];
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(128) void beam_step_kernel(mic_beam_step_args a) {
 }
 extern "C" int mic_beam_step(const mic_beam_step_args* a, void* stream) {
   MIC_CHECK(a && a->B > 0 && a->K >= 1 && a->K <= TOPK_MAX / 2 * 2 && 2 * a->K <= TOPK_MAX && a->max_len > 1 && a->cur_len >= 1 && a->cur_len < a->max_len,
-            "mic_beam_step: bad shape (K <= 4 supported: per-row candidates come from mic_row_lse_topk with k = 2K <= 8)");
+            "mic_beam_step: bad shape (K <= 8 supported: per-row candidates come from mic_row_lse_topk with k = 2K <= 16)");
   MIC_CHECK(a->cand_val && a->cand_idx && a->running_seq && a->running_scores && a->seq && a->scores && a->finished && a->src_row && a->next_token && a->flags, "mic_beam_step: null pointer");
   const size_t lds = (size_t)(3 * a->K * a->max_len + 8 * 2 * a->K + 8 * a->K) * 4;
   MIC_CHECK(lds <= 65536, "mic_beam_step: max_len too large for the LDS staging");

@@ -157,8 +157,8 @@ class FlaxCLIPVisionMBartGenerationMixin:
     def _beam_search(self, ehs, B, K, start_token, max_length, pad_token_id, eos_token_id, length_penalty, early_stopping, procs):
         from .modeling_clip_vision_mbart import ModelOutput
 
-        if 2 * K > 8:
-            raise NotImplementedError("num_beams > 4 needs a wider per-row top-k than this build ships (k <= 8)")
+        if 2 * K > 16:
+            raise NotImplementedError("num_beams > 8 needs a wider per-row top-k than this build ships (k = 2*num_beams <= 16)")
         dev, st = self.device, self.store
         R = B * K
         running_seq = torch.full((B, K, max_length), pad_token_id, dtype=torch.int32, device=dev)  # gen:751-757

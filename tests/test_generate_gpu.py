@@ -67,7 +67,9 @@ def test_greedy_ids_exact(dev, kw):
 
 
 @pytest.mark.parametrize("kw", [dict(max_length=10, forced_bos_token_id=996), dict(max_length=12), dict(max_length=8, decoder_start_token_id=998),
-                                dict(max_length=10, num_beams=2, length_penalty=1.0, early_stopping=False)])
+                                dict(max_length=10, num_beams=2, length_penalty=1.0, early_stopping=False),
+                                dict(max_length=9, num_beams=5), dict(max_length=8, num_beams=8, forced_bos_token_id=995),
+                                dict(max_length=9, num_beams=7, length_penalty=0.6)])
 def test_beam_ids_exact(dev, kw):
     rc, p, model = make_pair(torch.float32, dev, gelu="tanh", decoder_ln_eps=1e-6)
     B = 3
@@ -94,7 +96,8 @@ def test_beam_early_finish_eos_bias(dev):
     model.params = unflatten_tree({k: v.numpy() for k, v in p.items()})
     B = 4
     px, *_ = batch(rc, B, 12, seed=23)
-    for kw in (dict(max_length=12, num_beams=4, decoder_start_token_id=999), dict(max_length=12, num_beams=3, early_stopping=False, decoder_start_token_id=999)):
+    for kw in (dict(max_length=12, num_beams=4, decoder_start_token_id=999), dict(max_length=12, num_beams=3, early_stopping=False, decoder_start_token_id=999),
+               dict(max_length=12, num_beams=5, decoder_start_token_id=999)):  # 5 = the mbart-large-50 config default ("model has beam size 5", main.py:723)
         ref = _oracle_gen(rc, p, px, B, **kw)
         out = model.generate(px.numpy(), **kw)
         assert out["steps"] == ref.steps, (out["steps"], ref.steps)
