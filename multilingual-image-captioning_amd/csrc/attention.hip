@@ -340,7 +340,9 @@ extern "C" int mic_attn_bwd(int dtype, int B, int H, int Tq, int Tk, const void*
 }
 
 // ------------------------------------------------------------------ decode-time attention (K9d): one wave per (row, head)
-// HBM-bound.  8 lanes cover one cache slot's 64-element row (16 B per lane, a full 128-B line in bf16), so one wave
+// Latency-bound (measured ~15 us at one slot, 46 us at 63: dependent round trips x two residency rounds of the 16k waves;
+// re-mapping blocks so an image's beams share a CU, issuing V together with K, and LDS-free reductions all measured +-0).
+// 8 lanes cover one cache slot's 64-element row (16 B per lane, a full 128-B line in bf16), so one wave
 // instruction streams 8 slots fully coalesced for both K and V.  Scores: 8-dim partial dots reduced over the 8 lanes of a
 // slot group; softmax: wave reductions over slots; PV: each lane accumulates its 8 dims over its slots, then the 8 slot
 // groups are summed by xor-shuffles.  Slot ownership (beam-parent indirection) is looked up per slot.
@@ -373,9 +375,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(int R, int H, int max_
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc += qv[e] * kv[e];
     }
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    acc += __shfl_xor(acc, 4, 64);
+    acc = group8_sum(acc);  // the slot's 8 lanes
     sc[it] = slot < n ? acc : -INFINITY;
   }
   float m = sc[0];
@@ -400,10 +400,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(int R, int H, int max_
     }
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    o[e] += __shfl_xor(o[e], 8, 64);
-    o[e] += __shfl_xor(o[e], 16, 64);
-    o[e] += __shfl_xor(o[e], 32, 64);
+  for (int e = 0; e < 8; ++e) {  // sum the 8 slot groups (lanes ^8, ^16, ^32)
+    o[e] += dpp_f<DPP_ROR8>(o[e]);
+    o[e] += lane_xor16(o[e]);
+    o[e] += lane_xor32(o[e]);
   }
   if (grp == 0) st8(out + (size_t)r * ldo + h * 64 + sub * 8, o);
 }

@@ -66,15 +66,55 @@ __device__ __forceinline__ void st8(float* p, const float* v) {
   *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
 
-// ---- wave (64-lane) reductions by xor-shuffle
+// ---- wave (64-lane) reductions without the LDS crossbar.  __shfl_xor compiles to ds_bpermute_b32 (an LDS-pipe instruction,
+// ~8+ cycles per wave and a round trip of latency each); a 64-lane butterfly is six of them.  gfx950 can do every stage in the
+// VALU: lanes^1, ^2 by quad_perm DPP, the 8-lane group by row_half_mirror (i <-> 7-i) first, lanes^8 by row_ror:8,
+// lanes^16 by v_permlane16_swap and lanes^32 by v_permlane32_swap (both new on gfx950).  All lanes end with the result.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+#define DPP_HALF_MIRROR 0x141
+#define DPP_XOR1 0xB1   /* quad_perm [1,0,3,2] */
+#define DPP_XOR2 0x4E   /* quad_perm [2,3,0,1] */
+#define DPP_ROR8 0x128  /* row_ror:8 = lane ^ 8 inside a 16-lane row */
+__device__ __forceinline__ float lane_xor16(float v) {  // v[lane ^ 16]
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);  // r[0] = rows {0,0,2,2}, r[1] = rows {1,1,3,3} of v
+  const bool odd_row = (threadIdx.x >> 4) & 1;
+  return __builtin_bit_cast(float, odd_row ? r[0] : r[1]);
+}
+__device__ __forceinline__ float lane_xor32(float v) {  // v[lane ^ 32]
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);  // r[0] = {lo, lo}, r[1] = {hi, hi}
+  const bool hi = (threadIdx.x >> 5) & 1;
+  return __builtin_bit_cast(float, hi ? r[0] : r[1]);
+}
+// sum / max over every aligned group of 8 lanes (all 8 lanes receive it)
+__device__ __forceinline__ float group8_sum(float v) {
+  v += dpp_f<DPP_HALF_MIRROR>(v);
+  v += dpp_f<DPP_XOR1>(v);
+  v += dpp_f<DPP_XOR2>(v);
+  return v;
+}
+__device__ __forceinline__ float group8_max(float v) {
+  v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v));
+  v = fmaxf(v, dpp_f<DPP_XOR1>(v));
+  v = fmaxf(v, dpp_f<DPP_XOR2>(v));
+  return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v = group8_sum(v);
+  v += dpp_f<DPP_ROR8>(v);
+  v += lane_xor16(v);
+  v += lane_xor32(v);
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  v = group8_max(v);
+  v = fmaxf(v, dpp_f<DPP_ROR8>(v));
+  v = fmaxf(v, lane_xor16(v));
+  v = fmaxf(v, lane_xor32(v));
   return v;
 }
 
