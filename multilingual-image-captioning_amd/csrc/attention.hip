@@ -15,8 +15,14 @@ template <typename T> struct Tile;
 
 template <> struct Tile<uint16_t> {
   static constexpr int BYTES = 64 * 64 * 2;
-  // element (row, col) -> byte offset; 16-B chunk index XOR-swizzled by row (conflict-free ds_read_b128 fragments)
-  static __device__ __forceinline__ int off(int row, int col) { return row * 128 + ((((col >> 3) ^ (row & 7)) << 4) | ((col & 7) << 1)); }
+  // 16-B chunk index XOR-swizzled by row.  The same tile is read two ways: ds_read_b128 along k (lane <-> row: the 16-lane
+  // groups {0-3,12-15,20-27}/... cover 8 distinct row PAIRS, so any bijection of the pair index p = (row>>1)&7 is conflict-
+  // free) and ds_read_b64_tr_b16 across 4 consecutive rows x 4 chunks (rows k0,k0+1 vs k0+2,k0+3 must land in different
+  // aligned blocks of 4 chunks: bit 2 of the swizzle = bit 0 of p).  sw(row) = ((p & 1) << 2) | (p >> 1) satisfies both;
+  // row & 7 (the first version) measured 28 % / 42 % of LDS cycles as bank conflicts in the fwd / bwd kernels.
+  static __device__ __forceinline__ int sw(int row) { const int p = (row >> 1) & 7; return ((p & 1) << 2) | (p >> 1); }
+  // element (row, col) -> byte offset
+  static __device__ __forceinline__ int off(int row, int col) { return row * 128 + ((((col >> 3) ^ sw(row)) << 4) | ((col & 7) << 1)); }
   // stage rows [0,nrows) x 64 cols from src (row stride ld); rows >= nrows are zero
   template <int NT = 64>
   static __device__ __forceinline__ void stage(char* t, const uint16_t* src, int ld, int nrows, int lane) {
@@ -25,14 +31,14 @@ template <> struct Tile<uint16_t> {
       const int idx = it * NT + lane, row = idx >> 3, c = idx & 7;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (row < nrows) v = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + c * 8);
-      *reinterpret_cast<uint4*>(t + row * 128 + ((c ^ (row & 7)) << 4)) = v;
+      *reinterpret_cast<uint4*>(t + row * 128 + ((c ^ sw(row)) << 4)) = v;
     }
   }
   template <bool KM>
   static __device__ __forceinline__ bf16x8 frag(const char* t, int xb, int kk, int lane) {
     if (!KM) {
       const int row = xb + (lane & 31), kc = kk * 2 + (lane >> 5);
-      return *reinterpret_cast<const bf16x8*>(t + row * 128 + ((kc ^ (row & 7)) << 4));
+      return *reinterpret_cast<const bf16x8*>(t + row * 128 + ((kc ^ sw(row)) << 4));
     } else {
       const int g = lane >> 4, p = lane & 15;
       const int x = xb + 16 * (g & 1) + (p & 3) * 4;
