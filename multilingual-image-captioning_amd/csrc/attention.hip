@@ -59,8 +59,8 @@ template <> struct Tile<uint16_t> {
   }
   static __device__ __forceinline__ void store4(char* t, int row, int col0, const float* v) {
     uint2 o;
-    o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-    o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    o.x = f2bf_pk(v[0], v[1]);
+    o.y = f2bf_pk(v[2], v[3]);
     *reinterpret_cast<uint2*>(t + off(row, col0)) = o;
   }
 };

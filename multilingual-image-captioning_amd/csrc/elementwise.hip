@@ -488,8 +488,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(long n, float* __restrict__ 
     reinterpret_cast<float4*>(v)[e] = make_float4(va[0], va[1], va[2], va[3]);
     if (p_lp) {
       uint2 o;
-      o.x = (uint32_t)f2bf(pa[0]) | ((uint32_t)f2bf(pa[1]) << 16);
-      o.y = (uint32_t)f2bf(pa[2]) | ((uint32_t)f2bf(pa[3]) << 16);
+      o.x = f2bf_pk(pa[0], pa[1]);
+      o.y = f2bf_pk(pa[2], pa[3]);
       reinterpret_cast<uint2*>(p_lp)[e] = o;
     }
   }

@@ -316,14 +316,39 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
     }
   }
 
-  // epilogue: each wave restages an RP x WN fp32 block of its accumulators through its own LDS region, then the whole
-  // block streams them out: every thread owns 8 consecutive columns of a row (16-B vectors).
+  // epilogue.  Everything it needs from the launch table is copied into registers first: P lives in the kernarg segment
+  // behind a dynamic index, and inside the store loop every field access was a scalar load + wait (the compiler cannot hoist
+  // them across the global stores).  alpha and bias are folded into the accumulators here — a lane owns NJ columns, so the
+  // bias is NJ scalar loads per lane instead of a 32-B load (and a vmcnt wait behind the previous stores) per 8-column group.
+  EpiArgs E = P.epi;
+  const bool is_split = P.nsplit > 1;
+  const long long split_stride = P.split_stride;
+  {
+    float bj[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n0 + wc * WN + j * 32 + (lane & 31);
+      bj[j] = (E.bias && !is_split && n < N) ? E.bias[n] : 0.0f;
+    }
+    const float alpha = E.alpha;
+#pragma unroll
+    for (int i = 0; i < AI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * alpha + bj[j];
+    E.alpha = 1.0f;
+    E.bias = nullptr;
+  }
+  // each wave restages an RP x WN fp32 block of its accumulators through its own LDS region, then the whole block streams
+  // them out: every thread owns 8 consecutive columns of a row (16-B vectors).
   constexpr int RP = WM < 64 ? WM : 64;  // rows per pass
   constexpr int REGION = RP * WN;        // floats per wave region
   constexpr int CPR = WN / 8;            // 8-column chunks per region row
   constexpr int NGRP = NWAVES * RP * CPR;                 // 8-column groups per pass (whole tile)
   constexpr int NIT = (NGRP + NTHREADS - 1) / NTHREADS;   // ... per thread
   float* Cw = reinterpret_cast<float*>(smem) + wave * REGION;
+  const bool pre = !is_split && epilogue_pre_ok(E) && epilogue_vec_ok(E, 8);
 #pragma unroll
   for (int p = 0; p < WM / RP; ++p) {
     if (p > 0) __syncthreads();
@@ -338,14 +363,13 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
     }
     // side loads of all this thread's groups go out before the barrier (their latency hides behind it and each other)
     u32x4 zq[NIT], rq[NIT];
-    const bool is_split = P.nsplit > 1, pre = !is_split && epilogue_pre_ok(P.epi) && epilogue_vec_ok(P.epi, 8);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int id = it * NTHREADS + tid;
       const int w = id / (RP * CPR), rem = id % (RP * CPR);
       const int m = m0 + (w / WNW) * WM + p * RP + rem / CPR, n = n0 + (w % WNW) * WN + (rem % CPR) * 8;
       zq[it] = rq[it] = u32x4{0u, 0u, 0u, 0u};
-      if (pre && id < NGRP && m < M && n + 8 <= N) epilogue_prefetch8(P.epi, m, n, zq[it], rq[it]);
+      if (pre && id < NGRP && m < M && n + 8 <= N) epilogue_prefetch8(E, m, n, zq[it], rq[it]);
     }
     __syncthreads();
 #pragma unroll
@@ -362,23 +386,18 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
       v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
       const int cnt = min(8, N - n);
       if (is_split) {  // split-K: fp32 atomic accumulation into a zero-initialised C, or a plain store into this split's slab
-        float* c = (float*)P.epi.C + (size_t)m * P.epi.ldc + n;
-        if (P.split_stride > 0) {
-          c += (size_t)split * (size_t)P.split_stride;
-          if (cnt == 8 && (P.epi.ldc & 3) == 0) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] *= P.epi.alpha;
-            st8(c, v);
-          } else {
-            for (int i = 0; i < cnt; ++i) c[i] = v[i] * P.epi.alpha;
-          }
+        float* c = (float*)E.C + (size_t)m * E.ldc + n;
+        if (split_stride > 0) {
+          c += (size_t)split * (size_t)split_stride;
+          if (cnt == 8 && (E.ldc & 3) == 0) st8(c, v);
+          else for (int i = 0; i < cnt; ++i) c[i] = v[i];
         } else {
-          for (int i = 0; i < cnt; ++i) atomicAdd(c + i, v[i] * P.epi.alpha);
+          for (int i = 0; i < cnt; ++i) atomicAdd(c + i, v[i]);
         }
       } else if (pre && cnt == 8) {
-        epilogue_store8_pre(P.epi, m, n, v, zq[it], rq[it]);
+        epilogue_store8_pre(E, m, n, v, zq[it], rq[it]);
       } else {
-        epilogue_store8<uint16_t>(P.epi, m, n, v, cnt);
+        epilogue_store8<uint16_t>(E, m, n, v, cnt);
       }
     }
   }
