@@ -221,15 +221,30 @@ __device__ __forceinline__ void epilogue_store8_pre(const EpiArgs& e, int m, int
     for (int i = 0; i < 8; ++i) v[i] += b[i];
   }
   if (e.Zout) st8((uint16_t*)e.Zout + (size_t)m * e.ldz + n, v);
-  if (e.act) {
+  // the activation kind is tested once per group, not once per element (the compiler does not unswitch these loops itself)
+  if (e.act == MIC_ACT_GELU_TANH) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = act_fwd(MIC_ACT_GELU_TANH, round_to<uint16_t>(v[i]));
+  } else if (e.act == MIC_ACT_QUICK_GELU) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = act_fwd(MIC_ACT_QUICK_GELU, round_to<uint16_t>(v[i]));
+  } else if (e.act) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = act_fwd(e.act, round_to<uint16_t>(v[i]));
   }
   if (e.dact) {
     float z[8];
     unpack8(zc, z);
+    if (e.dact == MIC_ACT_GELU_TANH) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] *= act_bwd(e.dact, z[i]);
+      for (int i = 0; i < 8; ++i) v[i] *= act_bwd(MIC_ACT_GELU_TANH, z[i]);
+    } else if (e.dact == MIC_ACT_QUICK_GELU) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] *= act_bwd(MIC_ACT_QUICK_GELU, z[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] *= act_bwd(e.dact, z[i]);
+    }
   }
   if (e.drop_thr) {
 #pragma unroll

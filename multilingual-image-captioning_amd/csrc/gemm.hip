@@ -150,7 +150,9 @@ __device__ __forceinline__ void tile_coords(int lid, int tiles_m, int tiles_n, i
 //   the partial accumulators meet in LDS before the epilogue.  For launches whose tile count cannot fill the chip the
 //   K loop is a latency chain (load -> ds_write -> barrier -> ds_read -> MFMA, ~0.5 us per 64-k step at one block per CU);
 //   KG groups cut the chain KG-fold without atomics or extra launches.
-template <int WM, int WN, int WNW, int BKT, bool AK, bool BKM, int KG = 1>
+// PLAIN: every problem of the launch has the bare epilogue (C = alpha*acc + bias, bf16 or fp32, no split): the store loop
+//   is then two ds_read_b128, four v_cvt_pk_bf16_f32 and one 16-B store per group, with none of the per-group feature tests.
+template <int WM, int WN, int WNW, int BKT, bool AK, bool BKM, int KG = 1, bool PLAIN = false>
 __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kernel(LaunchTable tab) {
   constexpr int BM = 2 * WM, BN = WN * WNW, NWAVES = 2 * WNW, NTHREADS = 64 * NWAVES * KG;
   constexpr int UA = BM < 128 ? BM : 128, UB = BN < 128 ? BN : 128;  // rows per staged image (128, or 64 for the 64-wide tiles)
@@ -361,6 +363,31 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
           for (int r = 0; r < 16; ++r)
             Cw[(i2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * WN + j * 32 + (lane & 31)] = acc[(RP / 32) * p + i2][j][r];
     }
+    if constexpr (PLAIN) {
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int id = it * NTHREADS + tid;
+        const int w = id / (RP * CPR), rem = id % (RP * CPR);
+        const int row = rem / CPR, c8 = (rem % CPR) * 8;
+        const int m = m0 + (w / WNW) * WM + p * RP + row, n = n0 + (w % WNW) * WN + c8;
+        if (id >= NGRP || m >= M || n >= N) continue;
+        const float* src = reinterpret_cast<const float*>(smem) + w * REGION + row * WN + c8;
+        float v[8];
+        const float4 lo = *reinterpret_cast<const float4*>(src);
+        const float4 hi = *reinterpret_cast<const float4*>(src + 4);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+        if (n + 8 <= N) {  // host side guarantees 16-B alignment of C rows for PLAIN launches
+          if (E.c_f32) st8((float*)E.C + (size_t)m * E.ldc + n, v);
+          else st8((uint16_t*)E.C + (size_t)m * E.ldc + n, v);
+        } else {
+          for (int i = 0; i < N - n; ++i) {
+            if (E.c_f32) ((float*)E.C)[(size_t)m * E.ldc + n + i] = v[i];
+            else ((uint16_t*)E.C)[(size_t)m * E.ldc + n + i] = f2bf(v[i]);
+          }
+        }
+      }
+    } else {
     // side loads of all this thread's groups go out before the barrier (their latency hides behind it and each other)
     u32x4 zq[NIT], rq[NIT];
 #pragma unroll
@@ -399,6 +426,7 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
       } else {
         epilogue_store8<uint16_t>(E, m, n, v, cnt);
       }
+    }
     }
   }
 }
@@ -477,8 +505,8 @@ static int fill_epi(const mic_gemm_args* a, EpiArgs& e) {
   return MIC_OK;
 }
 
-template <int WM, int WN, int WNW, int BKT, int KG = 1>
-static void launch_cfg(const LaunchTable& tab, int akm, int bkm, hipStream_t s) {
+template <int WM, int WN, int WNW, int BKT, int KG, bool PLAIN>
+static void launch_cfg_p(const LaunchTable& tab, int akm, int bkm, hipStream_t s) {
   constexpr int BM = 2 * WM, BN = WN * WNW;
   size_t lds = (size_t)KG * 2 * (BM + BN) * BKT * 2;
   const size_t epi = (size_t)2 * WNW * (WM < 64 ? WM : 64) * WN * 4;  // the epilogue restages min(WM,64) x WN floats per wave
@@ -488,15 +516,29 @@ static void launch_cfg(const LaunchTable& tab, int akm, int bkm, hipStream_t s) 
   dim3 grid(tab.total_blocks), block(128 * WNW * KG);
 #define LAUNCH(AKM, BKMM)                                                                                                  \
   do {                                                                                                                     \
-    if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WN, WNW, BKT, AKM, BKMM, KG>), \
+    if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WN, WNW, BKT, AKM, BKMM, KG, PLAIN>), \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
-    hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, WNW, BKT, AKM, BKMM, KG>), grid, block, lds, s, tab);                     \
+    hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, WNW, BKT, AKM, BKMM, KG, PLAIN>), grid, block, lds, s, tab);                     \
   } while (0)
   if (!akm && !bkm) LAUNCH(false, false);
   else if (!akm && bkm) LAUNCH(false, true);
   else if (akm && bkm) LAUNCH(true, true);
   else LAUNCH(true, false);
 #undef LAUNCH
+}
+
+static bool table_is_plain(const LaunchTable& t) {
+  for (int i = 0; i < t.count; ++i) {
+    const EpiArgs& e = t.p[i].epi;
+    if (t.p[i].nsplit > 1 || e.act || e.Zout || e.dact || e.R || e.accumulate || e.drop_thr || (e.ldc & 7)) return false;
+    if (((uintptr_t)e.C & 15) != 0) return false;
+  }
+  return true;
+}
+template <int WM, int WN, int WNW, int BKT, int KG = 1>
+static void launch_cfg(const LaunchTable& tab, int akm, int bkm, hipStream_t s) {
+  if (table_is_plain(tab)) launch_cfg_p<WM, WN, WNW, BKT, KG, true>(tab, akm, bkm, s);
+  else launch_cfg_p<WM, WN, WNW, BKT, KG, false>(tab, akm, bkm, s);
 }
 
 static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
