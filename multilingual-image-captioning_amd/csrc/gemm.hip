@@ -209,6 +209,7 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
 #pragma unroll
   for (int i = 0; i < AI; ++i) bsum[i] = 0.0f;
   const bool do_rowsum = P.a_rowsum != nullptr;
+  const int rs_tiles_n = P.tiles_n, rs_k = P.rowsum_k;  // registers: a kernarg load inside the K loop also waits on the LDS reads
 
   const int nk_total = P.K / BKT;
   const int nk_per = (nk_total + P.nsplit - 1) / P.nsplit;
@@ -243,6 +244,7 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
   if (nk_loop > 0) __syncthreads();
   for (int t = 0; t < nk_loop; ++t) {
     if (t < nk) {
+      const bool rs_tile = do_rowsum && ((kt0 + t) % rs_tiles_n) == tn;  // this block's share of the A row sums
       const char* cur = gsm + (t & 1) * STAGE;
       const char* At = cur + a_half * HALF_A;
       const char* Bt = cur + NHA * HALF_A + b_half * HALF_B;
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
         for (int i = 0; i < AI; ++i) af[i] = read_frag<AK, BKT, UA>(At, a_off + i * 32, kk, lane);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) bfr[j] = read_frag<BKM, BKT, UB>(Bt, b_off + j * 32, kk, lane);
-        if (do_rowsum && (kk % WNW) == wc && ((kt0 + t) % P.tiles_n) == tn) {
+        if (rs_tile && (kk % WNW) == wc) {
           const int kb = (kt0 + t) * BKT + kk * 16 + 8 * (lane >> 5);  // this lane's 8 consecutive k
 #pragma unroll
           for (int i = 0; i < AI; ++i) {
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const float lo = __uint_as_float(w[q] << 16), hi = __uint_as_float(w[q] & 0xffff0000u);
-              sacc += (kb + 2 * q < P.rowsum_k ? lo : 0.0f) + (kb + 2 * q + 1 < P.rowsum_k ? hi : 0.0f);
+              sacc += (kb + 2 * q < rs_k ? lo : 0.0f) + (kb + 2 * q + 1 < rs_k ? hi : 0.0f);
             }
             bsum[i] += sacc;
           }
