@@ -150,8 +150,9 @@ __device__ __forceinline__ void tile_coords(int lid, int tiles_m, int tiles_n, i
 //   the partial accumulators meet in LDS before the epilogue.  For launches whose tile count cannot fill the chip the
 //   K loop is a latency chain (load -> ds_write -> barrier -> ds_read -> MFMA, ~0.5 us per 64-k step at one block per CU);
 //   KG groups cut the chain KG-fold without atomics or extra launches.
-// PLAIN: every problem of the launch has the bare epilogue (C = alpha*acc + bias, bf16 or fp32, no split): the store loop
-//   is then two ds_read_b128, four v_cvt_pk_bf16_f32 and one 16-B store per group, with none of the per-group feature tests.
+// PLAIN: every problem of the launch has the bare epilogue (C = dropout(alpha*acc + bias) + residual, bf16 or fp32, no
+//   activation / Z / accumulate / split): the store loop is then two ds_read_b128, four v_cvt_pk_bf16_f32 and one 16-B
+//   store per group, without the per-group feature tests of the generic path.
 template <int WM, int WN, int WNW, int BKT, bool AK, bool BKM, int KG = 1, bool PLAIN = false>
 __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kernel(LaunchTable tab) {
   constexpr int BM = 2 * WM, BN = WN * WNW, NWAVES = 2 * WNW, NTHREADS = 64 * NWAVES * KG;
@@ -366,6 +367,17 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
             Cw[(i2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * WN + j * 32 + (lane & 31)] = acc[(RP / 32) * p + i2][j][r];
     }
     if constexpr (PLAIN) {
+      // C = acc (+ dropout) (+ residual): the residual rows are fetched before the barrier like every side operand
+      u32x4 rq[NIT];
+      const bool has_r = E.R != nullptr;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int id = it * NTHREADS + tid;
+        const int w = id / (RP * CPR), rem = id % (RP * CPR);
+        const int m = m0 + (w / WNW) * WM + p * RP + rem / CPR, n = n0 + (w % WNW) * WN + (rem % CPR) * 8;
+        rq[it] = u32x4{0u, 0u, 0u, 0u};
+        if (has_r && id < NGRP && m < M && n + 8 <= N) rq[it] = *reinterpret_cast<const u32x4*>((const uint16_t*)E.R + (size_t)m * E.ldr + n);
+      }
       __syncthreads();
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
@@ -379,13 +391,26 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
         const float4 lo = *reinterpret_cast<const float4*>(src);
         const float4 hi = *reinterpret_cast<const float4*>(src + 4);
         v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-        if (n + 8 <= N) {  // host side guarantees 16-B alignment of C rows for PLAIN launches
+        if (E.drop_thr) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            v[i] = dropout_keep(E.drop_seed, (uint32_t)m * (uint32_t)E.N + (uint32_t)(n + i), E.drop_thr) ? v[i] * E.drop_scale : 0.0f;
+        }
+        if (n + 8 <= N) {  // host side guarantees 16-B alignment of the C (and R) rows for PLAIN launches
+          if (has_r) {
+            float r[8];
+            unpack8(rq[it], r);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += r[i];
+          }
           if (E.c_f32) st8((float*)E.C + (size_t)m * E.ldc + n, v);
           else st8((uint16_t*)E.C + (size_t)m * E.ldc + n, v);
         } else {
           for (int i = 0; i < N - n; ++i) {
-            if (E.c_f32) ((float*)E.C)[(size_t)m * E.ldc + n + i] = v[i];
-            else ((uint16_t*)E.C)[(size_t)m * E.ldc + n + i] = f2bf(v[i]);
+            float x = v[i];
+            if (has_r) x += bf2f(((const uint16_t*)E.R)[(size_t)m * E.ldr + n + i]);
+            if (E.c_f32) ((float*)E.C)[(size_t)m * E.ldc + n + i] = x;
+            else ((uint16_t*)E.C)[(size_t)m * E.ldc + n + i] = f2bf(x);
           }
         }
       }
@@ -532,8 +557,9 @@ static void launch_cfg_p(const LaunchTable& tab, int akm, int bkm, hipStream_t s
 static bool table_is_plain(const LaunchTable& t) {
   for (int i = 0; i < t.count; ++i) {
     const EpiArgs& e = t.p[i].epi;
-    if (t.p[i].nsplit > 1 || e.act || e.Zout || e.dact || e.R || e.accumulate || e.drop_thr || (e.ldc & 7)) return false;
+    if (t.p[i].nsplit > 1 || e.act || e.Zout || e.dact || e.accumulate || (e.ldc & 7)) return false;
     if (((uintptr_t)e.C & 15) != 0) return false;
+    if (e.R && ((e.ldr & 7) || ((uintptr_t)e.R & 15) || e.c_f32)) return false;
   }
   return true;
 }
