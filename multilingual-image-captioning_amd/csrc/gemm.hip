@@ -176,7 +176,7 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
 #pragma unroll
   for (int i = 1; i < MAX_PROBLEMS; ++i)
     if (i < tab.count && lid >= tab.p[i].block_begin) pi = i;
-  const Problem& P = tab.p[pi];
+  const Problem P = tab.p[pi];  // by value: one burst of scalar loads up front instead of a kernarg load (and wait) at every use
   const int local = lid - P.block_begin;
   int tile = local / P.nsplit, split = local - tile * P.nsplit;
   if (tab.count == 1 && P.nsplit > 1 && (P.nsplit & 7) == 0) {
