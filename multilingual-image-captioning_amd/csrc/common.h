@@ -133,14 +133,25 @@ __device__ __forceinline__ uint32_t dropout_threshold(float p) { return (uint32_
 __device__ __forceinline__ bool dropout_keep(uint32_t seed, uint32_t idx, uint32_t thr) { return mic_hash(seed, idx) >= thr; }
 
 // ---- activations
-// tanh through one v_exp_f32 + one v_rcp_f32 (abs error ~1e-7; saturates correctly at +-inf) — ocml's tanhf costs ~10x more
-// and the GEMM epilogue evaluates it once per FFN element.
-__device__ __forceinline__ float fast_tanh(float u) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * u)); }
+// The FFN activations run once per element inside GEMM epilogues, where the VALU is the bottleneck: each is written for the
+// fewest instructions — one v_exp_f32 (base 2, constants pre-multiplied by -log2 e) and one v_rcp_f32 each way.
+//   gelu_tanh(x) = 0.5 x (1 + tanh(c (x + a x^3))) = x * sigmoid(z),  z = x (2c + 2ca x^2)     (tanh u = 2 sigmoid(2u) - 1)
+//   gelu_tanh'(x) = s + x s (1 - s) dz/dx,  dz/dx = 2c + 6ca x^2
+//   quick_gelu(x) = x * sigmoid(1.702 x)
+#define MIC_LOG2E 1.4426950408889634f
+#define GELU_K1 1.5957691216057308f   /* 2 * sqrt(2/pi) */
+#define GELU_K2 0.07135481627261745f  /* 2 * sqrt(2/pi) * 0.044715 */
+__device__ __forceinline__ float sigmoid_neg_log2(float zl) {  // sigmoid(z) given zl = -z * log2(e)
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zl));
+}
 __device__ __forceinline__ float act_fwd(int act, float x) {
   switch (act) {
     case MIC_ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
-    case MIC_ACT_GELU_TANH: { float u = 0.7978845608028654f * (x + 0.044715f * x * x * x); return 0.5f * x * (1.0f + fast_tanh(u)); }
-    case MIC_ACT_QUICK_GELU: return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
+    case MIC_ACT_GELU_TANH: {
+      const float p = fmaf(-GELU_K2 * MIC_LOG2E, x * x, -GELU_K1 * MIC_LOG2E);
+      return x * sigmoid_neg_log2(x * p);
+    }
+    case MIC_ACT_QUICK_GELU: return x * sigmoid_neg_log2(x * (-1.702f * MIC_LOG2E));
     default: return x;
   }
 }
@@ -151,11 +162,16 @@ __device__ __forceinline__ float act_bwd(int act, float x) {
       return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
     }
     case MIC_ACT_GELU_TANH: {
-      float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-      float t = fast_tanh(u);
-      return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
+      const float x2 = x * x;
+      const float p = fmaf(-GELU_K2 * MIC_LOG2E, x2, -GELU_K1 * MIC_LOG2E);
+      const float s = sigmoid_neg_log2(x * p);
+      const float dz = fmaf(3.0f * GELU_K2, x2, GELU_K1);
+      return fmaf(x * s * (1.0f - s), dz, s);
     }
-    case MIC_ACT_QUICK_GELU: { float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); return s + 1.702f * x * s * (1.0f - s); }
+    case MIC_ACT_QUICK_GELU: {
+      const float s = sigmoid_neg_log2(x * (-1.702f * MIC_LOG2E));
+      return fmaf(1.702f * x * s, 1.0f - s, s);
+    }
     default: return 1.0f;
   }
 }
