@@ -543,8 +543,12 @@ static void launch_cfg_p(const LaunchTable& tab, int akm, int bkm, hipStream_t s
   dim3 grid(tab.total_blocks), block(128 * WNW * KG);
 #define LAUNCH(AKM, BKMM)                                                                                                  \
   do {                                                                                                                     \
-    if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WN, WNW, BKT, AKM, BKMM, KG, PLAIN>), \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+    static bool attr_set = false; /* per instantiation; lds is a compile-time constant of it */                          \
+    if (lds > 65536 && !attr_set) {                                                                                        \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WN, WNW, BKT, AKM, BKMM, KG, PLAIN>),        \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                           \
+      attr_set = true;                                                                                                     \
+    }                                                                                                                      \
     hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, WNW, BKT, AKM, BKMM, KG, PLAIN>), grid, block, lds, s, tab);                     \
   } while (0)
   if (!akm && !bkm) LAUNCH(false, false);
