@@ -16,7 +16,7 @@ for rows, width in ((4096, 1024), (3200, 768)):
         torch.cuda.synchronize(); e0.record()
         for _ in range(5):
             for x, dy, dres, dx, dxm in sets:
-                ops.layernorm_bwd(x, g, mean, rstd, dy, dx, None if os.environ.get("NOATOM") else dg, None if os.environ.get("NOATOM") else db, dres=dres, dxm=dxm, dropout_p=0.1, dropout_seed=3)
+                ops.layernorm_bwd(x, g, mean, rstd, dy, dx, None if os.environ.get("NOATOM") else dg, None if os.environ.get("NOATOM") else db, dres=dres, dxm=dxm, dropout_p=float(os.environ.get("LNP", "0.1")), dropout_seed=3)
         e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 40
     print(f"ln_bwd {rows}x{width}: {us:.1f} us  {rows*width*2*5/us/1e6:.2f} TB/s")
