@@ -123,6 +123,11 @@ __global__ __launch_bounds__(256) void row_lse_topk_kernel(int V, const T* __res
     tau = last;  // -inf when fewer than 8 threads saw an eligible value: then everything is a candidate
   }
   // ---- pass 2: exact per-thread top-k of the candidates >= tau
+  float t_safe = -INFINITY;
+  if (tau > -INFINITY) {
+    const float inv = raw ? (tau - bias) : ((tau - bias) + logsum) + mx;  // raw logit whose processed value is ~tau
+    t_safe = inv - 1e-5f * (fabsf(tau) + fabsf(bias) + fabsf(logsum) + fabsf(mx) + 1.0f);  // fp32 rounding of 3-4 ops is ~1e-7 relative
+  }
   float bv[KMAX];
   int bi[KMAX];
 #pragma unroll
@@ -140,6 +145,9 @@ __global__ __launch_bounds__(256) void row_lse_topk_kernel(int V, const T* __res
       if (ch >= nchunk) continue;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
+        // one compare per element in the RAW domain (the processed value is monotone in the logit; t_safe sits a safe
+        // margin below the raw image of tau), the exact processed-domain test only for the few that pass
+        if (!(v[u][i] >= t_safe)) continue;
         const int c = ch * 8 + i;
         if (c >= V) continue;
         float x = raw ? v[u][i] : (v[u][i] - mx) - logsum;   // log_softmax (gen:850)
