@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the C-ABI library is a build artefact (git-ignored): build it when a fresh checkout runs the tests before build()
+    lib = os.path.join(ROOT, "multilingual-image-captioning_amd", "libmic_hip.so")
+    if not os.path.exists(lib) and os.path.exists("/opt/rocm/bin/hipcc"):
+        import subprocess
+
+        subprocess.run(["make", "-C", os.path.join(ROOT, "multilingual-image-captioning_amd", "csrc"), "-j4"], check=False,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
 @pytest.fixture(scope="session")
