@@ -78,7 +78,8 @@ class FlaxCLIPVisionMBartGenerationMixin:
     def _proc_args(procs, cur_len: int, max_length: int, eos_token_id: int):
         """(forced_token, suppress_eos) for this step: MinLength -> ForcedBOS -> ForcedEOS (gen:412-419)."""
         forced = -1
-        suppress = procs["min_length"] is not None and cur_len < procs["min_length"]
+        # FlaxMinLengthLogitsProcessor: apply_penalty = 1 - clip(cur_len - min_length, 0, 1)  =>  EOS is -inf while cur_len <= min_length
+        suppress = procs["min_length"] is not None and cur_len <= procs["min_length"]
         if procs["forced_bos"] is not None and cur_len == 1:
             forced = procs["forced_bos"]
         if procs["forced_eos"] is not None and cur_len == max_length - 1:

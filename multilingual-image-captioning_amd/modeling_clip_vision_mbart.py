@@ -358,19 +358,43 @@ class FlaxCLIPVisionMBartForConditionalGeneration(FlaxCLIPVisionMBartPreTrainedM
         flat = model.store.export_flat("master")
         from .checkpoint import convert_pt_state_dict
 
-        def leaves(comp, prefix):
+        def leaves(comp, prefix, top):
             """component's Flax leaves (relative names); PyTorch checkpoints (`from_pt=True`, main.py:426) are converted
-            against the leaf names this model owns under `prefix`."""
+            against the leaf names this model owns under `prefix`.  Like HF `from_pretrained`, a head-model tree whose
+            weights sit under the base-model prefix (FlaxMBartForConditionalGeneration: `model/decoder/...`,
+            `model/shared/...` next to `final_logits_bias`; FlaxCLIPModel: `vision_model/...` next to `text_model/...`) is
+            unwrapped when none of the expected top-level keys `top` is present."""
             if getattr(comp, "pt_state", None) is not None:
                 expected = {k[len(prefix):] for k in flat if k.startswith(prefix)}
                 return convert_pt_state_dict(comp.pt_state, expected)
-            return flatten_tree(comp.params)
+            tree = comp.params
+            if isinstance(tree, dict) and not any(t in tree for t in top) and isinstance(tree.get(cls.base_model_prefix), dict):
+                tree = tree[cls.base_model_prefix]
+            return flatten_tree(tree)
 
-        for k, v in leaves(clip_model, "model/encoder/").items():
-            flat["model/encoder/" + k] = np.asarray(v)  # modeling:768
-        for k, v in leaves(mbart_model, "model/").items():  # FlaxMBartModel tree: shared / encoder / decoder
-            if k.startswith("decoder/") or k.startswith("shared/"):
-                flat["model/" + k] = np.asarray(v)  # modeling:769-770 (the mBART text encoder is not used)
+        def graft(comp, src_prefixes, dst_prefix, top, what):
+            """copy the component's leaves into `flat`; every leaf this model owns under dst_prefix + src_prefix must be
+            supplied with the right shape (the reference's params setter raises on missing keys, utils:112-116; a silent
+            partial load would leave random-init weights behind)."""
+            got = leaves(comp, dst_prefix, top)
+            need = {k for k in flat if any(k.startswith(dst_prefix + sp) for sp in src_prefixes)}
+            used = set()
+            for k, v in got.items():
+                if any(k.startswith(sp) for sp in src_prefixes) and dst_prefix + k in flat:
+                    v = np.asarray(v)
+                    if tuple(v.shape) != tuple(flat[dst_prefix + k].shape):
+                        raise ValueError(f"{what} checkpoint: leaf {k} has shape {tuple(v.shape)}, the model expects "
+                                         f"{tuple(flat[dst_prefix + k].shape)}")
+                    flat[dst_prefix + k] = v
+                    used.add(dst_prefix + k)
+            missing = sorted(need - used)
+            if missing:
+                raise ValueError(f"{what} checkpoint supplies {len(used)} of the {len(need)} parameters the model needs; "
+                                 f"missing e.g. {missing[:4]} (keys seen: {sorted(got)[:4]} ...)")
+
+        graft(clip_model, ("vision_model/",), "model/encoder/", ("vision_model",), "CLIP vision")  # modeling:768
+        # FlaxMBartModel tree: shared / encoder / decoder; the mBART text encoder is not used (modeling:769-770)
+        graft(mbart_model, ("decoder/", "shared/"), "model/", ("decoder", "shared"), "mBART")
         model.store.load_flat(flat)
         model._params_cache = None
         return model

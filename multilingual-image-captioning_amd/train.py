@@ -39,7 +39,9 @@ def create_learning_rate_fn(train_ds_size: int, train_batch_size: int, num_train
             frac = min(max(step / num_warmup_steps, 0.0), 1.0) if num_warmup_steps > 0 else 1.0
             return learning_rate * frac
         n = num_train_steps - num_warmup_steps
-        frac = min(max((step - num_warmup_steps) / n, 0.0), 1.0) if n > 0 else 1.0
+        if n <= 0:  # optax.linear_schedule with transition_steps <= 0 is the constant init_value
+            return learning_rate
+        frac = min(max((step - num_warmup_steps) / n, 0.0), 1.0)
         return learning_rate + (0.0 - learning_rate) * frac
 
     return schedule
@@ -316,4 +318,5 @@ class Trainer:
 
             dist.all_reduce(self.metrics_buf, op=dist.ReduceOp.SUM, group=self.group)
             self.metrics_buf /= self.world
-        return {"loss": self.metrics_buf[0], "learning_rate": self.metrics_buf[1]}
+        out = self.metrics_buf.clone()  # fresh storage per step: callers keep these around (main.py:776 `train_metrics.append`)
+        return {"loss": out[0], "learning_rate": out[1]}

@@ -41,7 +41,7 @@ class MinLength:
     eos_token_id: int
 
     def __call__(self, input_ids, scores, cur_len):
-        if cur_len < self.min_length:  # apply_penalty = 1 - clip(cur_len - min_length, 0, 1)
+        if cur_len <= self.min_length:  # apply_penalty = 1 - clip(cur_len - min_length, 0, 1): 1 while cur_len <= min_length
             scores = scores.copy()
             scores[:, self.eos_token_id] = -np.inf
         return scores

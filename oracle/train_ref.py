@@ -49,7 +49,9 @@ def linear_warmup_decay(step: int, lr: float, warmup_steps: int, total_steps: in
         frac = min(max(step / warmup_steps, 0.0), 1.0) if warmup_steps > 0 else 1.0
         return lr * frac
     n = total_steps - warmup_steps
-    frac = min(max((step - warmup_steps) / n, 0.0), 1.0) if n > 0 else 1.0
+    if n <= 0:  # optax.linear_schedule(transition_steps <= 0) returns the constant init_value
+        return lr
+    frac = min(max((step - warmup_steps) / n, 0.0), 1.0)
     return lr + (0.0 - lr) * frac
 
 

@@ -60,6 +60,59 @@ def test_from_clip_vision_mbart_pretrained_grafts_components(dev, tmp_path):
         Model.from_clip_vision_mbart_pretrained(None, mbart_dir, device=dev)
 
 
+def test_from_pretrained_components_head_model_layout_and_missing_leaves(dev, tmp_path):
+    """A FlaxMBartForConditionalGeneration checkpoint keeps its weights under `model/` next to `final_logits_bias`; HF
+    `from_pretrained` strips that base-model prefix (modeling:740-758 loads through FlaxMBartModel.from_pretrained).  The
+    graft must find them there, and must refuse a component that does not supply every decoder/embedding leaf instead of
+    silently keeping random-init weights."""
+    from mic_amd import FlaxCLIPVisionMBartForConditionalGeneration as Model
+    from mic_amd.checkpoint import save_flax_msgpack
+    from mic_amd.params import flatten_tree, unflatten_tree
+
+    rc, p, model = make_pair(torch.float32, dev)
+    tree = unflatten_tree({k: v.numpy() for k, v in p.items()})
+    clip_dir, mbart_dir, bad_dir = str(tmp_path / "clip"), str(tmp_path / "mbart"), str(tmp_path / "bad")
+    os.makedirs(clip_dir), os.makedirs(mbart_dir), os.makedirs(bad_dir)
+    save_flax_msgpack(os.path.join(clip_dir, "flax_model.msgpack"), tree["model"]["encoder"])
+    json.dump(model.config.clip_vision_config.to_dict(), open(os.path.join(clip_dir, "config.json"), "w"))
+    head_layout = {"model": {"shared": tree["model"]["shared"], "decoder": tree["model"]["decoder"],
+                             "encoder": {"ignored": np.zeros(3, np.float32)}},
+                   "final_logits_bias": np.ones((1, rc.vocab_size), np.float32)}
+    save_flax_msgpack(os.path.join(mbart_dir, "flax_model.msgpack"), head_layout)
+    json.dump(model.config.mbart_config.to_dict(), open(os.path.join(mbart_dir, "config.json"), "w"))
+    m = Model.from_clip_vision_mbart_pretrained(clip_dir, mbart_dir, seed=3, dtype="float32", device=dev)
+    got = flatten_tree(m.params)
+    for k, v in p.items():
+        if k.startswith(("model/encoder/", "model/decoder/", "model/shared/")):
+            assert np.array_equal(got[k], v.numpy()), k
+    assert np.count_nonzero(got["final_logits_bias"]) == 0  # the component's own bias is not grafted (modeling:766-770)
+    # a component without one decoder layer's leaves
+    dec = {k: v for k, v in tree["model"]["decoder"].items()}
+    dec["layers"] = {k: v for k, v in dec["layers"].items() if k != "1"}
+    save_flax_msgpack(os.path.join(bad_dir, "flax_model.msgpack"), {"shared": tree["model"]["shared"], "decoder": dec})
+    json.dump(model.config.mbart_config.to_dict(), open(os.path.join(bad_dir, "config.json"), "w"))
+    with pytest.raises(ValueError, match="mBART checkpoint supplies"):
+        Model.from_clip_vision_mbart_pretrained(clip_dir, bad_dir, device=dev)
+    with pytest.raises(ValueError, match="CLIP vision checkpoint supplies"):
+        Model.from_clip_vision_mbart_pretrained(mbart_dir, mbart_dir, device=dev)
+
+
+def test_step_metrics_do_not_alias(dev):
+    """main.py:776 appends every step's metric dict and averages later: entries must keep their own values."""
+    from mic_amd import Trainer, create_learning_rate_fn
+
+    rc, p, model = make_pair(torch.float32, dev)
+    tr = Trainer(model, create_learning_rate_fn(640, 2, 5, 3, 1e-2), seed=1)
+    mk = lambda s: dict(zip(("pixel_values", "input_ids", "attention_mask", "decoder_input_ids"), (x.numpy() for x in batch(rc, 2, 10, seed=s))))
+    kept = [tr.train_step(mk(40 + i)) for i in range(3)]
+    ev = tr.eval_step(mk(50))
+    torch.cuda.synchronize()
+    lrs = [float(k["learning_rate"]) for k in kept]
+    assert lrs[0] == 0.0 and lrs[1] > 0 and lrs[2] > lrs[1], lrs  # warm-up 0 -> lr: distinct values survive later steps
+    losses = [float(k["loss"]) for k in kept]
+    assert len({round(l, 6) for l in losses}) == 3 and float(ev["loss"]) not in losses
+
+
 def test_params_property_contract_and_params_kwarg(dev):
     from mic_amd.params import flatten_tree, unflatten_tree
 

@@ -118,6 +118,10 @@ def test_host_helpers_equal_oracle():
     f = create_learning_rate_fn(train_ds_size=6400, train_batch_size=64, num_train_epochs=7, num_warmup_steps=100, learning_rate=5e-5)
     for s in (0, 1, 50, 100, 101, 400, 699, 700, 900):
         assert abs(f(s) - train_ref.linear_warmup_decay(s, 5e-5, 100, 700)) < 1e-15
+    g = create_learning_rate_fn(train_ds_size=64, train_batch_size=64, num_train_epochs=3, num_warmup_steps=5, learning_rate=1e-3)
+    for s in (0, 2, 5, 9):  # 3 total steps < 5 warmup steps: no decay phase -> constant lr after warmup (optax)
+        assert g(s) == train_ref.linear_warmup_decay(s, 1e-3, 5, 3)
+    assert g(9) == 1e-3
 
 
 def test_plan_buckets():

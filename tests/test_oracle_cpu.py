@@ -108,6 +108,16 @@ def test_lr_schedule_kat():
     assert abs(f(4000) - lr * 0.5) < 1e-12 and abs(f(6999) - lr / 6000) < 1e-12 and f(7000) == 0.0 and f(9000) == 0.0
 
 
+def test_lr_schedule_without_decay_steps_is_constant():
+    """optax.linear_schedule(transition_steps <= 0) is the constant init_value: with warmup >= total steps the LR stays
+    at `learning_rate` after warmup instead of dropping to 0 (main.py:281-292)."""
+    from oracle import train_ref
+
+    assert train_ref.linear_warmup_decay(10, 3e-4, 10, 10) == 3e-4
+    assert train_ref.linear_warmup_decay(25, 3e-4, 10, 8) == 3e-4
+    assert train_ref.linear_warmup_decay(5, 3e-4, 10, 10) == 1.5e-4
+
+
 def test_adamw_one_step_kat():
     from oracle import train_ref
 
@@ -137,7 +147,9 @@ def test_greedy_replaces_eos_by_pad():
     seqs = G.greedy_search(G.ScriptedStepper(1, _table(6, lambda s, h: {3: 3.0})), 1, 4, 5, 1, 2, G.get_logits_processor(0, 5, 2, None, 2))
     assert seqs.tolist() == [[4, 3, 3, 3, 1]]  # ForcedEOS at the last step -> finished -> PAD in the last column
     seqs = G.greedy_search(G.ScriptedStepper(1, _table(6, lambda s, h: {2: 3.0, 3: 2.0})), 1, 4, 5, 1, 2, G.get_logits_processor(3, 5, 2, None, None))
-    assert seqs.tolist() == [[4, 3, 3, 1, 1]]  # MinLength suppresses EOS while cur_len < 3
+    # FlaxMinLengthLogitsProcessor: apply_penalty = 1 - clip(cur_len - min_length, 0, 1) => EOS (the raw winner at every
+    # step here) stays suppressed at cur_len == min_length == 3 and first wins at cur_len 4
+    assert seqs.tolist() == [[4, 3, 3, 3, 1]]
 
 
 def test_top_k_is_index_stable_and_handles_neg_inf():
