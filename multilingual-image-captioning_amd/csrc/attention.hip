@@ -296,6 +296,237 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(int H, int Tq, int Tk, co
   }
 }
 
+// ------------------------------------------------------------------ sequences longer than one 64x64 tile
+// (the reference's README names seq_len 128 as its next step; a ViT with more than 64 patch tokens lands here too)
+// Forward: one workgroup per (batch, head, 64-query block) walks the 64-key blocks with the online-softmax recurrence:
+// running row max / row sum in LDS, the four 32x32 output blocks in the waves' accumulators, rescaled by
+// alpha = exp(m_old - m_new) before each block's P V is added.  Per block the arithmetic is the single-tile kernel's.
+__device__ __forceinline__ unsigned long long load_key_mask_blk(const int32_t* key_mask, int b, int Tk, int k0, int lane) {
+  if (!key_mask) return ~0ull;
+  const int mv = k0 + lane < Tk ? key_mask[b * Tk + k0 + lane] : 0;
+  return __ballot(mv != 0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_tiled_kernel(int H, int Tq, int Tk, const T* __restrict__ q, int ldq,
+                                                             const T* __restrict__ k, int ldk, const T* __restrict__ v, int ldv,
+                                                             T* __restrict__ out, int ldo, const int32_t* __restrict__ key_mask,
+                                                             int causal, float* __restrict__ lse_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TB = Tile<T>::BYTES;
+  char* Qt = smem;
+  char* Kt = smem + TB;
+  char* Vt = smem + 2 * TB;
+  char* Pt = smem + 3 * TB;
+  float* pmax = reinterpret_cast<float*>(smem + 4 * TB);  // [2 jb][64 queries]
+  float* psum = pmax + 128;                               // [2 jb][64 queries]
+  float* m_run = psum + 128;                              // [64]
+  float* l_run = m_run + 64;                              // [64]
+  float* alpha_s = l_run + 64;                            // [64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nqb = (Tq + 63) >> 6;
+  const int qb = blockIdx.x % nqb, bh = blockIdx.x / nqb;
+  const int b = bh / H, h = bh % H;
+  const int q0 = qb * 64, nq = min(64, Tq - q0);
+  Tile<T>::template stage<256>(Qt, q + ((size_t)b * Tq + q0) * ldq + h * 64, ldq, nq, tid);
+  if (tid < 64) { m_run[tid] = -INFINITY; l_run[tid] = 0.f; }
+  const int ib = wave >> 1, jb = wave & 1, db = wave & 1;
+  const int i = ib * 32 + (lane & 31);  // this lane's query (local) in the score phase
+  f32x16 o;
+  zero16(o);
+  int nkb = (Tk + 63) >> 6;
+  if (causal) nkb = min(nkb, qb + 1);
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int k0 = kb * 64, nk = min(64, Tk - k0);
+    __syncthreads();  // the previous block's P V has read Kt / Vt / Pt
+    Tile<T>::template stage<256>(Kt, k + ((size_t)b * Tk + k0) * ldk + h * 64, ldk, nk, tid);
+    Tile<T>::template stage<256>(Vt, v + ((size_t)b * Tk + k0) * ldv + h * 64, ldv, nk, tid);
+    const unsigned long long km = load_key_mask_blk(key_mask, b, Tk, k0, lane);
+    __syncthreads();
+    f32x16 s;
+    zero16(s);
+    Tile<T>::template mma<false, false>(s, Kt, jb * 32, Qt, ib * 32, lane);
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = jb * 32 + acc_row(r, lane);
+      const bool ok = j < nk && (!causal || k0 + j <= q0 + i) && ((km >> j) & 1ull);
+      const float x = ok ? s[r] * SCALE : -INFINITY;
+      s[r] = x;
+      m = fmaxf(m, x);
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    if (lane < 32) pmax[jb * 64 + i] = m;
+    __syncthreads();
+    const float m_new = fmaxf(m_run[i], fmaxf(pmax[i], pmax[64 + i]));
+    const float m_safe = m_new == -INFINITY ? 0.f : m_new;  // a row with no admissible key so far: p = 0, not NaN
+    float l = 0.f;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      float pv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float p = __expf(s[g4 * 4 + e] - m_safe);
+        pv[e] = p;
+        l += p;
+      }
+      Tile<T>::store4(Pt, i, jb * 32 + 8 * g4 + 4 * (lane >> 5), pv);
+    }
+    l += __shfl_xor(l, 32, 64);
+    if (lane < 32) psum[jb * 64 + i] = l;
+    __syncthreads();
+    if (tid < 64) {
+      const float mo = m_run[tid], mn = fmaxf(mo, fmaxf(pmax[tid], pmax[64 + tid]));
+      const float al = mo == -INFINITY ? 0.f : __expf(mo - mn);
+      alpha_s[tid] = al;
+      l_run[tid] = l_run[tid] * al + psum[tid] + psum[64 + tid];
+      m_run[tid] = mn;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] *= alpha_s[ib * 32 + acc_row(r, lane)];
+    Tile<T>::template mma<false, true>(o, Pt, ib * 32, Vt, db * 32, lane);
+  }
+  __syncthreads();
+  if (tid < 64 && tid < nq && lse_out) lse_out[((size_t)b * H + h) * Tq + q0 + tid] = m_run[tid] + logf(l_run[tid]);
+  const int d = db * 32 + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int qi = ib * 32 + acc_row(r, lane);
+    if (qi < nq) ElemT<T>::st(out + ((size_t)b * Tq + q0 + qi) * ldo + h * 64 + d, o[r] / l_run[qi]);
+  }
+}
+
+// Backward: with the saved log-sum-exp every P block is exp(s - lse) directly, so the two reductions are independent:
+//   MODE 0: one workgroup per (batch, head, 64-query block) walks the key blocks and accumulates dQ = sum_j dS_ij K_j;
+//   MODE 1: one workgroup per (batch, head, 64-key block) walks the query blocks and accumulates dK = sum_i dS_ij^T Q_i,
+//           dV = sum_i P_ij^T dO_i.
+// No atomics, deterministic; the score blocks are computed twice (the contraction over the other index is the expensive part).
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void attn_bwd_tiled_kernel(int H, int Tq, int Tk, const T* __restrict__ q, int ldq,
+                                                             const T* __restrict__ k, int ldk, const T* __restrict__ v, int ldv,
+                                                             const T* __restrict__ out, int ldo, const T* __restrict__ dout, int lddo,
+                                                             const float* __restrict__ lse_in, const int32_t* __restrict__ key_mask,
+                                                             int causal, T* __restrict__ dq, int lddq, T* __restrict__ dk, int lddk,
+                                                             T* __restrict__ dv, int lddv) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TB = Tile<T>::BYTES;
+  char* Qt = smem;
+  char* Kt = smem + TB;
+  char* Vt = smem + 2 * TB;
+  char* dOt = smem + 3 * TB;
+  char* Pt = smem + 4 * TB;
+  char* dSt = smem + 5 * TB;
+  float* lse_s = reinterpret_cast<float*>(smem + 6 * TB);
+  float* delta_s = lse_s + 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nqb = (Tq + 63) >> 6, nkb = (Tk + 63) >> 6;
+  const int nfix = MODE == 0 ? nqb : nkb;
+  const int fix = blockIdx.x % nfix, bh = blockIdx.x / nfix;
+  const int b = bh / H, h = bh % H;
+
+  auto stage_q = [&](int qb) {
+    const int q0 = qb * 64, nq = min(64, Tq - q0);
+    Tile<T>::template stage<256>(Qt, q + ((size_t)b * Tq + q0) * ldq + h * 64, ldq, nq, tid);
+    Tile<T>::template stage<256>(dOt, dout + ((size_t)b * Tq + q0) * lddo + h * 64, lddo, nq, tid);
+    const int row = tid >> 2, part = tid & 3;  // delta_i = dO_i . O_i : thread t covers 16 of the 64 dims of row t>>2
+    float dl = 0.f;
+    if (row < nq) {
+      const T* orow = out + ((size_t)b * Tq + q0 + row) * ldo + h * 64 + part * 16;
+      const T* drow = dout + ((size_t)b * Tq + q0 + row) * lddo + h * 64 + part * 16;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float a[8], g[8];
+        ld8(orow + c * 8, a);
+        ld8(drow + c * 8, g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += a[e] * g[e];
+      }
+    }
+    dl += __shfl_xor(dl, 1, 64);
+    dl += __shfl_xor(dl, 2, 64);
+    if (part == 0) delta_s[row] = dl;
+    if (tid < 64) lse_s[tid] = tid < nq ? lse_in[((size_t)b * H + h) * Tq + q0 + tid] : 0.f;
+  };
+  auto stage_k = [&](int kb) {
+    const int k0 = kb * 64, nk = min(64, Tk - k0);
+    Tile<T>::template stage<256>(Kt, k + ((size_t)b * Tk + k0) * ldk + h * 64, ldk, nk, tid);
+    Tile<T>::template stage<256>(Vt, v + ((size_t)b * Tk + k0) * ldv + h * 64, ldv, nk, tid);
+  };
+  // P and dS blocks of the (qb, kb) pair into LDS (rows = queries); inadmissible pairs are exact zeros
+  auto scores = [&](int qb, int kb, unsigned long long km) {
+    const int q0 = qb * 64, k0 = kb * 64, nq = min(64, Tq - q0), nk = min(64, Tk - k0);
+    const int ib = wave >> 1, jb = wave & 1;
+    const int i = ib * 32 + (lane & 31);
+    const float lse_i = lse_s[i], delta_i = delta_s[i];
+    f32x16 sacc, dp;
+    zero16(sacc); zero16(dp);
+    Tile<T>::template mma<false, false>(sacc, Kt, jb * 32, Qt, ib * 32, lane);
+    Tile<T>::template mma<false, false>(dp, Vt, jb * 32, dOt, ib * 32, lane);
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      float pv[4], dsv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = g4 * 4 + e;
+        const int j = jb * 32 + acc_row(r, lane);
+        const bool ok = i < nq && j < nk && (!causal || k0 + j <= q0 + i) && ((km >> j) & 1ull);
+        const float p = ok ? __expf(sacc[r] * SCALE - lse_i) : 0.f;
+        pv[e] = p;
+        dsv[e] = p * (dp[r] - delta_i) * SCALE;
+      }
+      if (MODE == 1) Tile<T>::store4(Pt, i, jb * 32 + 8 * g4 + 4 * (lane >> 5), pv);
+      Tile<T>::store4(dSt, i, jb * 32 + 8 * g4 + 4 * (lane >> 5), dsv);
+    }
+  };
+  const int xb = wave >> 1, db = wave & 1;
+  const int d = db * 32 + (lane & 31);
+  if (MODE == 0) {
+    const int qb = fix, q0 = qb * 64, nq = min(64, Tq - q0);
+    stage_q(qb);
+    f32x16 a;
+    zero16(a);
+    const int jend = causal ? min(nkb, qb + 1) : nkb;
+    for (int kb = 0; kb < jend; ++kb) {
+      __syncthreads();
+      stage_k(kb);
+      const unsigned long long km = load_key_mask_blk(key_mask, b, Tk, kb * 64, lane);
+      __syncthreads();
+      scores(qb, kb, km);
+      __syncthreads();
+      Tile<T>::template mma<false, true>(a, dSt, xb * 32, Kt, db * 32, lane);  // dQ += dS K
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = xb * 32 + acc_row(r, lane);
+      if (i < nq) ElemT<T>::st(dq + ((size_t)b * Tq + q0 + i) * lddq + h * 64 + d, a[r]);
+    }
+  } else {
+    const int kb = fix, k0 = kb * 64, nk = min(64, Tk - k0);
+    stage_k(kb);
+    const unsigned long long km = load_key_mask_blk(key_mask, b, Tk, k0, lane);
+    f32x16 a, c;
+    zero16(a); zero16(c);
+    for (int qb = causal ? kb : 0; qb < nqb; ++qb) {
+      __syncthreads();
+      stage_q(qb);
+      __syncthreads();
+      scores(qb, kb, km);
+      __syncthreads();
+      Tile<T>::template mma<true, true>(a, dSt, xb * 32, Qt, db * 32, lane);   // dK += dS^T Q
+      Tile<T>::template mma<true, true>(c, Pt, xb * 32, dOt, db * 32, lane);   // dV += P^T dO
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = xb * 32 + acc_row(r, lane);
+      if (j < nk) {
+        ElemT<T>::st(dk + ((size_t)b * Tk + k0 + j) * lddk + h * 64 + d, a[r]);
+        ElemT<T>::st(dv + ((size_t)b * Tk + k0 + j) * lddv + h * 64 + d, c[r]);
+      }
+    }
+  }
+}
+
 template <typename K>
 static int set_lds(K kernel, size_t bytes) {
   if (bytes > 65536) {
@@ -308,10 +539,22 @@ static int set_lds(K kernel, size_t bytes) {
 extern "C" int mic_attn_fwd(int dtype, int B, int H, int Tq, int Tk, const void* q, int ldq, const void* k, int ldk,
                             const void* v, int ldv, void* out, int ldo, const int32_t* key_mask, int causal, float* lse,
                             void* stream) {
-  MIC_CHECK(B > 0 && H > 0 && Tq > 0 && Tq <= 64 && Tk > 0 && Tk <= 64, "mic_attn_fwd: bad shape B=%d H=%d Tq=%d Tk=%d", B, H, Tq, Tk);
+  MIC_CHECK(B > 0 && H > 0 && Tq > 0 && Tk > 0, "mic_attn_fwd: bad shape B=%d H=%d Tq=%d Tk=%d", B, H, Tq, Tk);
   MIC_CHECK(q && k && v && out, "mic_attn_fwd: null pointer");
   const int align = dtype == MIC_BF16 ? 8 : 4;
   MIC_CHECK(ldq % align == 0 && ldk % align == 0 && ldv % align == 0, "mic_attn_fwd: row strides must keep 16-B alignment");
+  if (Tq > 64 || Tk > 64) {  // online-softmax walk over 64-key blocks
+    dim3 grid(B * H * ((Tq + 63) / 64)), block(256);
+    if (dtype == MIC_BF16) {
+      hipLaunchKernelGGL(attn_fwd_tiled_kernel<uint16_t>, grid, block, 4 * Tile<uint16_t>::BYTES + 2048, (hipStream_t)stream, H, Tq, Tk, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk, (const uint16_t*)v, ldv, (uint16_t*)out, ldo, key_mask, causal, lse);
+    } else if (dtype == MIC_F32) {
+      const size_t lds = 4 * Tile<float>::BYTES + 2048;
+      if (int rc = set_lds(attn_fwd_tiled_kernel<float>, lds)) return rc;
+      hipLaunchKernelGGL(attn_fwd_tiled_kernel<float>, grid, block, lds, (hipStream_t)stream, H, Tq, Tk, (const float*)q, ldq, (const float*)k, ldk, (const float*)v, ldv, (float*)out, ldo, key_mask, causal, lse);
+    } else MIC_CHECK(false, "mic_attn_fwd: bad dtype");
+    MIC_LAUNCH_CHECK();
+    return MIC_OK;
+  }
   dim3 grid(B * H), block(256);
   if (dtype == MIC_BF16) {
     hipLaunchKernelGGL(attn_fwd_kernel<uint16_t>, grid, block, 4 * Tile<uint16_t>::BYTES + 1024, (hipStream_t)stream, H, Tq, Tk, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk, (const uint16_t*)v, ldv, (uint16_t*)out, ldo, key_mask, causal, lse);
@@ -328,10 +571,27 @@ extern "C" int mic_attn_bwd(int dtype, int B, int H, int Tq, int Tk, const void*
                             const void* v, int ldv, const void* out, int ldo, const void* dout, int lddo, const float* lse,
                             const int32_t* key_mask, int causal, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv,
                             void* stream) {
-  MIC_CHECK(B > 0 && H > 0 && Tq > 0 && Tq <= 64 && Tk > 0 && Tk <= 64, "mic_attn_bwd: bad shape");
+  MIC_CHECK(B > 0 && H > 0 && Tq > 0 && Tk > 0, "mic_attn_bwd: bad shape");
   MIC_CHECK(q && k && v && out && dout && lse && dq && dk && dv, "mic_attn_bwd: null pointer");
   const int align = dtype == MIC_BF16 ? 8 : 4;
   MIC_CHECK(ldq % align == 0 && ldk % align == 0 && ldv % align == 0 && ldo % align == 0 && lddo % align == 0, "mic_attn_bwd: row strides must keep 16-B alignment");
+  if (Tq > 64 || Tk > 64) {
+    dim3 gq(B * H * ((Tq + 63) / 64)), gk(B * H * ((Tk + 63) / 64)), block(256);
+#define BWD_TILED(TT)                                                                                                              \
+    do {                                                                                                                           \
+      const size_t lds = 6 * Tile<TT>::BYTES + 512;                                                                                \
+      if (int rc = set_lds(attn_bwd_tiled_kernel<TT, 0>, lds)) return rc;                                                          \
+      if (int rc = set_lds(attn_bwd_tiled_kernel<TT, 1>, lds)) return rc;                                                          \
+      hipLaunchKernelGGL((attn_bwd_tiled_kernel<TT, 0>), gq, block, lds, (hipStream_t)stream, H, Tq, Tk, (const TT*)q, ldq, (const TT*)k, ldk, (const TT*)v, ldv, (const TT*)out, ldo, (const TT*)dout, lddo, lse, key_mask, causal, (TT*)dq, lddq, (TT*)dk, lddk, (TT*)dv, lddv); \
+      hipLaunchKernelGGL((attn_bwd_tiled_kernel<TT, 1>), gk, block, lds, (hipStream_t)stream, H, Tq, Tk, (const TT*)q, ldq, (const TT*)k, ldk, (const TT*)v, ldv, (const TT*)out, ldo, (const TT*)dout, lddo, lse, key_mask, causal, (TT*)dq, lddq, (TT*)dk, lddk, (TT*)dv, lddv); \
+    } while (0)
+    if (dtype == MIC_BF16) BWD_TILED(uint16_t);
+    else if (dtype == MIC_F32) BWD_TILED(float);
+    else MIC_CHECK(false, "mic_attn_bwd: bad dtype");
+#undef BWD_TILED
+    MIC_LAUNCH_CHECK();
+    return MIC_OK;
+  }
   dim3 grid(B * H), block(256);
   if (dtype == MIC_BF16) {
     const size_t lds = 6 * Tile<uint16_t>::BYTES + 512;
@@ -352,6 +612,8 @@ extern "C" int mic_attn_bwd(int dtype, int B, int H, int Tq, int Tk, const void*
 // instruction streams 8 slots fully coalesced for both K and V.  Scores: 8-dim partial dots reduced over the 8 lanes of a
 // slot group; softmax: wave reductions over slots; PV: each lane accumulates its 8 dims over its slots, then the 8 slot
 // groups are summed by xor-shuffles.  Slot ownership (beam-parent indirection) is looked up per slot.
+// Caches longer than 64 slots (generate()'s config default max_length is 200, gen:205-209) are walked in chunks of 64 slots
+// with a running (max, sum, output) triple — the flash-decoding recurrence; a single chunk reduces to the plain softmax.
 template <typename T>
 __global__ __launch_bounds__(256) void attn_decode_kernel(int R, int H, int max_len, int cur, const T* __restrict__ q, int ldq,
                                                           const T* __restrict__ kc, const T* __restrict__ vc, int ldc,
@@ -361,61 +623,69 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(int R, int H, int max_
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wid >= R * H) return;
   const int r = wid / H, h = wid % H;
-  const int sub = lane & 7, grp = lane >> 3;  // 8 dims [sub*8, sub*8+8) of slot (it*8 + grp)
+  const int sub = lane & 7, grp = lane >> 3;  // 8 dims [sub*8, sub*8+8) of slot (c0 + it*8 + grp)
   float qv[8];
   ld8(q + (size_t)r * ldq + h * 64 + sub * 8, qv);
 #pragma unroll
   for (int e = 0; e < 8; ++e) qv[e] *= SCALE;
   const int n = min(cur + 1, max_len);
-  float sc[8];
-  int srow[8];
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int slot = it * 8 + grp;
-    float acc = 0.f;
-    srow[it] = 0;
-    if (slot < n) {
-      srow[it] = src_row ? src_row[(size_t)r * max_len + slot] : r / row_div;
-      float kv[8];
-      ld8(kc + ((size_t)srow[it] * max_len + slot) * ldc + h * 64 + sub * 8, kv);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc += qv[e] * kv[e];
-    }
-    acc = group8_sum(acc);  // the slot's 8 lanes
-    sc[it] = slot < n ? acc : -INFINITY;
-  }
-  float m = sc[0];
-#pragma unroll
-  for (int it = 1; it < 8; ++it) m = fmaxf(m, sc[it]);
-  m = wave_max(m);
-  float l = 0.f;
-#pragma unroll
-  for (int it = 0; it < 8; ++it) { sc[it] = __expf(sc[it] - m); l += sc[it]; }
-  l = wave_sum(l) * 0.125f;  // every slot's probability is replicated on its 8 lanes
-  const float inv = 1.0f / l;
+  float m_run = -INFINITY, l_run = 0.f;
   float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int c0 = 0; c0 < n; c0 += 64) {
+    float sc[8];
+    int srow[8];
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int slot = it * 8 + grp;
-    if (slot < n) {
-      float vv[8];
-      ld8(vc + ((size_t)srow[it] * max_len + slot) * ldc + h * 64 + sub * 8, vv);
-      const float p = sc[it] * inv;
+    for (int it = 0; it < 8; ++it) {
+      const int slot = c0 + it * 8 + grp;
+      float acc = 0.f;
+      srow[it] = 0;
+      if (slot < n) {
+        srow[it] = src_row ? src_row[(size_t)r * max_len + slot] : r / row_div;
+        float kv[8];
+        ld8(kc + ((size_t)srow[it] * max_len + slot) * ldc + h * 64 + sub * 8, kv);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] += p * vv[e];
+        for (int e = 0; e < 8; ++e) acc += qv[e] * kv[e];
+      }
+      acc = group8_sum(acc);  // the slot's 8 lanes
+      sc[it] = slot < n ? acc : -INFINITY;
+    }
+    float m = sc[0];
+#pragma unroll
+    for (int it = 1; it < 8; ++it) m = fmaxf(m, sc[it]);
+    m = fmaxf(wave_max(m), m_run);  // slot c0 is always valid, so m is finite
+    const float alpha = __expf(m_run - m);  // 0 for the first chunk (m_run = -inf)
+    float l = 0.f;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) { sc[it] = __expf(sc[it] - m); l += sc[it]; }
+    l_run = l_run * alpha + wave_sum(l) * 0.125f;  // every slot's probability is replicated on its 8 lanes
+    m_run = m;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] *= alpha;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int slot = c0 + it * 8 + grp;
+      if (slot < n) {
+        float vv[8];
+        ld8(vc + ((size_t)srow[it] * max_len + slot) * ldc + h * 64 + sub * 8, vv);
+        const float p = sc[it];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += p * vv[e];
+      }
     }
   }
+  const float inv = 1.0f / l_run;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {  // sum the 8 slot groups (lanes ^8, ^16, ^32)
     o[e] += dpp_f<DPP_ROR8>(o[e]);
     o[e] += lane_xor16(o[e]);
     o[e] += lane_xor32(o[e]);
+    o[e] *= inv;
   }
   if (grp == 0) st8(out + (size_t)r * ldo + h * 64 + sub * 8, o);
 }
 extern "C" int mic_attn_decode(int dtype, int R, int H, int max_len, int cur, const void* q, int ldq, const void* kc,
                                const void* vc, int ldc, const int32_t* src_row, int row_div, void* out, int ldo, void* stream) {
-  MIC_CHECK(R > 0 && H > 0 && max_len > 0 && max_len <= 64 && cur >= 0 && row_div >= 1, "mic_attn_decode: bad shape");
+  MIC_CHECK(R > 0 && H > 0 && max_len > 0 && cur >= 0 && row_div >= 1, "mic_attn_decode: bad shape R=%d H=%d max_len=%d cur=%d", R, H, max_len, cur);
   MIC_CHECK(q && kc && vc && out, "mic_attn_decode: null pointer");
   dim3 grid((R * H + 3) / 4), block(256);
   if (dtype == MIC_BF16)

@@ -44,6 +44,11 @@ class FlaxCLIPVisionMBartGenerationMixin:
             raise ValueError("`decoder_start_token_id` has to be defined for encoder-decoder generation.")  # gen:232-235
         do_sample = do_sample if do_sample is not None else mc.do_sample
         num_beams = num_beams if num_beams is not None else mc.num_beams
+        if max_length < 2:
+            raise ValueError(f"max_length={max_length}: generation needs room for the start token and one more")
+        if max_length > mc.max_position_embeddings:
+            # the learned position table has max_position_embeddings (+2 offset) rows; XLA's gather would clamp silently
+            raise ValueError(f"max_length={max_length} exceeds mbart_config.max_position_embeddings={mc.max_position_embeddings}")
         # gen:109-120: `params=` is NOT forwarded to encode (the encoder always uses self.params); the decoder uses it.
         enc = self.encode(input_ids, return_dict=True, **{k: v for k, v in model_kwargs.items()
                                                           if not (k.startswith("decoder_") or k.startswith("cross_attn"))})

@@ -196,7 +196,10 @@ def _attn_ref(q, k, v, causal, key_mask):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("Tq,Tk,H,causal,masked", [(50, 50, 12, False, False), (64, 64, 16, True, True), (64, 50, 16, False, False),
-                                                   (12, 12, 2, True, True), (12, 10, 2, False, False), (33, 64, 3, False, True)])
+                                                   (12, 12, 2, True, True), (12, 10, 2, False, False), (33, 64, 3, False, True),
+                                                   # longer than one 64x64 tile: online-softmax forward, two-pass backward
+                                                   (128, 128, 4, True, True), (200, 200, 2, True, True), (197, 197, 3, False, False),
+                                                   (130, 50, 2, False, False), (64, 197, 2, False, True), (65, 65, 1, True, False)])
 def test_attention_fwd_bwd(dev, dtype, Tq, Tk, H, causal, masked):
     from mic_amd import ops
 
@@ -272,6 +275,29 @@ def test_attn_decode_and_kv_append(dev, dtype):
     idx = torch.arange(R) // 4
     ref = _attn_ref(q.float().reshape(R, 1, H, D), hist_k[idx, :6].float().reshape(R, 6, H, D), hist_v[idx, :6].float().reshape(R, 6, H, D),
                     False, None).reshape(R, H * D)
+    assert relerr(out, ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("L,cur", [(200, 199), (200, 64), (130, 70), (64, 63)])
+def test_attn_decode_long_cache(dev, dtype, L, cur):
+    """Caches longer than 64 slots (generate()'s config default max_length is 200, gen:205-209): chunked walk with a running
+    (max, sum, output) triple; beam-parent slot indirection included."""
+    from mic_amd import ops
+
+    R, H, D = 6, 3, 64
+    g = torch.Generator().manual_seed(L * 1000 + cur)
+    hist_k, hist_v = rnd((R, L, H * D), g, dtype), rnd((R, L, H * D), g, dtype)
+    hist_k[2, 100 % L] *= 6.0  # a late dominant key: the running max must move in a later chunk
+    src = torch.randint(0, R, (R, L), generator=g, dtype=torch.int32)
+    q = rnd((R, H * D), g, dtype)
+    out = torch.empty((R, H * D), dtype=dtype, device=dev)
+    ops.attn_decode(q.to(dev), hist_k.to(dev), hist_v.to(dev), out, R, H, L, cur, ldq=H * D, ldo=H * D, src_row=src.to(dev))
+    torch.cuda.synchronize()
+    n = cur + 1
+    kk = torch.stack([hist_k[src[r, :n].long(), torch.arange(n)] for r in range(R)]).float().reshape(R, n, H, D)
+    vv = torch.stack([hist_v[src[r, :n].long(), torch.arange(n)] for r in range(R)]).float().reshape(R, n, H, D)
+    ref = _attn_ref(q.float().reshape(R, 1, H, D), kk, vv, False, None).reshape(R, H * D)
     assert relerr(out, ref) < tol(dtype)
 
 
