@@ -1,15 +1,21 @@
 """bench.py — train-step throughput of the ViT-B/32 + mBART-large-50 captioner on MI355X (BASELINE.json configs[1]:
-bf16 train step, batch 64 per GPU, 224x224 images, seq_len 64), one process per GPU.
+bf16 train step, batch 64 per GPU, 224x224 images, seq_len 64), one process per GPU, plus the beam-4 captions/sec leg
+(configs[3]) as `beam4_generate`.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 8 ...            # starts its own 8 ranks (torch.distributed.run as a CHILD process)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A step = forward + loss + backward + gradient all-reduce (RCCL, N > 1) + AdamW on synthetic data (random-init weights of
 the full architecture; fused dropout active as in training).  Prints ONE JSON line on rank 0.
+Variants: --dtype fp8 (configs[4]: e4m3/e5m2 QKV/FFN GEMMs), --dense-captions (n = 62 tokens in every caption: no padded
+label positions, the dense upper bound of SURVEY §8d), --pmc-traffic (re-measure roofline.traffic with two rocprofv3
+counter passes of this same command as child processes).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -17,12 +23,31 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 TRAIN_GFLOP_PER_SAMPLE = 201.3  # 3 x 67.1 GF fwd, dense, padding not discounted
-PEAK_BF16_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA peak
+PEAK_TFLOPS = {"bf16": 2500.0, "fp8": 5000.0, "f32": 157.3}  # MI355X_MICROARCH.md: dense MFMA peaks
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s is what a copy kernel reaches)
+BEAM_GFLOP_PER_CAPTION = 230.0  # 4 rows x 63 steps x 868.5 MF + encoder/cross-KV once
+DECODE_STEP_TFLOP, DECODE_STEP_GB = 0.89, 3.1  # one decoder step at 1024 rows (batch 256 x 4 beams), bf16
 
 
-def synth_batch(B, T, V, img, seed, lang_ids=(250004, 250008, 250003, 250005)):
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child `torch.distributed.run` (never exec from
+    a process that may touch the GPU; nothing here has imported torch yet) and pass its exit code on."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def synth_batch(B, T, V, img, seed, lang_ids=(250004, 250008, 250003, 250005), dense=False):
     """SURVEY §8(d) synthetic inputs: N(0,1) pixels clipped to [-1.8, 2.2]; labels [lang, n tokens, eos, pad...] with
-    ragged n ~ U{8..62}; decoder inputs by shift_tokens_right."""
+    ragged n ~ U{8..62} (dense: n = T-2 everywhere); decoder inputs by shift_tokens_right."""
     import numpy as np
 
     rng = np.random.default_rng(seed)
@@ -30,7 +55,7 @@ def synth_batch(B, T, V, img, seed, lang_ids=(250004, 250008, 250003, 250005)):
     labels = np.full((B, T), 1, dtype=np.int64)
     mask = np.zeros((B, T), dtype=np.int64)
     for b in range(B):
-        n = int(rng.integers(8, T - 1))
+        n = T - 2 if dense else int(rng.integers(8, T - 1))
         labels[b, 0] = lang_ids[b % 4] if V > 250008 else V - 4 + (b % 4)
         labels[b, 1:1 + n] = rng.integers(4, min(V, 250000), n)
         labels[b, 1 + n] = 2
@@ -40,46 +65,91 @@ def synth_batch(B, T, V, img, seed, lang_ids=(250004, 250008, 250003, 250005)):
     return {"pixel_values": px, "input_ids": labels, "attention_mask": mask, "decoder_input_ids": dec_in}
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The oracle (torch-CPU fp32 restatement of the reference path; NOT Flax) timed on this box's host cores: fwd+bwd
-    images/s at B=8 on the full-size model, bounded sample."""
+# ---------------------------------------------------------------------------------------------- CPU baselines (oracle)
+def cpu_baseline_train(budget_s=25.0):
+    """The oracle (torch-CPU fp32 restatement of the reference path; NOT Flax) on this box's host cores: train step
+    (fwd + bwd + AdamW) images/s at B=8 on the full-size model.  BASELINE.md §3 protocol: 3 warm-up + 10 timed iterations,
+    cut short when the timed part exceeds `budget_s` (the sample actually taken is stated)."""
     import torch
 
     from oracle import model_ref as M
     from oracle import train_ref
 
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
-    torch.set_num_threads(threads)
+    torch.set_num_threads(cores)
     rc = M.RefConfig()
     p = M.init_params(rc, seed=0)
-    import numpy as np
-
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in p.items()}
     b = synth_batch(8, 64, rc.vocab_size, rc.image_size, 7)
     t = {k: torch.from_numpy(v) for k, v in b.items()}
-    n, t_used = 0, 0.0
-    for it in range(4):
+    n, t_used, warm, n_warm = 0, 0.0, 0, 3
+    for it in range(13):
         t0 = time.time()
-        train_ref.loss_and_grads(rc, p, t["pixel_values"], t["input_ids"], t["attention_mask"], t["decoder_input_ids"])
+        _, g = train_ref.loss_and_grads(rc, p, t["pixel_values"], t["input_ids"], t["attention_mask"], t["decoder_input_ids"])
+        with torch.no_grad():
+            for k in p:
+                p[k], m[k], v2[k] = train_ref.adamw_update(p[k], g[k], m[k], v2[k], it, 5e-5)
         dt = time.time() - t0
-        if it > 0:
-            n += 8
-            t_used += dt
-        if t_used > seconds_budget:
+        if it < n_warm:
+            warm += 1
+            if it == 0 and dt > budget_s / 4:  # a slow host: one warm-up iteration only
+                n_warm = 1
+            continue
+        n += 8
+        t_used += dt
+        if t_used > budget_s:
             break
-    return {"value": round(n / t_used, 3), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"oracle (torch-CPU fp32 restatement, not Flax) fwd+bwd, full-size model, B=8 x {n // 8} timed iters after 1 warm-up, no optimizer"}
+    return {"value": round(n / t_used, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle (torch-CPU fp32 restatement, not Flax) train step fwd+bwd+AdamW, full-size model, B=8, "
+                      f"{warm} warm-up + {n // 8} timed iterations (protocol 3 + 10, cut at {budget_s:.0f} s of timed work), {cores} threads"}
 
 
-BEAM_GFLOP_PER_CAPTION = 230.0  # SURVEY §8(d): 4 rows x 63 steps x 868.5 MF + encoder/cross-KV once
+def cpu_baseline_beam(budget_s=30.0):
+    """Beam-4 captions/s of the oracle at B=8 (evaluation.py:80-94 shape: num_beams 4, max_length 64, forced BOS), one call.
+    Bounded: when the first 4 decoder steps predict more than `budget_s` for 63 steps, max_length is shortened and said so."""
+    import numpy as np
+    import torch
+
+    from oracle import generation_ref as G
+    from oracle import model_ref as M
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    rc = M.RefConfig()
+    p = M.init_params(rc, seed=0)
+    p["final_logits_bias"] = p["final_logits_bias"].clone()
+    p["final_logits_bias"][0, rc.eos_token_id] = -1e9  # as in the GPU leg: always the full number of steps
+    B, K = 8, 4
+    px = torch.from_numpy(np.clip(np.random.default_rng(99).standard_normal((B, rc.image_size, rc.image_size, 3), dtype=np.float32), -1.8, 2.2))
+
+    def run(L):
+        t0 = time.time()
+        with torch.no_grad():
+            ehs, _ = M.encode(rc, p, px, int32_cast=True)
+        r = G.generate(lambda rows: G.ModelStepper(rc, p, ehs.repeat_interleave(K, 0), L), B, G.GenDefaults(), num_beams=K,
+                       max_length=L, forced_bos_token_id=250004)
+        return time.time() - t0, r.steps
+
+    t5, _ = run(5)  # warm-up and probe: encoder + 4 steps
+    per_step = t5 / 5.0
+    L = 64 if per_step * 63 <= budget_s else max(8, int(budget_s / per_step))
+    dt, steps = run(L)
+    scale = 63.0 / steps  # captions/s for the full 63-step caption, extrapolated linearly when shortened
+    return {"value": round(B / (dt * scale), 4), "unit": "captions/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle (torch-CPU fp32 restatement, not Flax) beam-4 generate, full-size model, B=8, max_length {L} "
+                      f"({steps} decoder steps in {dt:.1f} s" + ("" if L == 64 else ", scaled to 63 steps") + f"), 1 call after a 4-step warm-up, {cores} threads"}
 
 
-def bench_generate(model, cfg, dev, batch=256, langs=(250004, 250008, 250003, 250005), max_length=64, seed=99):
+# ---------------------------------------------------------------------------------------------- beam-4 leg
+def bench_generate(model, cfg, dev, batch=256, langs=(250004, 250008, 250003, 250005), max_length=64, seed=99, roofline=True):
     """BASELINE configs[3]: beam-4 `.generate`, 4 forced-BOS languages (en/fr/de/es, one call each like evaluation.py:80-94),
     max_len 64, KV-cached, batch 256 on one GPU.
     final_logits_bias[eos] = -1e9 keeps every run at exactly 63 decoder steps (ForcedEOS still fires at the last step)."""
     import numpy as np
     import torch
+
+    from mic_amd import ops
 
     st = model.store
     eos = cfg.mbart_config.eos_token_id
@@ -100,9 +170,97 @@ def bench_generate(model, cfg, dev, batch=256, langs=(250004, 250008, 250003, 25
         n += batch
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"metric": "beam-4 captions/sec (configs[3]: batch 256, 4 beams, max_len 64, forced BOS, KV-cached)",
-            "value": round(n / dt, 1), "unit": "captions/sec", "ms_per_decoder_step": round(dt / (len(langs) * (max_length - 1)) * 1e3, 3),
-            "langs": len(langs), "batch": batch, "model_tflops": round(n * BEAM_GFLOP_PER_CAPTION / dt / 1e3, 1)}
+    steps = len(langs) * (max_length - 1)
+    ms_step = dt / steps * 1e3
+    res = {"metric": "beam-4 captions/sec (configs[3]: batch 256, 4 beams, max_len 64, forced BOS, KV-cached)",
+           "value": round(n / dt, 1), "unit": "captions/sec", "ms_per_decoder_step": round(ms_step, 3),
+           "langs": len(langs), "batch": batch, "model_tflops": round(n * BEAM_GFLOP_PER_CAPTION / dt / 1e3, 1)}
+    if not roofline:
+        return res
+    # one more, untimed call with every decode-attention and GEMM launch bracketed by HIP events on the launch stream
+    recs = []
+    orig_attn, orig_gemm = ops.attn_decode, ops.gemm
+    es = 2 if model.dtype == torch.bfloat16 else 4
+
+    def ev():
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def timed_attn(q, kc, vc, o, R, H, max_len, cur, *, ldq, ldo, ldc=None, src_row=None, row_div=1):
+        e0, e1 = ev()
+        e0.record()
+        r = orig_attn(q, kc, vc, o, R, H, max_len, cur, ldq=ldq, ldo=ldo, ldc=ldc, src_row=src_row, row_div=row_div)
+        e1.record()
+        slots = min(cur + 1, max_len)
+        rows = R if src_row is not None or row_div == 1 else (R + row_div - 1) // row_div  # distinct cache rows read
+        by = (rows * slots * 2 * H * 64 + 2 * R * H * 64) * es  # K and V of every valid slot once + q in + context out
+        recs.append(("attn", by, e0, e1))
+        return r
+
+    def timed_gemm(a, b, o, M, N, K, **kw):
+        e0, e1 = ev()
+        e0.record()
+        r = orig_gemm(a, b, o, M, N, K, **kw)
+        e1.record()
+        recs.append(("head" if N >= 65536 else "gemm", 2.0 * M * N * K, e0, e1))
+        return r
+
+    ops.attn_decode, ops.gemm = timed_attn, timed_gemm
+    try:
+        model.generate(px, forced_bos_token_id=langs[0], num_beams=4, max_length=max_length)
+        torch.cuda.synchronize()
+    finally:
+        ops.attn_decode, ops.gemm = orig_attn, orig_gemm
+
+    def agg(kind):
+        sel = [r for r in recs if r[0] == kind]
+        return sum(r[1] for r in sel), sum(r[2].elapsed_time(r[3]) for r in sel) * 1e-3, len(sel)
+
+    ab, at, an = agg("attn")
+    hf, ht, hn = agg("head")
+    gf, gt, gn = agg("gemm")
+    nst = max_length - 1
+    res["roofline"] = {"bound": "hbm", "kernel": "attn_decode_kernel", "achieved": round(ab / at / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                       "frac": round(ab / at / 1e9 / PEAK_HBM_GBS, 4), "traffic": None, "launches_per_step": round(an / nst, 1),
+                       "ms_per_step": round(at / nst * 1e3, 3), "algorithmic_MB_per_launch": round(ab / an / 1e6, 2),
+                       "note": "algorithmic bytes = K and V of every valid cache slot once (cross K/V once per image, shared by "
+                               "its beams) + q + output; HIP events around every launch of one untimed generate call"}
+    res["roofline_gemm"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                            "head": {"achieved": round(hf / ht / 1e12, 1), "frac": round(hf / ht / 1e12 / PEAK_TFLOPS["bf16"], 4),
+                                     "ms_per_step": round(ht / nst * 1e3, 3), "launches_per_step": round(hn / nst, 1)},
+                            "layers": {"achieved": round(gf / gt / 1e12, 1), "frac": round(gf / gt / 1e12 / PEAK_TFLOPS["bf16"], 4),
+                                       "ms_per_step": round(gt / nst * 1e3, 3), "launches_per_step": round(gn / nst, 1)}}
+    scale = batch * 4 / 1024.0  # SURVEY's step figures are for 1024 rows
+    res["step_vs_roofline"] = {"mfma_frac": round(DECODE_STEP_TFLOP * scale / (ms_step * 1e-3) / PEAK_TFLOPS["bf16"], 4),
+                               "hbm_frac": round(DECODE_STEP_GB * scale / (ms_step * 1e-3) / PEAK_HBM_GBS, 4),
+                               "note": f"whole decoder step: {DECODE_STEP_TFLOP} TFLOP and {DECODE_STEP_GB} GB per 1024 rows (SURVEY 8d) over ms_per_decoder_step"}
+    return res
+
+
+def pmc_traffic(argv, kernel_prefix="gemm_"):
+    """roofline.traffic measured for THIS command: two child rocprofv3 passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only) of
+    `bench.py --steps 1 --warmup 1`, summed over the GEMM kernels, FETCH_SIZE doubled (gfx950 correction of the microarch
+    guide), both x1024 B, divided by the number of GEMM launches."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+
+    tot, launches = 0.0, 0
+    for ctr, factor in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+        d = tempfile.mkdtemp(prefix="mic_pmc_", dir="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp")
+        cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__)] + \
+              [a for a in argv if a != "--pmc-traffic"] + ["--steps", "1", "--warmup", "1", "--no-roofline", "--no-generate", "--no-cpu-baseline"]
+        subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+        n = 0
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] == ctr and kernel_prefix in r["Kernel_Name"]:
+                    tot += float(r["Counter_Value"]) * 1024.0 * factor
+                    n += 1
+        launches = max(launches, n)
+        shutil.rmtree(d, ignore_errors=True)
+    return (tot / 2.0 / launches, launches / 2) if launches else (None, 0)  # 2 steps (1 warm-up + 1) per pass
 
 
 def main():
@@ -111,32 +269,43 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"])
     ap.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"],
                     help="gradient exchange precision for --gpus > 1 (fp32 = the reference's pmean; bf16 = opt-in, halves xGMI bytes)")
+    ap.add_argument("--sharded-optimizer", action="store_true", help="reduce-scatter gradients, AdamW on 1/N of the flat buffer, all-gather weights")
+    ap.add_argument("--dense-captions", action="store_true", help="every caption has T-2 tokens (no padded label positions): dense upper bound")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-generate", action="store_true", help="skip the beam-4 captions/sec leg")
     ap.add_argument("--gen-batch", type=int, default=256)
     ap.add_argument("--generate-only", action="store_true", help="profiling aid: only the beam-4 leg")
+    ap.add_argument("--pmc-traffic", action="store_true", help="measure roofline.traffic now (two rocprofv3 child passes, ~2 min)")
     ap.add_argument("--small", action="store_true", help="reduced model (debug only; result is NOT the benchmark)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL; must be set before the HIP runtime starts
     import torch
     import torch.distributed as dist
 
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL; must be set before the HIP runtime starts
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("MIC_BENCH_SHARE_GPU0"):  # debugging aid: all ranks on cuda:0, gradients over gloo (not a benchmark)
+    share = bool(os.environ.get("MIC_BENCH_SHARE_GPU0"))  # debugging aid: all ranks on cuda:0, gradients over gloo (not a benchmark)
+    if world > 1 and not share and torch.cuda.device_count() < world:
+        if rank == 0:
+            print(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) visible; set MIC_BENCH_SHARE_GPU0=1 to run all "
+                  "ranks on cuda:0 over gloo (a functional check, not a benchmark)", file=sys.stderr)
+        sys.exit(2)
+    if share:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if os.environ.get("MIC_BENCH_SHARE_GPU0"):
+        if share:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -150,13 +319,18 @@ def main():
                                     clip_vision_config=dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, image_size=64, patch_size=32))
     else:
         cfg = CLIPVisionMBartConfig(mbart_config={}, clip_vision_config={})
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
     model = FlaxCLIPVisionMBartForConditionalGeneration(cfg, seed=0, dtype=dtype, device=dev)
     B, T = args.batch, 64
     lr_fn = create_learning_rate_fn(train_ds_size=10_000_000, train_batch_size=B * world, num_train_epochs=7, num_warmup_steps=1000, learning_rate=5e-5)
-    tr = Trainer(model, lr_fn, seed=42, grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else None)
+    tkw = {}
+    if args.dtype == "fp8":
+        tkw["gemm_dtype"] = "fp8"
+    if args.sharded_optimizer:
+        tkw["sharded_optimizer"] = True
+    tr = Trainer(model, lr_fn, seed=42, grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else None, **tkw)
     V, img = cfg.mbart_config.vocab_size, cfg.clip_vision_config.image_size
-    batches = [synth_batch(B, T, V, img, 1234 + rank * 100 + i) for i in range(2)]
+    batches = [synth_batch(B, T, V, img, 1234 + rank * 100 + i, dense=args.dense_captions) for i in range(2)]
     # inputs resident in HBM before the timed region
     dbatches = [{k: torch.from_numpy(v).to(dev) for k, v in b.items()} for b in batches]
     from mic_amd import loss_rows
@@ -171,7 +345,7 @@ def main():
         torch.cuda.synchronize()
 
     if args.generate_only:
-        print(json.dumps(bench_generate(model, cfg, dev, batch=args.gen_batch)))
+        print(json.dumps(bench_generate(model, cfg, dev, batch=args.gen_batch, roofline=not args.no_roofline)))
         return
 
     for i in range(args.warmup):
@@ -190,12 +364,13 @@ def main():
     images_per_sec = world * B * args.steps / dt
 
     roofline = None
+    peak = PEAK_TFLOPS[args.dtype]
     if not args.no_roofline and rank != 0:
         tr.train_step(dbatches[0])  # the instrumented extra step below contains collectives: every rank takes part
         torch.cuda.synchronize()
     if not args.no_roofline and rank == 0:
-        # dominant kernel = the bf16 MFMA GEMM (gemm_bf16_kernel): every launch of one extra, untimed step is bracketed
-        # by HIP events on the launch stream; achieved = sum(2MNK) / sum(duration).
+        # dominant kernel = the MFMA GEMM (gemm_bf16_kernel / gemm_fp8_kernel): every launch of one extra, untimed step is
+        # bracketed by HIP events on the launch stream; achieved = sum(2MNK) / sum(duration).
         recs = []
         orig = ops.gemm
 
@@ -204,7 +379,7 @@ def main():
             e0.record()
             r = orig(a, b, out, M, N, K, **kw)
             e1.record()
-            recs.append((2.0 * M * N * K, e0, e1))
+            recs.append((2.0 * M * N * K, e0, e1, str(a.dtype)))
             return r
 
         orig_g = ops.gemm_grouped
@@ -214,7 +389,7 @@ def main():
             e0.record()
             r = orig_g(arg_list)
             e1.record()
-            recs.append((sum(2.0 * g.M * g.N * g.K for g in arg_list), e0, e1))
+            recs.append((sum(2.0 * g.M * g.N * g.K for g in arg_list), e0, e1, "grouped"))
             return r
 
         ops.gemm = timed_gemm
@@ -225,26 +400,40 @@ def main():
         flops = sum(r[0] for r in recs)
         ms = sum(r[1].elapsed_time(r[2]) for r in recs)
         ach = flops / (ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel" if dtype == torch.bfloat16 else "gemm_f32_kernel",
-                    "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else 157.3, "unit": "TFLOP/s",
-                    "frac": round(ach / (PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else 157.3), 4), "traffic": None,
-                    "launches_per_step": len(recs), "gemm_ms_per_step": round(ms, 3),
+        kname = {"bf16": "gemm_bf16_kernel", "f32": "gemm_f32_kernel", "fp8": "gemm_bf16_kernel + gemm_fp8_kernel"}[args.dtype]
+        roofline = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": len(recs), "gemm_ms_per_step": round(ms, 3),
                     "gemm_gflop_per_step": round(flops / 1e9, 1)}
-        # HBM bytes per launch come from separate rocprofv3 --pmc passes (a profiler cannot run inside this process); the
-        # committed summary of the last such pass over this same command is reported, with its provenance.
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_train_pmc_hbm_traffic.json")
-        if dtype == torch.bfloat16 and B == 64 and not args.small and os.path.exists(pmc):
-            t = json.load(open(pmc))
-            roofline["traffic"] = t["bytes_per_launch"]
-            roofline["traffic_unit"] = "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, avg over the step's GEMM launches)"
-            roofline["traffic_source"] = t["summary"]
+        if args.dtype == "fp8":
+            f8 = [r for r in recs if "float8" in r[3]]
+            if f8:
+                f8f, f8t = sum(r[0] for r in f8), sum(r[1].elapsed_time(r[2]) for r in f8) * 1e-3
+                roofline["fp8_gemms"] = {"achieved": round(f8f / f8t / 1e12, 1), "frac_of_fp8_peak": round(f8f / f8t / 1e12 / PEAK_TFLOPS["fp8"], 4),
+                                         "launches_per_step": len(f8), "ms_per_step": round(f8t * 1e3, 3)}
+            roofline["note"] = "peak = dense fp8 MFMA peak; only the QKV/FFN GEMMs run in fp8 (configs[4]), the rest in bf16"
+        if args.pmc_traffic:
+            tb, nl = pmc_traffic(sys.argv[1:])
+            roofline["traffic"] = None if tb is None else int(tb)
+            roofline["traffic_unit"] = "HBM bytes per GEMM launch (PMC FETCH_SIZE x2 + WRITE_SIZE, x1024 B), measured now by two rocprofv3 child passes"
+            roofline["traffic_launches_per_step"] = nl
+        else:
+            # HBM bytes per launch come from separate rocprofv3 --pmc passes (a profiler cannot wrap this very process); the
+            # committed summary of the last such passes over this same command is reported with the commit it was taken at.
+            for name in ("r2_train_pmc_hbm_traffic.json", "r1_train_pmc_hbm_traffic.json"):
+                pmc = os.path.join(ROOT, "profiles", name)
+                if args.dtype == "bf16" and B == 64 and not args.small and not args.dense_captions and os.path.exists(pmc):
+                    t = json.load(open(pmc))
+                    roofline["traffic"] = t["bytes_per_launch"]
+                    roofline["traffic_unit"] = "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, avg over the step's GEMM launches)"
+                    roofline["traffic_source"] = t["summary"] + " (committed counter passes of this command at commit " + t.get("commit", "0a85f1c, round 1") + "; --pmc-traffic re-measures)"
+                    break
     if world > 1:
         dist.barrier()
 
     gen = None
     if not args.no_generate:
         # generation is replicas-only (no collective): every rank decodes its own 256 images; report the sum
-        g = bench_generate(model, cfg, dev, batch=args.gen_batch if not args.small else 8)
+        g = bench_generate(model, cfg, dev, batch=args.gen_batch if not args.small else 8, roofline=(rank == 0 and not args.no_roofline))
         if world > 1:
             tv = torch.tensor([g["value"]], dtype=torch.float64, device=dev)
             dist.all_reduce(tv, op=dist.ReduceOp.SUM)
@@ -254,21 +443,30 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.small:
         try:
-            cpu = cpu_baseline()
+            cpu = cpu_baseline_train()
         except Exception as e:  # the baseline is a reported figure, never a dependency of the GPU number
             cpu = {"value": None, "unit": "images/sec", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        if gen is not None:
+            try:
+                gen["cpu_baseline"] = cpu_baseline_beam()
+            except Exception as e:
+                gen["cpu_baseline"] = {"value": None, "unit": "captions/sec", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
 
     if rank == 0:
         step_flops = TRAIN_GFLOP_PER_SAMPLE * 1e9 * B
+        head = ("logits/CE on all label positions (dense captions: every position carries loss)" if args.dense_captions else
+                "logits/CE on the label positions with loss mask 1 only (exact; ragged captions n~U{8..62})")
         line = {
             "metric": "train images/sec, ViT-B/32+mBART-50 (bf16 train step, batch 64/GPU, 224x224, seq_len 64)",
             "value": round(images_per_sec, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic (random-init weights, N(0,1) pixels, ragged random captions)",
-            "config": {"workload": "configs[1]: ViT-B/32 + mBART-large-50 train step (fwd+loss+bwd+all-reduce+AdamW), "
-                                   f"per-GPU batch {B}, 224x224 NHWC fp32 pixels, seq_len {T}, dropout 0.1" + (" [SMALL DEBUG MODEL]" if args.small else ""),
-                       "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}", "grad_allreduce": f"{args.grad_comm} flat buckets, RCCL, side stream",
-                       "lm_head": "logits/CE on the label positions with loss mask 1 only (exact; ragged captions n~U{8..62})"},
+            "dtype": args.dtype, "data": "synthetic (random-init weights, N(0,1) pixels, " + ("dense 62-token" if args.dense_captions else "ragged") + " random captions)",
+            "config": {"workload": ("configs[4]" if args.dtype == "fp8" else "configs[1]") + ": ViT-B/32 + mBART-large-50 train step (fwd+loss+bwd+all-reduce+AdamW), "
+                                   f"per-GPU batch {B}, 224x224 NHWC fp32 pixels, seq_len {T}, dropout 0.1" + (" [SMALL DEBUG MODEL]" if args.small else "")
+                                   + (" [ALL RANKS SHARE cuda:0 OVER gloo: functional check, not a benchmark]" if share and world > 1 else ""),
+                       "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}" + ("+sharded-optimizer" if args.sharded_optimizer else ""),
+                       "grad_allreduce": f"{args.grad_comm} flat buckets, RCCL, side stream",
+                       "lm_head": head, "gemm_dtype": "fp8 e4m3 (fwd) / e5m2 (grads) for QKV+FFN, bf16 elsewhere" if args.dtype == "fp8" else args.dtype},
             "model_tflops_per_gpu": round(step_flops * args.steps / dt / 1e12, 1),
             "final_loss": round(loss, 4),
             "roofline": roofline, "cpu_baseline": cpu, "beam4_generate": gen,

@@ -46,6 +46,13 @@ class Engine:
         self._cs_queue = []
         self.grad_progress = None  # callable(offset): every gradient with flat offset < offset is final (DDP overlap)
 
+    def set_gemm_dtype(self, name):
+        """"fp8": the QKV / FFN projections (BASELINE configs[4]) run as OCP fp8 GEMMs; None / "bf16": storage dtype."""
+        if name in (None, "bf16", "bfloat16", "f32", "float32"):
+            self.fp8 = False
+            return
+        raise ValueError(f"unknown gemm_dtype {name!r}")
+
     def _done(self, seg_name: str):
         """Report that the gradient segment `seg_name` (and, by layout order, everything before it) is final."""
         if self.grad_progress is not None:

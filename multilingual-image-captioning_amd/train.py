@@ -56,14 +56,17 @@ def loss_rows(attention_mask, labels):
     return idx, np.asarray(labels).reshape(-1)[idx].astype(np.int32)
 
 
-def plan_buckets(numel: int, bucket_elems: int, boundaries: List[int]) -> List[Tuple[int, int]]:
+def plan_buckets(numel: int, bucket_elems: int, boundaries: List[int], granule: int = 1) -> List[Tuple[int, int]]:
     """Contiguous [begin, end) slices of the flat gradient buffer, cut at segment boundaries, each >= bucket_elems
-    (except the last).  Pure host logic (tested on CPU)."""
+    (except the last).  `granule` > 1 (sharded optimizer: world * 64) rounds every interior cut DOWN to a multiple of it,
+    so each bucket splits evenly over the ranks; a bucket is still complete once backward has passed the segment boundary
+    the cut was derived from.  Pure host logic (tested on CPU)."""
     cuts, start = [], 0
     for b in sorted(set(boundaries)):
-        if b - start >= bucket_elems and b < numel:
-            cuts.append((start, b))
-            start = b
+        c = (b // granule) * granule
+        if c - start >= bucket_elems and c < numel:
+            cuts.append((start, c))
+            start = c
     cuts.append((start, numel))
     return cuts
 
@@ -71,19 +74,29 @@ def plan_buckets(numel: int, bucket_elems: int, boundaries: List[int]) -> List[T
 class GradReducer:
     """Bucketed all-reduce(mean) of the flat gradient buffer on a side stream (C1 of SURVEY §2.3), optionally followed —
     still on the side stream — by a per-bucket callback (the fused AdamW of that slice): HBM-bound optimizer traffic then
-    overlaps the MFMA-bound remainder of backward instead of trailing it."""
+    overlaps the MFMA-bound remainder of backward instead of trailing it.
+
+    sharded=True (ZeRO-1 style, same arithmetic): every bucket is REDUCE-SCATTERED instead of all-reduced — rank r receives
+    the summed gradients of the r-th 1/world of the bucket in place — `on_ready` then runs on that shard only, and the
+    tensors in `gather` (the compute-dtype weights) are ALL-GATHERED back over the bucket.  Per step and rank that is
+    (world-1)/world x (4 B + 2 B) per parameter on the wire instead of 2 x 4 B, and 1/world of the optimizer traffic.  A
+    bucket tail that does not divide by world x 64 elements (only the last bucket can have one) is all-reduced and updated on
+    every rank."""
 
     def __init__(self, flat_grad: torch.Tensor, buckets: List[Tuple[int, int]], group=None, on_ready=None, hold=None,
-                 comm_dtype: Optional[torch.dtype] = None):
+                 comm_dtype: Optional[torch.dtype] = None, sharded: bool = False, gather: Optional[List[torch.Tensor]] = None):
         import torch.distributed as dist
 
         self.dist, self.group = dist, group
         self.grad, self.buckets = flat_grad, buckets
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.cuda = flat_grad.is_cuda
         self.stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None       # collectives
         self.opt_stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None   # per-bucket optimizer work
-        self.on_ready = on_ready if self.cuda else None
+        self.sharded = bool(sharded) and self.world > 1
+        self.on_ready = on_ready if (self.cuda or self.sharded) else None
+        self.gather = list(gather or []) if self.sharded else []
         self.next = 0
         self.handles = []
         self.hold = hold  # (begin, end): buckets touching this range are reduced as usual but their on_ready is postponed
@@ -92,8 +105,29 @@ class GradReducer:
         # opt-in reduced-precision exchange (e.g. torch.bfloat16): every rank rounds its bucket, the collective sums in that
         # dtype, the result is widened back into the fp32 buffer.  Halves the xGMI bytes; NOT the reference's fp32 pmean.
         self.comm_dtype = comm_dtype if (comm_dtype is not None and comm_dtype != flat_grad.dtype) else None
+        if self.sharded and self.comm_dtype is not None:
+            raise ValueError("sharded optimizer: the reduce-scatter runs in the gradient dtype (grad_comm_dtype is an all-reduce option)")
         self.stage = (torch.empty(max(e - b for b, e in buckets), dtype=self.comm_dtype, device=flat_grad.device)
                       if self.comm_dtype is not None and self.world > 1 else None)
+
+    # ---- shard geometry
+    def split(self, b: int, e: int) -> Tuple[int, int, int]:
+        """(shard_begin, shard_end, main_end): [b, main_end) divides evenly over the ranks in 64-element units, this rank owns
+        [shard_begin, shard_end); [main_end, e) is the replicated tail."""
+        if not self.sharded:
+            return b, e, e
+        unit = self.world * 64
+        main = ((e - b) // unit) * unit
+        sh = main // self.world
+        return b + self.rank * sh, b + (self.rank + 1) * sh, b + main
+
+    def owned_ranges(self, b: int, e: int) -> List[Tuple[int, int]]:
+        """slices of bucket [b, e) this rank runs the optimizer on"""
+        sb, se, me = self.split(b, e)
+        out = [(sb, se)] if se > sb else []
+        if e > me and self.sharded:
+            out.append((me, e))
+        return out if self.sharded else [(b, e)]
 
     def _all_reduce(self, b: int, e: int, async_op: bool = False):
         if self.stage is None:
@@ -104,6 +138,28 @@ class GradReducer:
         self.grad[b:e].copy_(st)
         return None
 
+    def _reduce(self, b: int, e: int):
+        """the bucket's gradient exchange on the current stream / synchronously on CPU"""
+        if not self.sharded:
+            return self._all_reduce(b, e)
+        sb, se, me = self.split(b, e)
+        if me > b:  # in place: the output is this rank's slice of the input
+            self.dist.reduce_scatter_tensor(self.grad[sb:se], self.grad[b:me], op=self.dist.ReduceOp.SUM, group=self.group)
+        if e > me:
+            self.dist.all_reduce(self.grad[me:e], op=self.dist.ReduceOp.SUM, group=self.group)
+        return None
+
+    def _gather(self, b: int, e: int):
+        sb, se, me = self.split(b, e)
+        if me > b:
+            for t in self.gather:
+                self.dist.all_gather_into_tensor(t[b:me], t[sb:se], group=self.group)
+
+    def _ready(self, b: int, e: int):
+        if self.on_ready is not None:
+            for (x, y) in self.owned_ranges(b, e):
+                self.on_ready(x, y)
+
     @property
     def active(self) -> bool:
         return self.world > 1 or self.on_ready is not None
@@ -113,6 +169,17 @@ class GradReducer:
         self.handles = []
         self.held = []
         self.last_comm_event = None
+
+    def _after_ready_gather(self, items: List[Tuple[int, int]]):
+        """sharded: all-gather the refreshed weights of `items` on the collective stream, behind the optimizer stream"""
+        if not (self.sharded and self.gather and items):
+            return
+        ev = torch.cuda.Event()
+        ev.record(self.opt_stream)
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ev)
+            for (b, e) in items:
+                self._gather(b, e)
 
     def progress(self, offset_done: int):
         """Backward reports that every gradient with flat offset < offset_done is final."""
@@ -126,7 +193,7 @@ class GradReducer:
                 if self.world > 1:
                     with torch.cuda.stream(self.stream):
                         self.stream.wait_event(ev)
-                        self._all_reduce(b, e)
+                        self._reduce(b, e)
                         ev = torch.cuda.Event()
                         ev.record(self.stream)
                 self.last_comm_event = ev
@@ -137,7 +204,15 @@ class GradReducer:
                     with torch.cuda.stream(self.opt_stream):
                         self.opt_stream.wait_event(ev)
                         with ops.pinned_stream():  # launch on that stream, not on the step's pinned main stream
-                            self.on_ready(b, e)
+                            self._ready(b, e)
+                    self._after_ready_gather([(b, e)])
+            elif self.sharded:  # CPU tensors (host-logic tests over gloo): synchronous
+                self._reduce(b, e)
+                if self.hold is not None and b < self.hold[1] and e > self.hold[0]:
+                    self.held.append((b, e))
+                else:
+                    self._ready(b, e)
+                    self._gather(b, e)
             else:
                 h = self._all_reduce(b, e, async_op=True)
                 if h is not None:
@@ -147,7 +222,16 @@ class GradReducer:
     def release_held(self, before=None):
         """Run `before()` (e.g. the sparse embedding scatter) and then the postponed on_ready calls, on the optimizer stream,
         after every collective issued so far."""
-        if not self.cuda or (not self.held and before is None):
+        if not self.cuda:
+            if self.sharded:
+                if before is not None:
+                    before()
+                for (b, e) in self.held:
+                    self._ready(b, e)
+                    self._gather(b, e)
+                self.held = []
+            return
+        if not self.held and before is None:
             return
         ev = torch.cuda.Event()
         ev.record(self.stream if self.world > 1 else torch.cuda.current_stream())
@@ -158,9 +242,9 @@ class GradReducer:
             with ops.pinned_stream():
                 if before is not None:
                     before()
-                if self.on_ready is not None:
-                    for (b, e) in self.held:
-                        self.on_ready(b, e)
+                for (b, e) in self.held:
+                    self._ready(b, e)
+        self._after_ready_gather(self.held)
         self.held = []
 
     def finish(self):
@@ -180,7 +264,8 @@ class Trainer:
 
     def __init__(self, model, learning_rate_fn: Callable[[int], float], b1=0.9, b2=0.999, eps=1e-8, weight_decay=0.0,
                  label_smoothing_factor=0.0, seed: int = 42, bucket_mb: float = 64.0, group=None, compact_head: bool = True,
-                 overlap_optimizer: bool = True, grad_comm_dtype: Optional[torch.dtype] = None):
+                 overlap_optimizer: bool = True, grad_comm_dtype: Optional[torch.dtype] = None, sharded_optimizer: bool = False,
+                 gemm_dtype: Optional[str] = None):
         import torch.distributed as dist
 
         self.model, self.lr_fn = model, learning_rate_fn
@@ -194,14 +279,39 @@ class Trainer:
         st = model.store
         st.ensure_grads()
         st.ensure_opt_state()
+        if gemm_dtype is not None:
+            model.engine.set_gemm_dtype(gemm_dtype)
         self.hyper = torch.zeros(2, dtype=torch.float32, device=model.device)
         bounds = [s.offset for s in st.segs.values()]
-        self.buckets = plan_buckets(st.numel, int(bucket_mb * 1024 * 1024 / 4), bounds)
-        self.overlap_optimizer = overlap_optimizer
+        # sharded optimizer (data parallel only): reduce-scatter / AdamW on 1/world of every bucket / all-gather the weights
+        self.sharded = bool(sharded_optimizer) and self.world > 1
+        self.buckets = plan_buckets(st.numel, int(bucket_mb * 1024 * 1024 / 4), bounds, granule=self.world * 64 if self.sharded else 1)
+        self.overlap_optimizer = overlap_optimizer or self.sharded
         sh = st.segs["shared"]
-        self.reducer = GradReducer(st.grad, self.buckets, group, on_ready=self._adamw_slice if overlap_optimizer else None,
-                                   hold=(sh.offset, sh.offset + sh.numel), comm_dtype=grad_comm_dtype)
+        self.reducer = GradReducer(st.grad, self.buckets, group, on_ready=self._adamw_slice if self.overlap_optimizer else None,
+                                   hold=(sh.offset, sh.offset + sh.numel), comm_dtype=grad_comm_dtype, sharded=self.sharded,
+                                   gather=[st.lp])
         self.metrics_buf = torch.zeros(2, dtype=torch.float32, device=model.device)
+        self._state_dirty = False
+        if self.sharded:
+            model._state_sync = self.sync_full_state  # params export / checkpoints need every rank's master + moments
+
+    def sync_full_state(self):
+        """Sharded optimizer: the fp32 master weights and AdamW moments of a bucket are current only on the rank that owns the
+        shard.  All-gather them (a checkpoint / `model.params` export needs the full state on the exporting rank).  Collective:
+        every rank must call it (save_checkpoint and the `params` getter do)."""
+        if not (self.sharded and self._state_dirty):
+            return
+        import torch.distributed as dist
+
+        st = self.model.store
+        torch.cuda.synchronize(self.model.device) if self.model.device.type == "cuda" else None
+        for (b, e) in self.buckets:
+            sb, se, me = self.reducer.split(b, e)
+            if me > b:
+                for t in ([st.m, st.v] + ([st.master] if st.lp is not st.master else [])):
+                    dist.all_gather_into_tensor(t[b:me], t[sb:se], group=self.group)
+        self._state_dirty = False
 
     def _adamw_slice(self, b: int, e: int):
         """AdamW on flat slice [b, e) — runs on the reducer's side stream right after that bucket's all-reduce."""
@@ -268,6 +378,7 @@ class Trainer:
             ops.adamw(st.master, st.m, st.v, st.grad, None if st.lp is st.master else st.lp, self.hyper, self.b1, self.b2, self.eps,
                       self.wd, grad_scale=1.0 / self.world)
         m.invalidate_params_cache()
+        self._state_dirty = True
         self.step += 1
         self.metrics_buf[0:1].copy_(loss)
         self.metrics_buf[1] = lr
@@ -294,6 +405,7 @@ class Trainer:
         from .checkpoint import save_train_state
 
         ckpt = os.path.join(save_dir, f"ckpt-{self.step - 1}")
+        self.sync_full_state()  # collective in sharded mode: before the rank-0-only part
         if self.rank != 0 or (os.path.exists(ckpt) and not overwrite):  # main.py:304-305
             return ckpt
         torch.cuda.synchronize(self.model.device) if self.model.device.type == "cuda" else None

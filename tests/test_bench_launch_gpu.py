@@ -1,0 +1,58 @@
+"""`python bench.py --gpus N` must start its own ranks (the driver's N=1-style command line with N > 1) and print one JSON
+line.  A gpurun box has one GPU: MIC_BENCH_SHARE_GPU0=1 puts both ranks on cuda:0 with gloo as the gradient transport, so the
+launcher, the rank plumbing, the bucketed reducer, the sparse embedding exchange and the JSON contract are all exercised
+(the RCCL transport itself needs two devices)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env_extra=None, timeout=600):
+    env = dict(os.environ, **(env_extra or {}))
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--small", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + extra,
+                       env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    return r
+
+
+def test_bench_self_launches_two_ranks(dev):
+    r = _run(["--gpus", "2"], {"MIC_BENCH_SHARE_GPU0": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["unit"] == "images/sec"
+    assert d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2" and "functional check" in d["config"]["workload"]
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["beam4_generate"]["n_gpus"] == 2
+    assert abs(d["final_loss"]) < 100
+
+
+def test_bench_sharded_optimizer_two_ranks(dev):
+    r = _run(["--gpus", "2", "--sharded-optimizer", "--no-generate"], {"MIC_BENCH_SHARE_GPU0": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["config"]["parallelism"] == "dp2+sharded-optimizer" and d["value"] > 0
+
+
+def test_bench_refuses_more_ranks_than_gpus(dev):
+    import torch
+
+    n = torch.cuda.device_count() + 1
+    r = _run(["--gpus", str(n), "--no-generate"])
+    assert r.returncode != 0 and "MIC_BENCH_SHARE_GPU0" in (r.stderr + r.stdout)
+
+
+def test_bench_single_gpu_line_has_both_rooflines_and_dense_variant(dev):
+    r = _run(["--dense-captions"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and "dense" in d["data"] and d["roofline"]["bound"] == "mfma"
+    g = d["beam4_generate"]
+    assert g["roofline"]["bound"] == "hbm" and g["roofline"]["kernel"] == "attn_decode_kernel" and 0 < g["roofline"]["frac"] < 1
+    assert g["roofline_gemm"]["head"]["achieved"] > 0 and 0 < g["step_vs_roofline"]["hbm_frac"] < 1

@@ -131,6 +131,11 @@ def test_plan_buckets():
     assert b[0][0] == 0 and b[-1][1] == 1000 and all(x[1] == y[0] for x, y in zip(b, b[1:]))
     assert all(e - s >= 300 for s, e in b[:-1])
     assert plan_buckets(10, 100, [0, 5]) == [(0, 10)]
+    # sharded optimizer: interior cuts are rounded down to world*64 so that every bucket but the last splits evenly
+    g = plan_buckets(100_000, 20_000, [0, 7_001, 21_013, 45_777, 70_001, 99_990], granule=2 * 64)
+    assert g[0][0] == 0 and g[-1][1] == 100_000 and all(x[1] == y[0] for x, y in zip(g, g[1:]))
+    assert all(e % 128 == 0 for _, e in g[:-1]) and all(e - s >= 20_000 for s, e in g[:-1])
+    assert [e for _, e in g[:-1]] == [(x // 128) * 128 for x in (21_013, 45_777, 70_001, 99_990)]
 
 
 def _ddp_worker(rank, world, port, q):
@@ -185,6 +190,61 @@ def test_grad_reducer_gloo_world2():
         p.join(timeout=60)
     assert [r[1] for r in res] == [True, True]
     assert all(abs(r[2] - 1.5) < 1e-9 for r in res)
+
+
+def _sharded_worker(rank, world, port, q):
+    """Sharded optimizer host logic on CPU tensors over gloo: reduce-scatter in place, the update callback on the owned
+    slices only (incl. the replicated tail and a held bucket), all-gather of the updated weights."""
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import mic_amd  # noqa: F401
+    from mic_amd.train import GradReducer, plan_buckets
+
+    n = 5000 + 37  # not a multiple of world*64: the last bucket has a replicated tail
+    g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    w = torch.ones(n)
+    touched = torch.zeros(n)
+    buckets = plan_buckets(n, 1200, list(range(0, n, 500)), granule=world * 64)
+
+    def upd(b, e):  # "optimizer": w -= mean gradient, on the slices this rank owns
+        w[b:e] -= g[b:e] / world
+        touched[b:e] += 1
+
+    red = GradReducer(g, buckets, on_ready=upd, sharded=True, gather=[w], hold=(buckets[1][0], buckets[1][0] + 10))
+    red.start_step()
+    for off in list(range(500, n, 500)) + [n]:
+        red.progress(off)
+    red.release_held()
+    red.finish()
+    expect = 1.0 - torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world)) / world
+    own = sum(e - b for (x, y) in buckets for (b, e) in red.owned_ranges(x, y))
+    tail = n - (n // (world * 64)) * (world * 64) if buckets[-1][1] - buckets[-1][0] >= world * 64 else 0
+    ok = torch.allclose(w, expect) and int(touched.sum()) == own and touched.max() == 1
+    # every element is updated by exactly one rank, except the replicated tail (every rank)
+    tot = touched.clone()
+    dist.all_reduce(tot)
+    sb, se, me = red.split(*buckets[-1])
+    ok = ok and bool((tot[: me] == 1).all()) and bool((tot[me:] == world).all()) and me < n
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_sharded_reducer_gloo_world2():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert [r[1] for r in res] == [True, True]
 
 
 def test_optimizer_state_files_roundtrip(tmp_path):
