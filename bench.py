@@ -29,6 +29,31 @@ BEAM_GFLOP_PER_CAPTION = 230.0  # 4 rows x 63 steps x 868.5 MF + 
 DECODE_STEP_TFLOP, DECODE_STEP_GB = 0.89, 3.1  # one decoder step at 1024 rows (batch 256 x 4 beams), bf16
 
 
+_T0 = time.time()
+
+
+def note(msg: str):
+    """progress on stderr (stdout carries the ONE JSON line)"""
+    print(f"[bench +{time.time() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def host_threads() -> int:
+    """threads for the CPU baselines: the cores this process may run on (cgroup / affinity aware), capped at 64 — a pool box can
+    expose a few hundred logical CPUs to a container that is scheduled on a fraction of them, and torch's intra-op pool
+    degrades badly when oversubscribed"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:  # cgroup v2 quota
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks as a child `torch.distributed.run` (never exec from
     a process that may touch the GPU; nothing here has imported torch yet) and pass its exit code on."""
@@ -75,7 +100,7 @@ def cpu_baseline_train(budget_s=25.0):
     from oracle import model_ref as M
     from oracle import train_ref
 
-    cores = os.cpu_count() or 1
+    cores = host_threads()
     torch.set_num_threads(cores)
     rc = M.RefConfig()
     p = M.init_params(rc, seed=0)
@@ -91,6 +116,7 @@ def cpu_baseline_train(budget_s=25.0):
             for k in p:
                 p[k], m[k], v2[k] = train_ref.adamw_update(p[k], g[k], m[k], v2[k], it, 5e-5)
         dt = time.time() - t0
+        note(f"cpu baseline (train) iteration {it}: {dt:.1f} s")
         if it < n_warm:
             warm += 1
             if it == 0 and dt > budget_s / 4:  # a slow host: one warm-up iteration only
@@ -102,7 +128,7 @@ def cpu_baseline_train(budget_s=25.0):
             break
     return {"value": round(n / t_used, 3), "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": f"oracle (torch-CPU fp32 restatement, not Flax) train step fwd+bwd+AdamW, full-size model, B=8, "
-                      f"{warm} warm-up + {n // 8} timed iterations (protocol 3 + 10, cut at {budget_s:.0f} s of timed work), {cores} threads"}
+                      f"{warm} warm-up + {n // 8} timed iterations (protocol 3 + 10, cut at {budget_s:.0f} s of timed work), {cores} threads of {os.cpu_count()} logical CPUs"}
 
 
 def cpu_baseline_beam(budget_s=30.0):
@@ -114,7 +140,7 @@ def cpu_baseline_beam(budget_s=30.0):
     from oracle import generation_ref as G
     from oracle import model_ref as M
 
-    cores = os.cpu_count() or 1
+    cores = host_threads()
     torch.set_num_threads(cores)
     rc = M.RefConfig()
     p = M.init_params(rc, seed=0)
@@ -132,13 +158,14 @@ def cpu_baseline_beam(budget_s=30.0):
         return time.time() - t0, r.steps
 
     t5, _ = run(5)  # warm-up and probe: encoder + 4 steps
+    note(f"cpu baseline (beam-4) probe of 4 steps: {t5:.1f} s")
     per_step = t5 / 5.0
     L = 64 if per_step * 63 <= budget_s else max(8, int(budget_s / per_step))
     dt, steps = run(L)
     scale = 63.0 / steps  # captions/s for the full 63-step caption, extrapolated linearly when shortened
     return {"value": round(B / (dt * scale), 4), "unit": "captions/sec", "cores": cores, "kind": "port",
             "sample": f"oracle (torch-CPU fp32 restatement, not Flax) beam-4 generate, full-size model, B=8, max_length {L} "
-                      f"({steps} decoder steps in {dt:.1f} s" + ("" if L == 64 else ", scaled to 63 steps") + f"), 1 call after a 4-step warm-up, {cores} threads"}
+                      f"({steps} decoder steps in {dt:.1f} s" + ("" if L == 64 else ", scaled to 63 steps") + f"), 1 call after a 4-step warm-up, {cores} threads of {os.cpu_count()} logical CPUs"}
 
 
 # ---------------------------------------------------------------------------------------------- beam-4 leg
@@ -348,9 +375,13 @@ def main():
         print(json.dumps(bench_generate(model, cfg, dev, batch=args.gen_batch, roofline=not args.no_roofline)))
         return
 
+    if rank == 0:
+        note("model and batches ready; warm-up")
     for i in range(args.warmup):
         tr.train_step(dbatches[i % 2])
     barrier()
+    if rank == 0:
+        note("timed steps")
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = tr.train_step(dbatches[i % 2])
@@ -363,6 +394,8 @@ def main():
         dt = float(tmax.item())
     images_per_sec = world * B * args.steps / dt
 
+    if rank == 0:
+        note(f"{images_per_sec:.1f} images/s; roofline step")
     roofline = None
     peak = PEAK_TFLOPS[args.dtype]
     if not args.no_roofline and rank != 0:
@@ -430,6 +463,8 @@ def main():
     if world > 1:
         dist.barrier()
 
+    if rank == 0:
+        note("beam-4 leg")
     gen = None
     if not args.no_generate:
         # generation is replicas-only (no collective): every rank decodes its own 256 images; report the sum
@@ -442,6 +477,7 @@ def main():
         gen = g
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.small:
+        note(f"CPU baselines on {host_threads()} threads")
         try:
             cpu = cpu_baseline_train()
         except Exception as e:  # the baseline is a reported figure, never a dependency of the GPU number

@@ -30,6 +30,9 @@ extern "C" {
 
 #define MIC_BF16 0
 #define MIC_F32 1
+#define MIC_FP8 2  /* GEMM operands only: OCP fp8, one byte per element (BASELINE configs[4]) */
+#define MIC_E4M3 0 /* OCP e4m3fn: max 448 (activations, weights) */
+#define MIC_E5M2 1 /* OCP e5m2: max 57344 (gradients) */
 
 /* activation ids for GEMM epilogues */
 #define MIC_ACT_NONE 0
@@ -52,7 +55,7 @@ const char* mic_last_error(void);
  *   v *= act'(Zin[m,n]) (activation backward);  v = dropout(v; seed, p, index m*N+n);
  *   v += R[m,n];  v += C_old[m,n] (accumulate);  C[m,n] = v  (c_dtype)
  * Requirements: K % 64 == 0 for MIC_BF16 (callers zero-pad the reduction dimension); lda/ldb % 8 == 0 (bf16).
- * bf16 path: LDS-staged 128x128x64 or 256x256x64 tiles (direct global->LDS DMA, XOR-swizzled),
+ * bf16 path: LDS-staged 64x64x64, 128x128x64 or 256x256x64 tiles (operands through registers into XOR-swizzled LDS images),
  * v_mfma_f32_32x32x16_bf16, k-major operands through ds_read_b64_tr_b16.  f32 path: v_mfma_f32_32x32x2_f32 (exact fp32).
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
@@ -81,6 +84,14 @@ typedef struct {
                               the bias gradient colsum(dy) (nn.Dense bias; main.py:696 grads) from operand fragments the
                               kernel holds anyway — no extra pass over dy */
   int rowsum_k;            /* valid reduction rows for a_rowsum (0 = K) */
+  /* dtype == MIC_FP8 (BASELINE configs[4]; the reference has no counterpart, its dtypes are main.py:96-101): A and B are OCP
+   * fp8 bytes, both k-contiguous (a_kmajor = b_kmajor = 0), K % 128 == 0, lda/ldb in bytes and multiples of 16; R / Zin / Zout
+   * are bf16, C is c_dtype (bf16 or f32).  v = acc * a_scale_inv[0] * b_scale_inv[0] (device scalars written by
+   * mic_fp8_quantize: the per-tensor dequantisation factors) before bias.  v_mfma_scale_f32_32x32x64_f8f6f4 with unit block
+   * scales: fp32 accumulate at twice the bf16 MFMA rate, half the operand bytes. */
+  int a_fmt, b_fmt;                 /* MIC_E4M3 / MIC_E5M2 (B must be e4m3) */
+  const float* a_scale_inv;         /* device scalar or NULL (= 1) */
+  const float* b_scale_inv;
 } mic_gemm_args;
 int mic_gemm(const mic_gemm_args* a, void* stream);
 /* dst[r][c] (dst_dtype) = sum over s < n_slabs of src[s * slab_stride + r * ld_src + c] (fp32): the second half of a
@@ -90,6 +101,25 @@ int mic_sum_slabs(int dst_dtype, int n_slabs, long long slab_stride, int rows, i
 /* `count` GEMMs that share dtype and operand layouts in as few launches as possible (one launch per 8 problems):
  * the weight-gradient GEMMs of a layer have 36..256 output tiles each — grouped they fill the 256 CUs. */
 int mic_gemm_grouped(const mic_gemm_args* args, int count, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * fp8 operands for mic_gemm (BASELINE configs[4]; no reference counterpart — its dtypes are fp32/fp16/bf16, main.py:96-101).
+ * Per-tensor current scaling: mic_fp8_amax accumulates state[0] = max |x| (fp32 atomic max; the caller zeroes `state`),
+ * mic_fp8_quantize then writes q[r][c] = fp8(x[r][c] * FMAX / amax) (row-major) and / or the transposed copy
+ * qT[c][r] (rows zero-padded to rows_pad, so it can be the k-contiguous operand of the weight-gradient GEMM, which reduces
+ * over rows), and state[1] = amax / FMAX — the factor mic_gemm multiplies back (a_scale_inv / b_scale_inv).
+ * `items` is a HOST array; src is bf16 [rows][ld]; e4m3 (FMAX 448) for activations and weights, e5m2 (FMAX 57344) for gradients.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* src; int ld;      /* bf16 [rows][ld], cols % 8 == 0 */
+  int rows, cols, rows_pad;     /* rows_pad >= rows: qT gets rows_pad columns (0 = rows) */
+  void* q; int ldq;             /* [rows][ldq] bytes or NULL */
+  void* qT; int ldqT;           /* [cols][ldqT] bytes or NULL */
+  float* state;                 /* [2]: amax, 1 / scale */
+  int fmt;                      /* MIC_E4M3 / MIC_E5M2 */
+} mic_fp8_item;
+int mic_fp8_amax(const mic_fp8_item* items, int count, void* stream);
+int mic_fp8_quantize(const mic_fp8_item* items, int count, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm (flax nn.LayerNorm: biased variance, fp32 statistics; 3P).

@@ -10,7 +10,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmic_hip.so")
 
-MIC_BF16, MIC_F32 = 0, 1
+MIC_BF16, MIC_F32, MIC_FP8 = 0, 1, 2
+MIC_E4M3, MIC_E5M2 = 0, 1
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_QUICK_GELU = 0, 1, 2, 3
 ACT_IDS = {"none": 0, None: 0, "gelu": 1, "erf": 1, "gelu_erf": 1, "tanh": 2, "gelu_tanh": 2, "gelu_new": 2, "quick_gelu": 3}
 
@@ -28,7 +29,13 @@ class GemmArgs(C.Structure):
         ("dact", C.c_int), ("R", C.c_void_p), ("ldr", C.c_int), ("accumulate", C.c_int), ("dropout_p", C.c_float),
         ("dropout_seed", C.c_uint32), ("alpha", C.c_float), ("split_k", C.c_int),
         ("split_stride", C.c_longlong), ("a_rowsum", C.c_void_p), ("rowsum_k", C.c_int),
+        ("a_fmt", C.c_int), ("b_fmt", C.c_int), ("a_scale_inv", C.c_void_p), ("b_scale_inv", C.c_void_p),
     ]
+
+
+class Fp8Item(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("ld", C.c_int), ("rows", C.c_int), ("cols", C.c_int), ("rows_pad", C.c_int),
+                ("q", C.c_void_p), ("ldq", C.c_int), ("qT", C.c_void_p), ("ldqT", C.c_int), ("state", C.c_void_p), ("fmt", C.c_int)]
 
 
 class ColsumItem(C.Structure):
@@ -55,6 +62,8 @@ _SIGS = {
     "mic_last_error": ([], C.c_char_p),
     "mic_gemm": ([C.POINTER(GemmArgs), _p], C.c_int),
     "mic_gemm_grouped": ([C.POINTER(GemmArgs), _i, _p], C.c_int),
+    "mic_fp8_amax": ([C.POINTER(Fp8Item), _i, _p], C.c_int),
+    "mic_fp8_quantize": ([C.POINTER(Fp8Item), _i, _p], C.c_int),
     "mic_sum_slabs": ([_i, _i, C.c_longlong, _i, _i, _p, _i, _p, _i, _p], C.c_int),
     "mic_layernorm_fwd": ([_i, _i, _i, _p, _p, _p, _f, _p, _p, _p, _f, _u32, _p], C.c_int),
     "mic_layernorm_bwd": ([_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _u32, _f, _u32, _p], C.c_int),

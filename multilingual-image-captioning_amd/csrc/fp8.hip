@@ -1,0 +1,156 @@
+// fp8.hip — per-tensor-scaled OCP fp8 quantisation for the fp8 GEMM path (BASELINE configs[4]: QKV / FFN projections of the
+// ViT and the mBART decoder in fp8, fp32 accumulate).  The reference has no counterpart (its compute dtypes are fp32 / fp16 /
+// bf16, main.py:96-101, applied at main.py:425); the recipe is the usual one for fp8 training: e4m3 for activations and
+// weights, e5m2 for gradients, one scale per tensor taken from that tensor's CURRENT absolute maximum.
+//
+//   mic_fp8_amax      state[0] = max |x| over the valid region (atomic max on the float bits; caller zeroes state)
+//   mic_fp8_quantize  scale = FMAX / amax;  q[r][c] = fp8(x[r][c] * scale)  (row-major, k-contiguous for  x W^T  /  dy W)
+//                     qT[c][r] = the same bytes transposed, rows zero-padded to rows_pad (k-contiguous for  dy^T x : both
+//                     operands of the weight-gradient GEMM reduce over the row index);  state[1] = amax / FMAX, the
+//                     dequantisation factor the GEMM epilogue multiplies back (mic_gemm_args.a_scale_inv / b_scale_inv).
+// Both are table-driven (up to 8 tensors per launch): the 84 weight matrices are re-quantised once per optimizer step in a
+// handful of launches.  HBM-bound: 2 B read twice, 1 B written twice per element.
+#include "common.h"
+
+#define QMAX_ITEMS 8
+struct QItem {
+  const uint16_t* src; int ld;       // bf16 [rows][ld]
+  int rows, cols, rows_pad;
+  uint8_t* q; int ldq;               // [rows][ldq] or null
+  uint8_t* qT; int ldqT;             // [cols][ldqT >= rows_pad] or null
+  float* state;                      // [0] amax, [1] 1/scale
+  int fmt;                           // MIC_E4M3 / MIC_E5M2
+  int tiles_c, block_begin;
+};
+struct QTable { int count; int total_blocks; QItem it[QMAX_ITEMS]; };
+
+__device__ __forceinline__ const QItem& pick_item(const QTable& t, int bid, int& local) {
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < QMAX_ITEMS; ++i)
+    if (i < t.count && bid >= t.it[i].block_begin) pi = i;
+  local = bid - t.it[pi].block_begin;
+  return t.it[pi];
+}
+
+// one 64 x 64 tile per 256-thread block: thread t covers 8 columns (t & 7) of rows (t >> 3) and (t >> 3) + 32
+__global__ __launch_bounds__(256) void fp8_amax_kernel(QTable tab) {
+  int local;
+  const QItem& I = pick_item(tab, blockIdx.x, local);
+  const int tr = local / I.tiles_c, tc = local % I.tiles_c;
+  const int tid = threadIdx.x;
+  float m = 0.f;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int r = tr * 64 + h * 32 + (tid >> 3), c = tc * 64 + (tid & 7) * 8;
+    if (r < I.rows && c < I.cols) {
+      float v[8];
+      ld8(I.src + (size_t)r * I.ld + c, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) m = fmaxf(m, (c + e < I.cols) ? fabsf(v[e]) : 0.f);
+    }
+  }
+  m = wave_max(m);
+  if ((tid & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<int*>(I.state), __float_as_int(m));  // non-negative floats order as ints
+}
+
+__device__ __forceinline__ uint32_t cvt4(const float* v, int fmt) {  // 4 floats -> 4 fp8 bytes (RNE, OCP encodings on gfx950)
+  int w = 0;
+  if (fmt == MIC_E4M3) {
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+  } else {
+    w = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], w, false);
+    w = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], w, true);
+  }
+  return (uint32_t)w;
+}
+
+__global__ __launch_bounds__(256) void fp8_quantize_kernel(QTable tab) {
+  __shared__ __attribute__((aligned(16))) uint8_t tile[64][80];  // [col][row], 80-byte pitch: 16-B aligned rows of 64 bytes
+  int local;
+  const QItem& I = pick_item(tab, blockIdx.x, local);
+  const int tr = local / I.tiles_c, tc = local % I.tiles_c;
+  const int tid = threadIdx.x;
+  const float fmax = I.fmt == MIC_E4M3 ? 448.0f : 57344.0f;
+  const float amax = I.state[0];
+  const float scale = amax > 0.f ? fmax / amax : 1.0f;
+  if (local == 0 && tid == 0) I.state[1] = amax > 0.f ? amax / fmax : 1.0f;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int rl = h * 32 + (tid >> 3), cl = (tid & 7) * 8;
+    const int r = tr * 64 + rl, c = tc * 64 + cl;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (r < I.rows && c < I.cols) {
+      ld8(I.src + (size_t)r * I.ld + c, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (c + e < I.cols) ? fminf(fmaxf(v[e] * scale, -fmax), fmax) : 0.f;
+    }
+    const uint32_t lo = cvt4(v, I.fmt), hi = cvt4(v + 4, I.fmt);
+    if (I.q && r < I.rows && c < I.cols) *reinterpret_cast<uint2*>(I.q + (size_t)r * I.ldq + c) = make_uint2(lo, hi);
+    if (I.qT) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        tile[cl + e][rl] = (uint8_t)(lo >> (8 * e));
+        tile[cl + 4 + e][rl] = (uint8_t)(hi >> (8 * e));
+      }
+    }
+  }
+  if (!I.qT) return;
+  __syncthreads();
+  // transposed store: thread t writes 16 consecutive rows (t & 3) of column t >> 2
+  const int cl = tid >> 2, r0 = (tid & 3) * 16;
+  const int c = tc * 64 + cl, r = tr * 64 + r0;
+  if (c < I.cols && r < I.rows_pad)
+    *reinterpret_cast<uint4*>(I.qT + (size_t)c * I.ldqT + r) = *reinterpret_cast<const uint4*>(&tile[cl][r0]);
+}
+
+static int build_table(const mic_fp8_item* items, int n, QTable& t, bool need_out) {
+  t.count = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const mic_fp8_item& s = items[i];
+    MIC_CHECK(s.src && s.state && s.rows > 0 && s.cols > 0 && s.ld >= s.cols, "mic_fp8: bad item %d", i);
+    MIC_CHECK(s.cols % 8 == 0 && s.ld % 8 == 0 && ((uintptr_t)s.src & 15) == 0, "mic_fp8: cols / ld must be multiples of 8, src 16-B aligned");
+    MIC_CHECK(s.fmt == MIC_E4M3 || s.fmt == MIC_E5M2, "mic_fp8: bad format");
+    const int rows_pad = s.rows_pad > s.rows ? s.rows_pad : s.rows;
+    if (need_out) {
+      MIC_CHECK(s.q || s.qT, "mic_fp8_quantize: item %d has no output", i);
+      MIC_CHECK(!s.q || (s.ldq >= s.cols && s.ldq % 8 == 0 && ((uintptr_t)s.q & 7) == 0), "mic_fp8_quantize: bad q layout");
+      MIC_CHECK(!s.qT || (rows_pad % 16 == 0 && s.ldqT >= rows_pad && s.ldqT % 16 == 0 && ((uintptr_t)s.qT & 15) == 0),
+                "mic_fp8_quantize: qT needs rows_pad %% 16 == 0, ldqT %% 16 == 0");
+    }
+    QItem& d = t.it[i];
+    d.src = (const uint16_t*)s.src; d.ld = s.ld; d.rows = s.rows; d.cols = s.cols; d.rows_pad = rows_pad;
+    d.q = (uint8_t*)s.q; d.ldq = s.ldq; d.qT = (uint8_t*)s.qT; d.ldqT = s.ldqT; d.state = s.state; d.fmt = s.fmt;
+    d.tiles_c = (s.cols + 63) / 64;
+    d.block_begin = blocks;
+    blocks += ((need_out && s.qT ? rows_pad : s.rows) + 63) / 64 * d.tiles_c;
+  }
+  t.total_blocks = blocks;
+  return MIC_OK;
+}
+
+extern "C" int mic_fp8_amax(const mic_fp8_item* items, int count, void* stream) {
+  MIC_CHECK(items && count >= 1, "mic_fp8_amax: bad args");
+  for (int i = 0; i < count; i += QMAX_ITEMS) {
+    QTable t;
+    const int n = count - i < QMAX_ITEMS ? count - i : QMAX_ITEMS;
+    if (int rc = build_table(items + i, n, t, false)) return rc;
+    hipLaunchKernelGGL(fp8_amax_kernel, dim3(t.total_blocks), dim3(256), 0, (hipStream_t)stream, t);
+  }
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}
+
+extern "C" int mic_fp8_quantize(const mic_fp8_item* items, int count, void* stream) {
+  MIC_CHECK(items && count >= 1, "mic_fp8_quantize: bad args");
+  for (int i = 0; i < count; i += QMAX_ITEMS) {
+    QTable t;
+    const int n = count - i < QMAX_ITEMS ? count - i : QMAX_ITEMS;
+    if (int rc = build_table(items + i, n, t, true)) return rc;
+    hipLaunchKernelGGL(fp8_quantize_kernel, dim3(t.total_blocks), dim3(256), 0, (hipStream_t)stream, t);
+  }
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}

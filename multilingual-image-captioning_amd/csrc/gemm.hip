@@ -34,6 +34,9 @@
 #include "common.h"
 
 #define MAX_PROBLEMS 8
+#ifndef MIC_EPI_DIRECT
+#define MIC_EPI_DIRECT 1  // 1: accumulators kept TRANSPOSED (lane <-> output row), stored straight from registers; 0: LDS restage
+#endif
 #ifndef MIC_TINY_BELOW
 #define MIC_TINY_BELOW 128  // 128x128-tile count under which a launch uses 64x64 tiles (tools/bench_tile_cfg.py)
 #endif
@@ -44,6 +47,7 @@ struct Problem {
   int tiles_m, tiles_n, block_begin, nsplit;
   float* a_rowsum; int rowsum_k;
   long long split_stride;
+  const float* sa; const float* sb;  // fp8: device scalars, the operands' dequantisation factors (1 / quantisation scale)
   EpiArgs epi;
 };
 struct LaunchTable { int count; int total_blocks; Problem p[MAX_PROBLEMS]; };
@@ -127,6 +131,21 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int xb, int kk
   }
 }
 
+// fp8 operands (OCP e4m3 / e5m2, one byte per element) ride the SAME k-contiguous LDS image: a 128-B row is 128 k instead of
+// 64, and one v_mfma_scale_f32_32x32x64_f8f6f4 takes 32 bytes per lane = two 16-B chunks.  Lane l reads row xb + (l & 31),
+// chunks 4*mm + 2*(l >> 5) and the next one.  Which k a (lane half, byte) slot means inside the instruction is irrelevant
+// as long as A and B are loaded by the same rule (the contraction is a sum over matching slots).
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ i32x8 read_frag8(const char* lds_tile, int xb, int mm, int lane) {
+  const int row = xb + (lane & 31);
+  const int kc = mm * 4 + 2 * (lane >> 5);
+  const int sw = (row >> 1) & 7;
+  const u32x4 lo = *reinterpret_cast<const u32x4*>(lds_tile + row * 128 + (((kc) ^ sw) << 4));
+  const u32x4 hi = *reinterpret_cast<const u32x4*>(lds_tile + row * 128 + (((kc + 1) ^ sw) << 4));
+  i32x8 r = {(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+  return r;
+}
+
 __device__ __forceinline__ void tile_coords(int lid, int tiles_m, int tiles_n, int& tm, int& tn) {
   const int GROUP_M = 8;  // GROUP_M-tall column panels
   const int per_group = GROUP_M * tiles_n;
@@ -153,8 +172,12 @@ __device__ __forceinline__ void tile_coords(int lid, int tiles_m, int tiles_n, i
 // PLAIN: every problem of the launch has the bare epilogue (C = dropout(alpha*acc + bias) + residual, bf16 or fp32, no
 //   activation / Z / accumulate / split): the store loop is then two ds_read_b128, four v_cvt_pk_bf16_f32 and one 16-B
 //   store per group, without the per-group feature tests of the generic path.
-template <int WM, int WN, int WNW, int BKT, bool AK, bool BKM, int KG = 1, bool PLAIN = false>
+// F8: 0 = bf16 operands; 1 = fp8 e4m3 x e4m3 (forward); 2 = A e5m2 x B e4m3 (gradients x weights / saved activations).
+//   fp8 launches are NT only (both operands k-contiguous: the quantiser writes a transposed copy where one is needed); all
+//   sizes below stay in 2-byte units (K, lda, ldb = bytes / 2), so the staging code is shared.
+template <int WM, int WN, int WNW, int BKT, bool AK, bool BKM, int KG = 1, bool PLAIN = false, int F8 = 0>
 __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kernel(LaunchTable tab) {
+  static_assert(F8 == 0 || (!AK && !BKM && BKT == 64), "fp8: k-contiguous operands, 128-byte stages");
   constexpr int BM = 2 * WM, BN = WN * WNW, NWAVES = 2 * WNW, NTHREADS = 64 * NWAVES * KG;
   constexpr int UA = BM < 128 ? BM : 128, UB = BN < 128 ? BN : 128;  // rows per staged image (128, or 64 for the 64-wide tiles)
   constexpr int HALF_A = UA * BKT * 2, HALF_B = UB * BKT * 2;
@@ -249,6 +272,31 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
       const char* cur = gsm + (t & 1) * STAGE;
       const char* At = cur + a_half * HALF_A;
       const char* Bt = cur + NHA * HALF_A + b_half * HALF_B;
+      if constexpr (F8 != 0) {
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) {  // two K = 64 MFMAs per 128-byte stage
+          if (mm == 0 && t + 1 < nk) {
+            write_lds(gsm + ((t + 1) & 1) * STAGE);
+            if (t + 2 < nk) load_regs(t + 2);
+          }
+          i32x8 a8[AI], b8[NJ];
+#pragma unroll
+          for (int i = 0; i < AI; ++i) a8[i] = read_frag8(At, a_off + i * 32, mm, lane);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) b8[j] = read_frag8(Bt, b_off + j * 32, mm, lane);
+#pragma unroll
+          for (int i = 0; i < AI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#if MIC_EPI_DIRECT
+              acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8[j], a8[i], acc[i][j], 0, F8 == 2 ? 1 : 0, 0, 0x7f7f7f7f, 0,
+                                                                          0x7f7f7f7f);  // transposed product: first operand = B (e4m3)
+#else
+              acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i], b8[j], acc[i][j], F8 == 2 ? 1 : 0, 0, 0, 0x7f7f7f7f, 0,
+                                                                          0x7f7f7f7f);  // cbsz/blgp: 0 = e4m3, 1 = e5m2; scales 2^0
+#endif
+        }
+      } else {
 #pragma unroll
       for (int kk = 0; kk < KSTEPS; ++kk) {
         if (kk == STAGE_AT && t + 1 < nk) {
@@ -278,7 +326,14 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
 #pragma unroll
         for (int i = 0; i < AI; ++i)
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NJ; ++j) {
+#if MIC_EPI_DIRECT
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // (A B^T)^T: lane <-> row of C
+#else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+#endif
+          }
+      }
       }
     }
     __syncthreads();
@@ -328,6 +383,119 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
   EpiArgs E = P.epi;
   const bool is_split = P.nsplit > 1;
   const long long split_stride = P.split_stride;
+#if MIC_EPI_DIRECT
+  // Direct epilogue.  The main loop accumulated the TRANSPOSED product (first MFMA operand = B fragment), so in a 32x32
+  // accumulator block lane l owns output ROW (l & 31) and its 16 registers are the columns 8*(r>>2) + 4*(l>>5) + (r&3): four
+  // runs of 4 consecutive columns.  One v_permlane32_swap per register pair (runs 2p and 2p+1 of the two half-waves) turns
+  // them into 8 consecutive columns per lane — lanes 0-31: columns 16p..16p+7, lanes 32-63: 16p+8..16p+15 — which is exactly
+  // the (row, 8 columns) unit the fused epilogue works in: bias / activation / dropout / residual / Z / C all move as 16-B
+  // vectors straight from and to registers.  No LDS restage (it cost 5.4k cycles of a 30k-cycle 128x128 launch and 18k of a
+  // 256x256 tile: ds_write_b32 of every accumulator, two barriers per pass, a second pass of reads).
+  {
+    float alpha = E.alpha;
+    if constexpr (F8 != 0) alpha *= (P.sa ? *P.sa : 1.0f) * (P.sb ? *P.sb : 1.0f);  // dequantise: per-tensor scales of the two operands
+    const bool has_b = E.bias && !is_split;
+    const bool b_vec = has_b && (((uintptr_t)E.bias & 15) == 0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      float bj[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wc * WN + j * 32 + 8 * g + 4 * (lane >> 5);
+        if (b_vec && n + 4 <= N) {
+          const float4 t = *reinterpret_cast<const float4*>(E.bias + n);
+          bj[4 * g] = t.x; bj[4 * g + 1] = t.y; bj[4 * g + 2] = t.z; bj[4 * g + 3] = t.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bj[4 * g + e] = (has_b && n + e < N) ? E.bias[n + e] : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < AI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * alpha + bj[r];
+    }
+    E.alpha = 1.0f;
+    E.bias = nullptr;
+  }
+  if (kg == 0) {
+    const bool pre = !is_split && epilogue_pre_ok(E) && epilogue_vec_ok(E, 8);
+    const bool has_r = E.R != nullptr;
+    const int hh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int m = m0 + wr * WM + i * 32 + (lane & 31);
+      constexpr int NG = NJ * 2;  // (row, 8 columns) groups of this lane in row block i
+      u32x4 zq[NG], rq[NG];
+#pragma unroll
+      for (int q = 0; q < NG; ++q) {  // side operands of the whole row block first: their latency overlaps the swaps
+        const int n = n0 + wc * WN + (q >> 1) * 32 + 16 * (q & 1) + 8 * hh;
+        zq[q] = rq[q] = u32x4{0u, 0u, 0u, 0u};
+        if (m < M && n + 8 <= N) {
+          if constexpr (PLAIN) {
+            if (has_r) rq[q] = *reinterpret_cast<const u32x4*>((const uint16_t*)E.R + (size_t)m * E.ldr + n);
+          } else {
+            if (pre) epilogue_prefetch8(E, m, n, zq[q], rq[q]);
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NG; ++q) {
+        const int j = q >> 1, p = q & 1;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {  // every lane takes part in the exchange, also those whose row / columns are out of range
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][8 * p + e]), __float_as_uint(acc[i][j][8 * p + 4 + e]), false, false);
+          v[e] = __uint_as_float(sw[0]);
+          v[4 + e] = __uint_as_float(sw[1]);
+        }
+        const int n = n0 + wc * WN + j * 32 + 16 * p + 8 * hh;
+        if (m >= M || n >= N) continue;
+        const int cnt = min(8, N - n);
+        if constexpr (PLAIN) {
+          if (E.drop_thr) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              v[e] = dropout_keep(E.drop_seed, (uint32_t)m * (uint32_t)E.N + (uint32_t)(n + e), E.drop_thr) ? v[e] * E.drop_scale : 0.0f;
+          }
+          if (cnt == 8) {  // host side guarantees 16-B alignment of the C (and R) rows for PLAIN launches
+            if (has_r) {
+              float r[8];
+              unpack8(rq[q], r);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += r[e];
+            }
+            if (E.c_f32) st8((float*)E.C + (size_t)m * E.ldc + n, v);
+            else st8((uint16_t*)E.C + (size_t)m * E.ldc + n, v);
+          } else {
+            for (int e = 0; e < cnt; ++e) {
+              float x = v[e];
+              if (has_r) x += bf2f(((const uint16_t*)E.R)[(size_t)m * E.ldr + n + e]);
+              if (E.c_f32) ((float*)E.C)[(size_t)m * E.ldc + n + e] = x;
+              else ((uint16_t*)E.C)[(size_t)m * E.ldc + n + e] = f2bf(x);
+            }
+          }
+        } else {
+          if (is_split) {  // split-K: fp32 atomic accumulation into a zero-initialised C, or a plain store into this split's slab
+            float* c = (float*)E.C + (size_t)m * E.ldc + n;
+            if (split_stride > 0) {
+              c += (size_t)split * (size_t)split_stride;
+              if (cnt == 8 && (E.ldc & 3) == 0) st8(c, v);
+              else for (int e = 0; e < cnt; ++e) c[e] = v[e];
+            } else {
+              for (int e = 0; e < cnt; ++e) atomicAdd(c + e, v[e]);
+            }
+          } else if (pre && cnt == 8) {
+            epilogue_store8_pre(E, m, n, v, zq[q], rq[q]);
+          } else {
+            epilogue_store8<uint16_t>(E, m, n, v, cnt);
+          }
+        }
+      }
+    }
+  }
+}
+#else
   {
     float bj[NJ];
 #pragma unroll
@@ -335,7 +503,8 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
       const int n = n0 + wc * WN + j * 32 + (lane & 31);
       bj[j] = (E.bias && !is_split && n < N) ? E.bias[n] : 0.0f;
     }
-    const float alpha = E.alpha;
+    float alpha = E.alpha;
+    if constexpr (F8 != 0) alpha *= (P.sa ? *P.sa : 1.0f) * (P.sb ? *P.sb : 1.0f);  // dequantise: per-tensor scales of the two operands
 #pragma unroll
     for (int i = 0; i < AI; ++i)
 #pragma unroll
@@ -457,6 +626,7 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
     }
   }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------ f32
 // A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn].  64x64 tile, BK = 16, 4 waves each a 32x32 block.
@@ -509,7 +679,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 static int fill_epi(const mic_gemm_args* a, EpiArgs& e) {
   MIC_CHECK(a && a->A && a->B && a->C, "mic_gemm: null pointer");
   MIC_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "mic_gemm: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
-  MIC_CHECK(a->dtype == MIC_BF16 || a->dtype == MIC_F32, "mic_gemm: bad dtype %d", a->dtype);
+  MIC_CHECK(a->dtype == MIC_BF16 || a->dtype == MIC_F32 || a->dtype == MIC_FP8, "mic_gemm: bad dtype %d", a->dtype);
+  if (a->dtype == MIC_FP8) {
+    MIC_CHECK(a->c_dtype == MIC_BF16 || a->c_dtype == MIC_F32, "mic_gemm(fp8): C is bf16 or f32");
+    MIC_CHECK(!a->a_kmajor && !a->b_kmajor, "mic_gemm(fp8): both operands must be k-contiguous (mic_fp8_quantize writes the transposed copies)");
+    MIC_CHECK((a->a_fmt == MIC_E4M3 || a->a_fmt == MIC_E5M2) && a->b_fmt == MIC_E4M3, "mic_gemm(fp8): A is e4m3 or e5m2, B is e4m3");
+    MIC_CHECK(a->K % 128 == 0, "mic_gemm(fp8): K=%d must be a multiple of 128 (zero-pad the reduction dim)", a->K);
+    MIC_CHECK(a->lda % 16 == 0 && a->ldb % 16 == 0, "mic_gemm(fp8): lda/ldb must be multiples of 16 bytes");
+    MIC_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->B & 15) == 0, "mic_gemm(fp8): A/B must be 16-B aligned");
+    MIC_CHECK(a->split_k <= 1 && !a->a_rowsum, "mic_gemm(fp8): no split-K / row sums on the fp8 path");
+  } else
   MIC_CHECK(a->c_dtype == a->dtype || a->c_dtype == MIC_F32, "mic_gemm: c_dtype must be dtype or f32");
   MIC_CHECK(!(a->dact && !a->Zin), "mic_gemm: dact needs Zin");
   MIC_CHECK(a->dropout_p >= 0.f && a->dropout_p < 1.f, "mic_gemm: dropout_p out of range");
@@ -532,7 +711,7 @@ static int fill_epi(const mic_gemm_args* a, EpiArgs& e) {
   return MIC_OK;
 }
 
-template <int WM, int WN, int WNW, int BKT, int KG, bool PLAIN>
+template <int WM, int WN, int WNW, int BKT, int KG, bool PLAIN, int F8 = 0>
 static void launch_cfg_p(const LaunchTable& tab, int akm, int bkm, hipStream_t s) {
   constexpr int BM = 2 * WM, BN = WN * WNW;
   size_t lds = (size_t)KG * 2 * (BM + BN) * BKT * 2;
@@ -545,16 +724,20 @@ static void launch_cfg_p(const LaunchTable& tab, int akm, int bkm, hipStream_t s
   do {                                                                                                                     \
     static bool attr_set = false; /* per instantiation; lds is a compile-time constant of it */                          \
     if (lds > 65536 && !attr_set) {                                                                                        \
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WN, WNW, BKT, AKM, BKMM, KG, PLAIN>),        \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WN, WNW, BKT, AKM, BKMM, KG, PLAIN, F8>),    \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                           \
       attr_set = true;                                                                                                     \
     }                                                                                                                      \
-    hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, WNW, BKT, AKM, BKMM, KG, PLAIN>), grid, block, lds, s, tab);                     \
+    hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, WNW, BKT, AKM, BKMM, KG, PLAIN, F8>), grid, block, lds, s, tab);                 \
   } while (0)
-  if (!akm && !bkm) LAUNCH(false, false);
-  else if (!akm && bkm) LAUNCH(false, true);
-  else if (akm && bkm) LAUNCH(true, true);
-  else LAUNCH(true, false);
+  if constexpr (F8 != 0) {
+    LAUNCH(false, false);
+  } else {
+    if (!akm && !bkm) LAUNCH(false, false);
+    else if (!akm && bkm) LAUNCH(false, true);
+    else if (akm && bkm) LAUNCH(true, true);
+    else LAUNCH(true, false);
+  }
 #undef LAUNCH
 }
 
@@ -568,14 +751,22 @@ static bool table_is_plain(const LaunchTable& t) {
   return true;
 }
 template <int WM, int WN, int WNW, int BKT, int KG = 1>
-static void launch_cfg(const LaunchTable& tab, int akm, int bkm, hipStream_t s) {
-  if (table_is_plain(tab)) launch_cfg_p<WM, WN, WNW, BKT, KG, true>(tab, akm, bkm, s);
+static void launch_cfg(const LaunchTable& tab, int akm, int bkm, hipStream_t s, int f8 = 0) {
+  const bool plain = table_is_plain(tab);
+  if (f8 == 1) {
+    if (plain) launch_cfg_p<WM, WN, WNW, BKT, KG, true, 1>(tab, 0, 0, s);
+    else launch_cfg_p<WM, WN, WNW, BKT, KG, false, 1>(tab, 0, 0, s);
+  } else if (f8 == 2) {
+    if (plain) launch_cfg_p<WM, WN, WNW, BKT, KG, true, 2>(tab, 0, 0, s);
+    else launch_cfg_p<WM, WN, WNW, BKT, KG, false, 2>(tab, 0, 0, s);
+  } else if (plain) launch_cfg_p<WM, WN, WNW, BKT, KG, true>(tab, akm, bkm, s);
   else launch_cfg_p<WM, WN, WNW, BKT, KG, false>(tab, akm, bkm, s);
 }
 
 static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
   LaunchTable tab;
   tab.count = count;
+  const int f8 = args[0].dtype == MIC_FP8 ? (args[0].a_fmt == MIC_E5M2 ? 2 : 1) : 0;
   long tiles_big = 0, tiles_small = 0;
   for (int i = 0; i < count; ++i) {
     const int sp = args[i].split_k > 1 ? args[i].split_k : 1;
@@ -593,10 +784,16 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
   for (int i = 0; i < count; ++i) {
     Problem& p = tab.p[i];
     if (int rc = fill_epi(&args[i], p.epi)) return rc;
-    MIC_CHECK(args[i].a_kmajor == args[0].a_kmajor && args[i].b_kmajor == args[0].b_kmajor && args[i].dtype == MIC_BF16,
-              "mic_gemm_grouped: all problems of a group must share dtype (bf16) and operand layouts");
+    MIC_CHECK(args[i].a_kmajor == args[0].a_kmajor && args[i].b_kmajor == args[0].b_kmajor && args[i].dtype == args[0].dtype &&
+                  (args[i].dtype == MIC_BF16 || (args[i].dtype == MIC_FP8 && args[i].a_fmt == args[0].a_fmt)),
+              "mic_gemm_grouped: all problems of a group must share dtype (bf16 / fp8 format) and operand layouts");
     p.A = (const uint16_t*)args[i].A; p.B = (const uint16_t*)args[i].B;
     p.lda = args[i].lda; p.ldb = args[i].ldb; p.M = args[i].M; p.N = args[i].N; p.K = args[i].K;
+    p.sa = p.sb = nullptr;
+    if (f8) {  // the kernel counts K and the leading dimensions in 2-byte units
+      p.lda /= 2; p.ldb /= 2; p.K /= 2;
+      p.sa = args[i].a_scale_inv; p.sb = args[i].b_scale_inv;
+    }
     p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bm - 1) / bm;
     p.nsplit = args[i].split_k > 1 ? args[i].split_k : 1;
     if (p.nsplit > p.K / 64) p.nsplit = p.K / 64;
@@ -610,15 +807,15 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
     blocks += p.tiles_m * p.tiles_n * p.nsplit;
   }
   tab.total_blocks = blocks;
-  if (bm == 256) launch_cfg<128, 64, 4, 64>(tab, args[0].a_kmajor, args[0].b_kmajor, s);     // 256x256x64, 8 waves
+  if (bm == 256) launch_cfg<128, 64, 4, 64>(tab, args[0].a_kmajor, args[0].b_kmajor, s, f8);     // 256x256x64, 8 waves
   else if (bm == 128) {  // 128x128x64, 8 waves (measured better than the 4-wave 64x64 wave tile at every tile count);
                          // two K-groups (16 waves) when the launch is a single round of at most one block per CU
     static const int kg128 = [] { const char* e = getenv("MIC_GEMM_KG128"); return e ? atoi(e) : -1; }();
     int kmin = 1 << 30;
     for (int i = 0; i < count; ++i) kmin = tab.p[i].K / 64 / tab.p[i].nsplit < kmin ? tab.p[i].K / 64 / tab.p[i].nsplit : kmin;
     const bool two = kg128 >= 0 ? kg128 == 2 : (blocks <= 256 && kmin >= 8);
-    if (two) launch_cfg<64, 32, 4, 64, 2>(tab, args[0].a_kmajor, args[0].b_kmajor, s);
-    else launch_cfg<64, 32, 4, 64>(tab, args[0].a_kmajor, args[0].b_kmajor, s);
+    if (two) launch_cfg<64, 32, 4, 64, 2>(tab, args[0].a_kmajor, args[0].b_kmajor, s, f8);
+    else launch_cfg<64, 32, 4, 64>(tab, args[0].a_kmajor, args[0].b_kmajor, s, f8);
   }
   else {  // 64x64x64 tiles, 4 waves per K-group; K-groups while the grid leaves CUs under-occupied
     static const int kg_force = [] { const char* e = getenv("MIC_GEMM_KG"); return e ? atoi(e) : 0; }();
@@ -626,9 +823,9 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
     for (int i = 0; i < count; ++i) kmin = tab.p[i].K / 64 / tab.p[i].nsplit < kmin ? tab.p[i].K / 64 / tab.p[i].nsplit : kmin;
     int kgs = blocks <= 256 && kmin >= 16 ? 4 : (blocks <= 512 && kmin >= 8 ? 2 : 1);
     if (kg_force == 1 || kg_force == 2 || kg_force == 4) kgs = kg_force;
-    if (kgs == 4) launch_cfg<32, 32, 2, 64, 4>(tab, args[0].a_kmajor, args[0].b_kmajor, s);
-    else if (kgs == 2) launch_cfg<32, 32, 2, 64, 2>(tab, args[0].a_kmajor, args[0].b_kmajor, s);
-    else launch_cfg<32, 32, 2, 64>(tab, args[0].a_kmajor, args[0].b_kmajor, s);
+    if (kgs == 4) launch_cfg<32, 32, 2, 64, 4>(tab, args[0].a_kmajor, args[0].b_kmajor, s, f8);
+    else if (kgs == 2) launch_cfg<32, 32, 2, 64, 2>(tab, args[0].a_kmajor, args[0].b_kmajor, s, f8);
+    else launch_cfg<32, 32, 2, 64>(tab, args[0].a_kmajor, args[0].b_kmajor, s, f8);
   }
   MIC_LAUNCH_CHECK();
   return MIC_OK;
@@ -637,7 +834,7 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
 extern "C" int mic_gemm(const mic_gemm_args* a, void* stream) {
   MIC_CHECK(a, "mic_gemm: null args");
   hipStream_t s = (hipStream_t)stream;
-  if (a->dtype == MIC_BF16) return launch_bf16(a, 1, s);
+  if (a->dtype == MIC_BF16 || a->dtype == MIC_FP8) return launch_bf16(a, 1, s);
   EpiArgs e;
   if (int rc = fill_epi(a, e)) return rc;
   MIC_CHECK(a->split_k <= 1, "mic_gemm(f32): split_k is a bf16-path feature");
@@ -654,7 +851,7 @@ extern "C" int mic_gemm(const mic_gemm_args* a, void* stream) {
 extern "C" int mic_gemm_grouped(const mic_gemm_args* args, int count, void* stream) {
   MIC_CHECK(args && count >= 1, "mic_gemm_grouped: bad args");
   hipStream_t s = (hipStream_t)stream;
-  if (args[0].dtype != MIC_BF16) {  // parity mode: plain sequence
+  if (args[0].dtype != MIC_BF16 && args[0].dtype != MIC_FP8) {  // parity mode: plain sequence
     for (int i = 0; i < count; ++i)
       if (int rc = mic_gemm(&args[i], stream)) return rc;
     return MIC_OK;

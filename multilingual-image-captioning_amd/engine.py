@@ -44,14 +44,80 @@ class Engine:
         self.embed_rows = None     # (ids, dh0 buffer, M) of the last backward when deferred
         self._dw_queue = []
         self._cs_queue = []
+        self.fp8 = False
         self.grad_progress = None  # callable(offset): every gradient with flat offset < offset is final (DDP overlap)
 
+    # ------------------------------------------------------------------ fp8 GEMM operands (BASELINE configs[4])
+    FP8_KINDS = ("qkv", "cq", "ckv", "fc1", "fc2")  # the QKV and FFN projections of both towers; out-projections and the head stay bf16
+
     def set_gemm_dtype(self, name):
-        """"fp8": the QKV / FFN projections (BASELINE configs[4]) run as OCP fp8 GEMMs; None / "bf16": storage dtype."""
+        """"fp8": the QKV / FFN projections run as OCP fp8 GEMMs — e4m3 activations and weights, e5m2 gradients, per-tensor
+        current scaling, fp32 accumulate (forward, dX and dW).  None / "bf16": the storage dtype."""
         if name in (None, "bf16", "bfloat16", "f32", "float32"):
             self.fp8 = False
             return
-        raise ValueError(f"unknown gemm_dtype {name!r}")
+        if name != "fp8":
+            raise ValueError(f"unknown gemm_dtype {name!r}")
+        if self.dt != torch.bfloat16:
+            raise ValueError("gemm_dtype='fp8' needs the bfloat16 storage mode (dtype=bfloat16)")
+        P = self.P
+        self.fp8 = True
+        names = [f"dec{l}.{k}" for l in range(P.L) for k in self.FP8_KINDS] + [f"vit{l}.{k}" for l in range(P.vL) for k in ("qkv", "fc1", "fc2")]
+        self._w8 = {}
+        self._w8_state = torch.zeros((len(names), 2), dtype=torch.float32, device=self.dev)
+        for i, n in enumerate(names):
+            N, K = P.w(n + ".w").shape
+            self._w8[n] = (torch.empty((N, K), dtype=torch.float8_e4m3fn, device=self.dev),   # [out][in]: forward  x W^T
+                           torch.empty((K, N), dtype=torch.float8_e4m3fn, device=self.dev),   # [in][out]: dX = dy W
+                           self._w8_state[i])
+        self._w8_stale = True
+        self._a8_state = torch.zeros((4096, 2), dtype=torch.float32, device=self.dev)  # one (amax, 1/scale) slot per quantised activation
+        self._a8_slots: Dict[str, int] = {}
+        self._a8_cache: Dict = {}
+        self._dw8_queue = []
+
+    def fp8_weights_changed(self):
+        self._w8_stale = True
+
+    def _fp8_begin_pass(self):
+        """start of a forward(+backward) pass: re-quantise the weights if the optimizer moved them, clear the activation slots"""
+        if not self.fp8:
+            return
+        if self._w8_stale:
+            self._w8_state.zero_()
+            P = self.P
+            items = [ops.fp8_item(P.w(n + ".w"), q.shape[0], q.shape[1], st, torch.float8_e4m3fn, q=q, qT=qT) for n, (q, qT, st) in self._w8.items()]
+            ops.fp8_quantize(items)
+            self._w8_stale = False
+        self._a8_state.zero_()
+        self._a8_cache = {}
+
+    def _fp8_ok(self, wname: str) -> bool:
+        return self.fp8 and wname.split(".")[-1] in self.FP8_KINDS and wname in self._w8
+
+    def _a8_slot(self, tag: str) -> torch.Tensor:
+        i = self._a8_slots.get(tag)
+        if i is None:
+            i = self._a8_slots[tag] = len(self._a8_slots)
+            if i >= self._a8_state.shape[0]:
+                raise RuntimeError("fp8: out of activation scale slots")
+        return self._a8_state[i]
+
+    def _quant(self, x, rows: int, cols: int, tag: str, buf_tag: str, fmt, want_qT: bool, cache: bool):
+        """(q [rows][cols], qT [cols][rows_pad] or None, state) of bf16 x.  cache=True: x keeps its contents for the rest of the
+        pass (a saved per-layer activation, the encoder states every layer's cross-attention projects): quantised once."""
+        key = (x.data_ptr(), rows, cols, fmt)
+        hit = self._a8_cache.get(key) if cache else None
+        if hit is not None and (hit[1] is not None or not want_qT):
+            return hit
+        rp = _rup(rows, ROWPAD)
+        q = self.buf(buf_tag + ".q8", rows, cols, fmt)
+        qT = self.buf(buf_tag + ".q8T", cols, rp, fmt) if want_qT else None
+        st = self._a8_slot(tag)
+        ops.fp8_quantize([ops.fp8_item(x, rows, cols, st, fmt, q=q, qT=qT, rows_pad=rp)])
+        if cache:
+            self._a8_cache[key] = (q, qT, st)
+        return q, qT, st
 
     def _done(self, seg_name: str):
         """Report that the gradient segment `seg_name` (and, by layout order, everything before it) is final."""
@@ -82,15 +148,24 @@ class Engine:
         self._bufs.clear()
 
     # ------------------------------------------------------------------ small helpers
-    def linear(self, x, wname, out, M, *, act=0, zout=None, residual=None, drop_seed=None, bias=True):
+    def linear(self, x, wname, out, M, *, act=0, zout=None, residual=None, drop_seed=None, bias=True, save_tag=None, fp8=True,
+               stable_input=False):
+        """save_tag (fp8 mode, training forward): name under which the transposed fp8 copy of x is kept for the weight-gradient
+        GEMM of backward (dW = dy^T x reduces over rows: both operands must be row-contiguous)."""
         P = self.P
         w = P.w(wname + ".w")
         N, K = w.shape
         p = self.p_drop if drop_seed is not None else 0.0
+        if fp8 and self._fp8_ok(wname):
+            wq, _, ws = self._w8[wname]
+            xq, _, xs = self._quant(x, M, K, wname + ".x", (save_tag or "f8.") + wname.split(".")[-1] + ".x", torch.float8_e4m3fn,
+                                    want_qT=save_tag is not None, cache=save_tag is not None or stable_input)
+            return ops.gemm(xq, wq, out, M, N, K, bias=P.f32(wname + ".b") if bias else None, act=act, zout=zout, residual=residual,
+                            dropout_p=p, dropout_seed=drop_seed or 0, a_scale_inv=xs[1:], b_scale_inv=ws[1:])
         return ops.gemm(x, w, out, M, N, K, bias=P.f32(wname + ".b") if bias else None, act=act, zout=zout,
                         residual=residual, dropout_p=p, dropout_seed=drop_seed or 0)
 
-    def linear_bwd(self, wname, x, dy, M, *, dx=None, zin=None, dact=0, dx_accumulate=False, bias=True, defer=False):
+    def linear_bwd(self, wname, x, dy, M, *, dx=None, zin=None, dact=0, dx_accumulate=False, bias=True, defer=False, x_tag=True):
         """dW = dy^T x (fp32, overwrite), db = colsum(dy), optionally dx = (dy W) [* act'(zin)].
         defer=True queues the weight-gradient GEMM (nothing but the optimizer depends on it): the caller keeps dy and x
         intact until flush_dw() launches the layer's queue as ONE grouped GEMM (36..256-tile problems fill the chip
@@ -99,6 +174,30 @@ class Engine:
         w = P.w(wname + ".w")
         N, K = w.shape
         Mp = _rup(M, ROWPAD)
+        if self._fp8_ok(wname) and x_tag is not None:
+            # fp8: dy -> e5m2 (row-major for dX = dy W, transposed for dW = dy^T x); x^T was quantised in forward; W^T once per step
+            kind = wname.split(".")[0].rstrip("0123456789") + "." + wname.split(".")[-1]
+            dyq, dyqT, dys = self._quant(dy, M, N, wname + ".dy", "f8." + kind + ".dy", torch.float8_e5m2, want_qT=True, cache=False)
+            hit = self._a8_cache.get((x.data_ptr(), M, K, torch.float8_e4m3fn))
+            if hit is None or hit[1] is None:
+                raise RuntimeError(f"fp8 backward of {wname}: the forward pass did not keep x^T (save_tag missing)")
+            _, xqT, xs = hit
+            _, wqT, ws = self._w8[wname]
+            ga = ops.gemm_args(dyqT, xqT, P.g(wname + ".w"), N, K, Mp, a_scale_inv=dys[1:], b_scale_inv=xs[1:])
+            if defer:
+                self._dw8_queue.append((ga, wname, bias))
+            else:
+                ops.gemm_grouped([ga])
+            if bias:
+                if defer:
+                    self._cs_queue.append((dy, P.g(wname + ".b"), M, N, dy.stride(0)))
+                else:
+                    ops.colsum(dy, P.g(wname + ".b"), M, N, dy.stride(0), accumulate=True)
+            if dx is not None:
+                ops.gemm(dyq, wqT, dx, M, K, N, zin=zin, dact=dact, accumulate=dx_accumulate, a_scale_inv=dys[1:], b_scale_inv=ws[1:])
+            if not defer:
+                self._done(wname + ".w")
+            return dx
         # bf16: the bias gradient colsum(dy) rides on the dW GEMM (row sums of its A operand dy^T, from the fragments the
         # kernel already holds; fp32 atomics into the pre-zeroed atomic region).  fp32 mode keeps the separate column sum.
         fuse = bias and self.dt == torch.bfloat16
@@ -122,11 +221,18 @@ class Engine:
         if self._cs_queue:
             ops.colsum_grouped(self._cs_queue)
             self._cs_queue = []
+        names = []
+        if self.fp8 and self._dw8_queue:
+            ops.gemm_grouped([q[0] for q in self._dw8_queue])
+            names += [q[1] for q in self._dw8_queue]
+            self._dw8_queue = []
         if self._dw_queue:
             ops.gemm_grouped([q[0] for q in self._dw_queue])
-            _, wname, bias = self._dw_queue[-1]
+            names += [q[1] for q in self._dw_queue]
             self._dw_queue = []
-            self._done(wname + ".w")
+        if names:
+            # every queued gradient of the layer is in flight on this stream: report the one that sits last in the flat layout
+            self._done(max(names, key=lambda n: self.P.segs[n + ".w"].offset) + ".w")
 
     # ------------------------------------------------------------------ ViT
     def vit_forward(self, pixels: torch.Tensor, save: bool, trunc_int32: bool = False):
@@ -152,7 +258,7 @@ class Engine:
             st1 = self.buf(tag + "st1", 2, _rup(Mv, ROWPAD), torch.float32)
             ops.layernorm_fwd(x, P.f32(p + "ln1.g"), P.f32(p + "ln1.b"), self.vit_eps, a1, st1[0], st1[1], rows=Mv)
             qkv = self.buf(tag + "qkv", Mv, 3 * vd)
-            self.linear(a1, p + "qkv", qkv, Mv)
+            self.linear(a1, p + "qkv", qkv, Mv, save_tag=tag if save else None)
             ctx = self.buf(tag + "ctx", Mv, vd)
             lse = self.vec(tag + "lse", B * H * S)
             ops.attn_fwd(qkv, qkv[:, vd:], qkv[:, 2 * vd:], ctx, B, H, S, S, ldq=3 * vd, ldk=3 * vd, ldv=3 * vd, ldo=vd, lse=lse)
@@ -163,9 +269,9 @@ class Engine:
             ops.layernorm_fwd(xm, P.f32(p + "ln2.g"), P.f32(p + "ln2.b"), self.vit_eps, a2, st2[0], st2[1], rows=Mv)
             z = self.buf(tag + "z", Mv, vf)
             u = self.buf(tag + "u", Mv, vf)
-            self.linear(a2, p + "fc1", u, Mv, act=L.ACT_QUICK_GELU, zout=z)
+            self.linear(a2, p + "fc1", u, Mv, act=L.ACT_QUICK_GELU, zout=z, save_tag=tag if save else None)
             xo = self.buf(f"v{l}.xo" if save else f"v_.xo{l & 1}", Mv, vd)
-            self.linear(u, p + "fc2", xo, Mv, residual=xm)
+            self.linear(u, p + "fc2", xo, Mv, residual=xm, save_tag=tag if save else None)
             x = xo
         ehs = self.buf("v.ehs", Mv, P.d)
         self.linear(x, "vp", ehs, Mv)
@@ -242,7 +348,7 @@ class Engine:
             a = self.buf(tag + "a_sa", M, d)
             ops.layernorm_fwd(x, P.f32(p + "ln_sa.g"), P.f32(p + "ln_sa.b"), self.dec_eps, a, stats[0], stats[1], rows=M)
             qkv = self.buf(tag + "qkv", M, 3 * d)
-            self.linear(a, p + "qkv", qkv, M)
+            self.linear(a, p + "qkv", qkv, M, save_tag=tag if save else None)
             ctx = self.buf(tag + "ctx", M, d)
             lse = self.vec(tag + "lse", B * H * T)
             ops.attn_fwd(qkv, qkv[:, d:], qkv[:, 2 * d:], ctx, B, H, T, T, ldq=3 * d, ldk=3 * d, ldv=3 * d, ldo=d, key_mask=key_mask,
@@ -252,9 +358,9 @@ class Engine:
             a = self.buf(tag + "a_ca", M, d)
             ops.layernorm_fwd(x1, P.f32(p + "ln_ca.g"), P.f32(p + "ln_ca.b"), self.dec_eps, a, stats[2], stats[3], rows=M)
             q = self.buf(tag + "cq", M, d)
-            self.linear(a, p + "cq", q, M)
+            self.linear(a, p + "cq", q, M, save_tag=tag if save else None)
             kv = self.buf(tag + "ckv", Mv, 2 * d)
-            self.linear(ehs, p + "ckv", kv, Mv)
+            self.linear(ehs, p + "ckv", kv, Mv, save_tag="d.ehs." if save else None, stable_input=True)
             cctx = self.buf(tag + "cctx", M, d)
             clse = self.vec(tag + "clse", B * H * T)
             ops.attn_fwd(q, kv, kv[:, d:], cctx, B, H, T, S, ldq=d, ldk=2 * d, ldv=2 * d, ldo=d, lse=clse)
@@ -263,9 +369,9 @@ class Engine:
             a = self.buf(tag + "a_ff", M, d)
             ops.layernorm_fwd(x2, P.f32(p + "ln_ff.g"), P.f32(p + "ln_ff.b"), self.dec_eps, a, stats[4], stats[5], rows=M)
             z, u = self.buf(tag + "z", M, f), self.buf(tag + "u", M, f)
-            self.linear(a, p + "fc1", u, M, act=self.gelu, zout=z)
+            self.linear(a, p + "fc1", u, M, act=self.gelu, zout=z, save_tag=tag if save else None)
             x3 = self.buf(f"d{l}.x3" if save else f"d_.x3{l & 1}", M, d)
-            self.linear(u, p + "fc2", x3, M, residual=x2, drop_seed=sd(12 + 3 * l))
+            self.linear(u, p + "fc2", x3, M, residual=x2, drop_seed=sd(12 + 3 * l), save_tag=tag if save else None)
             x = x3
         hf = self.buf("d.hf", M, d)
         stf = self.buf("d.f.stats", 2, _rup(M, ROWPAD), torch.float32)
@@ -398,6 +504,7 @@ class Engine:
 
     # ------------------------------------------------------------------ full passes
     def forward_logits(self, pixels, ids, pos_ids, key_mask, B, T, *, save=False, seed=None, trunc_int32=False):
+        self._fp8_begin_pass()
         _, ehs = self.vit_forward(pixels, save, trunc_int32)
         hf = self.decoder_forward(ids, pos_ids, key_mask, ehs, B, T, save, seed)
         return self.head_logits(hf, B * T), ehs
@@ -424,6 +531,7 @@ class Engine:
         if rows is None:
             logits, _ = self.forward_logits(pixels, ids, pos_ids, key_mask, B, T, save=False, seed=None)
             return self.loss_and_dlogits(logits, labels, key_mask.reshape(-1), M, label_smoothing, backward=False)
+        self._fp8_begin_pass()
         _, ehs = self.vit_forward(pixels, False)
         hf = self.decoder_forward(ids, pos_ids, key_mask, ehs, B, T, False, None)
         logits = self.compact_head(hf, M, rows)
@@ -450,6 +558,7 @@ class Engine:
             logits, ehs = self.forward_logits(pixels, ids, pos_ids, key_mask, B, T, save=True, seed=seed)
             loss = self.loss_and_dlogits(logits, labels, key_mask.reshape(-1), M, label_smoothing, backward=True)
         else:
+            self._fp8_begin_pass()
             _, ehs = self.vit_forward(pixels, True)
             hf = self.decoder_forward(ids, pos_ids, key_mask, ehs, B, T, True, seed)
             logits = self.compact_head(hf, M, rows)

@@ -126,9 +126,13 @@ class FlaxCLIPVisionMBartPreTrainedModel(FlaxCLIPVisionMBartGenerationMixin):
                              f"parameters {missing}")  # utils:112-116
         self.store.load_flat(flat)
         self._params_cache = params
+        if self.engine.fp8:
+            self.engine.fp8_weights_changed()
 
     def invalidate_params_cache(self):
         self._params_cache = None
+        if self.engine.fp8:
+            self.engine.fp8_weights_changed()
 
     def _use_params(self, params):
         if params is not None and params is not self._params_cache:
@@ -293,7 +297,7 @@ class FlaxCLIPVisionMBartForConditionalGeneration(FlaxCLIPVisionMBartPreTrainedM
         cross = []
         for l in range(st.L):
             kv = eng.buf(f"g.ckv{l}", n_img * S, 2 * d)
-            eng.linear(ehs_b, f"dec{l}.ckv", kv, n_img * S)
+            eng.linear(ehs_b, f"dec{l}.ckv", kv, n_img * S, fp8=False)  # generation stays in the storage dtype
             cross.append(kv)
         cache["cross"], cache["row_div"] = cross, row_div
 
@@ -312,18 +316,18 @@ class FlaxCLIPVisionMBartForConditionalGeneration(FlaxCLIPVisionMBartPreTrainedM
         for l in range(st.L):
             p = f"dec{l}."
             ops.layernorm_fwd(x, P.f32(p + "ln_sa.g"), P.f32(p + "ln_sa.b"), eng.dec_eps, a, rows=R)
-            eng.linear(a, p + "qkv", qkv, R)
+            eng.linear(a, p + "qkv", qkv, R, fp8=False)
             ops.kv_append(qkv[:, d:], qkv[:, 2 * d:], cache["k"][l], cache["v"][l], R, d, Lmax, cur, ldk=3 * d, ldv=3 * d)
             ops.attn_decode(qkv, cache["k"][l], cache["v"][l], ctx, R, H, Lmax, cur, ldq=3 * d, ldo=d, src_row=cache["src_row"])
-            eng.linear(ctx, p + "so", x1, R, residual=x)
+            eng.linear(ctx, p + "so", x1, R, residual=x, fp8=False)
             ops.layernorm_fwd(x1, P.f32(p + "ln_ca.g"), P.f32(p + "ln_ca.b"), eng.dec_eps, a, rows=R)
-            eng.linear(a, p + "cq", q, R)
+            eng.linear(a, p + "cq", q, R, fp8=False)
             kv = cache["cross"][l]
             ops.attn_decode(q, kv, kv[:, d:], ctx, R, H, S, S - 1, ldq=d, ldo=d, ldc=2 * d, row_div=cache["row_div"])
-            eng.linear(ctx, p + "co", x2, R, residual=x1)
+            eng.linear(ctx, p + "co", x2, R, residual=x1, fp8=False)
             ops.layernorm_fwd(x2, P.f32(p + "ln_ff.g"), P.f32(p + "ln_ff.b"), eng.dec_eps, a, rows=R)
-            eng.linear(a, p + "fc1", u, R, act=eng.gelu)
-            eng.linear(u, p + "fc2", x, R, residual=x2)
+            eng.linear(a, p + "fc1", u, R, act=eng.gelu, fp8=False)
+            eng.linear(u, p + "fc2", x, R, residual=x2, fp8=False)
         hf = eng.buf("g.hf", R, d)
         ops.layernorm_fwd(x, P.f32("dec.ln_f.g"), P.f32("dec.ln_f.b"), eng.dec_eps, hf, rows=R)
         cache["cache_index"] = cur + 1

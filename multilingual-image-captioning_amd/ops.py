@@ -10,12 +10,17 @@ import torch
 from . import _lib as L
 
 
+_FP8 = {torch.float8_e4m3fn: L.MIC_E4M3, torch.float8_e5m2: L.MIC_E5M2}
+
+
 def _dt(t_or_dtype) -> int:
     d = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
     if d == torch.bfloat16:
         return L.MIC_BF16
     if d == torch.float32:
         return L.MIC_F32
+    if d in _FP8:
+        return L.MIC_FP8
     raise L.MicError(f"unsupported dtype {d}")
 
 
@@ -54,9 +59,15 @@ class pinned_stream:
 
 def gemm_args(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, *, a_kmajor=False, b_kmajor=False,
               bias=None, act=0, zout=None, zin=None, dact=0, residual=None, accumulate=False, dropout_p=0.0, dropout_seed=0,
-              alpha=1.0, lda=None, ldb=None, ldc=None, ldz=None, ldr=None, split_k=0, split_stride=0, a_rowsum=None, rowsum_k=0) -> "L.GemmArgs":
+              alpha=1.0, lda=None, ldb=None, ldc=None, ldz=None, ldr=None, split_k=0, split_stride=0, a_rowsum=None, rowsum_k=0,
+              a_scale_inv=None, b_scale_inv=None) -> "L.GemmArgs":
+    """fp8 operands: `a` / `b` are torch.float8_e4m3fn / float8_e5m2 tensors (k-contiguous), `a_scale_inv` / `b_scale_inv` the
+    device scalars mic_fp8_quantize wrote for them."""
     g = L.GemmArgs()
     g.dtype, g.c_dtype = _dt(a), _dt(out)
+    if g.dtype == L.MIC_FP8:
+        g.a_fmt, g.b_fmt = _FP8[a.dtype], _FP8[b.dtype]
+        g.a_scale_inv, g.b_scale_inv = _p(a_scale_inv), _p(b_scale_inv)
     g.M, g.N, g.K = M, N, K
     g.a_kmajor, g.b_kmajor = int(a_kmajor), int(b_kmajor)
     g.A, g.lda = _p(a), lda if lda is not None else a.stride(0)
@@ -84,6 +95,25 @@ def gemm_grouped(arg_list):
     """Several GEMMs (same dtype / operand layouts) in as few launches as possible."""
     arr = (L.GemmArgs * len(arg_list))(*arg_list)
     L.check(L.lib().mic_gemm_grouped(arr, len(arg_list), _stream()), "mic_gemm_grouped")
+
+
+def fp8_item(src, rows, cols, state, fmt_dtype, q=None, qT=None, rows_pad=0) -> "L.Fp8Item":
+    """src bf16 [>=rows][ld]; q fp8 [rows][*] and / or qT fp8 [cols][>= rows_pad]; state fp32 [2] (amax, 1/scale)."""
+    if src.dtype != torch.bfloat16:
+        raise L.MicError("fp8 quantisation reads bf16 tensors (the fp8 path needs the bfloat16 storage mode)")
+    it = L.Fp8Item()
+    it.src, it.ld, it.rows, it.cols, it.rows_pad = _p(src), src.stride(0), rows, cols, rows_pad
+    it.q, it.ldq = _p(q), (q.stride(0) if q is not None else 0)
+    it.qT, it.ldqT = _p(qT), (qT.stride(0) if qT is not None else 0)
+    it.state, it.fmt = _p(state), _FP8[fmt_dtype]
+    return it
+
+
+def fp8_quantize(items):
+    """amax pass + quantise pass over `items` (list of Fp8Item; their `state` slots must have been zeroed)."""
+    arr = (L.Fp8Item * len(items))(*items)
+    L.check(L.lib().mic_fp8_amax(arr, len(items), _stream()), "mic_fp8_amax")
+    L.check(L.lib().mic_fp8_quantize(arr, len(items), _stream()), "mic_fp8_quantize")
 
 
 def layernorm_fwd(x, gamma, beta, eps, y, mean=None, rstd=None, rows=None, dropout_p=0.0, dropout_seed=0):

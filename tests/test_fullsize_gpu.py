@@ -189,3 +189,148 @@ def test_baseline_beam4_batch256_properties_bf16(full):
     finally:
         st.f32("flb")[rc.eos_token_id] = 0.0
         st.refresh_lp()
+
+
+# ---------------------------------------------------------------- the benchmarked dtype (bf16) pinned to the fp32 oracle
+@pytest.fixture(scope="module")
+def decisive(dev):
+    """Full-size model whose logits have a trained-model-like spread: random init with the tied embedding scaled by 4
+    (logit std ~2.5 instead of ~0.6), so that an argmax / top-k decision has a margin worth comparing across precisions
+    (with the plain random init 250 054 nearly-tied logits make every precision, fp32 summation order included, pick
+    different tokens)."""
+    from mic_amd import CLIPVisionMBartConfig, FlaxCLIPVisionMBartForConditionalGeneration
+    from mic_amd.params import unflatten_tree
+    from oracle import model_ref as M
+
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    rc = M.RefConfig(gelu="tanh", decoder_ln_eps=1e-6)
+    p = M.init_params(rc, seed=11, perturb_ln=True)
+    p["model/shared/embedding"] = p["model/shared/embedding"] * 4.0
+    cfg = CLIPVisionMBartConfig(mbart_config={}, clip_vision_config={})
+    tree = unflatten_tree({k: v.numpy() for k, v in p.items()})
+    models = {}
+    for dt in (torch.float32, torch.bfloat16):
+        m = FlaxCLIPVisionMBartForConditionalGeneration(cfg, dtype=dt, device=dev)
+        m.params = tree
+        models[dt] = m
+    g = torch.Generator().manual_seed(15)
+    px = torch.randn(8, 224, 224, 3, generator=g).clamp(-1.8, 2.2)
+    with torch.no_grad():
+        ehs, _ = M.encode(rc, p, px)
+    return rc, p, models, px, ehs
+
+
+def _prefix_len(a, b):
+    ne = np.nonzero(a != b)[0]
+    return len(a) if ne.size == 0 else int(ne[0])
+
+
+def test_fullsize_generate_to_max_length_64_vs_oracle(decisive):
+    """configs[3]'s call shape at full model size, batch 8, to max_length 64 (63 decoder steps), greedy and beam-4 with a
+    forced BOS language code, against the oracle's restatement of gen:422-535 / 665-990 on the CPU model oracle.
+      float32 mode: token ids bit-exact over all 64 positions, beam scores within 1e-4 relative.
+      bfloat16 mode (what bench.py times): the same call; one different decision changes the rest of that caption, so the
+      floors are on (i) the tokens before the first divergence and (ii) the beam score of the returned hypothesis."""
+    from oracle import generation_ref as G
+
+    rc, p, models, px, ehs = decisive
+    B, L = px.shape[0], 64
+    res = {}
+    for K in (1, 4):
+        kw = dict(max_length=L, num_beams=K, forced_bos_token_id=250004 + K)
+        ref = G.generate(lambda rows: G.ModelStepper(rc, p, ehs.repeat_interleave(K, 0) if K > 1 else ehs, L), B, G.GenDefaults(), **kw)
+        ref_seq = ref if K == 1 else ref.sequences
+        out32 = models[torch.float32].generate(px.numpy(), **kw)
+        got32 = out32.sequences.cpu().numpy()
+        assert got32.shape == (B, L) and np.array_equal(got32, ref_seq), (K, np.argwhere(got32 != ref_seq)[:5])
+        if K > 1:
+            assert out32["steps"] == ref.steps
+            assert np.allclose(out32.scores.cpu().numpy(), ref.scores, rtol=1e-4, atol=1e-4)
+        out16 = models[torch.bfloat16].generate(px.numpy(), **kw)
+        got16 = out16.sequences.cpu().numpy()
+        agree = float((got16 == ref_seq).mean())
+        prefix = [_prefix_len(got16[b], ref_seq[b]) for b in range(B)]
+        res[K] = (agree, prefix)
+        print(f"bf16 vs fp32 oracle, num_beams={K}: token agreement {agree:.3f}, common prefix per caption {prefix}")
+        assert (got16[:, 0] == 2).all() and (got16[:, 1] == 250004 + K).all()
+        assert min(prefix) >= 2 and float(np.mean(prefix)) >= BF16_MIN_MEAN_PREFIX[K], (K, prefix)
+        assert agree >= BF16_MIN_AGREEMENT[K], (K, agree)
+        if K > 1:
+            s16, s32 = out16.scores.cpu().numpy(), ref.scores
+            rel = np.abs(s16 - s32) / np.abs(s32)
+            print(f"   beam scores: max relative difference {rel.max():.4f}")
+            assert rel.max() < 0.05, rel  # length-normalised log-probability of the returned hypothesis
+
+
+# floors for the bf16 leg above, set from the measured values (printed by the test) with margin
+BF16_MIN_MEAN_PREFIX = {1: 4.0, 4: 4.0}
+BF16_MIN_AGREEMENT = {1: 0.10, 4: 0.10}
+
+
+def test_fullsize_bf16_logit_error_absolute(decisive, full):
+    """North-star: "logits within 1e-3 (bf16)".  Measured against the fp32 oracle at full size, teacher-forced, absolute:
+    bf16 storage rounds a logit of magnitude 2..4 to a multiple of 2^-6 = 0.0156 (half an ulp = 7.8e-3 > 1e-3) before any
+    arithmetic error, so 1e-3 absolute is not representable in this dtype; what IS asserted: the error stays within a few ulps
+    of the stored format and the top-1 decision agrees where the fp32 margin exceeds the measured error."""
+    from oracle import model_ref as M
+
+    for name, (rc, p, models, px) in (("decisive", decisive[:4]), ("plain-init", (full[0], full[1], full[2], full[3][0]))):
+        g = torch.Generator().manual_seed(3)
+        B, T = 2, 64
+        pxx = px[:B]
+        ids = torch.randint(4, 250000, (B, T), generator=g)
+        mask = torch.ones(B, T, dtype=torch.int64)
+        with torch.no_grad():
+            ref = M.forward_logits(rc, p, pxx, ids, mask)
+        out = models[torch.bfloat16](pxx.numpy(), ids.numpy(), mask.numpy())[0].float().cpu()
+        d = (out - ref).abs()
+        scale = ref.abs().max().item()
+        ulp = 2.0 ** (np.floor(np.log2(scale)) - 7)  # bf16 spacing at the largest logit
+        top_ref = ref.topk(2, dim=-1)
+        margin = (top_ref.values[..., 0] - top_ref.values[..., 1])
+        same = (out.argmax(-1) == top_ref.indices[..., 0])
+        clear = margin > 4 * d.max()
+        print(f"{name}: |logit| max {scale:.3f} (bf16 ulp there {ulp:.4f}); abs err max {d.max():.4f} mean {d.mean():.5f} "
+              f"= {d.max() / scale:.2e} / {d.mean() / scale:.2e} of scale; top-1 agreement {same.float().mean():.3f}")
+        assert d.max().item() < 6 * ulp and d.mean().item() < 0.6 * ulp, (name, d.max().item(), d.mean().item(), ulp)
+        assert bool(same[clear].all())
+
+
+def test_baseline_train_batch64_linearity_equal_token_halves_bf16(full):
+    """Data-parallel linearity at configs[1] size with the per-rank normalisation taken out of the comparison: both half
+    batches carry the same number of loss tokens, so 1/n_half = 2/n_batch is an exact power-of-two factor on every bf16
+    dlogit and the mean of the two half-batch gradients must reproduce the full-batch gradient up to summation order —
+    a much tighter bound than the 5e-2 the unequal halves need."""
+    rc, p, models, _, _ = full
+    model = models[torch.bfloat16]
+    px, labels, mask, dec_in = _train_batch(64, 64, seed=12)
+    # rows 32..63 get the caption lengths of rows 0..31 (fresh tokens): equal token counts per half
+    g = torch.Generator().manual_seed(99)
+    for b in range(32):
+        n = int(mask[b].sum()) - 2
+        labels[32 + b] = 1
+        mask[32 + b] = 0
+        labels[32 + b, 0] = 250003 + (b % 4)
+        labels[32 + b, 1:1 + n] = torch.randint(4, 250000, (n,), generator=g)
+        labels[32 + b, 1 + n] = 2
+        mask[32 + b, :n + 2] = 1
+    dec_in = torch.full_like(labels, 1)
+    dec_in[:, 1:] = labels[:, :-1]
+    assert int(mask[:32].sum()) == int(mask[32:].sum())
+    l_c, g_c = _grads(model, px, labels, mask, dec_in, compact=True)
+    la, ga = _grads(model, px[:32], labels[:32], mask[:32], dec_in[:32], compact=True)
+    lb, gb = _grads(model, px[32:], labels[32:], mask[32:], dec_in[32:], compact=True)
+    assert abs((la + lb) / 2 - l_c) < 1e-4 * abs(l_c)
+    gm = (ga + gb) / 2  # pmean of the per-rank gradients (main.py:698)
+    st = model.store
+    worst = {}
+    for name in ("shared", "flb", "dec11.fc2.w", "dec6.cq.w", "dec0.qkv.w", "vit11.fc1.w", "vit0.fc1.w", "vp.w", "patch.w"):
+        s = st.segs[name]
+        a, b = gm[s.offset: s.offset + s.numel], g_c[s.offset: s.offset + s.numel]
+        worst[name] = ((a - b).abs().max() / b.abs().max()).item()
+        assert torch.nn.functional.cosine_similarity(a, b, dim=0).item() > 0.9999, name
+    print("equal-token halves, max |mean of halves - batch| / max|batch| per segment:", {k: round(v, 5) for k, v in worst.items()})
+    assert max(worst.values()) < LINEARITY_TOL, worst
+
+
+LINEARITY_TOL = 2e-2  # tightened from the measured values below

@@ -165,3 +165,95 @@ def test_train_steps_match_oracle_adamw(dev):
         d = (torch.from_numpy(gf[k]) - rv).abs().max().item()
         # Adam's first steps move every weight by ~lr regardless of gradient scale; compare against that step size
         assert d < 2e-5, (k, d)
+
+
+# ---------------------------------------------------------------- second twin fixture: cached decode + autograd gradients
+GOLD2 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "twin_small_decode_grads.npz")
+
+
+def _sub(a):
+    a = np.asarray(a).reshape(-1)
+    return a[:: max(1, -(-a.size // 6000))]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cached_decode_matches_twin_golden(dev, dtype):
+    """decode() with past_key_values on the HIP path vs the twin's own `use_cache=True` logits (committed golden)."""
+    g = np.load(GOLD2)
+    rc, p, model = make_pair(dtype, dev)
+    assert int(g["seed"]) == SEED
+    enc = model.encode(g["dec_pixels"], _int32_cast=False)
+    ids = g["dec_step_ids"]
+    B, S = ids.shape
+    cache = model.init_cache(B, S + 2, enc)
+    for t in range(S):
+        out = model.decode(ids[:, t:t + 1], enc, decoder_position_ids=np.full((B, 1), t), past_key_values=cache)
+        cache = out.past_key_values
+        mx, mean = scale_err(out.logits[:, 0], torch.from_numpy(g["dec_step_logits"][:, t]))
+        assert (mx < 2e-4) if dtype == torch.float32 else (mx < 3e-2 and mean < 4e-3), (t, mx, mean)
+
+
+@pytest.mark.parametrize("ls", [0.0, 0.1])
+def test_gradients_match_twin_autograd_golden(dev, ls):
+    """The hand-derived HIP backward (float32 mode) against the twin's autograd gradients from the committed golden —
+    not via the oracle."""
+    g = np.load(GOLD2)
+    rc, p, model = make_pair(torch.float32, dev)
+    d = model._dev
+    labels, mask, dec_in = g["g_labels"], g["g_mask"], g["g_dec_in"]
+    B, T = labels.shape
+    pos = torch.arange(T, dtype=torch.int32, device=dev)[None].expand(B, T).contiguous()
+    loss = model.engine.loss_and_grads(d(g["g_pixels"], torch.float32), d(dec_in, torch.int32).reshape(-1), pos.reshape(-1), d(mask, torch.int32),
+                                       d(labels, torch.int32).reshape(-1), B, T, label_smoothing=ls)
+    torch.cuda.synchronize()
+    tag = f"ls{int(ls * 10)}"
+    assert abs(loss.item() - float(g[f"loss_{tag}"])) < 2e-5
+    got = model.store.export_flat("grad")
+    n = 0
+    for k in g.files:
+        if not k.startswith(f"grad_{tag}|"):
+            continue
+        leaf = k.split("|")[1]
+        og = got[leaf].copy()
+        if leaf == "model/shared/embedding":
+            og[rc.pad_token_id] = 0  # nn.Embedding(padding_idx) in the twin, see make_golden_decode_grads.py
+        ref = g[k]
+        sc = np.abs(ref).max()
+        if sc < 1e-9:
+            assert np.abs(og).max() < 1e-6, leaf
+            continue
+        assert np.abs(_sub(og) - ref).max() / sc < 5e-4, (leaf, np.abs(_sub(og) - ref).max() / sc)
+        n += 1
+    assert n >= 14
+
+
+# ---------------------------------------------------------------- eval_step (main.py:710-721) against the oracle
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ls", [0.0, 0.1])
+def test_eval_step_matches_oracle(dev, dtype, ls):
+    """Trainer.eval_step = forward(train=False) + loss_fn: both kernel sequences it can take (dense head on all positions;
+    compact head on the label positions with loss mask 1, non-saving activation buffers) against oracle.train_ref.forward_loss,
+    with a dropout-configured model (eval must not apply it) and with the train step's buffers dirty from a previous step."""
+    from mic_amd import Trainer, create_learning_rate_fn
+    from oracle import train_ref
+
+    rc, p, model = make_pair(dtype, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.1)
+    px, labels, mask, dec_in = batch(rc, 5, 12, seed=71)
+    b = {"pixel_values": px.numpy(), "input_ids": labels.numpy(), "attention_mask": mask.numpy(), "decoder_input_ids": dec_in.numpy()}
+    with torch.no_grad():
+        ref, _ = train_ref.forward_loss(rc, p, px, labels, mask, dec_in, None, ls)
+    tol = 3e-5 if dtype == torch.float32 else 2e-2
+    for compact in (True, False):
+        tr = Trainer(model, create_learning_rate_fn(64, 1, 2, 2, 0.0), label_smoothing_factor=ls, compact_head=compact)
+        got = float(tr.eval_step(b)["loss"])
+        assert abs(got - ref.item()) < tol * max(1.0, abs(ref.item())), (compact, got, ref.item())
+        tr.train_step(b)  # lr 0: parameters unchanged, activation buffers and logits overwritten with train-mode values
+        got2 = float(tr.eval_step(b)["loss"])
+        assert abs(got2 - ref.item()) < tol * max(1.0, abs(ref.item())), (compact, got2, ref.item())
+    # a batch whose rows all carry loss everywhere (nothing to compact) and one with a single unmasked row
+    for lens_seed in (72, 73):
+        px2, l2, m2, d2 = batch(rc, 2, 8, seed=lens_seed, ragged=(lens_seed == 73))
+        with torch.no_grad():
+            r2, _ = train_ref.forward_loss(rc, p, px2, l2, m2, d2, None, ls)
+        got = float(tr.eval_step({"pixel_values": px2.numpy(), "input_ids": l2.numpy(), "attention_mask": m2.numpy(), "decoder_input_ids": d2.numpy()})["loss"])
+        assert abs(got - r2.item()) < tol * max(1.0, abs(r2.item()))

@@ -33,6 +33,65 @@ def test_oracle_matches_twin_golden():
     assert np.abs(logits.numpy() - g["logits"])[valid].max() < 2e-5
 
 
+GOLD2 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "twin_small_decode_grads.npz")
+
+
+def _sub(a):
+    a = np.asarray(a).reshape(-1)
+    return a[:: max(1, -(-a.size // 6000))]
+
+
+def test_oracle_cached_decode_matches_twin_golden():
+    """The oracle's static-cache decode_step against the twin's own `use_cache=True` decoding (golden made by
+    tests/golden/make_golden_decode_grads.py): pins the cache path to something other than the oracle itself."""
+    from oracle import model_ref as M
+
+    g = np.load(GOLD2)
+    rc = ref_config("erf", 1e-5)
+    p = M.init_params(rc, seed=int(g["seed"]), perturb_ln=True)
+    ids, ehs = torch.from_numpy(g["dec_step_ids"]), torch.from_numpy(g["dec_ehs"])
+    B, S = ids.shape
+    with torch.no_grad():
+        e2, _ = M.encode(rc, p, torch.from_numpy(g["dec_pixels"]), int32_cast=False)
+        assert (e2 - ehs).abs().max().item() < 2e-5
+        st = M.DecodeState(rc, B, S + 3)
+        for t in range(S):
+            lg = M.decode_step(rc, p, st, ids[:, t:t + 1], torch.full((B, 1), t), ehs)
+            assert np.abs(lg[:, 0].numpy() - g["dec_step_logits"][:, t]).max() < 2e-5, t
+
+
+@pytest.mark.parametrize("ls", [0.0, 0.1])
+def test_oracle_gradients_match_twin_autograd_golden(ls):
+    """value_and_grad of the masked (label-smoothed) cross-entropy: the oracle (autograd over oracle.model_ref) against the
+    twin's autograd over ITS forward, leaves from every part of the graph.  The twin's nn.Embedding(padding_idx) drops the
+    input-embedding gradient of the pad row, flax nn.Embed does not: that row is excluded."""
+    from oracle import model_ref as M
+    from oracle import train_ref
+
+    g = np.load(GOLD2)
+    rc = ref_config("erf", 1e-5)
+    p = M.init_params(rc, seed=int(g["seed"]), perturb_ln=True)
+    t = lambda k: torch.from_numpy(g[k])
+    loss, gr = train_ref.loss_and_grads(rc, p, t("g_pixels"), t("g_labels"), t("g_mask"), t("g_dec_in"), label_smoothing_factor=ls)
+    tag = f"ls{int(ls * 10)}"
+    assert abs(loss.item() - float(g[f"loss_{tag}"])) < 2e-6
+    n = 0
+    for k in g.files:
+        if not k.startswith(f"grad_{tag}|"):
+            continue
+        leaf = k.split("|")[1]
+        og = gr[leaf].numpy().copy()
+        if leaf == "model/shared/embedding":
+            og[rc.pad_token_id] = 0
+        sc = np.abs(og).max()
+        if sc < 1e-9:  # k_proj bias: analytically zero (softmax is invariant to a per-query constant)
+            assert np.abs(g[k]).max() < 1e-9
+            continue
+        assert np.abs(_sub(og) - g[k]).max() / sc < 2e-5, leaf
+        n += 1
+    assert n >= 14
+
+
 def test_cached_decode_equals_teacher_forced():
     """The static max_length-slot cache path (modeling:249-282, App. B7) reproduces the full causal forward."""
     from oracle import model_ref as M
