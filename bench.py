@@ -228,7 +228,7 @@ def bench_generate(model, cfg, dev, batch=256, langs=(250004, 250008, 250003, 25
         e0.record()
         r = orig_gemm(a, b, o, M, N, K, **kw)
         e1.record()
-        recs.append(("head" if N >= 65536 else "gemm", 2.0 * M * N * K, e0, e1))
+        recs.append(("head" if N == st.Vpad else "gemm", 2.0 * M * N * K, e0, e1))
         return r
 
     ops.attn_decode, ops.gemm = timed_attn, timed_gemm
@@ -240,7 +240,7 @@ def bench_generate(model, cfg, dev, batch=256, langs=(250004, 250008, 250003, 25
 
     def agg(kind):
         sel = [r for r in recs if r[0] == kind]
-        return sum(r[1] for r in sel), sum(r[2].elapsed_time(r[3]) for r in sel) * 1e-3, len(sel)
+        return sum(r[1] for r in sel), max(sum(r[2].elapsed_time(r[3]) for r in sel) * 1e-3, 1e-12), max(len(sel), 1)
 
     ab, at, an = agg("attn")
     hf, ht, hn = agg("head")

@@ -34,9 +34,6 @@
 #include "common.h"
 
 #define MAX_PROBLEMS 8
-#ifndef MIC_EPI_DIRECT
-#define MIC_EPI_DIRECT 1  // 1: accumulators kept TRANSPOSED (lane <-> output row), stored straight from registers; 0: LDS restage
-#endif
 #ifndef MIC_TINY_BELOW
 #define MIC_TINY_BELOW 128  // 128x128-tile count under which a launch uses 64x64 tiles (tools/bench_tile_cfg.py)
 #endif
@@ -288,13 +285,8 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
           for (int i = 0; i < AI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-#if MIC_EPI_DIRECT
-              acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8[j], a8[i], acc[i][j], 0, F8 == 2 ? 1 : 0, 0, 0x7f7f7f7f, 0,
-                                                                          0x7f7f7f7f);  // transposed product: first operand = B (e4m3)
-#else
               acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i], b8[j], acc[i][j], F8 == 2 ? 1 : 0, 0, 0, 0x7f7f7f7f, 0,
                                                                           0x7f7f7f7f);  // cbsz/blgp: 0 = e4m3, 1 = e5m2; scales 2^0
-#endif
         }
       } else {
 #pragma unroll
@@ -327,11 +319,7 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
         for (int i = 0; i < AI; ++i)
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
-#if MIC_EPI_DIRECT
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // (A B^T)^T: lane <-> row of C
-#else
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-#endif
           }
       }
       }
@@ -383,119 +371,6 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
   EpiArgs E = P.epi;
   const bool is_split = P.nsplit > 1;
   const long long split_stride = P.split_stride;
-#if MIC_EPI_DIRECT
-  // Direct epilogue.  The main loop accumulated the TRANSPOSED product (first MFMA operand = B fragment), so in a 32x32
-  // accumulator block lane l owns output ROW (l & 31) and its 16 registers are the columns 8*(r>>2) + 4*(l>>5) + (r&3): four
-  // runs of 4 consecutive columns.  One v_permlane32_swap per register pair (runs 2p and 2p+1 of the two half-waves) turns
-  // them into 8 consecutive columns per lane — lanes 0-31: columns 16p..16p+7, lanes 32-63: 16p+8..16p+15 — which is exactly
-  // the (row, 8 columns) unit the fused epilogue works in: bias / activation / dropout / residual / Z / C all move as 16-B
-  // vectors straight from and to registers.  No LDS restage (it cost 5.4k cycles of a 30k-cycle 128x128 launch and 18k of a
-  // 256x256 tile: ds_write_b32 of every accumulator, two barriers per pass, a second pass of reads).
-  {
-    float alpha = E.alpha;
-    if constexpr (F8 != 0) alpha *= (P.sa ? *P.sa : 1.0f) * (P.sb ? *P.sb : 1.0f);  // dequantise: per-tensor scales of the two operands
-    const bool has_b = E.bias && !is_split;
-    const bool b_vec = has_b && (((uintptr_t)E.bias & 15) == 0);
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      float bj[16];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wc * WN + j * 32 + 8 * g + 4 * (lane >> 5);
-        if (b_vec && n + 4 <= N) {
-          const float4 t = *reinterpret_cast<const float4*>(E.bias + n);
-          bj[4 * g] = t.x; bj[4 * g + 1] = t.y; bj[4 * g + 2] = t.z; bj[4 * g + 3] = t.w;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) bj[4 * g + e] = (has_b && n + e < N) ? E.bias[n + e] : 0.0f;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < AI; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * alpha + bj[r];
-    }
-    E.alpha = 1.0f;
-    E.bias = nullptr;
-  }
-  if (kg == 0) {
-    const bool pre = !is_split && epilogue_pre_ok(E) && epilogue_vec_ok(E, 8);
-    const bool has_r = E.R != nullptr;
-    const int hh = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      const int m = m0 + wr * WM + i * 32 + (lane & 31);
-      constexpr int NG = NJ * 2;  // (row, 8 columns) groups of this lane in row block i
-      u32x4 zq[NG], rq[NG];
-#pragma unroll
-      for (int q = 0; q < NG; ++q) {  // side operands of the whole row block first: their latency overlaps the swaps
-        const int n = n0 + wc * WN + (q >> 1) * 32 + 16 * (q & 1) + 8 * hh;
-        zq[q] = rq[q] = u32x4{0u, 0u, 0u, 0u};
-        if (m < M && n + 8 <= N) {
-          if constexpr (PLAIN) {
-            if (has_r) rq[q] = *reinterpret_cast<const u32x4*>((const uint16_t*)E.R + (size_t)m * E.ldr + n);
-          } else {
-            if (pre) epilogue_prefetch8(E, m, n, zq[q], rq[q]);
-          }
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < NG; ++q) {
-        const int j = q >> 1, p = q & 1;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {  // every lane takes part in the exchange, also those whose row / columns are out of range
-          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][8 * p + e]), __float_as_uint(acc[i][j][8 * p + 4 + e]), false, false);
-          v[e] = __uint_as_float(sw[0]);
-          v[4 + e] = __uint_as_float(sw[1]);
-        }
-        const int n = n0 + wc * WN + j * 32 + 16 * p + 8 * hh;
-        if (m >= M || n >= N) continue;
-        const int cnt = min(8, N - n);
-        if constexpr (PLAIN) {
-          if (E.drop_thr) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-              v[e] = dropout_keep(E.drop_seed, (uint32_t)m * (uint32_t)E.N + (uint32_t)(n + e), E.drop_thr) ? v[e] * E.drop_scale : 0.0f;
-          }
-          if (cnt == 8) {  // host side guarantees 16-B alignment of the C (and R) rows for PLAIN launches
-            if (has_r) {
-              float r[8];
-              unpack8(rq[q], r);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += r[e];
-            }
-            if (E.c_f32) st8((float*)E.C + (size_t)m * E.ldc + n, v);
-            else st8((uint16_t*)E.C + (size_t)m * E.ldc + n, v);
-          } else {
-            for (int e = 0; e < cnt; ++e) {
-              float x = v[e];
-              if (has_r) x += bf2f(((const uint16_t*)E.R)[(size_t)m * E.ldr + n + e]);
-              if (E.c_f32) ((float*)E.C)[(size_t)m * E.ldc + n + e] = x;
-              else ((uint16_t*)E.C)[(size_t)m * E.ldc + n + e] = f2bf(x);
-            }
-          }
-        } else {
-          if (is_split) {  // split-K: fp32 atomic accumulation into a zero-initialised C, or a plain store into this split's slab
-            float* c = (float*)E.C + (size_t)m * E.ldc + n;
-            if (split_stride > 0) {
-              c += (size_t)split * (size_t)split_stride;
-              if (cnt == 8 && (E.ldc & 3) == 0) st8(c, v);
-              else for (int e = 0; e < cnt; ++e) c[e] = v[e];
-            } else {
-              for (int e = 0; e < cnt; ++e) atomicAdd(c + e, v[e]);
-            }
-          } else if (pre && cnt == 8) {
-            epilogue_store8_pre(E, m, n, v, zq[q], rq[q]);
-          } else {
-            epilogue_store8<uint16_t>(E, m, n, v, cnt);
-          }
-        }
-      }
-    }
-  }
-}
-#else
   {
     float bj[NJ];
 #pragma unroll
@@ -626,7 +501,6 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
     }
   }
 }
-#endif
 
 // ------------------------------------------------------------------------------------------------ f32
 // A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn].  64x64 tile, BK = 16, 4 waves each a 32x32 block.

@@ -37,7 +37,8 @@ def test_quantize_matches_reference_bytes(dev, fmt, rows, cols):
     q = torch.zeros((rows, cols), dtype=fmt, device=dev)
     qT = torch.full((cols, rp), 1.0, dtype=torch.float32, device=dev).to(fmt)  # pre-filled: the pad columns must be zeroed
     st = torch.zeros(2, device=dev)
-    ops.fp8_quantize([ops.fp8_item(x.to(dev), rows, cols, st, fmt, q=q, qT=qT, rows_pad=rp)])
+    xd = x.to(dev)
+    ops.fp8_quantize([ops.fp8_item(xd, rows, cols, st, fmt, q=q, qT=qT, rows_pad=rp)])
     torch.cuda.synchronize()
     ref, amax, sinv = _quant_ref(x, fmt)
     assert abs(st[0].item() - amax) == 0 and abs(st[1].item() - sinv) < 1e-7 * max(sinv, 1)
@@ -57,13 +58,14 @@ def test_quantize_all_zero_tensor_and_grouping(dev):
     q = torch.ones((64, 64), dtype=torch.float32, device=dev).to(torch.float8_e4m3fn)
     st = torch.zeros((12, 2), device=dev)
     items = [ops.fp8_item(z, 64, 64, st[0], torch.float8_e4m3fn, q=q)]
-    xs, qs = [], []
+    xs, xd, qs = [], [], []
     g = torch.Generator().manual_seed(0)
     for i in range(1, 12):  # more than 8 items: two table launches
         x = (torch.randn(40 + 8 * i, 72, generator=g) * (i + 1)).to(torch.bfloat16)
         xs.append(x)
+        xd.append(x.to(dev))  # the item structs hold raw device pointers: keep the tensors alive
         qs.append(torch.empty((x.shape[0], 72), dtype=torch.float8_e4m3fn, device=dev))
-        items.append(ops.fp8_item(x.to(dev), x.shape[0], 72, st[i], torch.float8_e4m3fn, q=qs[-1]))
+        items.append(ops.fp8_item(xd[-1], x.shape[0], 72, st[i], torch.float8_e4m3fn, q=qs[-1]))
     ops.fp8_quantize(items)
     torch.cuda.synchronize()
     assert st[0, 0].item() == 0 and st[0, 1].item() == 1.0 and (q.cpu().float() == 0).all()
