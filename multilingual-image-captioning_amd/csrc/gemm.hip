@@ -31,128 +31,7 @@
 //
 // f32 kernel (the reference's default dtype; parity mode): 64x64x16 tiles, v_mfma_f32_32x32x2_f32 (bit-exact fp32
 // fma chain), generic strides.
-#include "common.h"
-
-#define MAX_PROBLEMS 8
-#ifndef MIC_TINY_BELOW
-#define MIC_TINY_BELOW 128  // 128x128-tile count under which a launch uses 64x64 tiles (tools/bench_tile_cfg.py)
-#endif
-
-struct Problem {
-  const uint16_t* A; const uint16_t* B;
-  int lda, ldb, M, N, K;
-  int tiles_m, tiles_n, block_begin, nsplit;
-  float* a_rowsum; int rowsum_k;
-  long long split_stride;
-  const float* sa; const float* sb;  // fp8: device scalars, the operands' dequantisation factors (1 / quantisation scale)
-  EpiArgs epi;
-};
-struct LaunchTable { int count; int total_blocks; Problem p[MAX_PROBLEMS]; };
-
-// --- stage one operand image (ROWS x BKT k, or BKT k x ROWS x; ROWS = 128 or 64) HBM/L2 -> registers -> LDS.
-//     Measured on gfx950: a global_load_lds (LDS-DMA) instruction costs ~100 cycles of issue time in the issuing wave's
-//     in-order stream; 8 of them per K-tile next to 16 MFMAs made every one-block-per-CU shape DMA-issue bound
-//     (1.3-1.4k cycles per K-tile against 512 MFMA cycles).  global_load_dwordx4 + ds_write_b128 issue in ~20 cycles a
-//     pair, cost 4 VGPRs per piece, and let the swizzle sit on the LDS destination.
-//     KMAJOR=false: src is [rows][ld] k-contiguous.  KMAJOR=true: src is [K][ld] x-contiguous.  `lim` = number of valid
-//     rows (resp. x) in src; out-of-range rows/chunks are redirected to a valid address (masked at the store).
-template <bool KMAJOR, int NWAVES, int BKT, int ROWS>
-struct HalfStager {
-  static_assert(ROWS == 128 || (ROWS == 64 && BKT == 64), "image = 128 rows (x) of BKT k, or 64 rows of 64 k");
-  static constexpr int NINST = ROWS * BKT * 2 / 1024;  // 1 KiB pieces per image
-  static constexpr int PER = NINST / NWAVES;
-  static_assert(PER >= 1, "too many waves for this image");
-  static __device__ __forceinline__ void coords(int q, int lane, int& row, int& c) {
-    if (!KMAJOR) {
-      if (BKT == 64) { row = q * 8 + (lane >> 3); c = lane & 7; }
-      else { row = q * 16 + (lane >> 2); c = lane & 3; }
-    } else if (ROWS == 128) { row = q * 4 + (lane >> 4); c = lane & 15; }   // [BKT k][128 x]: 256-B rows
-    else { row = q * 8 + (lane >> 3); c = lane & 7; }                       // [64 k][64 x]: 128-B rows
-  }
-  static __device__ __forceinline__ void load(u32x4 (&r)[PER], const uint16_t* __restrict__ src, int ld, int x0, int k0, int lim,
-                                              int wave, int lane) {
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      int row, c;
-      coords(wave * PER + i, lane, row, c);
-      const uint16_t* g;
-      if (!KMAJOR) {
-        int gr = x0 + row;
-        gr = gr < lim ? gr : lim - 1;
-        g = src + (size_t)gr * ld + k0 + c * 8;
-      } else {
-        int gx = x0 + c * 8;
-        gx = gx < lim ? gx : 0;
-        g = src + (size_t)(k0 + row) * ld + gx;
-      }
-      r[i] = *reinterpret_cast<const u32x4*>(g);
-    }
-  }
-  static __device__ __forceinline__ void store(const u32x4 (&r)[PER], char* lds_tile, int wave, int lane) {
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      int row, c;
-      coords(wave * PER + i, lane, row, c);
-      int off;
-      if (!KMAJOR) off = BKT == 64 ? row * 128 + ((c ^ ((row >> 1) & 7)) << 4) : row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
-      else if (ROWS == 128) off = row * 256 + ((c ^ ((row & 3) << 2)) << 4);
-      else off = row * 128 + ((c ^ (((row >> 1) & 1) << 2)) << 4);
-      *reinterpret_cast<u32x4*>(lds_tile + off) = r[i];
-    }
-  }
-};
-
-// --- read one 32(x) x 16(k) MFMA operand fragment: 8 consecutive k (kk*16 + 8*(lane>>5) ..) of x = xb + (lane&31)
-//     k-contiguous images: BKT=64 -> 128-B rows, chunk ^ ((row>>1)&7); BKT=32 -> 64-B rows, chunk ^ ((row>>2)&3); both are
-//     conflict-free for ds_read_b128's 16-lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31}.
-//     k-major images: [k][128 x] 256-B rows, chunk ^ ((k&3)<<2): the 4 k-rows one ds_read_b64_tr_b16 half-wave touches land
-//     on 4 different 64-B bank groups; [k][64 x] 128-B rows, chunk ^ (((k>>1)&1)<<2): rows k and k+2 would share a bank half.
-template <bool KMAJOR, int BKT, int ROWS>
-__device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int xb, int kk, int lane) {
-  if (!KMAJOR) {
-    const int row = xb + (lane & 31);
-    const int kc = kk * 2 + (lane >> 5);
-    if (BKT == 64) return *reinterpret_cast<const bf16x8*>(lds_tile + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
-    return *reinterpret_cast<const bf16x8*>(lds_tile + row * 64 + ((kc ^ ((row >> 2) & 3)) << 4));
-  } else {
-    const int g = lane >> 4, p = lane & 15;
-    const int x = xb + 16 * (g & 1) + (p & 3) * 4;
-    const int k = kk * 16 + 8 * (g >> 1) + (p >> 2);  // k & 3 == p >> 2 for both halves (k+4 keeps k&3 and (k>>1)&1)
-    constexpr int RB = ROWS * 2;
-    const int off = ROWS == 128 ? k * 256 + ((((x >> 3) ^ ((k & 3) << 2)) << 4) | ((x & 7) << 1))
-                                : k * 128 + ((((x >> 3) ^ (((k >> 1) & 1) << 2)) << 4) | ((x & 7) << 1));
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, lds_tile + off));
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, lds_tile + off + 4 * RB));
-    s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, r);
-  }
-}
-
-// fp8 operands (OCP e4m3 / e5m2, one byte per element) ride the SAME k-contiguous LDS image: a 128-B row is 128 k instead of
-// 64, and one v_mfma_scale_f32_32x32x64_f8f6f4 takes 32 bytes per lane = two 16-B chunks.  Lane l reads row xb + (l & 31),
-// chunks 4*mm + 2*(l >> 5) and the next one.  Which k a (lane half, byte) slot means inside the instruction is irrelevant
-// as long as A and B are loaded by the same rule (the contraction is a sum over matching slots).
-typedef int i32x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ i32x8 read_frag8(const char* lds_tile, int xb, int mm, int lane) {
-  const int row = xb + (lane & 31);
-  const int kc = mm * 4 + 2 * (lane >> 5);
-  const int sw = (row >> 1) & 7;
-  const u32x4 lo = *reinterpret_cast<const u32x4*>(lds_tile + row * 128 + (((kc) ^ sw) << 4));
-  const u32x4 hi = *reinterpret_cast<const u32x4*>(lds_tile + row * 128 + (((kc + 1) ^ sw) << 4));
-  i32x8 r = {(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
-  return r;
-}
-
-__device__ __forceinline__ void tile_coords(int lid, int tiles_m, int tiles_n, int& tm, int& tn) {
-  const int GROUP_M = 8;  // GROUP_M-tall column panels
-  const int per_group = GROUP_M * tiles_n;
-  const int gidx = lid / per_group;
-  const int first_m = gidx * GROUP_M;
-  const int gsz = min(tiles_m - first_m, GROUP_M);
-  const int in_g = lid - gidx * per_group;
-  tm = first_m + in_g % gsz;
-  tn = in_g / gsz;
-}
+#include "gemm_common.h"
 
 // Wave tile WM x WN (WM in {32,64,128}, WN in {32,64}); 2 waves along M, WNW along N.  BM = 2*WM, BN = WN*WNW.
 //   <32,32,2>  64x64,   4 waves : launches too small to give every CU a 128x128 tile; 32 KiB LDS, several blocks per CU
@@ -364,142 +243,7 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
     }
   }
 
-  // epilogue.  Everything it needs from the launch table is copied into registers first: P lives in the kernarg segment
-  // behind a dynamic index, and inside the store loop every field access was a scalar load + wait (the compiler cannot hoist
-  // them across the global stores).  alpha and bias are folded into the accumulators here — a lane owns NJ columns, so the
-  // bias is NJ scalar loads per lane instead of a 32-B load (and a vmcnt wait behind the previous stores) per 8-column group.
-  EpiArgs E = P.epi;
-  const bool is_split = P.nsplit > 1;
-  const long long split_stride = P.split_stride;
-  {
-    float bj[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int n = n0 + wc * WN + j * 32 + (lane & 31);
-      bj[j] = (E.bias && !is_split && n < N) ? E.bias[n] : 0.0f;
-    }
-    float alpha = E.alpha;
-    if constexpr (F8 != 0) alpha *= (P.sa ? *P.sa : 1.0f) * (P.sb ? *P.sb : 1.0f);  // dequantise: per-tensor scales of the two operands
-#pragma unroll
-    for (int i = 0; i < AI; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * alpha + bj[j];
-    E.alpha = 1.0f;
-    E.bias = nullptr;
-  }
-  // each wave restages an RP x WN fp32 block of its accumulators through its own LDS region, then the whole block streams
-  // them out: every thread owns 8 consecutive columns of a row (16-B vectors).
-  constexpr int RP = WM < 64 ? WM : 64;  // rows per pass
-  constexpr int REGION = RP * WN;        // floats per wave region
-  constexpr int CPR = WN / 8;            // 8-column chunks per region row
-  constexpr int NGRP = NWAVES * RP * CPR;                 // 8-column groups per pass (whole tile)
-  constexpr int NIT = (NGRP + NTHREADS - 1) / NTHREADS;   // ... per thread
-  float* Cw = reinterpret_cast<float*>(smem) + wave * REGION;
-  const bool pre = !is_split && epilogue_pre_ok(E) && epilogue_vec_ok(E, 8);
-#pragma unroll
-  for (int p = 0; p < WM / RP; ++p) {
-    if (p > 0) __syncthreads();
-    if (kg == 0) {
-#pragma unroll
-      for (int i2 = 0; i2 < RP / 32; ++i2)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            Cw[(i2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * WN + j * 32 + (lane & 31)] = acc[(RP / 32) * p + i2][j][r];
-    }
-    if constexpr (PLAIN) {
-      // C = acc (+ dropout) (+ residual): the residual rows are fetched before the barrier like every side operand
-      u32x4 rq[NIT];
-      const bool has_r = E.R != nullptr;
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int id = it * NTHREADS + tid;
-        const int w = id / (RP * CPR), rem = id % (RP * CPR);
-        const int m = m0 + (w / WNW) * WM + p * RP + rem / CPR, n = n0 + (w % WNW) * WN + (rem % CPR) * 8;
-        rq[it] = u32x4{0u, 0u, 0u, 0u};
-        if (has_r && id < NGRP && m < M && n + 8 <= N) rq[it] = *reinterpret_cast<const u32x4*>((const uint16_t*)E.R + (size_t)m * E.ldr + n);
-      }
-      __syncthreads();
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int id = it * NTHREADS + tid;
-        const int w = id / (RP * CPR), rem = id % (RP * CPR);
-        const int row = rem / CPR, c8 = (rem % CPR) * 8;
-        const int m = m0 + (w / WNW) * WM + p * RP + row, n = n0 + (w % WNW) * WN + c8;
-        if (id >= NGRP || m >= M || n >= N) continue;
-        const float* src = reinterpret_cast<const float*>(smem) + w * REGION + row * WN + c8;
-        float v[8];
-        const float4 lo = *reinterpret_cast<const float4*>(src);
-        const float4 hi = *reinterpret_cast<const float4*>(src + 4);
-        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-        if (E.drop_thr) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i)
-            v[i] = dropout_keep(E.drop_seed, (uint32_t)m * (uint32_t)E.N + (uint32_t)(n + i), E.drop_thr) ? v[i] * E.drop_scale : 0.0f;
-        }
-        if (n + 8 <= N) {  // host side guarantees 16-B alignment of the C (and R) rows for PLAIN launches
-          if (has_r) {
-            float r[8];
-            unpack8(rq[it], r);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] += r[i];
-          }
-          if (E.c_f32) st8((float*)E.C + (size_t)m * E.ldc + n, v);
-          else st8((uint16_t*)E.C + (size_t)m * E.ldc + n, v);
-        } else {
-          for (int i = 0; i < N - n; ++i) {
-            float x = v[i];
-            if (has_r) x += bf2f(((const uint16_t*)E.R)[(size_t)m * E.ldr + n + i]);
-            if (E.c_f32) ((float*)E.C)[(size_t)m * E.ldc + n + i] = x;
-            else ((uint16_t*)E.C)[(size_t)m * E.ldc + n + i] = f2bf(x);
-          }
-        }
-      }
-    } else {
-    // side loads of all this thread's groups go out before the barrier (their latency hides behind it and each other)
-    u32x4 zq[NIT], rq[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int id = it * NTHREADS + tid;
-      const int w = id / (RP * CPR), rem = id % (RP * CPR);
-      const int m = m0 + (w / WNW) * WM + p * RP + rem / CPR, n = n0 + (w % WNW) * WN + (rem % CPR) * 8;
-      zq[it] = rq[it] = u32x4{0u, 0u, 0u, 0u};
-      if (pre && id < NGRP && m < M && n + 8 <= N) epilogue_prefetch8(E, m, n, zq[it], rq[it]);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int id = it * NTHREADS + tid;
-      const int w = id / (RP * CPR), rem = id % (RP * CPR);
-      const int row = rem / CPR, c8 = (rem % CPR) * 8;
-      const int m = m0 + (w / WNW) * WM + p * RP + row, n = n0 + (w % WNW) * WN + c8;
-      if (id >= NGRP || m >= M || n >= N) continue;
-      const float* src = reinterpret_cast<const float*>(smem) + w * REGION + row * WN + c8;
-      float v[8];
-      const float4 lo = *reinterpret_cast<const float4*>(src);
-      const float4 hi = *reinterpret_cast<const float4*>(src + 4);
-      v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-      const int cnt = min(8, N - n);
-      if (is_split) {  // split-K: fp32 atomic accumulation into a zero-initialised C, or a plain store into this split's slab
-        float* c = (float*)E.C + (size_t)m * E.ldc + n;
-        if (split_stride > 0) {
-          c += (size_t)split * (size_t)split_stride;
-          if (cnt == 8 && (E.ldc & 3) == 0) st8(c, v);
-          else for (int i = 0; i < cnt; ++i) c[i] = v[i];
-        } else {
-          for (int i = 0; i < cnt; ++i) atomicAdd(c + i, v[i]);
-        }
-      } else if (pre && cnt == 8) {
-        epilogue_store8_pre(E, m, n, v, zq[it], rq[it]);
-      } else {
-        epilogue_store8<uint16_t>(E, m, n, v, cnt);
-      }
-    }
-    }
-  }
+  gemm_epilogue<WM, WN, WNW, KG, PLAIN, F8>(acc, P, smem, m0, n0, split, kg, wave, lane, tid);
 }
 
 // ------------------------------------------------------------------------------------------------ f32
@@ -681,7 +425,9 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
     blocks += p.tiles_m * p.tiles_n * p.nsplit;
   }
   tab.total_blocks = blocks;
-  if (bm == 256) launch_cfg<128, 64, 4, 64>(tab, args[0].a_kmajor, args[0].b_kmajor, s, f8);     // 256x256x64, 8 waves
+  static const int phased = [] { const char* e = getenv("MIC_GEMM_PHASED"); return e ? atoi(e) : 1; }();
+  if (bm == 256 && f8 == 0 && phased) launch_gemm_phased(tab, args[0].a_kmajor, args[0].b_kmajor, table_is_plain(tab), s);  // LDS-DMA, phased
+  else if (bm == 256) launch_cfg<128, 64, 4, 64>(tab, args[0].a_kmajor, args[0].b_kmajor, s, f8);     // 256x256x64, 8 waves
   else if (bm == 128) {  // 128x128x64, 8 waves (measured better than the 4-wave 64x64 wave tile at every tile count);
                          // two K-groups (16 waves) when the launch is a single round of at most one block per CU
     static const int kg128 = [] { const char* e = getenv("MIC_GEMM_KG128"); return e ? atoi(e) : -1; }();

@@ -149,8 +149,13 @@ def _sharded_worker(rank, world, port, q):
                 if abs(a[2][k] - b[2][k]).max() > 2e-5:
                     ok, msg = False, f"{dtype} master {k} differs by {abs(a[2][k] - b[2][k]).max()}"
                     break
-            if not (torch.allclose(a[3], b[3], rtol=1e-3, atol=1e-7) and torch.allclose(a[4], b[4], rtol=1e-3, atol=1e-9)):
-                ok, msg = False, f"{dtype} AdamW moments differ after sync_full_state"
+            # moments: relative to the largest entry (two separate runs: atomics order, and in bf16 the tile configuration of
+            # a GEMM may differ with the row count); a missing all-gather would leave whole shards at zero (error 1.0)
+            mtol = 1e-4 if dtype == torch.float32 else 2e-2
+            em = ((a[3] - b[3]).abs().max() / a[3].abs().max()).item()
+            ev = ((a[4] - b[4]).abs().max() / a[4].abs().max()).item()
+            if em > mtol or ev > mtol:
+                ok, msg = False, f"{dtype} AdamW moments differ after sync_full_state: m {em} v {ev}"
         # rank consistency: every rank holds the same weights
         chk = results[("sharded", torch.bfloat16)][1].double().sum().reshape(1).cpu()
         both = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
