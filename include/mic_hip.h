@@ -213,6 +213,9 @@ int mic_colsum_grouped(int dtype, const mic_colsum_item* items, int count, void*
 /* keep-mask (uint8, 1 = keep) that the fused dropout epilogues use for (seed, p) over n elements */
 int mic_dropout_mask(uint8_t* out, int64_t n, float p, uint32_t seed, void* stream);
 int mic_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);
+/* zero-fill `bytes` bytes on `stream` (the per-step clears: atomically accumulated gradients, row padding of compacted
+ * buffers, fp8 amax slots) */
+int mic_zero(void* p, int64_t bytes, void* stream);
 /* row gather/scatter: dst[dst_idx ? dst_idx[i] : i] = src[src_idx ? src_idx[i] : i], i < n.  Used to run the LM head and
  * the cross-entropy only on the label positions whose loss mask is 1 (main.py:678: masked positions contribute exactly 0). */
 int mic_copy_rows(int dtype, int n, int width, const void* src, int ld_src, const int32_t* src_idx, void* dst, int ld_dst,

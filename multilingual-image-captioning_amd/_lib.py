@@ -83,6 +83,7 @@ _SIGS = {
     "mic_colsum_grouped": ([_i, C.POINTER(ColsumItem), _i, _p], C.c_int),
     "mic_dropout_mask": ([_p, _i64, _f, _u32, _p], C.c_int),
     "mic_cast": ([_i, _i, _p, _p, _i64, _p], C.c_int),
+    "mic_zero": ([_p, _i64, _p], C.c_int),
     "mic_copy_rows": ([_i, _i, _i, _p, _i, _p, _p, _i, _p, _p], C.c_int),
     "mic_cast2d": ([_i, _i, _i, _i, _p, _i, _p, _i, _p], C.c_int),
     "mic_adamw": ([_i64, _p, _p, _p, _p, _p, _p, C.c_double, C.c_double, C.c_double, C.c_double, _f, _p], C.c_int),

@@ -614,7 +614,7 @@ extern "C" int mic_attn_bwd(int dtype, int B, int H, int Tq, int Tk, const void*
 // groups are summed by xor-shuffles.  Slot ownership (beam-parent indirection) is looked up per slot.
 // Caches longer than 64 slots (generate()'s config default max_length is 200, gen:205-209) are walked in chunks of 64 slots
 // with a running (max, sum, output) triple — the flash-decoding recurrence; a single chunk reduces to the plain softmax.
-template <typename T>
+template <typename T, bool CHUNKED>
 __global__ __launch_bounds__(256) void attn_decode_kernel(int R, int H, int max_len, int cur, const T* __restrict__ q, int ldq,
                                                           const T* __restrict__ kc, const T* __restrict__ vc, int ldc,
                                                           const int32_t* __restrict__ src_row, int row_div,
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(int R, int H, int max_
   const int n = min(cur + 1, max_len);
   float m_run = -INFINITY, l_run = 0.f;
   float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int c0 = 0; c0 < n; c0 += 64) {
+  for (int c0 = 0; c0 < (CHUNKED ? n : 1); c0 += 64) {  // !CHUNKED (caches of at most 64 slots): exactly one pass, no rescaling
     float sc[8];
     int srow[8];
 #pragma unroll
@@ -652,15 +652,21 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(int R, int H, int max_
     float m = sc[0];
 #pragma unroll
     for (int it = 1; it < 8; ++it) m = fmaxf(m, sc[it]);
-    m = fmaxf(wave_max(m), m_run);  // slot c0 is always valid, so m is finite
-    const float alpha = __expf(m_run - m);  // 0 for the first chunk (m_run = -inf)
+    m = wave_max(m);  // slot c0 is always valid, so m is finite
+    if (CHUNKED) m = fmaxf(m, m_run);
     float l = 0.f;
 #pragma unroll
     for (int it = 0; it < 8; ++it) { sc[it] = __expf(sc[it] - m); l += sc[it]; }
-    l_run = l_run * alpha + wave_sum(l) * 0.125f;  // every slot's probability is replicated on its 8 lanes
-    m_run = m;
+    l = wave_sum(l) * 0.125f;  // every slot's probability is replicated on its 8 lanes
+    if (CHUNKED) {
+      const float alpha = __expf(m_run - m);  // 0 for the first chunk (m_run = -inf)
+      l_run = l_run * alpha + l;
+      m_run = m;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] *= alpha;
+      for (int e = 0; e < 8; ++e) o[e] *= alpha;
+    } else {
+      l_run = l;
+    }
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int slot = c0 + it * 8 + grp;
@@ -688,11 +694,12 @@ extern "C" int mic_attn_decode(int dtype, int R, int H, int max_len, int cur, co
   MIC_CHECK(R > 0 && H > 0 && max_len > 0 && cur >= 0 && row_div >= 1, "mic_attn_decode: bad shape R=%d H=%d max_len=%d cur=%d", R, H, max_len, cur);
   MIC_CHECK(q && kc && vc && out, "mic_attn_decode: null pointer");
   dim3 grid((R * H + 3) / 4), block(256);
-  if (dtype == MIC_BF16)
-    hipLaunchKernelGGL(attn_decode_kernel<uint16_t>, grid, block, 0, (hipStream_t)stream, R, H, max_len, cur, (const uint16_t*)q, ldq, (const uint16_t*)kc, (const uint16_t*)vc, ldc, src_row, row_div, (uint16_t*)out, ldo);
-  else if (dtype == MIC_F32)
-    hipLaunchKernelGGL(attn_decode_kernel<float>, grid, block, 0, (hipStream_t)stream, R, H, max_len, cur, (const float*)q, ldq, (const float*)kc, (const float*)vc, ldc, src_row, row_div, (float*)out, ldo);
+  const bool chunked = (cur + 1 < max_len ? cur + 1 : max_len) > 64;
+#define DEC_LAUNCH(TT, CH) hipLaunchKernelGGL((attn_decode_kernel<TT, CH>), grid, block, 0, (hipStream_t)stream, R, H, max_len, cur, (const TT*)q, ldq, (const TT*)kc, (const TT*)vc, ldc, src_row, row_div, (TT*)out, ldo)
+  if (dtype == MIC_BF16) { if (chunked) DEC_LAUNCH(uint16_t, true); else DEC_LAUNCH(uint16_t, false); }
+  else if (dtype == MIC_F32) { if (chunked) DEC_LAUNCH(float, true); else DEC_LAUNCH(float, false); }
   else MIC_CHECK(false, "mic_attn_decode: bad dtype");
+#undef DEC_LAUNCH
   MIC_LAUNCH_CHECK();
   return MIC_OK;
 }

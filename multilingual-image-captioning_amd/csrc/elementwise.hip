@@ -420,6 +420,13 @@ extern "C" int mic_sum_slabs(int dst_dtype, int n_slabs, long long slab_stride, 
   return MIC_OK;
 }
 
+extern "C" int mic_zero(void* p, int64_t bytes, void* stream) {
+  MIC_CHECK(p && bytes > 0, "mic_zero: bad args");
+  hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
+  if (e != hipSuccess) { mic_set_error("mic_zero: %s", hipGetErrorString(e)); return MIC_ELAUNCH; }
+  return MIC_OK;
+}
+
 extern "C" int mic_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream) {
   MIC_CHECK(n > 0 && n < (1LL << 40), "mic_cast: bad n");
   // split into rows of <= 2^20 so the 2-D kernel's int shape holds

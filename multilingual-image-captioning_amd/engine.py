@@ -84,12 +84,12 @@ class Engine:
         if not self.fp8:
             return
         if self._w8_stale:
-            self._w8_state.zero_()
+            ops.zero(self._w8_state)
             P = self.P
             items = [ops.fp8_item(P.w(n + ".w"), q.shape[0], q.shape[1], st, torch.float8_e4m3fn, q=q, qT=qT) for n, (q, qT, st) in self._w8.items()]
             ops.fp8_quantize(items)
             self._w8_stale = False
-        self._a8_state.zero_()
+        ops.zero(self._a8_state[: max(len(self._a8_slots), 1)])
         self._a8_cache = {}
 
     def _fp8_ok(self, wname: str) -> bool:
@@ -406,7 +406,7 @@ class Engine:
             Mh = rows[1]
         Mhp = _rup(Mh, 64)
         if self.dt == torch.bfloat16:  # final_logits_bias gradient = row sums of dlogits^T, fused into the dE GEMM
-            P.g("flb").zero_()         # (atomics; this segment sits in front of the pre-zeroed atomic region)
+            ops.zero(P.g("flb"))        # (atomics; this segment sits in front of the pre-zeroed atomic region)
             ops.gemm(dlogits, hf, P.g("shared"), P.Vpad, d, Mhp, a_kmajor=True, b_kmajor=True, a_rowsum=P.g("flb"), rowsum_k=Mh)
         else:
             ops.colsum(dlogits, P.g("flb"), Mh, P.Vpad, dlogits.stride(0))
@@ -424,7 +424,7 @@ class Engine:
         else:
             ops.gemm(dlogits, P.w("shared"), dhc, Mh, d, P.Vpad, b_kmajor=True)
         if rows is not None:
-            dhf[:M].zero_()  # masked-out positions receive exactly zero gradient from the loss
+            ops.zero(dhf[:M])  # masked-out positions receive exactly zero gradient from the loss
             ops.copy_rows(dhc, dhf, Mh, d, dst_idx=rows[0])
         dx = self.buf("db.dx", M, d)
         dxm = self.buf("db.dxm_a", M, d)   # masked grad entering the FFN branch
@@ -518,11 +518,11 @@ class Engine:
         hfc = self.buf("d.hfc", M, P.d)
         ops.copy_rows(hf, hfc, Mc, P.d, src_idx=idx)
         if Mcp > Mc:
-            hfc[Mc:Mcp].zero_()
+            ops.zero(hfc[Mc:Mcp])
         logits = self.buf("d.logits", M, P.Vpad)
         ops.gemm(hfc, P.w("shared"), logits, Mc, P.Vpad, P.d, bias=P.f32("flb"))
         if Mcp > Mc:
-            logits[Mc:Mcp].zero_()  # reduction padding of the dE GEMM (rows of an earlier, longer batch may linger here)
+            ops.zero(logits[Mc:Mcp])  # reduction padding of the dE GEMM (rows of an earlier, longer batch may linger here)
         return logits
 
     def loss_only(self, pixels, ids, pos_ids, key_mask, labels, B, T, *, label_smoothing=0.0, rows=None, row_labels=None):
@@ -552,7 +552,7 @@ class Engine:
         the cross-entropy and their backward to those rows only (identical loss and gradients, ~(1 - Mc/M) less head work)."""
         P = self.P
         P.ensure_grads()
-        P.grad[P.atomic_begin:].zero_()
+        ops.zero(P.grad[P.atomic_begin:])
         M = B * T
         if rows is None:
             logits, ehs = self.forward_logits(pixels, ids, pos_ids, key_mask, B, T, save=True, seed=seed)

@@ -210,6 +210,16 @@ def cast(src, dst, n=None):
     return dst
 
 
+def zero(t: torch.Tensor):
+    """zero-fill a contiguous device tensor (or contiguous slice) on the launch stream"""
+    if t.numel() == 0:
+        return t
+    if not t.is_contiguous():
+        raise L.MicError("ops.zero needs a contiguous tensor")
+    L.check(L.lib().mic_zero(_p(t), t.numel() * t.element_size(), _stream()), "mic_zero")
+    return t
+
+
 def sum_slabs(src, n_slabs, slab_stride, dst, rows, cols, ld_src, ld_dst):
     L.check(L.lib().mic_sum_slabs(_dt(dst), n_slabs, int(slab_stride), rows, cols, _p(src), ld_src, _p(dst), ld_dst, _stream()), "mic_sum_slabs")
     return dst
