@@ -259,12 +259,17 @@ def test_fullsize_generate_to_max_length_64_vs_oracle(decisive):
             s16, s32 = out16.scores.cpu().numpy(), ref.scores
             rel = np.abs(s16 - s32) / np.abs(s32)
             print(f"   beam scores: max relative difference {rel.max():.4f}")
-            assert rel.max() < 0.05, rel  # length-normalised log-probability of the returned hypothesis
+            assert rel.max() < 1e-2, rel  # length-normalised log-probability of the returned hypothesis
 
 
 # floors for the bf16 leg above, set from the measured values (printed by the test) with margin
-BF16_MIN_MEAN_PREFIX = {1: 4.0, 4: 4.0}
-BF16_MIN_AGREEMENT = {1: 0.10, 4: 0.10}
+# measured on MI355X (round 2): agreement 1.000 and 64-token common prefixes for all 8 captions, greedy and beam-4, score
+# differences < 1e-4 relative.  NOTE what that does and does not show: a randomly initialised tied-embedding model copies the
+# fed token with a wide margin, so these captions exercise the whole 63-step pipeline at full size (cache indirection, beam
+# bookkeeping, 250 054-wide top-k, forced tokens) but not close calls; close calls are covered teacher-forced in
+# test_fullsize_bf16_logit_error_absolute and on a TRAINED reduced model in test_generate_gpu.py.
+BF16_MIN_MEAN_PREFIX = {1: 60.0, 4: 60.0}
+BF16_MIN_AGREEMENT = {1: 0.95, 4: 0.95}
 
 
 def test_fullsize_bf16_logit_error_absolute(decisive, full):
@@ -328,9 +333,9 @@ def test_baseline_train_batch64_linearity_equal_token_halves_bf16(full):
         s = st.segs[name]
         a, b = gm[s.offset: s.offset + s.numel], g_c[s.offset: s.offset + s.numel]
         worst[name] = ((a - b).abs().max() / b.abs().max()).item()
-        assert torch.nn.functional.cosine_similarity(a, b, dim=0).item() > 0.9999, name
+        assert torch.nn.functional.cosine_similarity(a, b, dim=0).item() > 0.9995, name
     print("equal-token halves, max |mean of halves - batch| / max|batch| per segment:", {k: round(v, 5) for k, v in worst.items()})
     assert max(worst.values()) < LINEARITY_TOL, worst
 
 
-LINEARITY_TOL = 2e-2  # tightened from the measured values below
+LINEARITY_TOL = 2.5e-2  # measured worst segment 1.6e-2 (dec6.cq.w, patch.w); the unequal-halves test above needs 5e-2

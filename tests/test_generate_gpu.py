@@ -106,16 +106,72 @@ def test_beam_early_finish_eos_bias(dev):
     assert (ref.sequences == rc.eos_token_id).any()  # finished hypotheses keep EOS (unlike greedy)
 
 
-def test_generate_bf16_runs_and_mostly_agrees(dev):
-    rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6)
-    B = 4
-    px, *_ = batch(rc, B, 12, seed=24)
-    kw = dict(max_length=10, num_beams=4, forced_bos_token_id=996)
-    ref = _oracle_gen(rc, p, px, B, **kw)
-    out = model.generate(px.numpy(), **kw)
-    got = out.sequences.cpu().numpy()
-    assert got.shape == ref.sequences.shape and (got[:, 0] == 2).all() and (got[:, 1] == 996).all()
-    print("bf16 beam-4 token agreement with the fp32 oracle:", float((got == ref.sequences).mean()))
+def _rule_batch(rc, classes, T=12, n=8):
+    """synthetic captioning task with a learnable, deterministic answer: the image is a constant colour that encodes a class c,
+    the caption is lang, s_1 = 100 + c, s_{t+1} = 100 + (3 (s_t - 100) + c + 1) mod 200, ..., eos"""
+    B = len(classes)
+    px = torch.zeros(B, rc.image_size, rc.image_size, 3)
+    labels = torch.full((B, T), rc.pad_token_id, dtype=torch.int64)
+    mask = torch.zeros((B, T), dtype=torch.int64)
+    for b, c in enumerate(classes):
+        px[b, :, :, 0], px[b, :, :, 1], px[b, :, :, 2] = (c & 1) * 2.0 - 1.0, ((c >> 1) & 1) * 2.0 - 1.0, ((c >> 2) & 1) * 2.0 - 1.0
+        s = 100 + c
+        labels[b, 0] = rc.vocab_size - 10
+        for t in range(n):
+            labels[b, 1 + t] = s
+            s = 100 + (3 * (s - 100) + c + 1) % 200
+        labels[b, 1 + n] = rc.eos_token_id
+        mask[b, : n + 2] = 1
+    dec_in = torch.full_like(labels, rc.pad_token_id)
+    dec_in[:, 1:] = labels[:, :-1]
+    return px, labels, mask, dec_in
+
+
+def test_generate_bf16_agrees_with_fp32_oracle_on_a_trained_model(dev):
+    """bfloat16 is what bench.py times; a randomly initialised model cannot tell whether its decisions survive the precision
+    change (its top-1 is the copy of the fed token by a wide margin, everything else is a 250k-way near-tie).  So: train the
+    reduced model with the float32 HIP path on a deterministic synthetic task until it has real, input-dependent decisions,
+    then decode the TRAINED weights three ways — fp32 oracle on the CPU (the reference algorithm), fp32 HIP, bf16 HIP.
+    Asserted: the model learned the rule; fp32 HIP ids == oracle ids; bf16 HIP token agreement with the oracle >= 0.97 and
+    beam scores within 2e-2 (greedy and beam-4)."""
+    from mic_amd import Trainer, create_learning_rate_fn
+    from mic_amd.params import flatten_tree, unflatten_tree
+
+    rc, p, model = make_pair(torch.float32, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.0)
+    tr = Trainer(model, create_learning_rate_fn(10_000, 1, 1, 20, 3e-3), seed=3)
+    g = torch.Generator().manual_seed(0)
+    for step in range(400):
+        cls = torch.randint(0, 8, (32,), generator=g).tolist()
+        px, labels, mask, dec_in = _rule_batch(rc, cls)
+        out = tr.train_step({"pixel_values": px.numpy(), "input_ids": labels.numpy(), "attention_mask": mask.numpy(), "decoder_input_ids": dec_in.numpy()})
+    final = float(out["loss"])
+    assert final < 0.05, final  # the task is learned: predictions now have margins
+    trained = model.params
+    p2 = {k: torch.from_numpy(np.asarray(v)) for k, v in flatten_tree(trained).items()}
+    _, _, m16 = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.0)
+    m16.params = unflatten_tree({k: v.numpy() for k, v in p2.items()})
+    cls = list(range(8))
+    px, labels, *_ = _rule_batch(rc, cls)
+    lang = rc.vocab_size - 10
+    for kw in (dict(max_length=12, num_beams=1, decoder_start_token_id=lang, forced_eos_token_id=None),
+               dict(max_length=12, num_beams=4, decoder_start_token_id=lang, forced_eos_token_id=None)):
+        K = kw["num_beams"]
+        ref = _oracle_gen(rc, p2, px, 8, **kw)
+        ref_seq = ref if K == 1 else ref.sequences
+        got32 = model.generate(px.numpy(), **kw)
+        assert np.array_equal(got32.sequences.cpu().numpy(), ref_seq)
+        # the decoded captions follow the rule (generation starts from the language code like main.py:820)
+        assert (ref_seq[:, 1:9] == labels[:, 1:9].numpy()).mean() > 0.95, ref_seq[:, :10]
+        got16 = m16.generate(px.numpy(), **kw)
+        seq16 = got16.sequences.cpu().numpy()
+        agree = float((seq16 == ref_seq).mean())
+        print(f"trained reduced model, num_beams={K}: bf16 token agreement with the fp32 oracle {agree:.3f}")
+        assert agree >= 0.97, (K, agree, seq16, ref_seq)
+        if K > 1:
+            full = (seq16 == ref_seq).all(axis=1)
+            d = np.abs(got16.scores.cpu().numpy() - ref.scores)[full]
+            print(f"   beam scores of identical hypotheses: max |difference| {d.max():.4f} (scores ~ {np.abs(ref.scores).mean():.3f})")
+            assert d.max() < 2e-2, d
 
 
 def test_generate_api_errors(dev):
