@@ -30,6 +30,7 @@ class GemmArgs(C.Structure):
         ("dropout_seed", C.c_uint32), ("alpha", C.c_float), ("split_k", C.c_int),
         ("split_stride", C.c_longlong), ("a_rowsum", C.c_void_p), ("rowsum_k", C.c_int),
         ("a_fmt", C.c_int), ("b_fmt", C.c_int), ("a_scale_inv", C.c_void_p), ("b_scale_inv", C.c_void_p),
+        ("rowstat", C.c_void_p), ("rowstat_ld", C.c_int), ("rowstat_nvalid", C.c_int),
     ]
 
 
@@ -77,6 +78,8 @@ _SIGS = {
     "mic_embed_fwd": ([_i, _i, _i, _p, _p, _p, _p, _f, _p, _p], C.c_int),
     "mic_embed_bwd": ([_i, _i, _i, _p, _p, _p, _f, _p, _p, _p], C.c_int),
     "mic_ce_rows": ([_i, _i, _i, _p, _i, _p, _p, _f, _p, _p, _p], C.c_int),
+    "mic_ce_rows_tiles": ([_i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p], C.c_int),
+    "mic_row_topk_tiles": ([_i, _i, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p], C.c_int),
     "mic_ce_reduce": ([_i, _p, _p, _p, _p, _p], C.c_int),
     "mic_ce_bwd": ([_i, _i, _i, _i, _p, _i, _p, _p, _f, _p, _p, _f, _p], C.c_int),
     "mic_colsum": ([_i, _i, _i, _p, _i, _p, _i, _p], C.c_int),

@@ -106,6 +106,19 @@ __device__ __forceinline__ float group8_max(float v) {
   v = fmaxf(v, dpp_f<DPP_XOR2>(v));
   return v;
 }
+// sum / max over each 32-lane half of the wave (all 32 lanes receive it)
+__device__ __forceinline__ float half_sum(float v) {
+  v = group8_sum(v);
+  v += dpp_f<DPP_ROR8>(v);
+  v += lane_xor16(v);
+  return v;
+}
+__device__ __forceinline__ float half_max(float v) {
+  v = group8_max(v);
+  v = fmaxf(v, dpp_f<DPP_ROR8>(v));
+  v = fmaxf(v, lane_xor16(v));
+  return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
   v = group8_sum(v);
   v += dpp_f<DPP_ROR8>(v);
@@ -187,6 +200,7 @@ struct EpiArgs {
   uint32_t drop_thr; uint32_t drop_seed; float drop_scale;
   float alpha;
   int N;
+  float* rowstat; int stat_ld; int stat_nvalid;  // bf16 GEMM only: per (row, column tile) softmax partials, see mic_gemm_args
 };
 template <typename T>
 __device__ __forceinline__ void epilogue_store(const EpiArgs& e, int m, int n, float v) {

@@ -198,6 +198,143 @@ extern "C" int mic_row_lse_topk(int dtype, int R, int V, const void* logits, int
   return MIC_OK;
 }
 
+// ------------------------------------------------------------------ per-row lse + top-k from the head GEMM's tile partials
+// The LM-head GEMM can emit, per row and 256-column tile, (max, sum exp(x - max)) of the logits it stores
+// (mic_gemm_args.rowstat).  Merging the ceil(V / 256) partials of a row gives its log-sum-exp without touching the logits,
+// and the k-th largest tile maximum is a lower bound tau on the row's k-th best logit (k distinct tiles each hold an element
+// >= their maximum), so only the few tiles whose maximum reaches tau can hold a top-k entry: the kernel reads 977 float2 and
+// ~k x 256 logits per row instead of streaming 250 054 logits twice.  Results are those of row_lse_topk_kernel: candidates
+// ordered (processed value desc, index asc) on the same fp32 arithmetic (x = (v - max) - log sum + bias).
+template <typename T>
+__global__ __launch_bounds__(256) void row_topk_tiles_kernel(int V, const T* __restrict__ logits, int ld, const float2* __restrict__ stat,
+                                                            int stat_ld, int ntiles, int k, int suppress_eos, int eos, int raw,
+                                                            const float* __restrict__ row_bias, float* __restrict__ top_val,
+                                                            int32_t* __restrict__ top_idx) {
+  constexpr int TPT = 8;  // tiles per thread: up to 2048 tiles (V <= 524 288)
+  __shared__ float sm[256], ss[256];
+  __shared__ int si[256];
+  __shared__ int cand[256];
+  __shared__ int ncand;
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float2* sr = stat + (size_t)row * stat_ld;
+  const T* lr = logits + (size_t)row * ld;
+  const float bias = row_bias ? row_bias[row] : 0.f;
+  float tm[TPT];
+  float m = -INFINITY, s = 0.f;
+#pragma unroll
+  for (int u = 0; u < TPT; ++u) {
+    const int t = tid + u * 256;
+    tm[u] = -INFINITY;
+    if (t < ntiles) {
+      const float2 p = sr[t];
+      tm[u] = p.x;
+      const float mn = fmaxf(m, p.x);
+      s = (mn == -INFINITY) ? 0.f : s * __expf(m - mn) + p.y * __expf(p.x - mn);
+      m = mn;
+    }
+  }
+  sm[tid] = m; ss[tid] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) {
+      const float m1 = sm[tid], m2 = sm[tid + o], mn = fmaxf(m1, m2);
+      ss[tid] = mn == -INFINITY ? 0.f : ss[tid] * __expf(m1 - mn) + ss[tid + o] * __expf(m2 - mn);
+      sm[tid] = mn;
+    }
+    __syncthreads();
+  }
+  const float mx = raw ? 0.f : sm[0];
+  const float logsum = raw ? 0.f : logf(ss[0]);
+  __syncthreads();
+  // tau = the kk-th largest tile maximum (one more when the EOS column, which may be a tile's maximum, is not eligible)
+  const int kk = k + (suppress_eos ? 1 : 0);
+  float tau = INFINITY;
+  {
+    float mine[TPT];
+#pragma unroll
+    for (int u = 0; u < TPT; ++u) mine[u] = tm[u];
+    for (int round = 0; round < kk; ++round) {
+      float best = -INFINITY;
+      int bu = 0;
+#pragma unroll
+      for (int u = 0; u < TPT; ++u) if (mine[u] > best) { best = mine[u]; bu = u; }
+      sm[tid] = best; si[tid] = tid;
+      __syncthreads();
+      for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o && better(sm[tid + o], si[tid + o], sm[tid], si[tid])) { sm[tid] = sm[tid + o]; si[tid] = si[tid + o]; }
+        __syncthreads();
+      }
+      tau = sm[0];
+      if (tid == si[0]) {
+#pragma unroll
+        for (int u = 0; u < TPT; ++u) if (u == bu) mine[u] = -INFINITY;
+      }
+      __syncthreads();
+    }
+  }
+  // tiles that can hold a top-k entry: maximum >= tau minus a margin that covers distinct logits collapsing to one fp32
+  // processed value (the same margin row_lse_topk_kernel uses)
+  const float t_safe = tau > -INFINITY ? tau - 1e-5f * (fabsf(tau) + fabsf(bias) + fabsf(logsum) + fabsf(mx) + 1.0f) : -INFINITY;
+  if (tid == 0) ncand = 0;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < TPT; ++u) {
+    const int t = tid + u * 256;
+    if (t < ntiles && tm[u] >= t_safe) {
+      const int slot = atomicAdd(&ncand, 1);
+      if (slot < 256) cand[slot] = t;
+    }
+  }
+  __syncthreads();
+  const int nc = ncand;
+  // k rounds: the best (processed value, index) that comes after the previous winner in the order (value desc, index asc)
+  float pv = INFINITY;
+  int pidx = -1;
+  for (int round = 0; round < k; ++round) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    auto consider = [&](int t) __attribute__((always_inline)) {
+      const int c = t * 256 + tid;
+      if (c >= V) return;
+      float x = ElemT<T>::ld(lr + c);
+      x = raw ? x : (x - mx) - logsum;
+      if (suppress_eos && c == eos) x = -INFINITY;
+      x += bias;
+      const bool after = x < pv || (x == pv && c > pidx);  // strictly behind the previous winner
+      if (after && better(x, c, bv, bi)) { bv = x; bi = c; }
+    };
+    if (nc <= 256) {
+      for (int q = 0; q < nc; ++q) consider(cand[q]);
+    } else {  // pathological ties (more than 256 tiles at the maximum): every tile is a candidate
+      for (int t = 0; t < ntiles; ++t) consider(t);
+    }
+    sm[tid] = bv; si[tid] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o && better(sm[tid + o], si[tid + o], sm[tid], si[tid])) { sm[tid] = sm[tid + o]; si[tid] = si[tid + o]; }
+      __syncthreads();
+    }
+    pv = sm[0]; pidx = si[0];
+    if (tid == 0) { top_val[(size_t)row * k + round] = pv; top_idx[(size_t)row * k + round] = pidx; }
+    __syncthreads();
+  }
+}
+extern "C" int mic_row_topk_tiles(int dtype, int R, int V, const void* logits, int ld, const float* rowstat, int stat_ld, int k,
+                                  int suppress_eos, int eos_token_id, int raw_logits, const float* row_bias, float* top_val,
+                                  int32_t* top_idx, void* stream) {
+  const int ntiles = (V + 255) / 256;
+  MIC_CHECK(R > 0 && V > 0 && ld >= V && k >= 1 && k <= TOPK_MAX && logits && rowstat && top_val && top_idx && stat_ld >= ntiles && ntiles <= 2048,
+            "mic_row_topk_tiles: bad args");
+  dim3 grid(R), block(256);
+  if (dtype == MIC_BF16)
+    hipLaunchKernelGGL(row_topk_tiles_kernel<uint16_t>, grid, block, 0, (hipStream_t)stream, V, (const uint16_t*)logits, ld, (const float2*)rowstat, stat_ld, ntiles, k, suppress_eos, eos_token_id, raw_logits, row_bias, top_val, top_idx);
+  else if (dtype == MIC_F32)
+    hipLaunchKernelGGL(row_topk_tiles_kernel<float>, grid, block, 0, (hipStream_t)stream, V, (const float*)logits, ld, (const float2*)rowstat, stat_ld, ntiles, k, suppress_eos, eos_token_id, raw_logits, row_bias, top_val, top_idx);
+  else MIC_CHECK(false, "mic_row_topk_tiles: bad dtype");
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}
+
 // ------------------------------------------------------------------ one beam_search_body_fn iteration (gen:857-966)
 // One 128-thread block per batch item; K <= 8 beams (2K*K <= 128 candidates).  All arithmetic is fp32 in
 // the reference's operation order so scores are bit-identical to the oracle.

@@ -215,6 +215,41 @@ extern "C" int mic_ce_rows(int dtype, int rows, int V, const void* logits, int l
     hipLaunchKernelGGL(ce_rows_kernel<T>, dim3(rows), dim3(256), 0, (hipStream_t)stream, V, (const T*)logits, ld, labels, mask, label_smoothing, row_lse, row_loss);
   });
 }
+// Cross-entropy forward from the head GEMM's per-tile softmax partials (mic_gemm_args.rowstat): one wave per row merges the
+// ceil(V / 256) (max, sum exp) pairs into the row's log-sum-exp and reads ONE logit (the label's) — no pass over the
+// [rows][250 054] logits.  Plain NLL only (label_smoothing == 0 needs no sum of the logits).
+template <typename T>
+__global__ __launch_bounds__(256) void ce_rows_tiles_kernel(int rows, const T* __restrict__ logits, int ld, const float2* __restrict__ stat,
+                                                           int stat_ld, int ntiles, const int32_t* __restrict__ labels,
+                                                           float* __restrict__ row_lse, float* __restrict__ row_loss) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float2* sr = stat + (size_t)row * stat_ld;
+  float m = -INFINITY, s = 0.f;
+  for (int t = lane; t < ntiles; t += 64) {
+    const float2 p = sr[t];
+    const float mn = fmaxf(m, p.x);
+    s = (mn == -INFINITY) ? 0.f : s * __expf(m - mn) + p.y * __expf(p.x - mn);
+    m = mn;
+  }
+  const float M = wave_max(m);
+  s = wave_sum(m == -INFINITY ? 0.f : s * __expf(m - M));
+  if (lane == 0) {
+    const float lse = M + logf(s);
+    row_lse[row] = lse;
+    row_loss[row] = lse - ElemT<T>::ld(logits + (size_t)row * ld + labels[row]);
+  }
+}
+extern "C" int mic_ce_rows_tiles(int dtype, int rows, int V, const void* logits, int ld, const float* rowstat, int stat_ld,
+                                 const int32_t* labels, float* row_lse, float* row_loss, void* stream) {
+  const int ntiles = (V + 255) / 256;
+  MIC_CHECK(rows > 0 && V > 1 && ld >= V && logits && rowstat && labels && row_lse && row_loss && stat_ld >= ntiles, "mic_ce_rows_tiles: bad args");
+  return dispatch_t(dtype, [&](auto* tag) {
+    using T = TYPE_OF(tag);
+    hipLaunchKernelGGL(ce_rows_tiles_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, rows, (const T*)logits, ld, (const float2*)rowstat, stat_ld, ntiles, labels, row_lse, row_loss);
+  });
+}
 __global__ __launch_bounds__(256) void ce_reduce_kernel(int rows, const float* __restrict__ row_loss,
                                                         const int32_t* __restrict__ mask, float* loss_out, float* denom_out) {
   __shared__ float sl[256], sd[256];

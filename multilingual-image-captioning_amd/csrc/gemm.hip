@@ -316,6 +316,12 @@ static int fill_epi(const mic_gemm_args* a, EpiArgs& e) {
   e.drop_thr = a->dropout_p > 0.f ? (uint32_t)fminf(a->dropout_p * 4294967296.0f, 4294967295.0f) : 0u;
   e.drop_seed = a->dropout_seed; e.drop_scale = 1.0f / (1.0f - a->dropout_p);
   e.alpha = a->alpha == 0.f ? 1.0f : a->alpha; e.N = a->N;
+  e.rowstat = a->rowstat; e.stat_ld = a->rowstat_ld; e.stat_nvalid = a->rowstat_nvalid > 0 ? a->rowstat_nvalid : a->N;
+  if (a->rowstat) {
+    MIC_CHECK(a->dtype == MIC_BF16 && a->split_k <= 1 && !a->act && !a->dact && !a->R && !a->accumulate && a->dropout_p == 0.f && !a->Zout,
+              "mic_gemm: rowstat goes with the bare bias epilogue of a bf16 GEMM (the LM head)");
+    MIC_CHECK(a->rowstat_ld >= (a->N + 255) / 256 && ((uintptr_t)a->rowstat & 7) == 0, "mic_gemm: rowstat needs ld >= ceil(N / 256) float2 entries per row");
+  }
   if (a->dtype == MIC_BF16) {
     MIC_CHECK(a->K % 64 == 0, "mic_gemm(bf16): K=%d must be a multiple of 64 (zero-pad the reduction dim)", a->K);
     MIC_CHECK(a->lda % 8 == 0 && a->ldb % 8 == 0, "mic_gemm(bf16): lda/ldb must be multiples of 8");
@@ -398,6 +404,8 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
   static const int tiny_below = [] { const char* e = getenv("MIC_TINY_BELOW"); return e ? atoi(e) : MIC_TINY_BELOW; }();
   int bm = tiles_big >= 200 ? 256 : (tiles_small < tiny_below ? 64 : 128);
   if (force == 256 || force == 128 || force == 64) bm = force;
+  for (int i = 0; i < count; ++i)
+    if (args[i].rowstat) bm = 256;  // the consumers of the softmax partials assume 256-column tiles
   int blocks = 0;
   for (int i = 0; i < count; ++i) {
     Problem& p = tab.p[i];

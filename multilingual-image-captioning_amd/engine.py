@@ -378,12 +378,20 @@ class Engine:
         ops.layernorm_fwd(x, P.f32("dec.ln_f.g"), P.f32("dec.ln_f.b"), self.dec_eps, hf, stf[0], stf[1], rows=M)
         return hf
 
-    def head_logits(self, hf, M: int, name: str = "d.logits"):
-        """Tied head (modeling:170-178): logits[M, Vpad] = hf @ shared^T + final_logits_bias (compute dtype)."""
+    def head_logits(self, hf, M: int, name: str = "d.logits", stats: bool = False):
+        """Tied head (modeling:170-178): logits[M, Vpad] = hf @ shared^T + final_logits_bias (compute dtype).
+        stats=True (bf16 mode): also returns the GEMM's per-tile softmax partials [M][ceil(Vpad/256)][2] (fp32) so that the
+        log-softmax downstream (cross-entropy, beam scores) needs no second pass over the logits."""
         P = self.P
         logits = self.buf(name, M, P.Vpad)
-        ops.gemm(hf, P.w("shared"), logits, M, P.Vpad, P.d, bias=P.f32("flb"))
-        return logits
+        stat = self.head_stats(name, M) if stats else None
+        ops.gemm(hf, P.w("shared"), logits, M, P.Vpad, P.d, bias=P.f32("flb"), rowstat=stat, rowstat_nvalid=P.V)
+        return (logits, stat) if stats else logits
+
+    def head_stats(self, name: str, M: int):
+        if self.dt != torch.bfloat16:
+            return None  # the fp32 (parity) GEMM kernel has no by-products: its consumers stream the logits
+        return self.buf(name + ".stat", M, 2 * ((self.P.Vpad + 255) // 256), torch.float32)
 
     def decoder_backward(self, B: int, T: int, ids, pos_ids, key_mask, ehs, dlogits, seed: Optional[int], rows=None):
         """Consumes dlogits [M,Vpad] (or [Mc,Vpad] for the compacted head: rows = (idx int32 [Mc], Mc)); writes all
@@ -492,21 +500,27 @@ class Engine:
         return dehs
 
     # ------------------------------------------------------------------ loss (main.py:658-680) on materialised logits
-    def loss_and_dlogits(self, logits, labels, mask, M: int, label_smoothing: float, backward: bool):
+    def loss_and_dlogits(self, logits, labels, mask, M: int, label_smoothing: float, backward: bool, stat=None):
         P = self.P
         lse, rl = self.vec("ce.lse", _rup(M, ROWPAD)), self.vec("ce.rowloss", _rup(M, ROWPAD))
         loss, denom = self.vec("ce.loss", 1), self.vec("ce.denom", 1)
-        ops.ce_rows(logits, logits.stride(0), P.V, labels, mask, label_smoothing, lse, rl, M)
+        if stat is not None and label_smoothing == 0.0:
+            ops.ce_rows_tiles(logits, logits.stride(0), P.V, stat, labels, lse, rl, M)  # lse from the head GEMM's tile partials
+        else:
+            ops.ce_rows(logits, logits.stride(0), P.V, labels, mask, label_smoothing, lse, rl, M)
         ops.ce_reduce(rl, mask, loss, denom, M)
         if backward:
             ops.ce_bwd(logits, logits.stride(0), P.V, P.Vpad, labels, mask, label_smoothing, lse, denom, M)
         return loss
 
     # ------------------------------------------------------------------ full passes
-    def forward_logits(self, pixels, ids, pos_ids, key_mask, B, T, *, save=False, seed=None, trunc_int32=False):
+    def forward_logits(self, pixels, ids, pos_ids, key_mask, B, T, *, save=False, seed=None, trunc_int32=False, stats=False):
         self._fp8_begin_pass()
         _, ehs = self.vit_forward(pixels, save, trunc_int32)
         hf = self.decoder_forward(ids, pos_ids, key_mask, ehs, B, T, save, seed)
+        if stats:
+            logits, stat = self.head_logits(hf, B * T, stats=True)
+            return logits, ehs, stat
         return self.head_logits(hf, B * T), ehs
 
     def compact_head(self, hf, M: int, rows):
@@ -520,22 +534,23 @@ class Engine:
         if Mcp > Mc:
             ops.zero(hfc[Mc:Mcp])
         logits = self.buf("d.logits", M, P.Vpad)
-        ops.gemm(hfc, P.w("shared"), logits, Mc, P.Vpad, P.d, bias=P.f32("flb"))
+        stat = self.head_stats("d.logits", M)
+        ops.gemm(hfc, P.w("shared"), logits, Mc, P.Vpad, P.d, bias=P.f32("flb"), rowstat=stat, rowstat_nvalid=P.V)
         if Mcp > Mc:
             ops.zero(logits[Mc:Mcp])  # reduction padding of the dE GEMM (rows of an earlier, longer batch may linger here)
-        return logits
+        return logits, stat
 
     def loss_only(self, pixels, ids, pos_ids, key_mask, labels, B, T, *, label_smoothing=0.0, rows=None, row_labels=None):
         """eval_step's forward + loss (main.py:710-716)."""
         M = B * T
         if rows is None:
-            logits, _ = self.forward_logits(pixels, ids, pos_ids, key_mask, B, T, save=False, seed=None)
-            return self.loss_and_dlogits(logits, labels, key_mask.reshape(-1), M, label_smoothing, backward=False)
+            logits, _, stat = self.forward_logits(pixels, ids, pos_ids, key_mask, B, T, save=False, seed=None, stats=True)
+            return self.loss_and_dlogits(logits, labels, key_mask.reshape(-1), M, label_smoothing, backward=False, stat=stat)
         self._fp8_begin_pass()
         _, ehs = self.vit_forward(pixels, False)
         hf = self.decoder_forward(ids, pos_ids, key_mask, ehs, B, T, False, None)
-        logits = self.compact_head(hf, M, rows)
-        return self.loss_and_dlogits(logits, row_labels, self.ones_i32(rows[1]), rows[1], label_smoothing, backward=False)
+        logits, stat = self.compact_head(hf, M, rows)
+        return self.loss_and_dlogits(logits, row_labels, self.ones_i32(rows[1]), rows[1], label_smoothing, backward=False, stat=stat)
 
     def ones_i32(self, n: int):
         key = f"ones_i32:{n}"
@@ -555,14 +570,14 @@ class Engine:
         ops.zero(P.grad[P.atomic_begin:])
         M = B * T
         if rows is None:
-            logits, ehs = self.forward_logits(pixels, ids, pos_ids, key_mask, B, T, save=True, seed=seed)
-            loss = self.loss_and_dlogits(logits, labels, key_mask.reshape(-1), M, label_smoothing, backward=True)
+            logits, ehs, stat = self.forward_logits(pixels, ids, pos_ids, key_mask, B, T, save=True, seed=seed, stats=True)
+            loss = self.loss_and_dlogits(logits, labels, key_mask.reshape(-1), M, label_smoothing, backward=True, stat=stat)
         else:
             self._fp8_begin_pass()
             _, ehs = self.vit_forward(pixels, True)
             hf = self.decoder_forward(ids, pos_ids, key_mask, ehs, B, T, True, seed)
-            logits = self.compact_head(hf, M, rows)
-            loss = self.loss_and_dlogits(logits, row_labels, self.ones_i32(rows[1]), rows[1], label_smoothing, backward=True)
+            logits, stat = self.compact_head(hf, M, rows)
+            loss = self.loss_and_dlogits(logits, row_labels, self.ones_i32(rows[1]), rows[1], label_smoothing, backward=True, stat=stat)
         dehs = self.decoder_backward(B, T, ids, pos_ids, key_mask, ehs, logits, seed, rows=rows)
         self.vit_backward(B, dehs)
         return loss

@@ -188,10 +188,16 @@ class FlaxCLIPVisionMBartGenerationMixin:
         steps = 0
         while True:
             with ops.pinned_stream():
-                logits = self._decode_step(cache, next_token, pos)  # gen:830-840
+                logits, stat = self._decode_step(cache, next_token, pos, stats=True)  # gen:830-840
                 forced, suppress = self._proc_args(procs, cur_len, max_length, eos_token_id)
-                ops.row_lse_topk(logits, logits.stride(0), st.V, 2 * K, cand_val, cand_idx, R, forced_token=forced, suppress_eos=suppress,
-                                 eos_token_id=eos_token_id, row_bias=running_scores.reshape(-1))  # gen:850-873 (per row)
+                if stat is not None and forced < 0:
+                    # log-softmax + top-2K from the head GEMM's per-tile partials: 977 pairs and a few 256-column tiles per row
+                    # instead of two passes over the 250 054 logits (same candidates, same order, same fp32 arithmetic)
+                    ops.row_topk_tiles(logits, logits.stride(0), st.V, stat, 2 * K, cand_val, cand_idx, R, suppress_eos=suppress,
+                                       eos_token_id=eos_token_id, row_bias=running_scores.reshape(-1))
+                else:
+                    ops.row_lse_topk(logits, logits.stride(0), st.V, 2 * K, cand_val, cand_idx, R, forced_token=forced, suppress_eos=suppress,
+                                     eos_token_id=eos_token_id, row_bias=running_scores.reshape(-1))  # gen:850-873 (per row)
                 ops.beam_step(B, K, max_length, st.V, cur_len, eos_token_id, pad_token_id, length_penalty, early_stopping, cand_val,
                               cand_idx, running_seq, running_scores, seq, scores, finished, src_row, next_token, flags)  # gen:872-966
             pos += 1

@@ -301,7 +301,8 @@ class FlaxCLIPVisionMBartForConditionalGeneration(FlaxCLIPVisionMBartPreTrainedM
             cross.append(kv)
         cache["cross"], cache["row_div"] = cross, row_div
 
-    def _decode_step(self, cache: dict, tokens: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
+    def _decode_step(self, cache: dict, tokens: torch.Tensor, pos: torch.Tensor, stats: bool = False):
+        """stats=True: returns (logits, per-tile softmax partials of the head GEMM or None in float32 mode)"""
         eng, st = self.engine, self.store
         P = st
         R, Lmax, cur = cache["rows"], cache["max_length"], cache["cache_index"]
@@ -331,7 +332,7 @@ class FlaxCLIPVisionMBartForConditionalGeneration(FlaxCLIPVisionMBartPreTrainedM
         hf = eng.buf("g.hf", R, d)
         ops.layernorm_fwd(x, P.f32("dec.ln_f.g"), P.f32("dec.ln_f.b"), eng.dec_eps, hf, rows=R)
         cache["cache_index"] = cur + 1
-        return eng.head_logits(hf, R, name="g.logits")
+        return eng.head_logits(hf, R, name="g.logits", stats=stats)
 
     # ------------------------------------------------------------------ construction (modeling:703-773)
     @classmethod

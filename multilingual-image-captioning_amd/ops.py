@@ -60,7 +60,7 @@ class pinned_stream:
 def gemm_args(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, *, a_kmajor=False, b_kmajor=False,
               bias=None, act=0, zout=None, zin=None, dact=0, residual=None, accumulate=False, dropout_p=0.0, dropout_seed=0,
               alpha=1.0, lda=None, ldb=None, ldc=None, ldz=None, ldr=None, split_k=0, split_stride=0, a_rowsum=None, rowsum_k=0,
-              a_scale_inv=None, b_scale_inv=None) -> "L.GemmArgs":
+              a_scale_inv=None, b_scale_inv=None, rowstat=None, rowstat_nvalid=0) -> "L.GemmArgs":
     """fp8 operands: `a` / `b` are torch.float8_e4m3fn / float8_e5m2 tensors (k-contiguous), `a_scale_inv` / `b_scale_inv` the
     device scalars mic_fp8_quantize wrote for them."""
     g = L.GemmArgs()
@@ -81,6 +81,8 @@ def gemm_args(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: in
     g.accumulate, g.dropout_p, g.dropout_seed, g.alpha = int(accumulate), float(dropout_p), int(dropout_seed) & 0xFFFFFFFF, float(alpha)
     g.split_k, g.split_stride = int(split_k), int(split_stride)
     g.a_rowsum, g.rowsum_k = _p(a_rowsum), int(rowsum_k)
+    if rowstat is not None:  # fp32 [rows][tiles][2]: softmax partials per 256-column tile (LM head)
+        g.rowstat, g.rowstat_ld, g.rowstat_nvalid = _p(rowstat), rowstat.stride(0) // 2, int(rowstat_nvalid)
     return g
 
 
@@ -177,6 +179,16 @@ def embed_bwd(ids, pos_ids, dh, scale, dtable, dpos_table, rows, width):
 
 def ce_rows(logits, ld, V, labels, mask, ls, row_lse, row_loss, rows):
     L.check(L.lib().mic_ce_rows(_dt(logits), rows, V, _p(logits), ld, _p(labels), _p(mask), float(ls), _p(row_lse), _p(row_loss), _stream()), "mic_ce_rows")
+
+
+def ce_rows_tiles(logits, ld, V, rowstat, labels, row_lse, row_loss, rows):
+    L.check(L.lib().mic_ce_rows_tiles(_dt(logits), rows, V, _p(logits), ld, _p(rowstat), rowstat.stride(0) // 2, _p(labels), _p(row_lse),
+                                      _p(row_loss), _stream()), "mic_ce_rows_tiles")
+
+
+def row_topk_tiles(logits, ld, V, rowstat, k, top_val, top_idx, R, *, suppress_eos=False, eos_token_id=2, raw_logits=False, row_bias=None):
+    L.check(L.lib().mic_row_topk_tiles(_dt(logits), R, V, _p(logits), ld, _p(rowstat), rowstat.stride(0) // 2, k, int(suppress_eos),
+                                       eos_token_id, int(raw_logits), _p(row_bias), _p(top_val), _p(top_idx), _stream()), "mic_row_topk_tiles")
 
 
 def ce_reduce(row_loss, mask, loss_out, denom_out, rows):

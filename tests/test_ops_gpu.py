@@ -515,3 +515,91 @@ def test_gemm_split_k_slabs_and_sum(dev):
 
     with pytest.raises(MicError):
         ops.gemm(a, w, ws, M, N, K, b_kmajor=True, split_k=8, split_stride=100)
+
+
+# ---------------------------------------------------------------- head GEMM softmax partials and their consumers
+@pytest.mark.parametrize("M,V,Vpad", [(300, 1003, 1024), (70, 5003, 5120), (1024, 250054, 250112)])
+def test_head_rowstat_topk_and_ce_from_tile_partials(dev, M, V, Vpad):
+    """mic_gemm's per-tile (max, sum exp) by-product against the stored logits, then its two consumers against the kernels
+    that stream the whole row: mic_row_topk_tiles == mic_row_lse_topk (indices identical, values to fp32 rounding — both are
+    checked against the oracle's log_softmax + top_k) and mic_ce_rows_tiles == mic_ce_rows."""
+    from mic_amd import ops
+    from oracle import generation_ref as G
+
+    K = 256
+    g = torch.Generator().manual_seed(M + V)
+    x = (torch.randn(M, K, generator=g)).to(torch.bfloat16)
+    w = torch.zeros(Vpad, K, dtype=torch.bfloat16)
+    w[:V] = (torch.randn(V, K, generator=g) * 0.2).to(torch.bfloat16)
+    bias = torch.zeros(Vpad)
+    bias[:V] = torch.randn(V, generator=g)
+    bias[2] = 25.0  # EOS dominates: suppress_eos has to look past a tile maximum
+    nt = (Vpad + 255) // 256
+    logits = torch.zeros((M, Vpad), dtype=torch.bfloat16, device=dev)
+    stat = torch.full((M, nt, 2), float("nan"), device=dev)
+    ops.gemm(x.to(dev), w.to(dev), logits, M, Vpad, K, bias=bias.to(dev), rowstat=stat, rowstat_nvalid=V)
+    torch.cuda.synchronize()
+    lg = logits.float().cpu()
+    # partials: exactly the stored values' maximum, sum exp to fp32 rounding
+    pad = torch.full((M, nt * 256), float("-inf"))
+    pad[:, :V] = lg[:, :V]
+    tiles = pad.reshape(M, nt, 256)
+    mx = tiles.max(-1).values
+    assert torch.equal(stat[:, :, 0].cpu(), mx)
+    sm = torch.exp(tiles - mx[..., None]).sum(-1)
+    assert ((stat[:, :, 1].cpu() - sm).abs() / sm).max().item() < 2e-5
+    # top-k consumer vs the full-row kernel and the oracle
+    R, k = min(M, 48), 8
+    rb = torch.linspace(-3.0, 0.0, R)
+    tv, ti = torch.empty((R, k), device=dev), torch.empty((R, k), dtype=torch.int32, device=dev)
+    tv2, ti2 = torch.empty((R, k), device=dev), torch.empty((R, k), dtype=torch.int32, device=dev)
+    for sup in (False, True):
+        ops.row_topk_tiles(logits, Vpad, V, stat, k, tv, ti, R, suppress_eos=sup, eos_token_id=2, row_bias=rb.to(dev))
+        ops.row_lse_topk(logits, Vpad, V, k, tv2, ti2, R, suppress_eos=sup, eos_token_id=2, row_bias=rb.to(dev))
+        torch.cuda.synchronize()
+        assert torch.equal(ti.cpu(), ti2.cpu()), sup
+        assert (tv.cpu() - tv2.cpu()).abs().max().item() < 2e-5
+        lp = G.log_softmax(lg[:R, :V].numpy())
+        if sup:
+            lp[:, 2] = -np.inf
+        rv, ri = G.top_k(lp + rb.numpy()[:, None], k)
+        assert np.array_equal(ti.cpu().numpy(), ri.astype(np.int32))
+        assert np.allclose(tv.cpu().numpy(), rv, rtol=1e-5, atol=2e-5)
+    # k = 16 (num_beams 8) and raw mode (no log-softmax)
+    tv, ti = torch.empty((R, 16), device=dev), torch.empty((R, 16), dtype=torch.int32, device=dev)
+    ops.row_topk_tiles(logits, Vpad, V, stat, 16, tv, ti, R, raw_logits=True)
+    torch.cuda.synchronize()
+    rv, ri = G.top_k(lg[:R, :V].numpy(), 16)
+    assert np.array_equal(ti.cpu().numpy(), ri.astype(np.int32)) and np.array_equal(tv.cpu().numpy(), rv)
+    # cross-entropy consumer
+    labels = torch.randint(0, V, (M,), generator=g).to(torch.int32)
+    ones = torch.ones(M, dtype=torch.int32)
+    l1, r1 = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    l2, r2 = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    ops.ce_rows_tiles(logits, Vpad, V, stat, labels.to(dev), l1, r1, M)
+    ops.ce_rows(logits, Vpad, V, labels.to(dev), ones.to(dev), 0.0, l2, r2, M)
+    torch.cuda.synchronize()
+    assert (l1 - l2).abs().max().item() < 2e-5 and (r1 - r2).abs().max().item() < 2e-5
+    ref = torch.logsumexp(lg[:, :V], -1)
+    assert (l1.cpu() - ref).abs().max().item() < 2e-5
+
+
+def test_row_topk_tiles_ties_across_many_tiles(dev):
+    """All logits equal (every tile at the maximum): index-stable ordering and the > 256 candidate-tile fallback."""
+    from mic_amd import ops
+
+    R, V = 3, 100_000
+    Vpad = (V + 255) // 256 * 256
+    logits = torch.zeros((R, Vpad), dtype=torch.bfloat16, device=dev)
+    logits[1, 77_777] = 1.0
+    nt = Vpad // 256
+    stat = torch.zeros((R, nt, 2), device=dev)
+    stat[:, :, 1] = 256.0
+    stat[:, nt - 1, 1] = V - (nt - 1) * 256
+    stat[1, 77_777 // 256, 0] = 1.0
+    stat[1, 77_777 // 256, 1] = 1.0 + 255.0 * float(np.exp(-1.0))
+    tv, ti = torch.empty((R, 8), device=dev), torch.empty((R, 8), dtype=torch.int32, device=dev)
+    ops.row_topk_tiles(logits, Vpad, V, stat, 8, tv, ti, R)
+    torch.cuda.synchronize()
+    assert ti[0].tolist() == list(range(8)) and ti[2].tolist() == list(range(8))
+    assert ti[1].tolist() == [77_777] + list(range(7))
