@@ -92,10 +92,10 @@ typedef struct {
   int a_fmt, b_fmt;                 /* MIC_E4M3 / MIC_E5M2 (B must be e4m3) */
   const float* a_scale_inv;         /* device scalar or NULL (= 1) */
   const float* b_scale_inv;
-  /* optional by-product of the LM-head GEMM (bf16, bias-only epilogue; forces 256-column tiles): rowstat[(m * rowstat_ld + t) * 2
-   * + {0, 1}] = max and sum exp(x - max) over the columns [256 t, 256 t + 256) & [0, rowstat_nvalid) of output row m, taken on
-   * the values as stored in C.  With them the log-softmax of main.py:672-675 / gen:850 needs no second pass over the
-   * [rows][250 054] logits: mic_ce_rows_tiles and mic_row_topk_tiles merge ceil(N / 256) partials per row. */
+  /* optional by-product of the LM-head GEMM (bf16, bias-only epilogue, N % 64 == 0): rowstat[(m * rowstat_ld + g) * 2 + {0, 1}]
+   * = max and sum exp(x - max) over the columns [64 g, 64 g + 64) & [0, rowstat_nvalid) of output row m, taken on the values as
+   * stored in C.  With them the log-softmax of main.py:672-675 / gen:850 needs no second pass over the [rows][250 054]
+   * logits: mic_ce_rows_tiles and mic_row_topk_tiles merge the N / 64 partials of a row. */
   float* rowstat; int rowstat_ld; int rowstat_nvalid;
 } mic_gemm_args;
 int mic_gemm(const mic_gemm_args* a, void* stream);
@@ -201,8 +201,8 @@ int mic_embed_bwd(int dtype, int rows, int width, const int32_t* ids, const int3
  * ------------------------------------------------------------------------------------------- */
 int mic_ce_rows(int dtype, int rows, int V, const void* logits, int ld, const int32_t* labels,
                 const int32_t* mask, float label_smoothing, float* row_lse, float* row_loss, void* stream);
-/* mic_ce_rows without the pass over the logits: row_lse from the head GEMM's per-tile partials (mic_gemm_args.rowstat,
- * [rows][stat_ld] float2), row_loss = lse - logits[label] (label_smoothing 0: plain NLL, main.py:674 with a one-hot target) */
+/* mic_ce_rows without the pass over the logits: row_lse from the head GEMM's per-granule partials (mic_gemm_args.rowstat,
+ * [rows][stat_ld] float2, 64 columns each), row_loss = lse - logits[label] (label_smoothing 0: plain NLL, main.py:674 with a one-hot target) */
 int mic_ce_rows_tiles(int dtype, int rows, int V, const void* logits, int ld, const float* rowstat, int stat_ld,
                       const int32_t* labels, float* row_lse, float* row_loss, void* stream);
 int mic_ce_reduce(int rows, const float* row_loss, const int32_t* mask, float* loss_out, float* denom_out,
@@ -256,8 +256,9 @@ int mic_row_lse_topk(int dtype, int R, int V, const void* logits, int ld, int k,
                      int suppress_eos, int eos_token_id, int raw_logits, const float* row_bias, float* top_val,
                      int32_t* top_idx, void* stream);
 
-/* mic_row_lse_topk's results (no forced token) from the head GEMM's per-tile partials: lse by merging ceil(V / 256) pairs, the
- * top-k by scanning only the tiles whose maximum reaches the k-th largest tile maximum (gen:850-873 without streaming the row) */
+/* mic_row_lse_topk's results (no forced token) from the head GEMM's per-granule partials: lse by merging ceil(V / 64) pairs, the
+ * top-k by scanning only the 64-column granules whose maximum reaches the k-th largest granule maximum (gen:850-873 without
+ * streaming the row) */
 int mic_row_topk_tiles(int dtype, int R, int V, const void* logits, int ld, const float* rowstat, int stat_ld, int k,
                        int suppress_eos, int eos_token_id, int raw_logits, const float* row_bias, float* top_val,
                        int32_t* top_idx, void* stream);

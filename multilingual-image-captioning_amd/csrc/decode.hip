@@ -199,18 +199,18 @@ extern "C" int mic_row_lse_topk(int dtype, int R, int V, const void* logits, int
 }
 
 // ------------------------------------------------------------------ per-row lse + top-k from the head GEMM's tile partials
-// The LM-head GEMM can emit, per row and 256-column tile, (max, sum exp(x - max)) of the logits it stores
-// (mic_gemm_args.rowstat).  Merging the ceil(V / 256) partials of a row gives its log-sum-exp without touching the logits,
-// and the k-th largest tile maximum is a lower bound tau on the row's k-th best logit (k distinct tiles each hold an element
-// >= their maximum), so only the few tiles whose maximum reaches tau can hold a top-k entry: the kernel reads 977 float2 and
-// ~k x 256 logits per row instead of streaming 250 054 logits twice.  Results are those of row_lse_topk_kernel: candidates
+// The LM-head GEMM can emit, per row and 64-column granule, (max, sum exp(x - max)) of the logits it stores
+// (mic_gemm_args.rowstat).  Merging the ceil(V / 64) partials of a row gives its log-sum-exp without touching the logits,
+// and the k-th largest granule maximum is a lower bound tau on the row's k-th best logit (k distinct granules each hold an
+// element >= their maximum), so only the few granules whose maximum reaches tau can hold a top-k entry: the kernel reads 3908
+// float2 and ~k x 64 logits per row instead of streaming 250 054 logits twice.  Results are those of row_lse_topk_kernel: candidates
 // ordered (processed value desc, index asc) on the same fp32 arithmetic (x = (v - max) - log sum + bias).
 template <typename T>
 __global__ __launch_bounds__(256) void row_topk_tiles_kernel(int V, const T* __restrict__ logits, int ld, const float2* __restrict__ stat,
                                                             int stat_ld, int ntiles, int k, int suppress_eos, int eos, int raw,
                                                             const float* __restrict__ row_bias, float* __restrict__ top_val,
                                                             int32_t* __restrict__ top_idx) {
-  constexpr int TPT = 8;  // tiles per thread: up to 2048 tiles (V <= 524 288)
+  constexpr int TPT = 16;  // granules per thread: up to 4096 granules of 64 columns (V <= 262 144)
   __shared__ float sm[256], ss[256];
   __shared__ int si[256];
   __shared__ int cand[256];
@@ -293,8 +293,8 @@ __global__ __launch_bounds__(256) void row_topk_tiles_kernel(int V, const T* __r
   for (int round = 0; round < k; ++round) {
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    auto consider = [&](int t) __attribute__((always_inline)) {
-      const int c = t * 256 + tid;
+    auto consider = [&](int t) __attribute__((always_inline)) {  // this thread's element of granule t
+      const int c = t * 64 + (tid & 63);
       if (c >= V) return;
       float x = ElemT<T>::ld(lr + c);
       x = raw ? x : (x - mx) - logsum;
@@ -303,10 +303,10 @@ __global__ __launch_bounds__(256) void row_topk_tiles_kernel(int V, const T* __r
       const bool after = x < pv || (x == pv && c > pidx);  // strictly behind the previous winner
       if (after && better(x, c, bv, bi)) { bv = x; bi = c; }
     };
-    if (nc <= 256) {
-      for (int q = 0; q < nc; ++q) consider(cand[q]);
-    } else {  // pathological ties (more than 256 tiles at the maximum): every tile is a candidate
-      for (int t = 0; t < ntiles; ++t) consider(t);
+    if (nc <= 256) {  // four granules per sweep (one per wave)
+      for (int q = tid >> 6; q < nc; q += 4) consider(cand[q]);
+    } else {  // pathological ties (more than 256 granules at the maximum): every granule is a candidate
+      for (int t = tid >> 6; t < ntiles; t += 4) consider(t);
     }
     sm[tid] = bv; si[tid] = bi;
     __syncthreads();
@@ -322,9 +322,9 @@ __global__ __launch_bounds__(256) void row_topk_tiles_kernel(int V, const T* __r
 extern "C" int mic_row_topk_tiles(int dtype, int R, int V, const void* logits, int ld, const float* rowstat, int stat_ld, int k,
                                   int suppress_eos, int eos_token_id, int raw_logits, const float* row_bias, float* top_val,
                                   int32_t* top_idx, void* stream) {
-  const int ntiles = (V + 255) / 256;
-  MIC_CHECK(R > 0 && V > 0 && ld >= V && k >= 1 && k <= TOPK_MAX && logits && rowstat && top_val && top_idx && stat_ld >= ntiles && ntiles <= 2048,
-            "mic_row_topk_tiles: bad args");
+  const int ntiles = (V + 63) / 64;
+  MIC_CHECK(R > 0 && V > 0 && ld >= V && k >= 1 && k <= TOPK_MAX && logits && rowstat && top_val && top_idx && stat_ld >= ntiles && ntiles <= 4096,
+            "mic_row_topk_tiles: bad args (V <= 262144)");
   dim3 grid(R), block(256);
   if (dtype == MIC_BF16)
     hipLaunchKernelGGL(row_topk_tiles_kernel<uint16_t>, grid, block, 0, (hipStream_t)stream, V, (const uint16_t*)logits, ld, (const float2*)rowstat, stat_ld, ntiles, k, suppress_eos, eos_token_id, raw_logits, row_bias, top_val, top_idx);

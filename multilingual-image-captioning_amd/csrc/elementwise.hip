@@ -216,7 +216,7 @@ extern "C" int mic_ce_rows(int dtype, int rows, int V, const void* logits, int l
   });
 }
 // Cross-entropy forward from the head GEMM's per-tile softmax partials (mic_gemm_args.rowstat): one wave per row merges the
-// ceil(V / 256) (max, sum exp) pairs into the row's log-sum-exp and reads ONE logit (the label's) — no pass over the
+// ceil(V / 64) (max, sum exp) pairs into the row's log-sum-exp and reads ONE logit (the label's) — no pass over the
 // [rows][250 054] logits.  Plain NLL only (label_smoothing == 0 needs no sum of the logits).
 template <typename T>
 __global__ __launch_bounds__(256) void ce_rows_tiles_kernel(int rows, const T* __restrict__ logits, int ld, const float2* __restrict__ stat,
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void ce_rows_tiles_kernel(int rows, const T* _
 }
 extern "C" int mic_ce_rows_tiles(int dtype, int rows, int V, const void* logits, int ld, const float* rowstat, int stat_ld,
                                  const int32_t* labels, float* row_lse, float* row_loss, void* stream) {
-  const int ntiles = (V + 255) / 256;
+  const int ntiles = (V + 63) / 64;
   MIC_CHECK(rows > 0 && V > 1 && ld >= V && logits && rowstat && labels && row_lse && row_loss && stat_ld >= ntiles, "mic_ce_rows_tiles: bad args");
   return dispatch_t(dtype, [&](auto* tag) {
     using T = TYPE_OF(tag);

@@ -320,7 +320,8 @@ static int fill_epi(const mic_gemm_args* a, EpiArgs& e) {
   if (a->rowstat) {
     MIC_CHECK(a->dtype == MIC_BF16 && a->split_k <= 1 && !a->act && !a->dact && !a->R && !a->accumulate && a->dropout_p == 0.f && !a->Zout,
               "mic_gemm: rowstat goes with the bare bias epilogue of a bf16 GEMM (the LM head)");
-    MIC_CHECK(a->rowstat_ld >= (a->N + 255) / 256 && ((uintptr_t)a->rowstat & 7) == 0, "mic_gemm: rowstat needs ld >= ceil(N / 256) float2 entries per row");
+    MIC_CHECK(a->N % 64 == 0 && a->ldc % 8 == 0 && ((uintptr_t)a->C & 15) == 0, "mic_gemm: rowstat needs N %% 64 == 0 and a 16-B aligned C");
+    MIC_CHECK(a->rowstat_ld >= a->N / 64 && ((uintptr_t)a->rowstat & 7) == 0, "mic_gemm: rowstat needs ld >= N / 64 float2 entries per row");
   }
   if (a->dtype == MIC_BF16) {
     MIC_CHECK(a->K % 64 == 0, "mic_gemm(bf16): K=%d must be a multiple of 64 (zero-pad the reduction dim)", a->K);
@@ -405,7 +406,7 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
   int bm = tiles_big >= 200 ? 256 : (tiles_small < tiny_below ? 64 : 128);
   if (force == 256 || force == 128 || force == 64) bm = force;
   for (int i = 0; i < count; ++i)
-    if (args[i].rowstat) bm = 256;  // the consumers of the softmax partials assume 256-column tiles
+    if (args[i].rowstat) bm = 256;  // softmax partials per 64-column granule = the wave tile width of this configuration
   int blocks = 0;
   for (int i = 0; i < count; ++i) {
     Problem& p = tab.p[i];

@@ -163,50 +163,6 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], c
     E.alpha = 1.0f;
     E.bias = nullptr;
   }
-  // optional by-product for the LM head (E.rowstat): per output row and column tile, max and sum exp(x - max) over the tile's
-  // valid columns of the values AS STORED (rounded to the output dtype), i.e. the softmax partials of that slice of the
-  // logits row.  The consumer (mic_ce_rows_tiles / mic_row_topk_tiles) merges the tiles_n partials of a row instead of
-  // streaming the 250 054-wide row again.  A lane holds column (lane & 31) of 16 rows per 32x32 block: reduce over the 32
-  // lanes of a half-wave in registers, then over the WNW waves that share the rows through LDS.
-  if (E.rowstat != nullptr) {
-    float2* st = reinterpret_cast<float2*>(smem);  // [WNW][2 * WM rows]
-    if (kg == 0) {
-#pragma unroll
-      for (int i = 0; i < AI; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v[NJ];
-          float mx = -INFINITY;
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            const int n = n0 + wc * WN + j * 32 + (lane & 31);
-            v[j] = n < E.stat_nvalid ? (E.c_f32 ? acc[i][j][r] : bf2f(f2bf(acc[i][j][r]))) : -INFINITY;
-            mx = fmaxf(mx, v[j]);
-          }
-          mx = half_max(mx);
-          float sm = 0.0f;
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) sm += v[j] > -INFINITY ? __expf(v[j] - mx) : 0.0f;
-          sm = half_sum(sm);
-          if ((lane & 31) == 0) st[wc * (2 * WM) + wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = make_float2(mx, sm);
-        }
-    }
-    __syncthreads();
-    if (tid < 2 * WM) {
-      float mx = -INFINITY;
-#pragma unroll
-      for (int w = 0; w < WNW; ++w) mx = fmaxf(mx, st[w * (2 * WM) + tid].x);
-      float sm = 0.0f;
-#pragma unroll
-      for (int w = 0; w < WNW; ++w) {
-        const float2 t = st[w * (2 * WM) + tid];
-        sm += t.x > -INFINITY ? t.y * __expf(t.x - mx) : 0.0f;
-      }
-      const int m = m0 + tid;
-      if (m < M) reinterpret_cast<float2*>(E.rowstat)[(size_t)m * E.stat_ld + (n0 / (WN * WNW))] = make_float2(mx, sm);
-    }
-    __syncthreads();
-  }
   // each wave restages an RP x WN fp32 block of its accumulators through its own LDS region, then the whole block streams
   // them out: every thread owns 8 consecutive columns of a row (16-B vectors).
   constexpr int RP = WM < 64 ? WM : 64;  // rows per pass
@@ -267,6 +223,25 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], c
           }
           if (E.c_f32) st8((float*)E.C + (size_t)m * E.ldc + n, v);
           else st8((uint16_t*)E.C + (size_t)m * E.ldc + n, v);
+          if (E.rowstat != nullptr) {
+            // by-product for the LM head: (max, sum exp(x - max)) of the values AS STORED over this row's WN-column granule.
+            // The 8 threads that hold the granule's 8-column chunks are 8 consecutive lanes: thread-local over 8 values, then
+            // three DPP steps.  Consumers (mic_ce_rows_tiles / mic_row_topk_tiles) merge the granules of a row instead of
+            // streaming the 250 054-wide row again.
+            float mx = -INFINITY;
+            float x[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              x[i] = n + i < E.stat_nvalid ? (E.c_f32 ? v[i] : bf2f(f2bf(v[i]))) : -INFINITY;
+              mx = fmaxf(mx, x[i]);
+            }
+            const float gm = group8_max(mx);
+            float sm = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sm += x[i] > -INFINITY ? __expf(x[i] - gm) : 0.0f;
+            sm = group8_sum(sm);
+            if ((tid & 7) == 0) reinterpret_cast<float2*>(E.rowstat)[(size_t)m * E.stat_ld + n / WN] = make_float2(gm, sm);
+          }
         } else {
           for (int i = 0; i < N - n; ++i) {
             float x = v[i];

@@ -380,7 +380,7 @@ class Engine:
 
     def head_logits(self, hf, M: int, name: str = "d.logits", stats: bool = False):
         """Tied head (modeling:170-178): logits[M, Vpad] = hf @ shared^T + final_logits_bias (compute dtype).
-        stats=True (bf16 mode): also returns the GEMM's per-tile softmax partials [M][ceil(Vpad/256)][2] (fp32) so that the
+        stats=True (bf16 mode): also returns the GEMM's softmax partials per 64-column granule [M][Vpad/64][2] (fp32) so that the
         log-softmax downstream (cross-entropy, beam scores) needs no second pass over the logits."""
         P = self.P
         logits = self.buf(name, M, P.Vpad)
@@ -391,7 +391,7 @@ class Engine:
     def head_stats(self, name: str, M: int):
         if self.dt != torch.bfloat16:
             return None  # the fp32 (parity) GEMM kernel has no by-products: its consumers stream the logits
-        return self.buf(name + ".stat", M, 2 * ((self.P.Vpad + 255) // 256), torch.float32)
+        return self.buf(name + ".stat", M, 2 * (self.P.Vpad // 64), torch.float32)  # (max, sum exp) per 64-column granule
 
     def decoder_backward(self, B: int, T: int, ids, pos_ids, key_mask, ehs, dlogits, seed: Optional[int], rows=None):
         """Consumes dlogits [M,Vpad] (or [Mc,Vpad] for the compacted head: rows = (idx int32 [Mc], Mc)); writes all

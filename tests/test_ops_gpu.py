@@ -518,7 +518,7 @@ def test_gemm_split_k_slabs_and_sum(dev):
 
 
 # ---------------------------------------------------------------- head GEMM softmax partials and their consumers
-@pytest.mark.parametrize("M,V,Vpad", [(300, 1003, 1024), (70, 5003, 5120), (1024, 250054, 250112)])
+@pytest.mark.parametrize("M,V,Vpad", [(300, 1003, 1024), (70, 5003, 5056), (1024, 250054, 250112)])
 def test_head_rowstat_topk_and_ce_from_tile_partials(dev, M, V, Vpad):
     """mic_gemm's per-tile (max, sum exp) by-product against the stored logits, then its two consumers against the kernels
     that stream the whole row: mic_row_topk_tiles == mic_row_lse_topk (indices identical, values to fp32 rounding — both are
@@ -534,20 +534,21 @@ def test_head_rowstat_topk_and_ce_from_tile_partials(dev, M, V, Vpad):
     bias = torch.zeros(Vpad)
     bias[:V] = torch.randn(V, generator=g)
     bias[2] = 25.0  # EOS dominates: suppress_eos has to look past a tile maximum
-    nt = (Vpad + 255) // 256
+    nt = Vpad // 64
     logits = torch.zeros((M, Vpad), dtype=torch.bfloat16, device=dev)
     stat = torch.full((M, nt, 2), float("nan"), device=dev)
     ops.gemm(x.to(dev), w.to(dev), logits, M, Vpad, K, bias=bias.to(dev), rowstat=stat, rowstat_nvalid=V)
     torch.cuda.synchronize()
     lg = logits.float().cpu()
     # partials: exactly the stored values' maximum, sum exp to fp32 rounding
-    pad = torch.full((M, nt * 256), float("-inf"))
+    pad = torch.full((M, nt * 64), float("-inf"))
     pad[:, :V] = lg[:, :V]
-    tiles = pad.reshape(M, nt, 256)
+    tiles = pad.reshape(M, nt, 64)
     mx = tiles.max(-1).values
-    assert torch.equal(stat[:, :, 0].cpu(), mx)
-    sm = torch.exp(tiles - mx[..., None]).sum(-1)
-    assert ((stat[:, :, 1].cpu() - sm).abs() / sm).max().item() < 2e-5
+    live = mx > float("-inf")  # granules entirely beyond V carry (-inf, 0)
+    assert torch.equal(stat[:, :, 0].cpu()[live], mx[live]) and (stat[:, :, 0].cpu()[~live] == float("-inf")).all()
+    sm = torch.exp(tiles - torch.where(live, mx, torch.zeros_like(mx))[..., None]).sum(-1)
+    assert ((stat[:, :, 1].cpu() - sm).abs()[live] / sm[live]).max().item() < 2e-5 and (stat[:, :, 1].cpu()[~live] == 0).all()
     # top-k consumer vs the full-row kernel and the oracle
     R, k = min(M, 48), 8
     rb = torch.linspace(-3.0, 0.0, R)
@@ -585,19 +586,19 @@ def test_head_rowstat_topk_and_ce_from_tile_partials(dev, M, V, Vpad):
 
 
 def test_row_topk_tiles_ties_across_many_tiles(dev):
-    """All logits equal (every tile at the maximum): index-stable ordering and the > 256 candidate-tile fallback."""
+    """All logits equal (every granule at the maximum): index-stable ordering and the > 256 candidate-granule fallback."""
     from mic_amd import ops
 
     R, V = 3, 100_000
-    Vpad = (V + 255) // 256 * 256
+    Vpad = (V + 63) // 64 * 64
     logits = torch.zeros((R, Vpad), dtype=torch.bfloat16, device=dev)
     logits[1, 77_777] = 1.0
-    nt = Vpad // 256
+    nt = Vpad // 64
     stat = torch.zeros((R, nt, 2), device=dev)
-    stat[:, :, 1] = 256.0
-    stat[:, nt - 1, 1] = V - (nt - 1) * 256
-    stat[1, 77_777 // 256, 0] = 1.0
-    stat[1, 77_777 // 256, 1] = 1.0 + 255.0 * float(np.exp(-1.0))
+    stat[:, :, 1] = 64.0
+    stat[:, nt - 1, 1] = V - (nt - 1) * 64
+    stat[1, 77_777 // 64, 0] = 1.0
+    stat[1, 77_777 // 64, 1] = 1.0 + 63.0 * float(np.exp(-1.0))
     tv, ti = torch.empty((R, 8), device=dev), torch.empty((R, 8), dtype=torch.int32, device=dev)
     ops.row_topk_tiles(logits, Vpad, V, stat, 8, tv, ti, R)
     torch.cuda.synchronize()
