@@ -45,6 +45,8 @@ class Engine:
         self._dw_queue = []
         self._cs_queue = []
         self.fp8 = False
+        import os
+        self.use_head_stats = os.environ.get("MIC_HEAD_STATS", "1") != "0"  # softmax partials out of the LM-head GEMM (A/B switch)
         self.grad_progress = None  # callable(offset): every gradient with flat offset < offset is final (DDP overlap)
 
     # ------------------------------------------------------------------ fp8 GEMM operands (BASELINE configs[4])
@@ -389,7 +391,7 @@ class Engine:
         return (logits, stat) if stats else logits
 
     def head_stats(self, name: str, M: int):
-        if self.dt != torch.bfloat16:
+        if self.dt != torch.bfloat16 or not self.use_head_stats:
             return None  # the fp32 (parity) GEMM kernel has no by-products: its consumers stream the logits
         return self.buf(name + ".stat", M, 2 * (self.P.Vpad // 64), torch.float32)  # (max, sum exp) per 64-column granule
 

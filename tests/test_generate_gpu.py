@@ -132,8 +132,9 @@ def test_generate_bf16_agrees_with_fp32_oracle_on_a_trained_model(dev):
     change (its top-1 is the copy of the fed token by a wide margin, everything else is a 250k-way near-tie).  So: train the
     reduced model with the float32 HIP path on a deterministic synthetic task until it has real, input-dependent decisions,
     then decode the TRAINED weights three ways — fp32 oracle on the CPU (the reference algorithm), fp32 HIP, bf16 HIP.
-    Asserted: the model learned the rule; fp32 HIP ids == oracle ids; bf16 HIP token agreement with the oracle >= 0.97 and
-    beam scores within 2e-2 (greedy and beam-4)."""
+    Asserted: the training loss is small; fp32 HIP ids == oracle ids; bf16 HIP: at least 6 of 8 captions identical to the oracle's
+    (greedy and beam-4), beam scores of identical hypotheses within 2e-2, and teacher-forced top-1 identical wherever the fp32
+    margin exceeds 4x the measured bf16 logit error."""
     from mic_amd import Trainer, create_learning_rate_fn
     from mic_amd.params import flatten_tree, unflatten_tree
 
@@ -153,6 +154,8 @@ def test_generate_bf16_agrees_with_fp32_oracle_on_a_trained_model(dev):
     cls = list(range(8))
     px, labels, *_ = _rule_batch(rc, cls)
     lang = rc.vocab_size - 10
+    from oracle import model_ref as M
+
     for kw in (dict(max_length=12, num_beams=1, decoder_start_token_id=lang, forced_eos_token_id=None),
                dict(max_length=12, num_beams=4, decoder_start_token_id=lang, forced_eos_token_id=None)):
         K = kw["num_beams"]
@@ -165,13 +168,29 @@ def test_generate_bf16_agrees_with_fp32_oracle_on_a_trained_model(dev):
         got16 = m16.generate(px.numpy(), **kw)
         seq16 = got16.sequences.cpu().numpy()
         agree = float((seq16 == ref_seq).mean())
-        print(f"trained reduced model, num_beams={K}: bf16 token agreement with the fp32 oracle {agree:.3f}")
-        assert agree >= 0.97, (K, agree, seq16, ref_seq)
-        if K > 1:
-            full = (seq16 == ref_seq).all(axis=1)
-            d = np.abs(got16.scores.cpu().numpy() - ref.scores)[full]
+        whole = (seq16 == ref_seq).all(axis=1)
+        print(f"trained reduced model, num_beams={K}: bf16 token agreement with the fp32 oracle {agree:.3f}, {int(whole.sum())}/8 captions identical")
+        # free-running: one flipped near-tie changes the rest of that caption, so the floor is per caption (training itself is
+        # not bit-reproducible — fp32 atomics — so which steps are near-ties varies from run to run)
+        assert whole.sum() >= 6 and agree >= 0.75, (K, agree, seq16, ref_seq)
+        if K > 1 and whole.any():
+            d = np.abs(got16.scores.cpu().numpy() - ref.scores)[whole]
             print(f"   beam scores of identical hypotheses: max |difference| {d.max():.4f} (scores ~ {np.abs(ref.scores).mean():.3f})")
             assert d.max() < 2e-2, d
+        if K == 1:
+            # teacher-forced on the oracle's own captions: wherever the fp32 decision has a margin, bf16 must make the same one
+            ids = torch.from_numpy(ref_seq.astype(np.int64))
+            with torch.no_grad():
+                lo = M.forward_logits(rc, p2, px, ids, torch.ones_like(ids))
+            l16 = m16(px.numpy(), ref_seq, np.ones_like(ref_seq))[0].float().cpu()
+            top2 = lo.topk(2, dim=-1)
+            margin = top2.values[..., 0] - top2.values[..., 1]
+            err = (l16 - lo).abs().max().item()
+            clear = margin > 4 * err
+            same = l16.argmax(-1) == top2.indices[..., 0]
+            print(f"   teacher-forced: max |bf16 - fp32| logit {err:.3f}; {int(clear.sum())}/{clear.numel()} positions have a margin > 4x that; "
+                  f"top-1 agreement overall {same.float().mean():.3f}")
+            assert bool(same[clear].all()) and clear.float().mean() > 0.5 and same.float().mean() > 0.9
 
 
 def test_generate_api_errors(dev):
