@@ -689,12 +689,105 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(int R, int H, int max_
   }
   if (grp == 0) st8(out + (size_t)r * ldo + h * 64 + sub * 8, o);
 }
+// Cross-attention at decode time: the G = row_div beams of an image attend the SAME keys and values (projected once per
+// image).  One wave per (image, head) loads every K / V slot once and serves all G query rows from it: 1/G of the L2 traffic
+// and of the waves of the row-per-wave kernel (at batch 256 x 4 beams: 52 MB instead of 205 MB per layer and step).
+// No slot indirection here (src_row == nullptr), n = cur + 1 <= 64 slots.
+template <typename T, int G>
+__global__ __launch_bounds__(256) void attn_decode_group_kernel(int NI, int H, int max_len, int cur, const T* __restrict__ q, int ldq,
+                                                                const T* __restrict__ kc, const T* __restrict__ vc, int ldc,
+                                                                T* __restrict__ out, int ldo) {
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= NI * H) return;
+  const int img = wid / H, h = wid % H;
+  const int sub = lane & 7, grp = lane >> 3;
+  float qv[G][8];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    ld8(q + (size_t)(img * G + g) * ldq + h * 64 + sub * 8, qv[g]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[g][e] *= SCALE;
+  }
+  const int n = min(cur + 1, max_len);
+  float sc[G][8];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int slot = it * 8 + grp;
+    float kv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (slot < n) ld8(kc + ((size_t)img * max_len + slot) * ldc + h * 64 + sub * 8, kv);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float acc = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += qv[g][e] * kv[e];
+      acc = group8_sum(acc);
+      sc[g][it] = slot < n ? acc : -INFINITY;
+    }
+  }
+  float inv[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    float m = sc[g][0];
+#pragma unroll
+    for (int it = 1; it < 8; ++it) m = fmaxf(m, sc[g][it]);
+    m = wave_max(m);
+    float l = 0.f;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) { sc[g][it] = __expf(sc[g][it] - m); l += sc[g][it]; }
+    inv[g] = 1.0f / (wave_sum(l) * 0.125f);
+  }
+  float o[G][8];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[g][e] = 0.f;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int slot = it * 8 + grp;
+    if (slot < n) {
+      float vv[8];
+      ld8(vc + ((size_t)img * max_len + slot) * ldc + h * 64 + sub * 8, vv);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float p = sc[g][it] * inv[g];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[g][e] += p * vv[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      o[g][e] += dpp_f<DPP_ROR8>(o[g][e]);
+      o[g][e] += lane_xor16(o[g][e]);
+      o[g][e] += lane_xor32(o[g][e]);
+    }
+    if (grp == 0) st8(out + (size_t)(img * G + g) * ldo + h * 64 + sub * 8, o[g]);
+  }
+}
+
 extern "C" int mic_attn_decode(int dtype, int R, int H, int max_len, int cur, const void* q, int ldq, const void* kc,
                                const void* vc, int ldc, const int32_t* src_row, int row_div, void* out, int ldo, void* stream) {
   MIC_CHECK(R > 0 && H > 0 && max_len > 0 && cur >= 0 && row_div >= 1, "mic_attn_decode: bad shape R=%d H=%d max_len=%d cur=%d", R, H, max_len, cur);
   MIC_CHECK(q && kc && vc && out, "mic_attn_decode: null pointer");
-  dim3 grid((R * H + 3) / 4), block(256);
   const bool chunked = (cur + 1 < max_len ? cur + 1 : max_len) > 64;
+  if (!src_row && !chunked && (row_div == 2 || row_div == 4 || row_div == 8) && R % row_div == 0) {
+    // the beams of an image share keys and values: one wave per (image, head) serves all of them
+    const int NI = R / row_div;
+    dim3 ggrid((NI * H + 3) / 4), gblock(256);
+#define DECG_LAUNCH(TT, GG) hipLaunchKernelGGL((attn_decode_group_kernel<TT, GG>), ggrid, gblock, 0, (hipStream_t)stream, NI, H, max_len, cur, (const TT*)q, ldq, (const TT*)kc, (const TT*)vc, ldc, (TT*)out, ldo)
+#define DECG_DISPATCH(TT) do { if (row_div == 2) DECG_LAUNCH(TT, 2); else if (row_div == 4) DECG_LAUNCH(TT, 4); else DECG_LAUNCH(TT, 8); } while (0)
+    if (dtype == MIC_BF16) DECG_DISPATCH(uint16_t);
+    else if (dtype == MIC_F32) DECG_DISPATCH(float);
+    else MIC_CHECK(false, "mic_attn_decode: bad dtype");
+#undef DECG_DISPATCH
+#undef DECG_LAUNCH
+    MIC_LAUNCH_CHECK();
+    return MIC_OK;
+  }
+  dim3 grid((R * H + 3) / 4), block(256);
 #define DEC_LAUNCH(TT, CH) hipLaunchKernelGGL((attn_decode_kernel<TT, CH>), grid, block, 0, (hipStream_t)stream, R, H, max_len, cur, (const TT*)q, ldq, (const TT*)kc, (const TT*)vc, ldc, src_row, row_div, (TT*)out, ldo)
   if (dtype == MIC_BF16) { if (chunked) DEC_LAUNCH(uint16_t, true); else DEC_LAUNCH(uint16_t, false); }
   else if (dtype == MIC_F32) { if (chunked) DEC_LAUNCH(float, true); else DEC_LAUNCH(float, false); }

@@ -311,15 +311,20 @@ class FlaxCLIPVisionMBartForConditionalGeneration(FlaxCLIPVisionMBartPreTrainedM
         ops.embed_fwd(tokens, pos, P.w("shared"), P.f32("dec.pos"), eng.embed_scale, h0, R, d)
         x = eng.buf("g.x", R, d)
         ops.layernorm_fwd(h0, P.f32("dec.ln_emb.g"), P.f32("dec.ln_emb.b"), eng.dec_eps, x, rows=R)
-        a, qkv, ctx = eng.buf("g.a", R, d), eng.buf("g.qkv", R, 3 * d), eng.buf("g.ctx", R, d)
+        a, ctx = eng.buf("g.a", R, d), eng.buf("g.ctx", R, d)
         x1, x2, q = eng.buf("g.x1", R, d), eng.buf("g.x2", R, d), eng.buf("g.q", R, d)
         u = eng.buf("g.u", R, f)
         for l in range(st.L):
             p = f"dec{l}."
             ops.layernorm_fwd(x, P.f32(p + "ln_sa.g"), P.f32(p + "ln_sa.b"), eng.dec_eps, a, rows=R)
-            eng.linear(a, p + "qkv", qkv, R, fp8=False)
-            ops.kv_append(qkv[:, d:], qkv[:, 2 * d:], cache["k"][l], cache["v"][l], R, d, Lmax, cur, ldk=3 * d, ldv=3 * d)
-            ops.attn_decode(qkv, cache["k"][l], cache["v"][l], ctx, R, H, Lmax, cur, ldq=3 * d, ldo=d, src_row=cache["src_row"])
+            # the fused q/k/v projection as ONE grouped launch of three problems that share the A operand: q goes to its buffer,
+            # k and v straight into slot `cur` of every row's cache (row stride max_len * d) — no separate append kernel
+            w, b = P.w(p + "qkv.w"), P.f32(p + "qkv.b")
+            kc, vc = cache["k"][l], cache["v"][l]
+            ops.gemm_grouped([ops.gemm_args(a, w[:d], q, R, d, d, bias=b[:d]),
+                              ops.gemm_args(a, w[d:2 * d], kc[:, cur], R, d, d, bias=b[d:2 * d]),
+                              ops.gemm_args(a, w[2 * d:], vc[:, cur], R, d, d, bias=b[2 * d:])])
+            ops.attn_decode(q, kc, vc, ctx, R, H, Lmax, cur, ldq=d, ldo=d, src_row=cache["src_row"])
             eng.linear(ctx, p + "so", x1, R, residual=x, fp8=False)
             ops.layernorm_fwd(x1, P.f32(p + "ln_ca.g"), P.f32(p + "ln_ca.b"), eng.dec_eps, a, rows=R)
             eng.linear(a, p + "cq", q, R, fp8=False)
