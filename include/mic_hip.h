@@ -278,6 +278,9 @@ typedef struct {
   int32_t* src_row;           /* [B*K][max_len] in/out: KV-cache slot ownership (beam-parent indirection) */
   int32_t* next_token;        /* [B*K] out: token each running beam feeds next step */
   int32_t* flags;             /* [B][2] out: per item {all finished, improvement impossible} for the loop cond */
+  int32_t* gstate;            /* optional [8], zeroed by the caller before the first step: the loop condition of gen:798-820 kept on
+                                 the device — [3] = search has ended (later launches are no-ops), [4] = steps taken; lets the host
+                                 enqueue decoder steps ahead instead of synchronising after each one */
 } mic_beam_step_args;
 int mic_beam_step(const mic_beam_step_args* a, void* stream);
 

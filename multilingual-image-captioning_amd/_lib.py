@@ -49,7 +49,7 @@ class BeamStepArgs(C.Structure):
         ("eos_token_id", C.c_int), ("pad_token_id", C.c_int), ("length_penalty", C.c_float), ("early_stopping", C.c_int),
         ("cand_val", C.c_void_p), ("cand_idx", C.c_void_p), ("running_seq", C.c_void_p), ("running_scores", C.c_void_p),
         ("seq", C.c_void_p), ("scores", C.c_void_p), ("finished", C.c_void_p), ("src_row", C.c_void_p),
-        ("next_token", C.c_void_p), ("flags", C.c_void_p),
+        ("next_token", C.c_void_p), ("flags", C.c_void_p), ("gstate", C.c_void_p),
     ]
 
 

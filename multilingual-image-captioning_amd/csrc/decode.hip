@@ -342,6 +342,9 @@ __global__ __launch_bounds__(128) void beam_step_kernel(mic_beam_step_args a) {
   extern __shared__ int32_t lds_i[];
   const int K = a.K, C = 2 * K, L = a.max_len, V = a.V;
   const int b = blockIdx.x, tid = threadIdx.x;
+  // loop state on the device (gen:798-820 evaluated by the last block of every step): once the search has ended, further
+  // launches of this kernel leave the state alone, so the host may enqueue steps ahead of reading the flag
+  if (a.gstate && __hip_atomic_load(a.gstate + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
   int32_t* old_run = lds_i;                 // [K][L]
   int32_t* old_seq = old_run + K * L;       // [K][L]
   int32_t* old_src = old_seq + K * L;       // [K][L]
@@ -455,6 +458,22 @@ __global__ __launch_bounds__(128) void beam_step_kernel(mic_beam_step_args a) {
     for (int kx = 0; kx < K; ++kx) { const float worst = nf[kx] ? mn : NEG_BIG; improve &= (worst < best_running); }
     a.flags[b * 2 + 0] = all_fin;
     a.flags[b * 2 + 1] = improve;
+    if (a.gstate) {
+      // gstate: [0] items with every beam finished, [1] items that can still improve, [2] arrival ticket, [3] done, [4] steps taken
+      if (all_fin) atomicAdd(a.gstate + 0, 1);
+      if (improve) atomicAdd(a.gstate + 1, 1);
+      __threadfence();
+      if (atomicAdd(a.gstate + 2, 1) == a.B - 1) {  // last item of this step
+        __threadfence();
+        const int nfin = __hip_atomic_load(a.gstate + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int nimp = __hip_atomic_load(a.gstate + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int stop = (nfin == a.B && a.early_stopping) || nimp != a.B || a.cur_len + 1 >= L;
+        a.gstate[0] = 0; a.gstate[1] = 0; a.gstate[2] = 0;
+        a.gstate[4] += 1;
+        __threadfence();
+        if (stop) __hip_atomic_store(a.gstate + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
 }
 extern "C" int mic_beam_step(const mic_beam_step_args* a, void* stream) {

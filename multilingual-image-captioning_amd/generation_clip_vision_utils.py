@@ -183,34 +183,31 @@ class FlaxCLIPVisionMBartGenerationMixin:
         self._decode_set_encoder(cache, ehs.reshape(B * st.S, st.d), B, K)
         cand_val = torch.empty((R, 2 * K), dtype=torch.float32, device=dev)
         cand_idx = torch.empty((R, 2 * K), dtype=torch.int32, device=dev)
-        pos = torch.zeros(R, dtype=torch.int32, device=dev)
+        pos_all = torch.arange(max_length, dtype=torch.int32, device=dev).repeat_interleave(R)  # position ids of every step
+        # beam_search_cond_fn (gen:798-820) lives on the device: mic_beam_step evaluates it on the new state, and once it says
+        # stop every later mic_beam_step launch is a no-op.  The host therefore enqueues decoder steps without waiting and
+        # looks at the flag only every few steps (the reference's lax.while_loop has no host in the loop either, gen:976).
+        gstate = torch.zeros(8, dtype=torch.int32, device=dev)
+        poll = 8
         cur_len = 1
-        steps = 0
-        while True:
+        while cur_len < max_length:
             with ops.pinned_stream():
-                logits, stat = self._decode_step(cache, next_token, pos, stats=True)  # gen:830-840
+                logits, stat = self._decode_step(cache, next_token, pos_all[(cur_len - 1) * R: cur_len * R], stats=True)  # gen:830-840
                 forced, suppress = self._proc_args(procs, cur_len, max_length, eos_token_id)
                 if stat is not None and forced < 0:
-                    # log-softmax + top-2K from the head GEMM's per-tile partials: 977 pairs and a few 256-column tiles per row
-                    # instead of two passes over the 250 054 logits (same candidates, same order, same fp32 arithmetic)
+                    # log-softmax + top-2K from the head GEMM's per-granule partials: 3908 pairs and a few 64-column granules per
+                    # row instead of two passes over the 250 054 logits (same candidates, same order, same fp32 arithmetic)
                     ops.row_topk_tiles(logits, logits.stride(0), st.V, stat, 2 * K, cand_val, cand_idx, R, suppress_eos=suppress,
                                        eos_token_id=eos_token_id, row_bias=running_scores.reshape(-1))
                 else:
                     ops.row_lse_topk(logits, logits.stride(0), st.V, 2 * K, cand_val, cand_idx, R, forced_token=forced, suppress_eos=suppress,
                                      eos_token_id=eos_token_id, row_bias=running_scores.reshape(-1))  # gen:850-873 (per row)
                 ops.beam_step(B, K, max_length, st.V, cur_len, eos_token_id, pad_token_id, length_penalty, early_stopping, cand_val,
-                              cand_idx, running_seq, running_scores, seq, scores, finished, src_row, next_token, flags)  # gen:872-966
-            pos += 1
+                              cand_idx, running_seq, running_scores, seq, scores, finished, src_row, next_token, flags, gstate=gstate)  # gen:872-966
             cur_len += 1
-            steps += 1
-            # beam_search_cond_fn (gen:798-820) on the new state
-            if not (cur_len < max_length):
+            if cur_len < max_length and (cur_len - 1) % poll == 0 and int(gstate[3].item()) != 0:
                 break
-            fl = flags.cpu()
-            all_finished = bool(fl[:, 0].all().item())
-            improve = bool(fl[:, 1].all().item())
-            if (all_finished and early_stopping) or not improve:
-                break
+        steps = int(gstate[4].item())
         any_fin = finished.bool().any(dim=1)  # gen:980
         out_seq = torch.where(any_fin[:, None, None], seq, running_seq)  # gen:981-983
         out_scores = torch.where(any_fin[:, None], scores, running_scores)  # gen:984

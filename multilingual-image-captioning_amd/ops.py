@@ -260,13 +260,14 @@ def row_lse_topk(logits, ld, V, k, top_val, top_idx, R, *, forced_token=-1, supp
 
 
 def beam_step(B, K, max_len, V, cur_len, eos, pad, length_penalty, early_stopping, cand_val, cand_idx, running_seq, running_scores,
-              seq, scores, finished, src_row, next_token, flags):
+              seq, scores, finished, src_row, next_token, flags, gstate=None):
     a = L.BeamStepArgs()
     a.B, a.K, a.max_len, a.V, a.cur_len = B, K, max_len, V, cur_len
     a.eos_token_id, a.pad_token_id, a.length_penalty, a.early_stopping = eos, pad, float(length_penalty), int(bool(early_stopping))
     a.cand_val, a.cand_idx = _p(cand_val), _p(cand_idx)
     a.running_seq, a.running_scores, a.seq, a.scores = _p(running_seq), _p(running_scores), _p(seq), _p(scores)
     a.finished, a.src_row, a.next_token, a.flags = _p(finished), _p(src_row), _p(next_token), _p(flags)
+    a.gstate = _p(gstate)
     L.check(L.lib().mic_beam_step(C.byref(a), _stream()), "mic_beam_step")
 
 
