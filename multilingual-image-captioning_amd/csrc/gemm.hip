@@ -347,7 +347,10 @@ static void launch_cfg_p(const LaunchTable& tab, int akm, int bkm, hipStream_t s
   dim3 grid(tab.total_blocks), block(128 * WNW * KG);
 #define LAUNCH(AKM, BKMM)                                                                                                  \
   do {                                                                                                                     \
-    static bool attr_set = false; /* per instantiation; lds is a compile-time constant of it */                          \
+    static bool attr_set_dev[64] = {}; /* per instantiation AND device (the attribute belongs to the device's code object) */ \
+    int dev_ = 0;                                                                                                          \
+    (void)hipGetDevice(&dev_);                                                                                             \
+    bool& attr_set = attr_set_dev[dev_ & 63];                                                                              \
     if (lds > 65536 && !attr_set) {                                                                                        \
       hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WN, WNW, BKT, AKM, BKMM, KG, PLAIN, F8>),    \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                           \

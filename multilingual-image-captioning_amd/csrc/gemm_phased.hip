@@ -240,7 +240,10 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(LaunchTable tab) {
 template <bool AK, bool BKM, bool PLAIN>
 void launch_one(const LaunchTable& tab, hipStream_t s) {
   constexpr int lds = 2 * STAGE;
-  static bool attr_set = false;
+  static bool attr_set_dev[64] = {};  // per instantiation and device
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  bool& attr_set = attr_set_dev[dev_ & 63];
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_phased_kernel<AK, BKM, PLAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;

@@ -107,8 +107,10 @@ class GradReducer:
         self.comm_dtype = comm_dtype if (comm_dtype is not None and comm_dtype != flat_grad.dtype) else None
         if self.sharded and self.comm_dtype is not None:
             raise ValueError("sharded optimizer: the reduce-scatter runs in the gradient dtype (grad_comm_dtype is an all-reduce option)")
-        self.stage = (torch.empty(max(e - b for b, e in buckets), dtype=self.comm_dtype, device=flat_grad.device)
+        # two staging buffers used alternately: the narrowing copy of bucket k+1 does not wait for the widening copy of bucket k
+        self.stage = ([torch.empty(max(e - b for b, e in buckets), dtype=self.comm_dtype, device=flat_grad.device) for _ in range(2)]
                       if self.comm_dtype is not None and self.world > 1 else None)
+        self._stage_i = 0
 
     # ---- shard geometry
     def split(self, b: int, e: int) -> Tuple[int, int, int]:
@@ -132,7 +134,8 @@ class GradReducer:
     def _all_reduce(self, b: int, e: int, async_op: bool = False):
         if self.stage is None:
             return self.dist.all_reduce(self.grad[b:e], op=self.dist.ReduceOp.SUM, group=self.group, async_op=async_op)
-        st = self.stage[: e - b]
+        st = self.stage[self._stage_i][: e - b]
+        self._stage_i ^= 1
         st.copy_(self.grad[b:e])
         self.dist.all_reduce(st, op=self.dist.ReduceOp.SUM, group=self.group)
         self.grad[b:e].copy_(st)
