@@ -1,0 +1,44 @@
+"""How much of a beam-4 decoder step is host launch time?  Times the host-side issue of `_decode_step` (perf_counter around the
+call; nothing in it synchronises) beside the wall clock per decoder step of a full generate call (BASELINE configs[3]).
+If issue time ~ wall time the loop is launch-bound and graph replay pays; if issue << wall the GPU is the bottleneck."""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("multilingual-image-captioning_amd")
+
+dev = torch.device("cuda:0")
+cfg = pkg.CLIPVisionMBartConfig(mbart_config={}, clip_vision_config={})
+model = pkg.FlaxCLIPVisionMBartForConditionalGeneration(cfg, seed=0, dtype=torch.bfloat16, device=dev)
+st = model.store
+st.f32("flb")[cfg.mbart_config.eos_token_id] = -1e9
+st.refresh_lp()
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+px = torch.from_numpy(np.clip(np.random.default_rng(0).standard_normal((B, 224, 224, 3), dtype=np.float32), -1.8, 2.2)).to(dev)
+model.generate(px, forced_bos_token_id=250004, num_beams=4, max_length=64)
+torch.cuda.synchronize()
+acc = {"t": 0.0, "n": 0}
+orig = model._decode_step
+
+
+def timed(*a, **k):
+    t0 = time.perf_counter()
+    r = orig(*a, **k)
+    acc["t"] += time.perf_counter() - t0
+    acc["n"] += 1
+    return r
+
+
+model._decode_step = timed
+t0 = time.perf_counter()
+for _ in range(3):
+    out = model.generate(px, forced_bos_token_id=250004, num_beams=4, max_length=64)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print(f"batch {B}: wall {dt / acc['n'] * 1e3:.3f} ms per decoder step; host issue of _decode_step {acc['t'] / acc['n'] * 1e3:.3f} ms per step "
+      f"({acc['n']} steps)")

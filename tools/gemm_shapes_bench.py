@@ -1,0 +1,82 @@
+"""Per-shape GEMM timing: mic_gemm (this repo) beside torch.matmul (hipBLASLt / rocBLAS) on the train step's GEMM shapes.
+
+A yardstick, not a product path: it tells which shapes of the step are far from what the vendor library reaches on the same
+box, i.e. where kernel work pays.  Shapes are those of BASELINE configs[1] (batch 64 per GPU, T = 64, ViT-B/32 + mBART-large):
+
+    python tools/gemm_shapes_bench.py            # prints one line per (shape, layout)
+"""
+import importlib
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("multilingual-image-captioning_amd")
+ops = importlib.import_module("multilingual-image-captioning_amd.ops")
+
+dev = torch.device("cuda:0")
+MV, MD = 64 * 50, 64 * 64  # encoder rows (B * 50 patches+cls), decoder rows (B * T)
+SHAPES = [
+    # name, M, N, K
+    ("vit qkv", MV, 3 * 768, 768),
+    ("vit out", MV, 768, 768),
+    ("vit fc1", MV, 3072, 768),
+    ("vit fc2", MV, 768, 3072),
+    ("dec qkv", MD, 3 * 1024, 1024),
+    ("dec out/cq", MD, 1024, 1024),
+    ("dec ckv", MV, 2 * 1024, 1024),
+    ("dec fc1", MD, 4096, 1024),
+    ("dec fc2", MD, 1024, 4096),
+    ("head", 2048, 250112, 1024),
+]
+# one beam-4 decoder step (configs[3]: 256 images x 4 beams = 1024 rows), forward only
+DECODE = [
+    ("gen d x d", 1024, 1024, 1024),
+    ("gen qkv", 1024, 3072, 1024),
+    ("gen fc1", 1024, 4096, 1024),
+    ("gen fc2", 1024, 1024, 4096),
+    ("gen head", 1024, 250112, 1024),
+]
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3  # us
+
+
+def main():
+    torch.manual_seed(0)
+    print(f"{'shape':12s} {'layout':4s} {'M':>6s} {'N':>7s} {'K':>6s} {'mic us':>9s} {'lib us':>9s} {'mic TF/s':>9s} {'lib TF/s':>9s} {'mic/lib':>8s}")
+    for name, M, N, K in (DECODE if "--decode" in sys.argv else SHAPES):
+        # the three GEMMs of one linear layer: forward y = x W^T (NT), dX = dy W (NN), dW = dy^T x (TN)
+        x = torch.randn(M, K, device=dev).bfloat16()
+        w = torch.randn(N, K, device=dev).bfloat16()
+        dy = torch.randn(M, N, device=dev).bfloat16()
+        y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        dx = torch.empty(M, K, device=dev, dtype=torch.bfloat16)
+        dw = torch.empty(N, K, device=dev, dtype=torch.float32)
+        dwl = torch.empty(N, K, device=dev, dtype=torch.bfloat16)
+        cases = [
+            ("NT", lambda: ops.gemm(x, w, y, M, N, K), lambda: torch.matmul(x, w.t(), out=y)),
+            ("NN", lambda: ops.gemm(dy, w, dx, M, K, N, b_kmajor=True), lambda: torch.matmul(dy, w, out=dx)),
+            ("TN", lambda: ops.gemm(dy, x, dw, N, K, M, a_kmajor=True, b_kmajor=True), lambda: torch.matmul(dy.t(), x, out=dwl)),
+        ]
+        fl = 2.0 * M * N * K
+        if name.startswith("gen"):
+            cases = cases[:1]
+        for lay, mine, lib in cases:
+            tm, tl = timeit(mine), timeit(lib)
+            print(f"{name:12s} {lay:4s} {M:6d} {N:7d} {K:6d} {tm:9.1f} {tl:9.1f} {fl / tm * 1e-6:9.1f} {fl / tl * 1e-6:9.1f} {tm / tl:8.2f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
