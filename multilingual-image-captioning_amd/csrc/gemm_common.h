@@ -21,6 +21,8 @@ struct Problem {
 struct LaunchTable { int count; int total_blocks; Problem p[MAX_PROBLEMS]; };
 // gemm_phased.hip: 256x256 tiles, LDS-DMA operands, four-phase K-tile schedule (bf16 operands, no K-groups)
 void launch_gemm_phased(const LaunchTable& tab, int akm, int bkm, bool plain, hipStream_t s);
+// gemm_w4.hip: 256x256 tiles on four waves (wave tile 128x128, accumulators in AGPRs), hand-pipelined K-tile (bf16, no row sums)
+void launch_gemm_w4(const LaunchTable& tab, int akm, int bkm, bool plain, hipStream_t s);
 
 // --- stage one operand image (ROWS x BKT k, or BKT k x ROWS x; ROWS = 128 or 64) HBM/L2 -> registers -> LDS.
 //     Measured on gfx950: a global_load_lds (LDS-DMA) instruction costs ~100 cycles of issue time in the issuing wave's
@@ -60,6 +62,31 @@ struct HalfStager {
       }
       r[i] = *reinterpret_cast<const u32x4*>(g);
     }
+  }
+  // single pieces (gemm_w4.hip interleaves them with its fragment reads by hand)
+  static __device__ __forceinline__ void load1(u32x4& r, const uint16_t* __restrict__ src, int ld, int x0, int k0, int lim, int q, int lane) {
+    int row, c;
+    coords(q, lane, row, c);
+    const uint16_t* g;
+    if (!KMAJOR) {
+      int gr = x0 + row;
+      gr = gr < lim ? gr : lim - 1;
+      g = src + (size_t)gr * ld + k0 + c * 8;
+    } else {
+      int gx = x0 + c * 8;
+      gx = gx < lim ? gx : 0;
+      g = src + (size_t)(k0 + row) * ld + gx;
+    }
+    r = *reinterpret_cast<const u32x4*>(g);
+  }
+  static __device__ __forceinline__ void store1(const u32x4& r, char* lds_tile, int q, int lane) {
+    int row, c;
+    coords(q, lane, row, c);
+    int off;
+    if (!KMAJOR) off = BKT == 64 ? row * 128 + ((c ^ ((row >> 1) & 7)) << 4) : row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
+    else if (ROWS == 128) off = row * 256 + ((c ^ ((row & 3) << 2)) << 4);
+    else off = row * 128 + ((c ^ (((row >> 1) & 1) << 2)) << 4);
+    *reinterpret_cast<u32x4*>(lds_tile + off) = r;
   }
   static __device__ __forceinline__ void store(const u32x4 (&r)[PER], char* lds_tile, int wave, int lane) {
 #pragma unroll
@@ -224,7 +251,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], c
           if (E.c_f32) st8((float*)E.C + (size_t)m * E.ldc + n, v);
           else st8((uint16_t*)E.C + (size_t)m * E.ldc + n, v);
           if (E.rowstat != nullptr) {
-            // by-product for the LM head: (max, sum exp(x - max)) of the values AS STORED over this row's WN-column granule.
+            // by-product for the LM head: (max, sum exp(x - max)) of the values AS STORED over this row's 64-column granule.
             // The 8 threads that hold the granule's 8-column chunks are 8 consecutive lanes: thread-local over 8 values, then
             // three DPP steps.  Consumers (mic_ce_rows_tiles / mic_row_topk_tiles) merge the granules of a row instead of
             // streaming the 250 054-wide row again.
@@ -240,7 +267,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], c
 #pragma unroll
             for (int i = 0; i < 8; ++i) sm += x[i] > -INFINITY ? __expf(x[i] - gm) : 0.0f;
             sm = group8_sum(sm);
-            if ((tid & 7) == 0) reinterpret_cast<float2*>(E.rowstat)[(size_t)m * E.stat_ld + n / WN] = make_float2(gm, sm);
+            if ((tid & 7) == 0) reinterpret_cast<float2*>(E.rowstat)[(size_t)m * E.stat_ld + n / 64] = make_float2(gm, sm);
           }
         } else {
           for (int i = 0; i < N - n; ++i) {

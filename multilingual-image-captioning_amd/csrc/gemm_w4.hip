@@ -1,0 +1,217 @@
+// gemm_w4.hip — the 256x256x64 bf16 tile on FOUR waves (2 x 2), wave tile 128 x 128, one wave per SIMD.
+//
+// Why: the 8-wave 256x256 kernel (gemm.hip, wave tile 128 x 64) moves 192 KB of LDS reads + 64 KB of LDS writes per K-tile and
+// CU — in-kernel stamps put the LDS pipe alone at ~1.6 k cycles per K-tile against 2.05 k cycles of MFMA issue, and the two do
+// not overlap perfectly.  A 128 x 128 wave tile needs 128 KB of reads for the same 256x256x64 MFMA work (-33 %);
+// it is also what the vendor library's best kernel for these shapes does (profiles/r2_gemm_vs_library.txt: MT256x256x64,
+// MIWT8_8).  The price: 256 accumulator registers per lane (AGPRs), so ONE wave per SIMD — nobody else hides this wave's LDS
+// and global-load latency, the overlap has to be written into its own instruction stream.  A first plain-HIP version of this
+// tiling (round 1) was slower than the 8-wave kernel for exactly that reason.  Here the K-tile is software-pipelined by hand
+// and the interleave is pinned with __builtin_amdgcn_sched_group_barrier:
+//
+//   k-step 0:  16 MFMA (fragments kk=0)  ||  LDS reads of fragments kk=1  ||  ds_write of tile t+1's A images (from registers)
+//   k-step 1:  16 MFMA (kk=1)            ||  reads kk=2                   ||  ds_write of tile t+1's B images, global loads A(t+2)
+//   k-step 2:  16 MFMA (kk=2)            ||  reads kk=3                   ||  global loads B(t+2)
+//   k-step 3:  lgkmcnt(0) + s_barrier;  16 MFMA (kk=3)  ||  reads of tile t+1's fragments kk=0 from the other LDS stage
+//
+// One barrier per K-tile, placed where everything it orders was issued >= one k-step (512 MFMA cycles) earlier.  The tile in
+// flight travels HBM/L2 -> registers (16 x global_load_dwordx4 per lane, three k-steps ahead of its ds_write) -> swizzled LDS
+// images, the same images and fragment reads as gemm.hip (HalfStager / read_frag), and the same launch table, XCD-aware tile
+// order and fused epilogue (gemm_common.h).  Loads past the last K-tile are clamped to it (harmless re-reads) so the loop body
+// is branch-free — one scheduling region.
+//
+// MEASURED (MI355X, round 2; head forward 2048 x 250112 x 1024, NT): the ISA has exactly the interleave above (no scratch in
+// the loop, 256 VGPR + 256 AGPR), results are bit-identical to gemm.hip's kernel — and it is SLOWER: 1467 us against 1201 us
+// for the 8-wave kernel (vendor library 941 us).  Compile-time ablations of this loop (-DW4_...):
+//     MFMAs + barrier only (W4_NO_STORE + W4_NO_READ) 1007 us   <- the floor of this tile loop; the library sits on it
+//     + fragment reads from LDS (W4_NO_STORE)          1027 us   <- LDS reads hide completely
+//     + ds_writes + global loads that always hit (W4_ABLATE_LOADS, every load = K-tile 0)   1279 us
+//     + real operand stream                             1467 us
+// i.e. the 16 ds_write_b128 + 16 global loads per lane and K-tile cost 25 % even from cache, and their latency another 15 %:
+// with ONE wave per SIMD there is exactly one K-tile (64 VGPRs) in flight and every vmcnt wait in front of a ds_write stops
+// the MFMA stream; tools/bench_lds_rw.hip puts ds_write_b128 at 77 B/clk/CU against 241 B/clk/CU for ds_read_b128, so the
+// 64 KB of LDS writes per K-tile (~850 cycles) are the largest single LDS cost, packed here into two of the four k-steps.
+// Two register sets (two K-tiles in flight) and writes spread over all four k-steps would be the next step; the compiler
+// has no VGPRs left for it in this form.  Kept opt-in (MIC_GEMM_W4=1) as the measured starting point.
+#include "gemm_common.h"
+
+namespace {
+
+#define W4_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+constexpr int SG_MFMA = 0x008, SG_VMEM_RD = 0x020, SG_DS_RD = 0x100, SG_DS_WR = 0x200;
+
+template <bool AK, bool BKM, bool PLAIN>
+__global__ __launch_bounds__(256, 1) void gemm_w4_kernel(LaunchTable tab) {
+  constexpr int WM = 128, WN = 128, WNW = 2, BM = 256, BN = 256, BKT = 64, NWAVES = 4, AI = 4, NJ = 4;
+  constexpr int HALF = 128 * BKT * 2, STAGE = 4 * HALF;  // [A rows 0-127 | A rows 128-255 | B cols 0-127 | B cols 128-255]
+  constexpr int RA = AK ? 2 : 1, RB = BKM ? 2 : 1;      // LDS read instructions per fragment (k-major: 2 x ds_read_b64_tr_b16)
+  using SA = HalfStager<AK, NWAVES, BKT, 128>;
+  using SB = HalfStager<BKM, NWAVES, BKT, 128>;
+  static_assert(SA::PER == 4 && SB::PER == 4, "16 pieces per image over 4 waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int lid;
+  {
+    const int bid = blockIdx.x, nwg = tab.total_blocks;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_PROBLEMS; ++i)
+    if (i < tab.count && lid >= tab.p[i].block_begin) pi = i;
+  const Problem P = tab.p[pi];
+  const int local = lid - P.block_begin;
+  int tile = local / P.nsplit, split = local - tile * P.nsplit;
+  if (tab.count == 1 && P.nsplit > 1 && (P.nsplit & 7) == 0) {  // split-K with K-range <-> XCD affinity (see gemm.hip)
+    const int T = P.tiles_m * P.tiles_n, S = P.nsplit >> 3, j = blockIdx.x >> 3;
+    split = (blockIdx.x & 7) * S + j / T;
+    tile = j % T;
+  }
+  int tm, tn;
+  tile_coords(tile, P.tiles_m, P.tiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int M = P.M, N = P.N;
+  const uint16_t* __restrict__ A = P.A;
+  const uint16_t* __restrict__ B = P.B;
+  const int lda = P.lda, ldb = P.ldb;
+  const int wr = wave / WNW, wc = wave % WNW;
+
+  f32x16 acc[AI][NJ];
+#pragma unroll
+  for (int i = 0; i < AI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int nk_total = P.K / BKT;
+  const int nk_per = (nk_total + P.nsplit - 1) / P.nsplit;
+  const int kt0 = split * nk_per, kt1 = min(nk_total, kt0 + nk_per);
+  const int nk = max(kt1 - kt0, 0);
+
+  u32x4 ra[2][4], rb[2][4];  // the K-tile in flight: this lane's 16-B pieces of the two A and the two B images (n = 4*h + i)
+  // NOTE on program order: the compiler cannot prove that a ds_write into the other LDS stage does not alias a ds_read from this
+  // one, so LDS reads and writes keep their SOURCE order — the interleave below is therefore written out piece by piece and
+  // the sched_group_barrier pipeline only has to place the MFMAs and global loads in between.
+  auto load_a1 = [&](int t, int n) __attribute__((always_inline)) {
+#ifdef W4_ABLATE_LOADS
+    const int tt = kt0 + (t & 0);
+#else
+    const int tt = kt0 + (t < nk ? t : nk - 1);
+#endif
+    SA::load1(ra[n >> 2][n & 3], A, lda, m0 + (n >> 2) * 128, tt * BKT, M, wave * 4 + (n & 3), lane);
+  };
+  auto load_b1 = [&](int t, int n) __attribute__((always_inline)) {
+#ifdef W4_ABLATE_LOADS
+    const int tt = kt0 + (t & 0);
+#else
+    const int tt = kt0 + (t < nk ? t : nk - 1);
+#endif
+    SB::load1(rb[n >> 2][n & 3], B, ldb, n0 + (n >> 2) * 128, tt * BKT, N, wave * 4 + (n & 3), lane);
+  };
+#ifdef W4_NO_STORE
+  auto store_a1 = [&](char* buf, int n) __attribute__((always_inline)) { if (nk < 0) SA::store1(ra[n >> 2][n & 3], buf + (n >> 2) * HALF, wave * 4 + (n & 3), lane); };
+  auto store_b1 = [&](char* buf, int n) __attribute__((always_inline)) { if (nk < 0) SB::store1(rb[n >> 2][n & 3], buf + (2 + (n >> 2)) * HALF, wave * 4 + (n & 3), lane); };
+#else
+  auto store_a1 = [&](char* buf, int n) __attribute__((always_inline)) { SA::store1(ra[n >> 2][n & 3], buf + (n >> 2) * HALF, wave * 4 + (n & 3), lane); };
+  auto store_b1 = [&](char* buf, int n) __attribute__((always_inline)) { SB::store1(rb[n >> 2][n & 3], buf + (2 + (n >> 2)) * HALF, wave * 4 + (n & 3), lane); };
+#endif
+  bf16x8 af[2][AI], bfr[2][NJ];  // fragment double buffer: k-step kk multiplies [kk & 1] while [(kk + 1) & 1] is being read
+  auto read1 = [&](const char* stage, int kk, int slot, int n) __attribute__((always_inline)) {  // n < 4: A fragment n, else B fragment n - 4
+    if (n < 4) af[slot][n] = read_frag<AK, BKT, 128>(stage + wr * HALF, n * 32, kk, lane);
+    else bfr[slot][n - 4] = read_frag<BKM, BKT, 128>(stage + (2 + wc) * HALF, (n - 4) * 32, kk, lane);
+  };
+  auto mfmas = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[slot][i], bfr[slot][j], acc[i][j], 0, 0, 0);
+  };
+
+  if (nk > 0) {
+#pragma unroll
+    for (int n = 0; n < 8; ++n) { load_a1(0, n); load_b1(0, n); }
+#pragma unroll
+    for (int n = 0; n < 8; ++n) { store_a1(smem, n); store_b1(smem, n); }
+#pragma unroll
+    for (int n = 0; n < 8; ++n) { load_a1(1, n); load_b1(1, n); }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 8; ++n) read1(smem, 0, 0, n);
+  }
+#ifdef W4_NO_READ
+  auto read1_loop = [&](const char*, int, int, int) __attribute__((always_inline)) {};
+#else
+  auto& read1_loop = read1;
+#endif
+  for (int t = 0; t < nk; ++t) {
+    char* const cur = smem + (t & 1) * STAGE;
+    char* const nxt = smem + ((t + 1) & 1) * STAGE;
+    // ---- k-step 0: fragments kk=1 in, tile t+1's A images out to LDS
+#pragma unroll
+    for (int n = 0; n < 8; ++n) { read1_loop(cur, 1, 1, n); store_a1(nxt, n); }
+    mfmas(0);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) { W4_SGB(SG_MFMA, 1); W4_SGB(SG_DS_RD, RA); W4_SGB(SG_MFMA, 1); W4_SGB(SG_DS_WR, 1); }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) { W4_SGB(SG_MFMA, 1); W4_SGB(SG_DS_RD, RB); W4_SGB(SG_MFMA, 1); W4_SGB(SG_DS_WR, 1); }
+    // ---- k-step 1: fragments kk=2 in, B images out, A(t+2) requested
+#pragma unroll
+    for (int n = 0; n < 8; ++n) { read1_loop(cur, 2, 0, n); store_b1(nxt, n); load_a1(t + 2, n); }
+    mfmas(1);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) { W4_SGB(SG_MFMA, 1); W4_SGB(SG_DS_RD, RA); W4_SGB(SG_VMEM_RD, 1); W4_SGB(SG_MFMA, 1); W4_SGB(SG_DS_WR, 1); }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) { W4_SGB(SG_MFMA, 1); W4_SGB(SG_DS_RD, RB); W4_SGB(SG_VMEM_RD, 1); W4_SGB(SG_MFMA, 1); W4_SGB(SG_DS_WR, 1); }
+    // ---- k-step 2: fragments kk=3 in, B(t+2) requested
+#pragma unroll
+    for (int n = 0; n < 8; ++n) { read1_loop(cur, 3, 1, n); load_b1(t + 2, n); }
+    mfmas(0);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) { W4_SGB(SG_MFMA, 1); W4_SGB(SG_DS_RD, RA); W4_SGB(SG_VMEM_RD, 1); W4_SGB(SG_MFMA, 1); }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) { W4_SGB(SG_MFMA, 1); W4_SGB(SG_DS_RD, RB); W4_SGB(SG_VMEM_RD, 1); W4_SGB(SG_MFMA, 1); }
+    // ---- k-step 3: every wave's images of tile t+1 are in LDS (written two k-steps ago) and every wave's reads of this stage
+    //      are issued and retired: one barrier, then the next tile's first fragments under this k-step's MFMAs
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 8; ++n) read1_loop(nxt, 0, 0, n);
+    mfmas(1);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) { W4_SGB(SG_MFMA, 1); W4_SGB(SG_DS_RD, RA); W4_SGB(SG_MFMA, 1); }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) { W4_SGB(SG_MFMA, 1); W4_SGB(SG_DS_RD, RB); W4_SGB(SG_MFMA, 1); }
+  }
+  __syncthreads();  // the LDS stages become the epilogue's restage buffers
+  gemm_epilogue<WM, WN, WNW, 1, PLAIN, 0>(acc, P, smem, m0, n0, split, 0, wave, lane, tid);
+}
+
+template <bool AK, bool BKM, bool PLAIN>
+void launch_one(const LaunchTable& tab, hipStream_t s) {
+  constexpr int LDS = 2 * 4 * 128 * 64 * 2;  // two stages of four 16-KiB images = the epilogue's 4 x (64 x 128) fp32 regions
+  static bool attr_set_dev[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  bool& attr_set = attr_set_dev[dev & 63];
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<AK, BKM, PLAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_w4_kernel<AK, BKM, PLAIN>), dim3(tab.total_blocks), dim3(256), LDS, s, tab);
+}
+
+}  // namespace
+
+void launch_gemm_w4(const LaunchTable& tab, int akm, int bkm, bool plain, hipStream_t s) {
+#define W4_LAUNCH(A_, B_)                         \
+  do {                                            \
+    if (plain) launch_one<A_, B_, true>(tab, s);  \
+    else launch_one<A_, B_, false>(tab, s);       \
+  } while (0)
+  if (!akm && !bkm) W4_LAUNCH(false, false);
+  else if (!akm && bkm) W4_LAUNCH(false, true);
+  else if (akm && bkm) W4_LAUNCH(true, true);
+  else W4_LAUNCH(true, false);
+#undef W4_LAUNCH
+}
