@@ -299,6 +299,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"])
     ap.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"],
                     help="gradient exchange precision for --gpus > 1 (fp32 = the reference's pmean; bf16 = opt-in, halves xGMI bytes)")
+    ap.add_argument("--fp8-scaling", default="delayed", choices=["delayed", "current"],
+                    help="--dtype fp8: scale from the previous step's amax (one pass per tensor) or from the current amax (two)")
     ap.add_argument("--sharded-optimizer", action="store_true", help="reduce-scatter gradients, AdamW on 1/N of the flat buffer, all-gather weights")
     ap.add_argument("--dense-captions", action="store_true", help="every caption has T-2 tokens (no padded label positions): dense upper bound")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -353,6 +355,7 @@ def main():
     tkw = {}
     if args.dtype == "fp8":
         tkw["gemm_dtype"] = "fp8"
+        tkw["fp8_scaling"] = args.fp8_scaling
     if args.sharded_optimizer:
         tkw["sharded_optimizer"] = True
     tr = Trainer(model, lr_fn, seed=42, grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else None, **tkw)

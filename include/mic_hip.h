@@ -121,10 +121,18 @@ typedef struct {
   void* q; int ldq;             /* [rows][ldq] bytes or NULL */
   void* qT; int ldqT;           /* [cols][ldqT] bytes or NULL */
   float* state;                 /* [2]: amax, 1 / scale */
+  float* amax_next;             /* delayed scaling: table of partial maxima (see below) or NULL */
   int fmt;                      /* MIC_E4M3 / MIC_E5M2 */
 } mic_fp8_item;
 int mic_fp8_amax(const mic_fp8_item* items, int count, void* stream);
 int mic_fp8_quantize(const mic_fp8_item* items, int count, void* stream);
+/* Delayed scaling: an item with amax_next != NULL is quantised by mic_fp8_quantize ALONE with the scale taken from the amax
+ * already in state[0] (values beyond it saturate at +-FMAX) while max |x| of this pass is accumulated into the tensor's table
+ * of partial maxima amax_next[0 .. mic_fp8_amax_partials()) (fp32 atomic max, one per 64x64 tile, spread over the table;
+ * caller-zeroed) — the tensor is read once instead of twice.  mic_fp8_roll_amax: for slot i < count, state[i * stride_floats]
+ * = max(partials[i * P .. (i+1) * P)) if that is > 0, and the partials are cleared — called at the start of a pass. */
+int mic_fp8_amax_partials(void);
+int mic_fp8_roll_amax(float* state, int stride_floats, float* partials, int count, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm (flax nn.LayerNorm: biased variance, fp32 statistics; 3P).

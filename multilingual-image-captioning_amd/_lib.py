@@ -36,7 +36,8 @@ class GemmArgs(C.Structure):
 
 class Fp8Item(C.Structure):
     _fields_ = [("src", C.c_void_p), ("ld", C.c_int), ("rows", C.c_int), ("cols", C.c_int), ("rows_pad", C.c_int),
-                ("q", C.c_void_p), ("ldq", C.c_int), ("qT", C.c_void_p), ("ldqT", C.c_int), ("state", C.c_void_p), ("fmt", C.c_int)]
+                ("q", C.c_void_p), ("ldq", C.c_int), ("qT", C.c_void_p), ("ldqT", C.c_int), ("state", C.c_void_p), ("amax_next", C.c_void_p),
+                ("fmt", C.c_int)]
 
 
 class ColsumItem(C.Structure):
@@ -65,6 +66,8 @@ _SIGS = {
     "mic_gemm_grouped": ([C.POINTER(GemmArgs), _i, _p], C.c_int),
     "mic_fp8_amax": ([C.POINTER(Fp8Item), _i, _p], C.c_int),
     "mic_fp8_quantize": ([C.POINTER(Fp8Item), _i, _p], C.c_int),
+    "mic_fp8_amax_partials": ([], C.c_int),
+    "mic_fp8_roll_amax": ([_p, _i, _p, _i, _p], C.c_int),
     "mic_sum_slabs": ([_i, _i, C.c_longlong, _i, _i, _p, _i, _p, _i, _p], C.c_int),
     "mic_layernorm_fwd": ([_i, _i, _i, _p, _p, _p, _f, _p, _p, _p, _f, _u32, _p], C.c_int),
     "mic_layernorm_bwd": ([_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _u32, _f, _u32, _p], C.c_int),

@@ -10,6 +10,12 @@
 //                     dequantisation factor the GEMM epilogue multiplies back (mic_gemm_args.a_scale_inv / b_scale_inv).
 // Both are table-driven (up to 8 tensors per launch): the 84 weight matrices are re-quantised once per optimizer step in a
 // handful of launches.  HBM-bound: 2 B read twice, 1 B written twice per element.
+//
+// Delayed scaling (the usual production recipe: the scale of step t comes from the amax observed at step t-1): an item with
+// `amax_next` set is quantised with the scale already in state[0] — no mic_fp8_amax pass, the tensor is read ONCE — while the
+// quantiser records this pass's max |x| in the tensor's table of partial maxima amax_next[0..1023] (one atomic per 64x64 tile,
+// spread over the table); mic_fp8_roll_amax reduces the table into state[0] at the start of the next pass.  Values beyond the
+// old amax saturate at +-FMAX (the clamp below).
 #include "common.h"
 
 #define QMAX_ITEMS 8
@@ -19,6 +25,7 @@ struct QItem {
   uint8_t* q; int ldq;               // [rows][ldq] or null
   uint8_t* qT; int ldqT;             // [cols][ldqT >= rows_pad] or null
   float* state;                      // [0] amax, [1] 1/scale
+  float* amax_next;                  // delayed scaling: [FP8_AMAX_PARTIALS] partial maxima of THIS pass (atomic max) or null
   int fmt;                           // MIC_E4M3 / MIC_E5M2
   int tiles_c, block_begin;
 };
@@ -87,8 +94,14 @@ __device__ __forceinline__ uint32_t cvt4(const float* v, int fmt) {  // 4 floats
   return (uint32_t)w;
 }
 
+#define FP8_AMAX_PARTIALS 1024  // delayed scaling: per-tensor partial maxima (tile t lands in entry t % 1024): one atomic per
+                                // block, spread over 1024 addresses — 1024 atomics on ONE address cost ~12 us (L2 serialises them)
+// 128 (rows) x 64 (cols) tiles: thread t covers 8 columns (t & 7) of rows (t >> 3) + 32 h, h < 4 — four 16-B loads in flight per
+// thread, 128-B row segments in, 64-B segments of q and full 128-B lines of qT out (the 64 x 64 version measured 11 us for a
+// 4096 x 1024 tensor, 1.5 TB/s: too little work per block).
 __global__ __launch_bounds__(256) void fp8_quantize_kernel(QTable tab) {
-  __shared__ __attribute__((aligned(16))) uint8_t tile[64][80];  // [col][row], 80-byte pitch: 16-B aligned rows of 64 bytes
+  __shared__ __attribute__((aligned(16))) uint8_t tile[64][144];  // [col][row], 144-byte pitch: 16-B aligned rows of 128 bytes
+  __shared__ float red[4];
   int local;
   const QItem& I = pick_item(tab, blockIdx.x, local);
   const int tr = local / I.tiles_c, tc = local % I.tiles_c;
@@ -97,17 +110,26 @@ __global__ __launch_bounds__(256) void fp8_quantize_kernel(QTable tab) {
   const float amax = I.state[0];
   const float scale = amax > 0.f ? fmax / amax : 1.0f;
   if (local == 0 && tid == 0) I.state[1] = amax > 0.f ? amax / fmax : 1.0f;
+  float m = 0.f;
+  const int cl = (tid & 7) * 8, c = tc * 64 + cl;
+  float v[4][8];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int rl = h * 32 + (tid >> 3), cl = (tid & 7) * 8;
-    const int r = tr * 64 + rl, c = tc * 64 + cl;
-    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (r < I.rows && c < I.cols) {
-      ld8(I.src + (size_t)r * I.ld + c, v);
+  for (int h = 0; h < 4; ++h) {
+    const int r = tr * 128 + h * 32 + (tid >> 3);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (c + e < I.cols) ? fminf(fmaxf(v[e] * scale, -fmax), fmax) : 0.f;
+    for (int e = 0; e < 8; ++e) v[h][e] = 0.f;
+    if (r < I.rows && c < I.cols) ld8(I.src + (size_t)r * I.ld + c, v[h]);
+  }
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    const int rl = h * 32 + (tid >> 3), r = tr * 128 + rl;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = (c + e < I.cols) ? v[h][e] : 0.f;
+      m = fmaxf(m, fabsf(x));
+      v[h][e] = fminf(fmaxf(x * scale, -fmax), fmax);
     }
-    const uint32_t lo = cvt4(v, I.fmt), hi = cvt4(v + 4, I.fmt);
+    const uint32_t lo = cvt4(v[h], I.fmt), hi = cvt4(v[h] + 4, I.fmt);
     if (I.q && r < I.rows && c < I.cols) *reinterpret_cast<uint2*>(I.q + (size_t)r * I.ldq + c) = make_uint2(lo, hi);
     if (I.qT) {
 #pragma unroll
@@ -117,16 +139,44 @@ __global__ __launch_bounds__(256) void fp8_quantize_kernel(QTable tab) {
       }
     }
   }
+  if (I.amax_next) {  // delayed scaling: this tile's max |x| into the tensor's partial-maximum table
+    m = wave_max(m);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+  }
+  if (I.qT || I.amax_next) __syncthreads();
+  if (I.amax_next && tid == 0) {
+    const float x = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (x > 0.f) atomicMax(reinterpret_cast<int*>(I.amax_next + (local & (FP8_AMAX_PARTIALS - 1))), __float_as_int(x));
+  }
   if (!I.qT) return;
-  __syncthreads();
-  // transposed store: thread t writes 16 consecutive rows (t & 3) of column t >> 2
-  const int cl = tid >> 2, r0 = (tid & 3) * 16;
-  const int c = tc * 64 + cl, r = tr * 64 + r0;
-  if (c < I.cols && r < I.rows_pad)
-    *reinterpret_cast<uint4*>(I.qT + (size_t)c * I.ldqT + r) = *reinterpret_cast<const uint4*>(&tile[cl][r0]);
+  // transposed store: thread t writes rows [32 (t & 3), +32) of column t >> 2 as two 16-B pieces
+  const int ct = tid >> 2, r0 = (tid & 3) * 32;
+  const int cg = tc * 64 + ct;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int r = tr * 128 + r0 + u * 16;
+    if (cg < I.cols && r < I.rows_pad)
+      *reinterpret_cast<uint4*>(I.qT + (size_t)cg * I.ldqT + r) = *reinterpret_cast<const uint4*>(&tile[ct][r0 + u * 16]);
+  }
+}
+
+// start of a pass under delayed scaling: slot i's amax becomes the maximum of the partials recorded during the previous pass
+// (if any were), and the partials are cleared.  One wave per slot.
+__global__ __launch_bounds__(64) void fp8_roll_kernel(float* state, int stride, float* partials, int count) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  if (i >= count) return;
+  float* p = partials + (size_t)i * FP8_AMAX_PARTIALS;
+  float m = 0.f;
+  for (int j = lane; j < FP8_AMAX_PARTIALS; j += 64) {
+    m = fmaxf(m, p[j]);
+    p[j] = 0.f;
+  }
+  m = wave_max(m);
+  if (lane == 0 && m > 0.f) state[(size_t)i * stride] = m;
 }
 
 static int build_table(const mic_fp8_item* items, int n, QTable& t, bool need_out) {
+  const int tile_rows = need_out ? 128 : 64;  // the quantiser walks 128 x 64 tiles, the amax pass 64 x 64
   t.count = n;
   int blocks = 0;
   for (int i = 0; i < n; ++i) {
@@ -143,10 +193,10 @@ static int build_table(const mic_fp8_item* items, int n, QTable& t, bool need_ou
     }
     QItem& d = t.it[i];
     d.src = (const uint16_t*)s.src; d.ld = s.ld; d.rows = s.rows; d.cols = s.cols; d.rows_pad = rows_pad;
-    d.q = (uint8_t*)s.q; d.ldq = s.ldq; d.qT = (uint8_t*)s.qT; d.ldqT = s.ldqT; d.state = s.state; d.fmt = s.fmt;
+    d.q = (uint8_t*)s.q; d.ldq = s.ldq; d.qT = (uint8_t*)s.qT; d.ldqT = s.ldqT; d.state = s.state; d.amax_next = s.amax_next; d.fmt = s.fmt;
     d.tiles_c = (s.cols + 63) / 64;
     d.block_begin = blocks;
-    blocks += ((need_out && s.qT ? rows_pad : s.rows) + 63) / 64 * d.tiles_c;
+    blocks += ((need_out && s.qT ? rows_pad : s.rows) + tile_rows - 1) / tile_rows * d.tiles_c;
   }
   t.total_blocks = blocks;
   return MIC_OK;
@@ -173,6 +223,15 @@ extern "C" int mic_fp8_quantize(const mic_fp8_item* items, int count, void* stre
     if (int rc = build_table(items + i, n, t, true)) return rc;
     hipLaunchKernelGGL(fp8_quantize_kernel, dim3(t.total_blocks), dim3(256), 0, (hipStream_t)stream, t);
   }
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}
+
+extern "C" int mic_fp8_amax_partials(void) { return FP8_AMAX_PARTIALS; }
+
+extern "C" int mic_fp8_roll_amax(float* state, int stride_floats, float* partials, int count, void* stream) {
+  MIC_CHECK(state && partials && stride_floats >= 1 && count >= 1, "mic_fp8_roll_amax: bad args");
+  hipLaunchKernelGGL(fp8_roll_kernel, dim3(count), dim3(64), 0, (hipStream_t)stream, state, stride_floats, partials, count);
   MIC_LAUNCH_CHECK();
   return MIC_OK;
 }

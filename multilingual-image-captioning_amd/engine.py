@@ -52,18 +52,26 @@ class Engine:
     # ------------------------------------------------------------------ fp8 GEMM operands (BASELINE configs[4])
     FP8_KINDS = ("qkv", "cq", "ckv", "fc1", "fc2")  # the QKV and FFN projections of both towers; out-projections and the head stay bf16
 
-    def set_gemm_dtype(self, name):
-        """"fp8": the QKV / FFN projections run as OCP fp8 GEMMs — e4m3 activations and weights, e5m2 gradients, per-tensor
-        current scaling, fp32 accumulate (forward, dX and dW).  None / "bf16": the storage dtype."""
+    def set_gemm_dtype(self, name, scaling: str = "delayed"):
+        """"fp8": the QKV / FFN projections run as OCP fp8 GEMMs — e4m3 activations and weights, e5m2 gradients, one scale per
+        tensor, fp32 accumulate (forward, dX and dW).  None / "bf16": the storage dtype.
+        scaling="current": every activation / gradient tensor is scaled by its own absolute maximum (two passes over the
+        tensor: amax, then quantise).  scaling="delayed" (default; the usual production recipe): the scale comes from the
+        amax the same tensor had in the previous pass, the quantiser records the new amax on the way (one pass); values
+        that outgrow the old amax saturate at +-FMAX for that one pass.  A tensor seen for the first time is scaled by its
+        current amax.  Weights are always re-quantised with their current amax, once per optimizer step."""
         if name in (None, "bf16", "bfloat16", "f32", "float32"):
             self.fp8 = False
             return
         if name != "fp8":
             raise ValueError(f"unknown gemm_dtype {name!r}")
+        if scaling not in ("delayed", "current"):
+            raise ValueError(f"fp8 scaling must be 'delayed' or 'current', got {scaling!r}")
         if self.dt != torch.bfloat16:
             raise ValueError("gemm_dtype='fp8' needs the bfloat16 storage mode (dtype=bfloat16)")
         P = self.P
         self.fp8 = True
+        self.fp8_scaling = scaling
         names = [f"dec{l}.{k}" for l in range(P.L) for k in self.FP8_KINDS] + [f"vit{l}.{k}" for l in range(P.vL) for k in ("qkv", "fc1", "fc2")]
         self._w8 = {}
         self._w8_state = torch.zeros((len(names), 2), dtype=torch.float32, device=self.dev)
@@ -73,8 +81,11 @@ class Engine:
                            torch.empty((K, N), dtype=torch.float8_e4m3fn, device=self.dev),   # [in][out]: dX = dy W
                            self._w8_state[i])
         self._w8_stale = True
-        self._a8_state = torch.zeros((4096, 2), dtype=torch.float32, device=self.dev)  # one (amax, 1/scale) slot per quantised activation
+        # one (amax, 1/scale) slot per quantised activation / gradient tensor; delayed scaling: + its table of partial maxima
+        self._a8_state = torch.zeros((1024, 2), dtype=torch.float32, device=self.dev)
+        self._a8_part = torch.zeros((1024, ops.fp8_amax_partials()), dtype=torch.float32, device=self.dev) if scaling == "delayed" else None
         self._a8_slots: Dict[str, int] = {}
+        self._a8_ready = set()   # delayed scaling: tags whose slot carries the previous pass's amax
         self._a8_cache: Dict = {}
         self._dw8_queue = []
 
@@ -82,7 +93,8 @@ class Engine:
         self._w8_stale = True
 
     def _fp8_begin_pass(self):
-        """start of a forward(+backward) pass: re-quantise the weights if the optimizer moved them, clear the activation slots"""
+        """start of a forward(+backward) pass: re-quantise the weights if the optimizer moved them; current scaling: clear the
+        activation slots; delayed scaling: last pass's recorded amax becomes this pass's scale source"""
         if not self.fp8:
             return
         if self._w8_stale:
@@ -91,19 +103,25 @@ class Engine:
             items = [ops.fp8_item(P.w(n + ".w"), q.shape[0], q.shape[1], st, torch.float8_e4m3fn, q=q, qT=qT) for n, (q, qT, st) in self._w8.items()]
             ops.fp8_quantize(items)
             self._w8_stale = False
-        ops.zero(self._a8_state[: max(len(self._a8_slots), 1)])
+        n = len(self._a8_slots)
+        if self.fp8_scaling == "delayed":
+            if n:
+                ops.fp8_roll_amax(self._a8_state, self._a8_part, n)
+            self._a8_ready = set(self._a8_slots)
+        else:
+            ops.zero(self._a8_state[: max(n, 1)])
         self._a8_cache = {}
 
     def _fp8_ok(self, wname: str) -> bool:
         return self.fp8 and wname.split(".")[-1] in self.FP8_KINDS and wname in self._w8
 
-    def _a8_slot(self, tag: str) -> torch.Tensor:
+    def _a8_slot(self, tag: str) -> int:
         i = self._a8_slots.get(tag)
         if i is None:
             i = self._a8_slots[tag] = len(self._a8_slots)
             if i >= self._a8_state.shape[0]:
                 raise RuntimeError("fp8: out of activation scale slots")
-        return self._a8_state[i]
+        return i
 
     def _quant(self, x, rows: int, cols: int, tag: str, buf_tag: str, fmt, want_qT: bool, cache: bool):
         """(q [rows][cols], qT [cols][rows_pad] or None, state) of bf16 x.  cache=True: x keeps its contents for the rest of the
@@ -115,8 +133,16 @@ class Engine:
         rp = _rup(rows, ROWPAD)
         q = self.buf(buf_tag + ".q8", rows, cols, fmt)
         qT = self.buf(buf_tag + ".q8T", cols, rp, fmt) if want_qT else None
-        st = self._a8_slot(tag)
-        ops.fp8_quantize([ops.fp8_item(x, rows, cols, st, fmt, q=q, qT=qT, rows_pad=rp)])
+        slot = self._a8_slot(tag)
+        st = self._a8_state[slot]
+        delayed = self.fp8_scaling == "delayed"
+        if hit is not None:
+            # same tensor quantised earlier in this pass without the transposed copy: reuse its scale, do not count it twice
+            ops.fp8_quantize([ops.fp8_item(x, rows, cols, hit[2], fmt, q=q, qT=qT, rows_pad=rp)], amax_pass=False)
+            st = hit[2]
+        else:
+            item = ops.fp8_item(x, rows, cols, st, fmt, q=q, qT=qT, rows_pad=rp, amax_next=self._a8_part[slot] if delayed else None)
+            ops.fp8_quantize([item], amax_pass=not (delayed and tag in self._a8_ready))
         if cache:
             self._a8_cache[key] = (q, qT, st)
         return q, qT, st

@@ -99,23 +99,36 @@ def gemm_grouped(arg_list):
     L.check(L.lib().mic_gemm_grouped(arr, len(arg_list), _stream()), "mic_gemm_grouped")
 
 
-def fp8_item(src, rows, cols, state, fmt_dtype, q=None, qT=None, rows_pad=0) -> "L.Fp8Item":
-    """src bf16 [>=rows][ld]; q fp8 [rows][*] and / or qT fp8 [cols][>= rows_pad]; state fp32 [2] (amax, 1/scale)."""
+def fp8_item(src, rows, cols, state, fmt_dtype, q=None, qT=None, rows_pad=0, amax_next=None) -> "L.Fp8Item":
+    """src bf16 [>=rows][ld]; q fp8 [rows][*] and / or qT fp8 [cols][>= rows_pad]; state fp32 [2] (amax, 1/scale);
+    amax_next fp32 [fp8_amax_partials()]: delayed scaling (quantise with the scale in `state`, record this pass's partial maxima)."""
     if src.dtype != torch.bfloat16:
         raise L.MicError("fp8 quantisation reads bf16 tensors (the fp8 path needs the bfloat16 storage mode)")
     it = L.Fp8Item()
     it.src, it.ld, it.rows, it.cols, it.rows_pad = _p(src), src.stride(0), rows, cols, rows_pad
     it.q, it.ldq = _p(q), (q.stride(0) if q is not None else 0)
     it.qT, it.ldqT = _p(qT), (qT.stride(0) if qT is not None else 0)
-    it.state, it.fmt = _p(state), _FP8[fmt_dtype]
+    it.state, it.amax_next, it.fmt = _p(state), _p(amax_next), _FP8[fmt_dtype]
     return it
 
 
-def fp8_quantize(items):
-    """amax pass + quantise pass over `items` (list of Fp8Item; their `state` slots must have been zeroed)."""
+def fp8_quantize(items, amax_pass: bool = True):
+    """amax pass + quantise pass over `items` (list of Fp8Item; their `state` slots must have been zeroed).
+    amax_pass=False: delayed scaling — the scales are already in the items' `state`, only the quantiser runs."""
     arr = (L.Fp8Item * len(items))(*items)
-    L.check(L.lib().mic_fp8_amax(arr, len(items), _stream()), "mic_fp8_amax")
+    if amax_pass:
+        L.check(L.lib().mic_fp8_amax(arr, len(items), _stream()), "mic_fp8_amax")
     L.check(L.lib().mic_fp8_quantize(arr, len(items), _stream()), "mic_fp8_quantize")
+
+
+def fp8_amax_partials() -> int:
+    """entries of a tensor's partial-maximum table (delayed scaling)"""
+    return int(L.lib().mic_fp8_amax_partials())
+
+
+def fp8_roll_amax(state: torch.Tensor, partials: torch.Tensor, count: int):
+    """state fp32 [slots][>= 1] (amax first), partials fp32 [slots][fp8_amax_partials()]: start of a pass under delayed scaling."""
+    L.check(L.lib().mic_fp8_roll_amax(_p(state), state.stride(0), _p(partials), count, _stream()), "mic_fp8_roll_amax")
 
 
 def layernorm_fwd(x, gamma, beta, eps, y, mean=None, rstd=None, rows=None, dropout_p=0.0, dropout_seed=0):

@@ -268,7 +268,7 @@ class Trainer:
     def __init__(self, model, learning_rate_fn: Callable[[int], float], b1=0.9, b2=0.999, eps=1e-8, weight_decay=0.0,
                  label_smoothing_factor=0.0, seed: int = 42, bucket_mb: float = 64.0, group=None, compact_head: bool = True,
                  overlap_optimizer: bool = True, grad_comm_dtype: Optional[torch.dtype] = None, sharded_optimizer: bool = False,
-                 gemm_dtype: Optional[str] = None):
+                 gemm_dtype: Optional[str] = None, fp8_scaling: str = "delayed"):
         import torch.distributed as dist
 
         self.model, self.lr_fn = model, learning_rate_fn
@@ -283,7 +283,7 @@ class Trainer:
         st.ensure_grads()
         st.ensure_opt_state()
         if gemm_dtype is not None:
-            model.engine.set_gemm_dtype(gemm_dtype)
+            model.engine.set_gemm_dtype(gemm_dtype, scaling=fp8_scaling)
         self.hyper = torch.zeros(2, dtype=torch.float32, device=model.device)
         bounds = [s.offset for s in st.segs.values()]
         # sharded optimizer (data parallel only): reduce-scatter / AdamW on 1/world of every bucket / all-gather the weights
