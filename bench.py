@@ -187,7 +187,8 @@ def bench_generate(model, cfg, dev, batch=256, langs=(250004, 250008, 250003, 25
     px = torch.from_numpy(np.clip(rng.standard_normal((batch, img, img, 3), dtype=np.float32), -1.8, 2.2)).to(dev)
     V = cfg.mbart_config.vocab_size
     langs = [l if l < V else V - 4 + i for i, l in enumerate(langs)]
-    out = model.generate(px, forced_bos_token_id=langs[0], num_beams=4, max_length=max_length)  # warm-up (allocations)
+    for _ in range(2):  # warm-up: the first call allocates the decode plan (with MIC_DECODE_GRAPHS=1 the second captures its step graphs)
+        out = model.generate(px, forced_bos_token_id=langs[0], num_beams=4, max_length=max_length)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     n = 0

@@ -11,6 +11,18 @@ instead.  `_sample` (gen:537-663): the categorical draw is `mic_
 threefry2x32 stream); by default it draws from the RAW logits exactly like the reference does (its processed/warped logits
 are computed and dropped, gen:620-627); `sample_from_processed_logits=True` applies processors, temperature, top-k and
 top-p (`mic_warp_thresholds`).
+
+Decode plans and launch-free decoder steps: a decoder step is ~140 kernel launches whose arguments depend only on (batch,
+beams, max_length, processors, step index) — never on the data.  Greedy and beam search keep a `_DecodePlan` per such
+configuration: its device state (sequences, scores, KV cache, slot table ...) lives at fixed addresses and is re-initialised in
+place per call (no 3 GB cache allocation + zero fill per generate call).  With `MIC_DECODE_GRAPHS=1` the second call of a plan
+additionally captures step t of the loop into a hipGraph (one graph per step index: the cache slot, the valid length and the
+processor switches are baked-in launch arguments) and from then on a step is ONE graph launch.  The host never waits inside
+the loop except for a stop-flag poll every 8 steps (`lax.while_loop` in the reference has no host in it either, gen:976).
+MEASURED (MI355X, ROCm 7.2, tools/decode_host_probe.py, ms per decoder step, graphs vs eager): batch 256 x 4 beams 2.71 vs
+2.70 (GPU-bound either way), batch 32: 1.61 vs 1.62, batch 4: 1.47 vs 1.57 — a replayed 140-node graph costs what 140
+back-to-back launches cost (~10 us per dependent kernel on this stack), so the graphs are correct (tests) but buy nothing
+here and stay opt-in; fewer, fatter kernels per step are what would move small-batch latency.
 """
 from __future__ import annotations
 
@@ -21,6 +33,44 @@ import torch
 from . import ops
 
 NEG = -1.0e7
+_POLL = 8          # decoder steps between two looks at the device-side stop flag
+_MAX_PLANS = 2     # decode plans kept per model (each owns a KV cache: 24 x rows x max_length x d_model elements)
+
+
+class _DecodePlan:
+    """Fixed-address device state of one generate configuration + its captured decoder steps."""
+
+    def __init__(self):
+        self.t = {}          # name -> persistent tensor
+        self.graphs = {}     # cur_len -> torch.cuda.CUDAGraph
+        self.calls = 0
+        self.stream = None   # capture stream
+
+    def run_step(self, cur_len: int, fn, use_graphs: bool):
+        """fn() issues the launches of decoder step `cur_len` on the current stream.  First call of a plan: eager.  Later calls:
+        replay the step's graph, capturing it the first time (capture executes nothing; the replay does)."""
+        if not use_graphs or self.calls == 0:
+            fn()
+            return
+        g = self.graphs.get(cur_len)
+        if g is None:
+            if self.stream is None:
+                self.stream = torch.cuda.Stream()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(self.stream):
+                g.capture_begin(capture_error_mode="thread_local")
+                try:
+                    fn()
+                finally:
+                    g.capture_end()
+            self.graphs[cur_len] = g
+        g.replay()
+
+
+def _graphs_enabled(dev) -> bool:
+    import os
+
+    return dev.type == "cuda" and os.environ.get("MIC_DECODE_GRAPHS", "0") == "1"
 
 
 class FlaxCLIPVisionMBartGenerationMixin:
@@ -92,31 +142,83 @@ class FlaxCLIPVisionMBartGenerationMixin:
         return forced, suppress
 
     # ------------------------------------------------------------------ gen:422-535
+    def _decode_plan(self, key, build) -> _DecodePlan:
+        """LRU of `_MAX_PLANS` decode plans; `build(plan)` allocates a new plan's tensors."""
+        from collections import OrderedDict
+
+        plans = self.__dict__.setdefault("_decode_plans", OrderedDict())
+        plan = plans.get(key)
+        if plan is None:
+            while len(plans) >= _MAX_PLANS:
+                plans.popitem(last=False)
+            plan = plans[key] = _DecodePlan()
+            build(plan)
+        plans.move_to_end(key)
+        return plan
+
+    def release_decode_plans(self):
+        """drop the cached decode plans (their KV caches and captured graphs)"""
+        self.__dict__.pop("_decode_plans", None)
+
+    def _plan_cache(self, plan: _DecodePlan, rows: int, max_length: int) -> dict:
+        """the plan's self-attention cache (modeling:249-282: static length max_length).  Not re-zeroed between calls: a step
+        only reads the slots <= its own index, all written earlier in the same call."""
+        if "k0" not in plan.t:
+            c = self.init_cache(rows, max_length)
+            for l, (k, v) in enumerate(zip(c["k"], c["v"])):
+                plan.t[f"k{l}"], plan.t[f"v{l}"] = k, v
+        L = self.store.L
+        return {"k": [plan.t[f"k{l}"] for l in range(L)], "v": [plan.t[f"v{l}"] for l in range(L)], "cache_index": 0,
+                "max_length": max_length, "rows": rows, "src_row": None, "cross": None, "row_div": 1}
+
     def _greedy_search(self, ehs, B, start_token, max_length, pad_token_id, eos_token_id, procs):
         from .modeling_clip_vision_mbart import ModelOutput
 
         dev, st = self.device, self.store
-        sequences = torch.full((B, max_length), pad_token_id, dtype=torch.int32, device=dev)  # gen:457
+
+        def build(plan):
+            t = plan.t
+            t["sequences"] = torch.empty((B, max_length), dtype=torch.int32, device=dev)
+            t["finished"] = torch.empty(B, dtype=torch.int32, device=dev)
+            t["next_token"] = torch.empty((B,), dtype=torch.int32, device=dev)
+            t["top_val"] = torch.empty((B, 1), dtype=torch.float32, device=dev)
+            t["top_idx"] = torch.empty((B, 1), dtype=torch.int32, device=dev)
+            t["pos_all"] = torch.arange(max_length, dtype=torch.int32, device=dev).repeat_interleave(B)
+
+        plan = self._decode_plan(("greedy", B, max_length, pad_token_id, eos_token_id, procs["min_length"], procs["forced_eos"], self.dtype),
+                                 build)
+        t = plan.t
+        sequences, finished, next_token, top_val, top_idx, pos_all = (t[k] for k in ("sequences", "finished", "next_token", "top_val",
+                                                                                     "top_idx", "pos_all"))
+        sequences.fill_(pad_token_id)  # gen:457
         sequences[:, 0] = start_token
-        finished = torch.zeros(B, dtype=torch.int32, device=dev)
-        next_token = torch.full((B,), start_token, dtype=torch.int32, device=dev)
-        cache = self.init_cache(B, max_length)
+        finished.zero_()
+        next_token.fill_(start_token)
+        cache = self._plan_cache(plan, B, max_length)
         self._decode_set_encoder(cache, ehs.reshape(B * st.S, st.d), B, 1)
-        top_val = torch.empty((B, 1), dtype=torch.float32, device=dev)
-        top_idx = torch.empty((B, 1), dtype=torch.int32, device=dev)
-        pos = torch.zeros(B, dtype=torch.int32, device=dev)
+        use_graphs = _graphs_enabled(dev)
+
+        def step(cur_len):
+            def fn():
+                with ops.pinned_stream():
+                    cache["cache_index"] = cur_len - 1
+                    logits = self._decode_step(cache, next_token, pos_all[(cur_len - 1) * B: cur_len * B])
+                    forced, suppress = self._proc_args(procs, cur_len, max_length, eos_token_id)
+                    ops.row_lse_topk(logits, logits.stride(0), st.V, 1, top_val, top_idx, B, forced_token=forced, suppress_eos=suppress,
+                                     eos_token_id=eos_token_id, raw_logits=True)
+                    ops.greedy_step(B, max_length, cur_len, eos_token_id, pad_token_id, top_idx, 1, sequences, finished, next_token)
+            return fn
+
+        # gen:480-487 stops when every row has finished.  A finished row only ever receives PAD (gen:501-507) into a buffer that
+        # is PAD already, so steps issued after that point change nothing: the flag is looked at every _POLL steps, not every step.
         cur_len = 1
-        while True:
-            if cur_len == max_length or bool(finished.all().item()):  # gen:480-487
+        while cur_len < max_length:
+            if (cur_len - 1) % _POLL == 0 and cur_len > 1 and bool(finished.all().item()):
                 break
-            logits = self._decode_step(cache, next_token, pos)
-            forced, suppress = self._proc_args(procs, cur_len, max_length, eos_token_id)
-            ops.row_lse_topk(logits, logits.stride(0), st.V, 1, top_val, top_idx, B, forced_token=forced, suppress_eos=suppress,
-                             eos_token_id=eos_token_id, raw_logits=True)
-            ops.greedy_step(B, max_length, cur_len, eos_token_id, pad_token_id, top_idx, 1, sequences, finished, next_token)
-            pos += 1
+            plan.run_step(cur_len, step(cur_len), use_graphs and cur_len > 1)  # step 1 carries the call's forced-BOS id: never captured
             cur_len += 1
-        return ModelOutput(sequences=sequences)
+        plan.calls += 1
+        return ModelOutput(sequences=sequences.clone())
 
     # ------------------------------------------------------------------ gen:537-663
     def _sample(self, ehs, B, start_token, max_length, pad_token_id, eos_token_id, prng_key, procs, warp, from_processed: bool):
@@ -167,46 +269,75 @@ class FlaxCLIPVisionMBartGenerationMixin:
             raise NotImplementedError("num_beams > 8 needs a wider per-row top-k than this build ships (k = 2*num_beams <= 16)")
         dev, st = self.device, self.store
         R = B * K
-        running_seq = torch.full((B, K, max_length), pad_token_id, dtype=torch.int32, device=dev)  # gen:751-757
+
+        def build(plan):
+            t = plan.t
+            t["running_seq"] = torch.empty((B, K, max_length), dtype=torch.int32, device=dev)
+            t["seq"] = torch.empty((B, K, max_length), dtype=torch.int32, device=dev)
+            t["finished"] = torch.empty((B, K), dtype=torch.int32, device=dev)
+            t["running_scores"] = torch.empty((B, K), dtype=torch.float32, device=dev)
+            t["scores"] = torch.empty((B, K), dtype=torch.float32, device=dev)
+            t["next_token"] = torch.empty((R,), dtype=torch.int32, device=dev)
+            t["src_row"] = torch.empty((R, max_length), dtype=torch.int32, device=dev)
+            t["flags"] = torch.empty((B, 2), dtype=torch.int32, device=dev)
+            t["cand_val"] = torch.empty((R, 2 * K), dtype=torch.float32, device=dev)
+            t["cand_idx"] = torch.empty((R, 2 * K), dtype=torch.int32, device=dev)
+            t["pos_all"] = torch.arange(max_length, dtype=torch.int32, device=dev).repeat_interleave(R)  # position ids of every step
+            t["gstate"] = torch.empty(8, dtype=torch.int32, device=dev)
+            t["score0"] = torch.tensor([0.0] + [NEG] * (K - 1), dtype=torch.float32, device=dev).repeat(B, 1).contiguous()
+            t["rows"] = torch.arange(R, dtype=torch.int32, device=dev)
+
+        plan = self._decode_plan(("beam", B, K, max_length, pad_token_id, eos_token_id, float(length_penalty), bool(early_stopping),
+                                  procs["min_length"], procs["forced_eos"], self.dtype), build)
+        t = plan.t
+        running_seq, seq, finished, running_scores, scores = t["running_seq"], t["seq"], t["finished"], t["running_scores"], t["scores"]
+        next_token, src_row, flags, cand_val, cand_idx, pos_all, gstate = (t[k] for k in ("next_token", "src_row", "flags", "cand_val",
+                                                                                          "cand_idx", "pos_all", "gstate"))
+        running_seq.fill_(pad_token_id)  # gen:751-757
         running_seq[:, :, 0] = start_token
-        seq = torch.full((B, K, max_length), pad_token_id, dtype=torch.int32, device=dev)
-        finished = torch.zeros((B, K), dtype=torch.int32, device=dev)  # gen:760
-        running_scores = torch.tensor([0.0] + [NEG] * (K - 1), dtype=torch.float32, device=dev).repeat(B, 1).contiguous()  # gen:763-765
-        scores = torch.full((B, K), NEG, dtype=torch.float32, device=dev)  # gen:766
-        next_token = torch.full((R,), start_token, dtype=torch.int32, device=dev)
-        src_row = torch.zeros((R, max_length), dtype=torch.int32, device=dev)
-        src_row[:, 0] = torch.arange(R, dtype=torch.int32, device=dev)
-        flags = torch.zeros((B, 2), dtype=torch.int32, device=dev)
-        cache = self.init_cache(R, max_length)
+        seq.fill_(pad_token_id)
+        finished.zero_()  # gen:760
+        running_scores.copy_(t["score0"])  # gen:763-765
+        scores.fill_(NEG)  # gen:766
+        next_token.fill_(start_token)
+        src_row.zero_()
+        src_row[:, 0] = t["rows"]
+        flags.zero_()
+        cache = self._plan_cache(plan, R, max_length)
         cache["src_row"] = src_row
         # encoder states are shared by an image's K beams (gen:299-307 broadcasts them; here: row r reads image r // K)
         self._decode_set_encoder(cache, ehs.reshape(B * st.S, st.d), B, K)
-        cand_val = torch.empty((R, 2 * K), dtype=torch.float32, device=dev)
-        cand_idx = torch.empty((R, 2 * K), dtype=torch.int32, device=dev)
-        pos_all = torch.arange(max_length, dtype=torch.int32, device=dev).repeat_interleave(R)  # position ids of every step
         # beam_search_cond_fn (gen:798-820) lives on the device: mic_beam_step evaluates it on the new state, and once it says
-        # stop every later mic_beam_step launch is a no-op.  The host therefore enqueues decoder steps without waiting and
-        # looks at the flag only every few steps (the reference's lax.while_loop has no host in the loop either, gen:976).
-        gstate = torch.zeros(8, dtype=torch.int32, device=dev)
-        poll = 8
+        # stop every later mic_beam_step launch is a no-op.  The host therefore enqueues decoder steps (graph replays once the
+        # plan is warm) without waiting and looks at the flag only every _POLL steps.
+        gstate.zero_()
+        use_graphs = _graphs_enabled(dev)
+
+        def step(cur_len):
+            def fn():
+                with ops.pinned_stream():
+                    cache["cache_index"] = cur_len - 1
+                    logits, stat = self._decode_step(cache, next_token, pos_all[(cur_len - 1) * R: cur_len * R], stats=True)  # gen:830-840
+                    forced, suppress = self._proc_args(procs, cur_len, max_length, eos_token_id)
+                    if stat is not None and forced < 0:
+                        # log-softmax + top-2K from the head GEMM's per-granule partials: 3908 pairs and a few 64-column granules
+                        # per row instead of two passes over the 250 054 logits (same candidates, same order, same fp32 arithmetic)
+                        ops.row_topk_tiles(logits, logits.stride(0), st.V, stat, 2 * K, cand_val, cand_idx, R, suppress_eos=suppress,
+                                           eos_token_id=eos_token_id, row_bias=running_scores.reshape(-1))
+                    else:
+                        ops.row_lse_topk(logits, logits.stride(0), st.V, 2 * K, cand_val, cand_idx, R, forced_token=forced,
+                                         suppress_eos=suppress, eos_token_id=eos_token_id, row_bias=running_scores.reshape(-1))  # gen:850-873
+                    ops.beam_step(B, K, max_length, st.V, cur_len, eos_token_id, pad_token_id, length_penalty, early_stopping, cand_val,
+                                  cand_idx, running_seq, running_scores, seq, scores, finished, src_row, next_token, flags, gstate=gstate)  # gen:872-966
+            return fn
+
         cur_len = 1
         while cur_len < max_length:
-            with ops.pinned_stream():
-                logits, stat = self._decode_step(cache, next_token, pos_all[(cur_len - 1) * R: cur_len * R], stats=True)  # gen:830-840
-                forced, suppress = self._proc_args(procs, cur_len, max_length, eos_token_id)
-                if stat is not None and forced < 0:
-                    # log-softmax + top-2K from the head GEMM's per-granule partials: 3908 pairs and a few 64-column granules per
-                    # row instead of two passes over the 250 054 logits (same candidates, same order, same fp32 arithmetic)
-                    ops.row_topk_tiles(logits, logits.stride(0), st.V, stat, 2 * K, cand_val, cand_idx, R, suppress_eos=suppress,
-                                       eos_token_id=eos_token_id, row_bias=running_scores.reshape(-1))
-                else:
-                    ops.row_lse_topk(logits, logits.stride(0), st.V, 2 * K, cand_val, cand_idx, R, forced_token=forced, suppress_eos=suppress,
-                                     eos_token_id=eos_token_id, row_bias=running_scores.reshape(-1))  # gen:850-873 (per row)
-                ops.beam_step(B, K, max_length, st.V, cur_len, eos_token_id, pad_token_id, length_penalty, early_stopping, cand_val,
-                              cand_idx, running_seq, running_scores, seq, scores, finished, src_row, next_token, flags, gstate=gstate)  # gen:872-966
+            plan.run_step(cur_len, step(cur_len), use_graphs and cur_len > 1)  # step 1 carries the call's forced-BOS id: never captured
             cur_len += 1
-            if cur_len < max_length and (cur_len - 1) % poll == 0 and int(gstate[3].item()) != 0:
+            if cur_len < max_length and (cur_len - 1) % _POLL == 0 and int(gstate[3].item()) != 0:
                 break
+        plan.calls += 1
         steps = int(gstate[4].item())
         any_fin = finished.bool().any(dim=1)  # gen:980
         out_seq = torch.where(any_fin[:, None, None], seq, running_seq)  # gen:981-983

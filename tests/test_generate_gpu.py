@@ -106,6 +106,51 @@ def test_beam_early_finish_eos_bias(dev):
     assert (ref.sequences == rc.eos_token_id).any()  # finished hypotheses keep EOS (unlike greedy)
 
 
+def test_decode_plan_graph_replay_matches_oracle(dev, monkeypatch):
+    """Launch-free decoder steps (MIC_DECODE_GRAPHS=1): call 1 of a (batch, beams, max_length, processors) configuration runs eagerly, call 2 captures
+    every step t >= 2 into a hipGraph and replays it, call 3 only replays.  Every call — different images, different forced-BOS
+    ids (step 1 is never captured), with and without early finishes — must give the oracle's ids, scores and step count, and
+    the same as the eager path (MIC_DECODE_GRAPHS=0)."""
+    from mic_amd.params import unflatten_tree
+
+    monkeypatch.setenv("MIC_DECODE_GRAPHS", "1")   # opt-in (measured: no gain on this stack, see generation_clip_vision_utils.py)
+    rc, p, model = make_pair(torch.float32, dev, gelu="tanh", decoder_ln_eps=1e-6)
+    B = 3
+    for use_eos_bias in (False, True):
+        if use_eos_bias:  # beams finish early: the device-side stop flag and the "no-op after stop" launches inside replayed graphs
+            p = dict(p)
+            flb = p["final_logits_bias"].clone()
+            flb[0, rc.eos_token_id] = 6.0
+            p["final_logits_bias"] = flb
+            model.params = unflatten_tree({k: v.numpy() for k, v in p.items()})
+        for kw in (dict(max_length=12, num_beams=4), dict(max_length=20, num_beams=1)):
+            model.release_decode_plans()
+            for call, (seed, bos) in enumerate([(31, 996), (32, 995), (33, 994), (34, 996)]):
+                px, *_ = batch(rc, B, 12, seed=seed)
+                k2 = dict(kw, forced_bos_token_id=bos)
+                ref = _oracle_gen(rc, p, px, B, **k2)
+                out = model.generate(px.numpy(), **k2)
+                plan = next(iter(model._decode_plans.values()))
+                assert plan.calls == call + 1 and len(model._decode_plans) == 1
+                if call >= 1:
+                    assert len(plan.graphs) > 0 and 1 not in plan.graphs   # steps >= 2 captured, step 1 never
+                ref_seq = ref.sequences if kw["num_beams"] > 1 else ref
+                assert np.array_equal(out.sequences.cpu().numpy(), ref_seq), (use_eos_bias, kw, call)
+                if kw["num_beams"] > 1:
+                    assert out["steps"] == ref.steps
+                    assert np.allclose(out.scores.cpu().numpy(), ref.scores, rtol=1e-4, atol=1e-4)
+            # the same last call without graphs: identical
+            monkeypatch.setenv("MIC_DECODE_GRAPHS", "0")
+            eager = model.generate(px.numpy(), **k2)
+            monkeypatch.setenv("MIC_DECODE_GRAPHS", "1")
+            assert torch.equal(eager.sequences, out.sequences)
+    # at most _MAX_PLANS plans are kept
+    px, *_ = batch(rc, B, 12, seed=40)
+    for L in (6, 7, 8):
+        model.generate(px.numpy(), max_length=L, num_beams=2)
+    assert len(model._decode_plans) == 2
+
+
 def _rule_batch(rc, classes, T=12, n=8):
     """synthetic captioning task with a learnable, deterministic answer: the image is a constant colour that encodes a class c,
     the caption is lang, s_1 = 100 + c, s_{t+1} = 100 + (3 (s_t - 100) + c + 1) mod 200, ..., eos"""
