@@ -48,6 +48,13 @@ class Engine:
         import os
         self.use_head_stats = os.environ.get("MIC_HEAD_STATS", "1") != "0"  # softmax partials out of the LM-head GEMM (A/B switch)
         self.grad_progress = None  # callable(offset): every gradient with flat offset < offset is final (DDP overlap)
+        # weight-gradient GEMMs on a second stream (bf16 / f32 GEMM modes): nothing but the optimizer depends on dW, so a layer's
+        # grouped dW launch runs beside the NEXT layer's dX chain (LayerNorm / attention backward and the small dX GEMMs leave
+        # most CUs idle).  The gradient operands dW reads are double-buffered by layer parity; A/B switch MIC_DW_OVERLAP=0|1.
+        self.dw_overlap = self.dev.type == "cuda" and os.environ.get("MIC_DW_OVERLAP", "1") != "0"
+        self._dw_stream = None
+        self._dw_events = []
+        self._dw_side = False  # True while launching on the dW stream
 
     # ------------------------------------------------------------------ fp8 GEMM operands (BASELINE configs[4])
     FP8_KINDS = ("qkv", "cq", "ckv", "fc1", "fc2")  # the QKV and FFN projections of both towers; out-projections and the head stay bf16
@@ -150,6 +157,8 @@ class Engine:
     def _done(self, seg_name: str):
         """Report that the gradient segment `seg_name` (and, by layout order, everything before it) is final."""
         if self.grad_progress is not None:
+            if self._dw_events and not self._dw_side:
+                torch.cuda.current_stream().wait_event(self._dw_events[-1])  # "everything before it" includes the dW stream's work
             s = self.P.segs[seg_name]
             self.grad_progress(s.offset + s.numel)
 
@@ -245,7 +254,52 @@ class Engine:
             self._done(wname + ".w")
         return dx
 
+    def dyb(self, name: str, l: int, rows: int, cols: int) -> torch.Tensor:
+        """gradient buffer that a queued weight-gradient GEMM reads: one per layer parity when dW runs on its own stream (the
+        next layer's backward rewrites the other one), a single buffer otherwise"""
+        return self.buf(f"{name}.{l & 1}" if self._dw_on() else name, rows, cols)
+
+    def _dw_on(self) -> bool:
+        return self.dw_overlap and not self.fp8
+
     def flush_dw(self):
+        """Launch the layer's queued weight-gradient GEMMs (and bias column sums) as grouped launches — on the dW stream when
+        enabled: it waits for everything enqueued so far (the operands' producers), main goes on with the next layer and
+        only waits for the dW launch of TWO layers back (the one that read the buffers the next layer is about to rewrite)."""
+        if not (self._cs_queue or self._dw_queue or (self.fp8 and self._dw8_queue)):
+            return
+        side = None
+        if self._dw_on():
+            if self._dw_stream is None:
+                self._dw_stream = torch.cuda.Stream(device=self.dev)
+            side = self._dw_stream
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            side.wait_event(ev)
+        import contextlib
+
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            with (ops.pinned_stream() if side is not None else contextlib.nullcontext()):
+                self._dw_side = side is not None
+                try:
+                    self._flush_dw_launches()
+                finally:
+                    self._dw_side = False
+            if side is not None:
+                done = torch.cuda.Event()
+                done.record(side)
+                self._dw_events.append(done)
+        if side is not None and len(self._dw_events) >= 2:
+            torch.cuda.current_stream().wait_event(self._dw_events[-2])
+            del self._dw_events[:-2]
+
+    def dw_join(self):
+        """end of backward: the step's stream waits for the dW stream (next forward rewrites the saved activations dW reads)"""
+        if self._dw_events:
+            torch.cuda.current_stream().wait_event(self._dw_events[-1])
+            self._dw_events = []
+
+    def _flush_dw_launches(self):
         if self._cs_queue:
             ops.colsum_grouped(self._cs_queue)
             self._cs_queue = []
@@ -318,7 +372,7 @@ class Engine:
         S, vd, vf, H = P.S, P.vd, P.vffn, P.vH
         Mv, Mp = B * S, B * (S - 1)
         x_last = self.buf(f"v{P.vL - 1}.xo", Mv, vd)
-        dx = self.buf("vb.dx", Mv, vd)
+        dx = self.dyb("vb.dx", P.vL - 1, Mv, vd)
         self.linear_bwd("vp", x_last, dehs, Mv, dx=dx)
         for l in reversed(range(P.vL)):
             tag, p = f"v{l}.", f"vit{l}."
@@ -327,19 +381,20 @@ class Engine:
             st1, st2 = self.buf(tag + "st1", 2, _rup(Mv, ROWPAD), torch.float32), self.buf(tag + "st2", 2, _rup(Mv, ROWPAD), torch.float32)
             lse = self.vec(tag + "lse", B * H * S)
             x_in = self.buf(f"v{l - 1}.xo", Mv, vd) if l > 0 else self.buf("v.x0", Mv, vd)
-            dz = self.buf("vb.dz", Mv, vf)
+            dz = self.dyb("vb.dz", l, Mv, vf)
             self.linear_bwd(p + "fc2", u, dx, Mv, dx=dz, zin=z, dact=L.ACT_QUICK_GELU, defer=True)
             da = self.buf("vb.da", Mv, vd)
             self.linear_bwd(p + "fc1", a2, dz, Mv, dx=da, defer=True)
-            dxm = self.buf("vb.dxm", Mv, vd)
+            dxm = self.dyb("vb.dxm", l, Mv, vd)
             ops.layernorm_bwd(xm, P.f32(p + "ln2.g"), st2[0], st2[1], da, dxm, P.g(p + "ln2.g"), P.g(p + "ln2.b"), rows=Mv, dres=dx)
             dctx = self.buf("vb.dctx", Mv, vd)
             self.linear_bwd(p + "o", ctx, dxm, Mv, dx=dctx, defer=True)
-            dqkv = self.buf("vb.dqkv", Mv, 3 * vd)
+            dqkv = self.dyb("vb.dqkv", l, Mv, 3 * vd)
             ops.attn_bwd(qkv, qkv[:, vd:], qkv[:, 2 * vd:], ctx, dctx, lse, dqkv, dqkv[:, vd:], dqkv[:, 2 * vd:], B, H, S, S,
                          ldq=3 * vd, ldk=3 * vd, ldv=3 * vd, ldo=vd, lddo=vd, lddq=3 * vd, lddk=3 * vd, lddv=3 * vd)
             self.linear_bwd(p + "qkv", a1, dqkv, Mv, dx=da, defer=True)
             self.flush_dw()  # before LN1 backward overwrites dx (the fc2 gradient operand)
+            dx = self.dyb("vb.dx", l - 1, Mv, vd)  # the layer below's residual-stream gradient (= its fc2 dW operand)
             ops.layernorm_bwd(x_in, P.f32(p + "ln1.g"), st1[0], st1[1], da, dx, P.g(p + "ln1.g"), P.g(p + "ln1.b"), rows=Mv, dres=dxm)
         emb = self.buf("v.emb", Mv, vd)
         st = self.buf("v.pre.stats", 2, _rup(Mv, ROWPAD), torch.float32)
@@ -463,9 +518,9 @@ class Engine:
             ops.zero(dhf[:M])  # masked-out positions receive exactly zero gradient from the loss
             ops.copy_rows(dhc, dhf, Mh, d, dst_idx=rows[0])
         dx = self.buf("db.dx", M, d)
-        dxm = self.buf("db.dxm_a", M, d)   # masked grad entering the FFN branch
-        dxm_b = self.buf("db.dxm_b", M, d)  # ... the cross-attention branch
-        dxm_c = self.buf("db.dxm_c", M, d)  # ... the self-attention branch (kept apart: deferred dW GEMMs read them)
+        # masked gradients entering the FFN / cross-attention / self-attention branches and the other operands of the deferred
+        # weight-gradient GEMMs come from dyb(): one buffer per layer parity while dW runs on its own stream
+        dxm = self.dyb("db.dxm_a", P.L - 1, M, d)
         stf = self.buf("d.f.stats", 2, _rup(M, ROWPAD), torch.float32)
         x_last = self.buf(f"d{P.L - 1}.x3", M, d)
         ops.layernorm_bwd(x_last, P.f32("dec.ln_f.g"), stf[0], stf[1], dhf, dx, P.g("dec.ln_f.g"), P.g("dec.ln_f.b"), rows=M,
@@ -481,7 +536,8 @@ class Engine:
             lse, clse = self.vec(tag + "lse", B * H * T), self.vec(tag + "clse", B * H * T)
             x_in = self.buf(f"d{l - 1}.x3", M, d) if l > 0 else self.buf("d.x0", M, d)
             # --- FFN branch: x3 = x2 + drop(fc2(gelu(fc1(LN(x2)))));  dxm = dropout-masked dx3
-            dz = self.buf("db.dz", M, f)
+            dxm_b, dxm_c = self.dyb("db.dxm_b", l, M, d), self.dyb("db.dxm_c", l, M, d)
+            dz = self.dyb("db.dz", l, M, f)
             self.linear_bwd(p + "fc2", u, dxm, M, dx=dz, zin=z, dact=self.gelu, defer=True)
             da = self.buf("db.da", M, d)
             self.linear_bwd(p + "fc1", a_ff, dz, M, dx=da, defer=True)
@@ -491,8 +547,8 @@ class Engine:
             # --- cross-attention branch
             dctx = self.buf("db.dctx", M, d)
             self.linear_bwd(p + "co", cctx, dxm_b, M, dx=dctx, defer=True)
-            dq = self.buf("db.dq", M, d)
-            dkv = self.buf("db.dkv", Mv, 2 * d)
+            dq = self.dyb("db.dq", l, M, d)
+            dkv = self.dyb("db.dkv", l, Mv, 2 * d)
             ops.attn_bwd(cq, ckv, ckv[:, d:], cctx, dctx, clse, dq, dkv, dkv[:, d:], B, H, T, S, ldq=d, ldk=2 * d, ldv=2 * d, ldo=d,
                          lddo=d, lddq=d, lddk=2 * d, lddv=2 * d)
             self.linear_bwd(p + "cq", a_ca, dq, M, dx=da, defer=True)
@@ -502,11 +558,12 @@ class Engine:
                               dres=dx2, dxm=dxm_c, dropout_p=pd, dropout_seed=sd(10 + 3 * l))
             # --- self-attention branch
             self.linear_bwd(p + "so", ctx, dxm_c, M, dx=dctx, defer=True)
-            dqkv = self.buf("db.dqkv", M, 3 * d)
+            dqkv = self.dyb("db.dqkv", l, M, 3 * d)
             ops.attn_bwd(qkv, qkv[:, d:], qkv[:, 2 * d:], ctx, dctx, lse, dqkv, dqkv[:, d:], dqkv[:, 2 * d:], B, H, T, T, ldq=3 * d,
                          ldk=3 * d, ldv=3 * d, ldo=d, lddo=d, lddq=3 * d, lddk=3 * d, lddv=3 * d, key_mask=key_mask, causal=True)
             self.linear_bwd(p + "qkv", a_sa, dqkv, M, dx=da, defer=True)
             self.flush_dw()  # the layer's 7 weight-gradient GEMMs as one grouped launch (before dxm_a is rewritten)
+            dxm = self.dyb("db.dxm_a", l - 1, M, d)
             if l > 0:
                 ops.layernorm_bwd(x_in, P.f32(p + "ln_sa.g"), stats[0], stats[1], da, dx, P.g(p + "ln_sa.g"), P.g(p + "ln_sa.b"), rows=M,
                                   dres=dx1, dxm=dxm, dropout_p=pd, dropout_seed=sd(12 + 3 * (l - 1)))
@@ -608,4 +665,5 @@ class Engine:
             loss = self.loss_and_dlogits(logits, row_labels, self.ones_i32(rows[1]), rows[1], label_smoothing, backward=True, stat=stat)
         dehs = self.decoder_backward(B, T, ids, pos_ids, key_mask, ehs, logits, seed, rows=rows)
         self.vit_backward(B, dehs)
+        self.dw_join()
         return loss
