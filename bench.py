@@ -431,8 +431,13 @@ def main():
 
         ops.gemm = timed_gemm
         ops.gemm_grouped = timed_grouped
+        # the instrumented step keeps the weight-gradient GEMMs on the main stream: on their own stream (the default) they overlap
+        # the next layer's kernels and an event pair would time two kernels sharing the chip, not the kernel
+        eng = model.engine
+        overlap, eng.dw_overlap = eng.dw_overlap, False
         tr.train_step(dbatches[0])
         torch.cuda.synchronize()
+        eng.dw_overlap = overlap
         ops.gemm, ops.gemm_grouped = orig, orig_g
         flops = sum(r[0] for r in recs)
         ms = sum(r[1].elapsed_time(r[2]) for r in recs)
