@@ -257,3 +257,33 @@ def test_eval_step_matches_oracle(dev, dtype, ls):
             r2, _ = train_ref.forward_loss(rc, p, px2, l2, m2, d2, None, ls)
         got = float(tr.eval_step({"pixel_values": px2.numpy(), "input_ids": l2.numpy(), "attention_mask": m2.numpy(), "decoder_input_ids": d2.numpy()})["loss"])
         assert abs(got - r2.item()) < tol * max(1.0, abs(r2.item()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_weight_gradient_stream_gives_the_same_gradients(dev, dtype):
+    """Engine.flush_dw puts a layer's weight-gradient GEMMs on their own stream (operands double-buffered by layer parity).  The
+    gradients must not depend on it: three steps with the stream against three without — equal up to the summation order of
+    the fp32 atomics (bias / LayerNorm column sums) — and the schedule must survive back-to-back steps that reuse the buffers."""
+    rc, p, model = make_pair(dtype, dev, gelu="tanh", decoder_ln_eps=1e-6, d_layers=4, v_layers=3)
+    B, T = 4, 12
+    d = lambda x, t: model._dev(x, t)
+    pos = torch.arange(T, dtype=torch.int32, device=dev)[None].expand(B, T).contiguous()
+    eng = model.engine
+    assert eng.dw_overlap   # the default on a GPU
+    res = {}
+    for overlap in (True, False):
+        eng.dw_overlap = overlap
+        outs = []
+        for step in range(3):
+            px, labels, mask, dec_in = batch(rc, B, T, seed=50 + step)
+            loss = eng.loss_and_grads(d(px, torch.float32), d(dec_in, torch.int32).reshape(-1), pos.reshape(-1), d(mask, torch.int32),
+                                      d(labels, torch.int32).reshape(-1), B, T, seed=900 + step)
+            outs.append((loss, model.store.grad.clone()))   # enqueued behind the step on the main stream: no host sync in between
+        torch.cuda.synchronize()
+        res[overlap] = [(l.item(), g.cpu()) for l, g in outs]
+        assert not eng._dw_events   # joined at the end of every backward
+    eng.dw_overlap = True
+    for (la, ga), (lb, gb) in zip(res[True], res[False]):
+        assert abs(la - lb) <= 1e-6 * abs(lb)
+        scale = gb.abs().max().item()
+        assert (ga - gb).abs().max().item() <= 1e-5 * scale, ((ga - gb).abs().max().item(), scale)
