@@ -97,6 +97,18 @@ typedef struct {
    * stored in C.  With them the log-softmax of main.py:672-675 / gen:850 needs no second pass over the [rows][250 054]
    * logits: mic_ce_rows_tiles and mic_row_topk_tiles merge the N / 64 partials of a row. */
   float* rowstat; int rowstat_ld; int rowstat_nvalid;
+  /* LayerNorm folded around the GEMM (bf16, decode path; the LayerNorms of modeling_flax_mbart's decoder layer, T2):
+   *   LN(x) W^T = rstd (x (gamma o W)^T - mu g) + beta W^T,   g[n] = sum_k gamma[k] W[n][k]
+   * so a Linear whose input is LN(x) runs on the RAW x with the pre-scaled weight B = gamma o W (mic_ln_fold_weight) and an
+   * epilogue that needs only (sum, sum of squares) of each A row: a_ln_stats int64 [M][2] (2^20 fixed point), a_ln_colsum = g fp32 [N],
+   * a_ln_width = the normalised width, a_ln_eps; `bias` must then be bias' = bias + beta W^T (also from mic_ln_fold_weight).
+   * Producer side: rowsum2 int64 [M][2] (caller-zeroed) receives (sum, sum of squares) x 2^20 of every output row AS STORED
+   * (one pair of integer atomics per row and wave-tile column: integer adds commute, so the result does not depend on the
+   * order the column tiles finish in — generate stays run-to-run deterministic and independent of the batch order) — the
+   * stats the next folded LayerNorm needs, so the normalised activations are never written and the LayerNorm kernel launch
+   * disappears.  N % 128 == 0, bare or residual epilogue. */
+  const long long* a_ln_stats; const float* a_ln_colsum; int a_ln_width; float a_ln_eps;
+  long long* rowsum2;
 } mic_gemm_args;
 int mic_gemm(const mic_gemm_args* a, void* stream);
 /* dst[r][c] (dst_dtype) = sum over s < n_slabs of src[s * slab_stride + r * ld_src + c] (fp32): the second half of a
@@ -106,6 +118,11 @@ int mic_sum_slabs(int dst_dtype, int n_slabs, long long slab_stride, int rows, i
 /* `count` GEMMs that share dtype and operand layouts in as few launches as possible (one launch per 8 problems):
  * the weight-gradient GEMMs of a layer have 36..256 output tiles each — grouped they fill the 256 CUs. */
 int mic_gemm_grouped(const mic_gemm_args* args, int count, void* stream);
+/* Operands of a LayerNorm-folded Linear (see mic_gemm_args.a_ln_stats): for w [N][K] (the compute-dtype weight), gamma / beta
+ * fp32 [K], bias fp32 [N] or NULL:  w_fold[n][k] = round(w[n][k] * gamma[k]),  colsum[n] = sum_k w_fold[n][k] (of the ROUNDED
+ * values: the epilogue subtracts exactly what the MFMAs added),  bias_fold[n] = bias[n] + sum_k w[n][k] beta[k]. */
+int mic_ln_fold_weight(int dtype, int N, int K, const void* w, int ldw, const float* gamma, const float* beta, const float* bias,
+                       void* w_fold, int ldwf, float* colsum, float* bias_fold, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * fp8 operands for mic_gemm (BASELINE configs[4]; no reference counterpart — its dtypes are fp32/fp16/bf16, main.py:96-101).

@@ -31,6 +31,8 @@ class GemmArgs(C.Structure):
         ("split_stride", C.c_longlong), ("a_rowsum", C.c_void_p), ("rowsum_k", C.c_int),
         ("a_fmt", C.c_int), ("b_fmt", C.c_int), ("a_scale_inv", C.c_void_p), ("b_scale_inv", C.c_void_p),
         ("rowstat", C.c_void_p), ("rowstat_ld", C.c_int), ("rowstat_nvalid", C.c_int),
+        ("a_ln_stats", C.c_void_p), ("a_ln_colsum", C.c_void_p), ("a_ln_width", C.c_int), ("a_ln_eps", C.c_float),
+        ("rowsum2", C.c_void_p),
     ]
 
 
@@ -64,6 +66,7 @@ _SIGS = {
     "mic_last_error": ([], C.c_char_p),
     "mic_gemm": ([C.POINTER(GemmArgs), _p], C.c_int),
     "mic_gemm_grouped": ([C.POINTER(GemmArgs), _i, _p], C.c_int),
+    "mic_ln_fold_weight": ([_i, _i, _i, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p], C.c_int),
     "mic_fp8_amax": ([C.POINTER(Fp8Item), _i, _p], C.c_int),
     "mic_fp8_quantize": ([C.POINTER(Fp8Item), _i, _p], C.c_int),
     "mic_fp8_amax_partials": ([], C.c_int),

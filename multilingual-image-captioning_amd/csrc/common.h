@@ -106,6 +106,16 @@ __device__ __forceinline__ float group8_max(float v) {
   v = fmaxf(v, dpp_f<DPP_XOR2>(v));
   return v;
 }
+// sum over every aligned group of G lanes, G in {4, 8, 16}
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+  static_assert(G == 4 || G == 8 || G == 16, "group of 4, 8 or 16 lanes");
+  if (G >= 8) v += dpp_f<DPP_HALF_MIRROR>(v);
+  v += dpp_f<DPP_XOR1>(v);
+  v += dpp_f<DPP_XOR2>(v);
+  if (G == 16) v += dpp_f<DPP_ROR8>(v);
+  return v;
+}
 // sum / max over each 32-lane half of the wave (all 32 lanes receive it)
 __device__ __forceinline__ float half_sum(float v) {
   v = group8_sum(v);
@@ -201,6 +211,12 @@ struct EpiArgs {
   float alpha;
   int N;
   float* rowstat; int stat_ld; int stat_nvalid;  // bf16 GEMM only: per (row, column tile) softmax partials, see mic_gemm_args
+  // LayerNorm folded around the GEMM (bf16 GEMM only, see mic_gemm_args): ln_stats = (sum, sum of squares) of every A row,
+  // ln_g[n] = sum_k gamma_k W[n][k]; the epilogue turns acc = x . (gamma o W)^T into LN(x) . W^T.  rowsum2: by-product of a
+  // producer GEMM, (sum, sum of squares) of every output row as stored — 2^20 fixed point in int64, so that the atomics of
+  // the column tiles add up to the same bits in any order (run-to-run and batch-permutation determinism of generate).
+  const long long* ln_stats; const float* ln_g; const float* ln_bias; float ln_inv_d, ln_eps;
+  long long* rowsum2;
 };
 template <typename T>
 __device__ __forceinline__ void epilogue_store(const EpiArgs& e, int m, int n, float v) {
@@ -231,6 +247,20 @@ __device__ __forceinline__ void unpack8(u32x4 u, float* o) {
 }
 __device__ __forceinline__ bool epilogue_vec_ok(const EpiArgs& e, int cnt) {
   return cnt == 8 && (e.ldc & 7) == 0 && (!e.Zout || (e.ldz & 7) == 0) && (!e.Zin || (e.ldz & 7) == 0) && (!e.R || (e.ldr & 7) == 0);
+}
+#define MIC_ROWSUM_SCALE 1048576.0f            /* 2^20: |sum of squares| up to 8.8e12 fits an int64 */
+#define MIC_ROWSUM_INV_SCALE 9.5367431640625e-7f /* 2^-20 */
+// LayerNorm folded around the GEMM: v[i] = acc of x . (gamma o W)^T for row m, columns n .. n+7  ->  LN(x) . W^T + bias'
+//   LN(x) . W^T = rstd (x . (gamma o W)^T - mu g) + beta . W^T,  g[n] = sum_k gamma_k W[n][k];  bias' = bias + beta . W^T
+__device__ __forceinline__ void ln_fold_apply8(const EpiArgs& e, int m, int n, float* v) {
+  const longlong2 s = reinterpret_cast<const longlong2*>(e.ln_stats)[m];
+  const float mu = (float)s.x * (MIC_ROWSUM_INV_SCALE * e.ln_inv_d);
+  const float rstd = rsqrtf(fmaxf((float)s.y * (MIC_ROWSUM_INV_SCALE * e.ln_inv_d) - mu * mu, 0.0f) + e.ln_eps);
+  float g[8], b[8];
+  ld8(e.ln_g + n, g);
+  ld8(e.ln_bias + n, b);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = fmaf(rstd, v[i] - mu * g[i], b[i]);
 }
 // bf16 epilogue split in two so a thread can issue the side loads (Zin / residual / accumulate-into-C) of ALL its 8-column
 // groups before it starts computing and storing: inside the store loop every such load would cost a full memory latency.

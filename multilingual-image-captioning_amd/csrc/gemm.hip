@@ -323,6 +323,21 @@ static int fill_epi(const mic_gemm_args* a, EpiArgs& e) {
     MIC_CHECK(a->N % 64 == 0 && a->ldc % 8 == 0 && ((uintptr_t)a->C & 15) == 0, "mic_gemm: rowstat needs N %% 64 == 0 and a 16-B aligned C");
     MIC_CHECK(a->rowstat_ld >= a->N / 64 && ((uintptr_t)a->rowstat & 7) == 0, "mic_gemm: rowstat needs ld >= N / 64 float2 entries per row");
   }
+  e.ln_stats = a->a_ln_stats; e.ln_g = a->a_ln_colsum; e.ln_bias = nullptr; e.ln_inv_d = 0.f; e.ln_eps = a->a_ln_eps;
+  e.rowsum2 = a->rowsum2;
+  if (a->a_ln_stats) {
+    MIC_CHECK(a->dtype == MIC_BF16 && a->a_ln_colsum && a->bias && a->a_ln_width > 0, "mic_gemm: a folded LayerNorm needs bf16 operands, a_ln_colsum, bias' and a_ln_width");
+    MIC_CHECK(a->split_k <= 1 && !a->dact && !a->accumulate && (a->alpha == 0.f || a->alpha == 1.f), "mic_gemm: folded LayerNorm: no split-K / dact / accumulate / alpha");
+    MIC_CHECK(a->N % 8 == 0 && a->ldc % 8 == 0 && ((uintptr_t)a->C & 15) == 0 && (!a->R || a->ldr % 8 == 0) && (!a->Zout || a->ldz % 8 == 0),
+              "mic_gemm: folded LayerNorm needs the vector epilogue (N, ldc, ldr, ldz multiples of 8, 16-B aligned C)");
+    e.ln_bias = a->bias; e.bias = nullptr; e.ln_inv_d = 1.0f / (float)a->a_ln_width;
+  }
+  if (a->rowsum2) {
+    MIC_CHECK(a->dtype == MIC_BF16 && a->N % 128 == 0 && a->split_k <= 1 && !a->act && !a->dact && !a->Zout && !a->accumulate,
+              "mic_gemm: rowsum2 goes with the bare / residual epilogue of a bf16 GEMM, N %% 128 == 0");
+    MIC_CHECK(a->ldc % 8 == 0 && ((uintptr_t)a->C & 15) == 0 && (!a->R || (a->ldr % 8 == 0 && ((uintptr_t)a->R & 15) == 0 && a->c_dtype != MIC_F32)),
+              "mic_gemm: rowsum2 needs the PLAIN store path (16-B aligned C / R rows)");
+  }
   if (a->dtype == MIC_BF16) {
     MIC_CHECK(a->K % 64 == 0, "mic_gemm(bf16): K=%d must be a multiple of 64 (zero-pad the reduction dim)", a->K);
     MIC_CHECK(a->lda % 8 == 0 && a->ldb % 8 == 0, "mic_gemm(bf16): lda/ldb must be multiples of 8");
@@ -437,6 +452,8 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
     blocks += p.tiles_m * p.tiles_n * p.nsplit;
   }
   tab.total_blocks = blocks;
+  for (int i = 0; i < count; ++i)
+    MIC_CHECK(!args[i].rowsum2 || table_is_plain(tab), "mic_gemm_grouped: rowsum2 needs every problem of the launch on the bare / residual epilogue");
   static const int phased = [] { const char* e = getenv("MIC_GEMM_PHASED"); return e ? atoi(e) : 0; }();  // opt-in: measured slower
   static const int w4 = [] { const char* e = getenv("MIC_GEMM_W4"); return e ? atoi(e) : 0; }();  // opt-in: measured slower
   bool any_rowsum = false;

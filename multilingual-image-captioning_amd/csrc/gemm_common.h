@@ -188,8 +188,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], c
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * alpha + bj[j];
     E.alpha = 1.0f;
-    E.bias = nullptr;
+    E.bias = nullptr;  // (a folded-LayerNorm launch has no E.bias: its bias' is ln_bias, added per row group in the store loop)
   }
+  const bool ln_fold = E.ln_stats != nullptr;
   // each wave restages an RP x WN fp32 block of its accumulators through its own LDS region, then the whole block streams
   // them out: every thread owns 8 consecutive columns of a row (16-B vectors).
   constexpr int RP = WM < 64 ? WM : 64;  // rows per pass
@@ -236,6 +237,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], c
         const float4 lo = *reinterpret_cast<const float4*>(src);
         const float4 hi = *reinterpret_cast<const float4*>(src + 4);
         v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+        if (ln_fold) ln_fold_apply8(E, m, n, v);
         if (E.drop_thr) {
 #pragma unroll
           for (int i = 0; i < 8; ++i)
@@ -250,6 +252,26 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], c
           }
           if (E.c_f32) st8((float*)E.C + (size_t)m * E.ldc + n, v);
           else st8((uint16_t*)E.C + (size_t)m * E.ldc + n, v);
+          if (E.rowsum2 != nullptr) {
+            // by-product for the next LayerNorm (folded into ITS consumer GEMM): sum and sum of squares of this output row as
+            // stored; the CPR lanes that hold one region row's chunks are consecutive, one pair of int64 atomics per (row, WN columns)
+            float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const float x = E.c_f32 ? v[i] : bf2f(f2bf(v[i]));
+              s1 += x;
+              s2 = fmaf(x, x, s2);
+            }
+            s1 = group_sum<CPR>(s1);
+            s2 = group_sum<CPR>(s2);
+            if ((tid & (CPR - 1)) == 0) {  // fixed point: integer atomics commute, the sums are the same bits in any order
+              const float lim = 4.0e18f;
+              const long long i1 = __float2ll_rn(fminf(fmaxf(s1 * MIC_ROWSUM_SCALE, -lim), lim));
+              const long long i2 = __float2ll_rn(fminf(s2 * MIC_ROWSUM_SCALE, lim));
+              atomicAdd(reinterpret_cast<unsigned long long*>(E.rowsum2 + 2 * (size_t)m), (unsigned long long)i1);
+              atomicAdd(reinterpret_cast<unsigned long long*>(E.rowsum2 + 2 * (size_t)m + 1), (unsigned long long)i2);
+            }
+          }
           if (E.rowstat != nullptr) {
             // by-product for the LM head: (max, sum exp(x - max)) of the values AS STORED over this row's 64-column granule.
             // The 8 threads that hold the granule's 8-column chunks are 8 consecutive lanes: thread-local over 8 values, then
@@ -313,6 +335,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], c
           for (int i = 0; i < cnt; ++i) atomicAdd(c + i, v[i]);
         }
       } else if (pre && cnt == 8) {
+        if (ln_fold) ln_fold_apply8(E, m, n, v);
         epilogue_store8_pre(E, m, n, v, zq[it], rq[it]);
       } else {
         epilogue_store8<uint16_t>(E, m, n, v, cnt);

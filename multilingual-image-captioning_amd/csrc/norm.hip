@@ -204,3 +204,49 @@ extern "C" int mic_layernorm_bwd(int dtype, int rows, int width, const void* x, 
   MIC_LAUNCH_CHECK();
   return MIC_OK;
 }
+
+// ------------------------------------------------------------------ LayerNorm folded into the consumer Linear (decode path)
+// one wave per output row n of w [N][K]:  w_fold = round(w * gamma),  colsum = sum of the ROUNDED products,  bias_fold = bias + w . beta
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fold_weight_kernel(int N, int K, const T* __restrict__ w, int ldw, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ bias,
+                                                             T* __restrict__ wf, int ldwf, float* __restrict__ colsum,
+                                                             float* __restrict__ bias_fold) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  float g = 0.f, b = 0.f;
+  for (int k = lane * 8; k < K; k += 64 * 8) {
+    float v[8], ga[8], be[8], o[8];
+    ld8(w + (size_t)n * ldw + k, v);
+    ld8(gamma + k, ga);
+    ld8(beta + k, be);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      o[i] = round_to<T>(v[i] * ga[i]);
+      g += o[i];
+      b = fmaf(v[i], be[i], b);
+    }
+    st8(wf + (size_t)n * ldwf + k, o);
+  }
+  g = wave_sum(g);
+  b = wave_sum(b);
+  if (lane == 0) {
+    colsum[n] = g;
+    bias_fold[n] = b + (bias ? bias[n] : 0.f);
+  }
+}
+extern "C" int mic_ln_fold_weight(int dtype, int N, int K, const void* w, int ldw, const float* gamma, const float* beta,
+                                  const float* bias, void* w_fold, int ldwf, float* colsum, float* bias_fold, void* stream) {
+  MIC_CHECK(N > 0 && K > 0 && K % 8 == 0 && ldw % 8 == 0 && ldwf % 8 == 0 && w && gamma && beta && w_fold && colsum && bias_fold,
+            "mic_ln_fold_weight: bad args (K, ldw, ldwf multiples of 8)");
+  dim3 grid((N + 3) / 4), block(256);
+  if (dtype == MIC_BF16)
+    hipLaunchKernelGGL(ln_fold_weight_kernel<uint16_t>, grid, block, 0, (hipStream_t)stream, N, K, (const uint16_t*)w, ldw, gamma, beta, bias,
+                       (uint16_t*)w_fold, ldwf, colsum, bias_fold);
+  else if (dtype == MIC_F32)
+    hipLaunchKernelGGL(ln_fold_weight_kernel<float>, grid, block, 0, (hipStream_t)stream, N, K, (const float*)w, ldw, gamma, beta, bias,
+                       (float*)w_fold, ldwf, colsum, bias_fold);
+  else MIC_CHECK(false, "mic_ln_fold_weight: bad dtype");
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}

@@ -52,6 +52,10 @@ class Engine:
         # grouped dW launch runs beside the NEXT layer's dX chain (LayerNorm / attention backward and the small dX GEMMs leave
         # most CUs idle).  The gradient operands dW reads are double-buffered by layer parity; A/B switch MIC_DW_OVERLAP=0|1.
         self.dw_overlap = self.dev.type == "cuda" and os.environ.get("MIC_DW_OVERLAP", "1") != "0"
+        # decoder-step LayerNorms folded around the GEMMs (bfloat16 generate path): A/B switch
+        self.decode_ln_fold = self.dev.type == "cuda" and os.environ.get("MIC_DECODE_LNFOLD", "1") != "0"
+        self._lnf = {}
+        self._lnf_version = -1
         self._dw_stream = None
         self._dw_events = []
         self._dw_side = False  # True while launching on the dW stream
@@ -253,6 +257,24 @@ class Engine:
         if not defer:
             self._done(wname + ".w")
         return dx
+
+    def ln_folded(self, wname: str, ln: str):
+        """(gamma o W, colsum, bias') of Linear `wname` behind LayerNorm `ln` (mic_ln_fold_weight), rebuilt when the weights
+        changed (ParamStore.version): the operands of a LayerNorm-folded GEMM (mic_gemm_args.a_ln_stats)"""
+        P = self.P
+        ver = getattr(P, "version", 0)
+        if ver != self._lnf_version:
+            self._lnf_fresh = set()
+            self._lnf_version = ver
+        hit = self._lnf.get(wname)
+        if hit is None:
+            w = P.w(wname + ".w")
+            hit = self._lnf[wname] = (torch.empty_like(w), torch.empty(w.shape[0], dtype=torch.float32, device=self.dev),
+                                      torch.empty(w.shape[0], dtype=torch.float32, device=self.dev))
+        if wname not in self._lnf_fresh:
+            ops.ln_fold_weight(P.w(wname + ".w"), P.f32(ln + ".g"), P.f32(ln + ".b"), P.f32(wname + ".b"), *hit)
+            self._lnf_fresh.add(wname)
+        return hit
 
     def dyb(self, name: str, l: int, rows: int, cols: int) -> torch.Tensor:
         """gradient buffer that a queued weight-gradient GEMM reads: one per layer parity when dW runs on its own stream (the

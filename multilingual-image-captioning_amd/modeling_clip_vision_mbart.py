@@ -131,6 +131,7 @@ class FlaxCLIPVisionMBartPreTrainedModel(FlaxCLIPVisionMBartGenerationMixin):
 
     def invalidate_params_cache(self):
         self._params_cache = None
+        self.store.version = getattr(self.store, "version", 0) + 1
         if self.engine.fp8:
             self.engine.fp8_weights_changed()
 
@@ -300,13 +301,27 @@ class FlaxCLIPVisionMBartForConditionalGeneration(FlaxCLIPVisionMBartPreTrainedM
             eng.linear(ehs_b, f"dec{l}.ckv", kv, n_img * S, fp8=False)  # generation stays in the storage dtype
             cross.append(kv)
         cache["cross"], cache["row_div"] = cross, row_div
+        if eng.decode_ln_fold and self.dtype == torch.bfloat16:
+            # the LayerNorm-folded weights of the decoder step, rebuilt here (once per generate call at most) if the weights moved
+            for l in range(st.L):
+                p = f"dec{l}."
+                for wn, ln in ((p + "qkv", p + "ln_sa"), (p + "cq", p + "ln_ca"), (p + "fc1", p + "ln_ff")):
+                    if l > 0 or not wn.endswith("qkv"):
+                        eng.ln_folded(wn, ln)
 
     def _decode_step(self, cache: dict, tokens: torch.Tensor, pos: torch.Tensor, stats: bool = False):
-        """stats=True: returns (logits, per-tile softmax partials of the head GEMM or None in float32 mode)"""
+        """stats=True: returns (logits, per-tile softmax partials of the head GEMM or None in float32 mode)
+
+        bfloat16 mode folds the decoder layer's LayerNorms around the GEMMs (engine.ln_folded / mic_gemm_args.a_ln_stats): the
+        GEMM that writes a residual-stream tensor (self-attention out, cross-attention out, fc2) also accumulates (sum, sum of
+        squares) of every row it stores, and the Linear that consumes LN(that tensor) runs on the raw rows with gamma folded
+        into its weight and finishes the normalisation in its epilogue — 35 of the 38 LayerNorm launches of a decoder step and
+        their activation round trips disappear (MIC_DECODE_LNFOLD=0 keeps the explicit kernels; float32 mode always does)."""
         eng, st = self.engine, self.store
         P = st
         R, Lmax, cur = cache["rows"], cache["max_length"], cache["cache_index"]
         d, f, H, S = st.d, st.ffn, st.H, st.S
+        fold = eng.decode_ln_fold and self.dtype == torch.bfloat16
         h0 = eng.buf("g.h0", R, d)
         ops.embed_fwd(tokens, pos, P.w("shared"), P.f32("dec.pos"), eng.embed_scale, h0, R, d)
         x = eng.buf("g.x", R, d)
@@ -314,26 +329,50 @@ class FlaxCLIPVisionMBartForConditionalGeneration(FlaxCLIPVisionMBartPreTrainedM
         a, ctx = eng.buf("g.a", R, d), eng.buf("g.ctx", R, d)
         x1, x2, q = eng.buf("g.x1", R, d), eng.buf("g.x2", R, d), eng.buf("g.q", R, d)
         u = eng.buf("g.u", R, f)
+        if fold:
+            # (sum, sum of squares) per row of x (layer input; layer 0's comes from an explicit LayerNorm), x1, x2 — zeroed once per step
+            lnst = eng.buf("g.lnstats", st.L * 3 * R, 2, torch.int64)[: st.L * 3 * R].view(st.L, 3, R, 2)  # 2^20 fixed point
+            ops.zero(lnst)
+        eps = eng.dec_eps
         for l in range(st.L):
             p = f"dec{l}."
-            ops.layernorm_fwd(x, P.f32(p + "ln_sa.g"), P.f32(p + "ln_sa.b"), eng.dec_eps, a, rows=R)
+            kc, vc = cache["k"][l], cache["v"][l]
             # the fused q/k/v projection as ONE grouped launch of three problems that share the A operand: q goes to its buffer,
             # k and v straight into slot `cur` of every row's cache (row stride max_len * d) — no separate append kernel
-            w, b = P.w(p + "qkv.w"), P.f32(p + "qkv.b")
-            kc, vc = cache["k"][l], cache["v"][l]
-            ops.gemm_grouped([ops.gemm_args(a, w[:d], q, R, d, d, bias=b[:d]),
-                              ops.gemm_args(a, w[d:2 * d], kc[:, cur], R, d, d, bias=b[d:2 * d]),
-                              ops.gemm_args(a, w[2 * d:], vc[:, cur], R, d, d, bias=b[2 * d:])])
+            if fold and l > 0:
+                w, cs, b = eng.ln_folded(p + "qkv", p + "ln_sa")
+                lk = dict(ln_stats=lnst[l, 0], ln_width=d, ln_eps=eps)
+                ops.gemm_grouped([ops.gemm_args(x, w[:d], q, R, d, d, bias=b[:d], ln_colsum=cs[:d], **lk),
+                                  ops.gemm_args(x, w[d:2 * d], kc[:, cur], R, d, d, bias=b[d:2 * d], ln_colsum=cs[d:2 * d], **lk),
+                                  ops.gemm_args(x, w[2 * d:], vc[:, cur], R, d, d, bias=b[2 * d:], ln_colsum=cs[2 * d:], **lk)])
+            else:
+                ops.layernorm_fwd(x, P.f32(p + "ln_sa.g"), P.f32(p + "ln_sa.b"), eps, a, rows=R)
+                w, b = P.w(p + "qkv.w"), P.f32(p + "qkv.b")
+                ops.gemm_grouped([ops.gemm_args(a, w[:d], q, R, d, d, bias=b[:d]),
+                                  ops.gemm_args(a, w[d:2 * d], kc[:, cur], R, d, d, bias=b[d:2 * d]),
+                                  ops.gemm_args(a, w[2 * d:], vc[:, cur], R, d, d, bias=b[2 * d:])])
             ops.attn_decode(q, kc, vc, ctx, R, H, Lmax, cur, ldq=d, ldo=d, src_row=cache["src_row"])
-            eng.linear(ctx, p + "so", x1, R, residual=x, fp8=False)
-            ops.layernorm_fwd(x1, P.f32(p + "ln_ca.g"), P.f32(p + "ln_ca.b"), eng.dec_eps, a, rows=R)
-            eng.linear(a, p + "cq", q, R, fp8=False)
+            if fold:
+                ops.gemm(ctx, P.w(p + "so.w"), x1, R, d, d, bias=P.f32(p + "so.b"), residual=x, rowsum2=lnst[l, 1])
+                w, cs, b = eng.ln_folded(p + "cq", p + "ln_ca")
+                ops.gemm(x1, w, q, R, d, d, bias=b, ln_stats=lnst[l, 1], ln_colsum=cs, ln_width=d, ln_eps=eps)
+            else:
+                eng.linear(ctx, p + "so", x1, R, residual=x, fp8=False)
+                ops.layernorm_fwd(x1, P.f32(p + "ln_ca.g"), P.f32(p + "ln_ca.b"), eps, a, rows=R)
+                eng.linear(a, p + "cq", q, R, fp8=False)
             kv = cache["cross"][l]
             ops.attn_decode(q, kv, kv[:, d:], ctx, R, H, S, S - 1, ldq=d, ldo=d, ldc=2 * d, row_div=cache["row_div"])
-            eng.linear(ctx, p + "co", x2, R, residual=x1, fp8=False)
-            ops.layernorm_fwd(x2, P.f32(p + "ln_ff.g"), P.f32(p + "ln_ff.b"), eng.dec_eps, a, rows=R)
-            eng.linear(a, p + "fc1", u, R, act=eng.gelu, fp8=False)
-            eng.linear(u, p + "fc2", x, R, residual=x2, fp8=False)
+            if fold:
+                ops.gemm(ctx, P.w(p + "co.w"), x2, R, d, d, bias=P.f32(p + "co.b"), residual=x1, rowsum2=lnst[l, 2])
+                w, cs, b = eng.ln_folded(p + "fc1", p + "ln_ff")
+                ops.gemm(x2, w, u, R, f, d, bias=b, act=eng.gelu, ln_stats=lnst[l, 2], ln_colsum=cs, ln_width=d, ln_eps=eps)
+                ops.gemm(u, P.w(p + "fc2.w"), x, R, d, f, bias=P.f32(p + "fc2.b"), residual=x2,
+                         rowsum2=lnst[l + 1, 0] if l + 1 < st.L else None)
+            else:
+                eng.linear(ctx, p + "co", x2, R, residual=x1, fp8=False)
+                ops.layernorm_fwd(x2, P.f32(p + "ln_ff.g"), P.f32(p + "ln_ff.b"), eps, a, rows=R)
+                eng.linear(a, p + "fc1", u, R, act=eng.gelu, fp8=False)
+                eng.linear(u, p + "fc2", x, R, residual=x2, fp8=False)
         hf = eng.buf("g.hf", R, d)
         ops.layernorm_fwd(x, P.f32("dec.ln_f.g"), P.f32("dec.ln_f.b"), eng.dec_eps, hf, rows=R)
         cache["cache_index"] = cur + 1

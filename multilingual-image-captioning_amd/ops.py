@@ -60,7 +60,8 @@ class pinned_stream:
 def gemm_args(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, *, a_kmajor=False, b_kmajor=False,
               bias=None, act=0, zout=None, zin=None, dact=0, residual=None, accumulate=False, dropout_p=0.0, dropout_seed=0,
               alpha=1.0, lda=None, ldb=None, ldc=None, ldz=None, ldr=None, split_k=0, split_stride=0, a_rowsum=None, rowsum_k=0,
-              a_scale_inv=None, b_scale_inv=None, rowstat=None, rowstat_nvalid=0) -> "L.GemmArgs":
+              a_scale_inv=None, b_scale_inv=None, rowstat=None, rowstat_nvalid=0, ln_stats=None, ln_colsum=None, ln_width=0,
+              ln_eps=0.0, rowsum2=None) -> "L.GemmArgs":
     """fp8 operands: `a` / `b` are torch.float8_e4m3fn / float8_e5m2 tensors (k-contiguous), `a_scale_inv` / `b_scale_inv` the
     device scalars mic_fp8_quantize wrote for them."""
     g = L.GemmArgs()
@@ -83,6 +84,9 @@ def gemm_args(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: in
     g.a_rowsum, g.rowsum_k = _p(a_rowsum), int(rowsum_k)
     if rowstat is not None:  # fp32 [rows][tiles][2]: softmax partials per 256-column tile (LM head)
         g.rowstat, g.rowstat_ld, g.rowstat_nvalid = _p(rowstat), rowstat.stride(0) // 2, int(rowstat_nvalid)
+    if ln_stats is not None:  # LayerNorm folded around the GEMM: b = gamma o W, bias = bias' (ln_fold_weight), stats of the A rows
+        g.a_ln_stats, g.a_ln_colsum, g.a_ln_width, g.a_ln_eps = _p(ln_stats), _p(ln_colsum), int(ln_width), float(ln_eps)
+    g.rowsum2 = _p(rowsum2)  # int64 [M][2]: (sum, sum of squares) x 2^20 of the stored output rows, accumulated
     return g
 
 
@@ -97,6 +101,13 @@ def gemm_grouped(arg_list):
     """Several GEMMs (same dtype / operand layouts) in as few launches as possible."""
     arr = (L.GemmArgs * len(arg_list))(*arg_list)
     L.check(L.lib().mic_gemm_grouped(arr, len(arg_list), _stream()), "mic_gemm_grouped")
+
+
+def ln_fold_weight(w, gamma, beta, bias, w_fold, colsum, bias_fold):
+    """w [N][K] -> w_fold = round(w * gamma), colsum[n] = sum_k w_fold[n][k], bias_fold = bias + w . beta (see gemm_args ln_*)"""
+    N, K = w.shape
+    L.check(L.lib().mic_ln_fold_weight(_dt(w), N, K, _p(w), w.stride(0), _p(gamma), _p(beta), _p(bias), _p(w_fold), w_fold.stride(0),
+                                       _p(colsum), _p(bias_fold), _stream()), "mic_ln_fold_weight")
 
 
 def fp8_item(src, rows, cols, state, fmt_dtype, q=None, qT=None, rows_pad=0, amax_next=None) -> "L.Fp8Item":

@@ -155,6 +155,7 @@ class ParamStore:
             self.v = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
 
     def refresh_lp(self):
+        self.version = getattr(self, "version", 0) + 1  # anything derived from the weights (folded / quantised copies) is stale
         if self.lp is not self.master:
             from . import ops
             ops.cast(self.master, self.lp)

@@ -604,3 +604,67 @@ def test_row_topk_tiles_ties_across_many_tiles(dev):
     torch.cuda.synchronize()
     assert ti[0].tolist() == list(range(8)) and ti[2].tolist() == list(range(8))
     assert ti[1].tolist() == [77_777] + list(range(7))
+
+
+@pytest.mark.parametrize("M,N,K,act", [(1024, 1024, 1024, 0), (1000, 3072, 1024, 0), (4096, 1024, 1024, 0), (1024, 4096, 1024, 2),
+                                        (2304, 12288, 256, 0), (200, 128, 128, 3)])
+def test_gemm_layernorm_fold_and_rowsum2(dev, M, N, K, act):
+    """LayerNorm folded around the GEMM (decode path): a producer GEMM stores x = a0 b0^T + r and accumulates (sum, sum of
+    squares) of every stored row (rowsum2); the consumer runs on the RAW x with gamma folded into its weight
+    (mic_ln_fold_weight) and finishes LN in its epilogue.  Reference: LayerNorm (fp32 math on the stored bf16 x, output rounded
+    to bf16 like mic_layernorm_fwd) followed by the plain Linear.  The fold skips that rounding, so the two agree to bf16
+    rounding of the activations, not bit for bit: 1.2e-2 of the output scale."""
+    from mic_amd import ops
+    from mic_amd import _lib as L
+
+    g = torch.Generator().manual_seed(M + N + K)
+    dt = torch.bfloat16
+    a0, b0, r = rnd((M, 64), g, dt), rnd((K, 64), g, dt, 0.3), rnd((M, K), g, dt, 1.0)
+    r += 0.7   # a common-mode offset: the epilogue's  acc - mu g  has something to cancel
+    x = torch.zeros((M, K), dtype=dt, device=dev)
+    st = torch.zeros((M, 2), dtype=torch.int64, device=dev)   # (sum, sum of squares) x 2^20
+    ops.gemm(a0.to(dev), b0.to(dev), x, M, K, 64, residual=r.to(dev), rowsum2=st)
+    torch.cuda.synchronize()
+    xr = (a0.float() @ b0.float().T + r.float()).to(dt)
+    assert relerr(x, xr) < tol(dt)
+    xs = x.float().cpu()
+    sf = st.cpu().double() / 2 ** 20
+    assert relerr(sf[:, 0], xs.double().sum(1)) < 1e-5 and relerr(sf[:, 1], (xs.double() ** 2).sum(1)) < 1e-5
+    st2 = torch.zeros_like(st)   # integer atomics: the same bits whatever order the column tiles finish in
+    ops.gemm(a0.to(dev), b0.to(dev), x, M, K, 64, residual=r.to(dev), rowsum2=st2)
+    torch.cuda.synchronize()
+    assert torch.equal(st, st2)
+    gamma, beta = 1 + 0.2 * torch.randn(K, generator=g), 0.2 * torch.randn(K, generator=g)
+    w, bias = rnd((N, K), g, dt, 0.05), 0.1 * torch.randn(N, generator=g)
+    wf = torch.empty((N, K), dtype=dt, device=dev)
+    cs, bf = torch.empty(N, device=dev), torch.empty(N, device=dev)
+    ops.ln_fold_weight(w.to(dev), gamma.to(dev), beta.to(dev), bias.to(dev), wf, cs, bf)
+    torch.cuda.synchronize()
+    wfr = (w.float() * gamma[None]).to(dt)
+    assert torch.equal(wf.cpu(), wfr)
+    assert relerr(cs, wfr.float().sum(1)) < 1e-5 and relerr(bf, bias + w.float() @ beta) < 1e-5
+    out = torch.empty((M, N), dtype=dt, device=dev)
+    eps = 1e-5
+    ops.gemm(x, wf, out, M, N, K, bias=bf, act=act, ln_stats=st, ln_colsum=cs, ln_width=K, ln_eps=eps)
+    torch.cuda.synchronize()
+    ln = torch.nn.functional.layer_norm(xs, (K,), gamma, beta, eps).to(dt).float()
+    ref = ln @ w.float().T + bias
+    if act == 2:
+        ref = torch.nn.functional.gelu(ref.to(dt).float(), approximate="tanh")
+    elif act == 3:
+        z = ref.to(dt).float()
+        ref = z * torch.sigmoid(1.702 * z)
+    assert relerr(out, ref) < 1.2e-2, relerr(out, ref)
+    # grouped: two folded problems sharing A (the q / k of a decoder layer)
+    o1, o2 = torch.empty((M, N // 2), dtype=dt, device=dev), torch.empty((M, N // 2), dtype=dt, device=dev)
+    h = N // 2
+    lk = dict(ln_stats=st, ln_width=K, ln_eps=eps)
+    ops.gemm_grouped([ops.gemm_args(x, wf[:h], o1, M, h, K, bias=bf[:h], act=act, ln_colsum=cs[:h], **lk),
+                      ops.gemm_args(x, wf[h:], o2, M, h, K, bias=bf[h:], act=act, ln_colsum=cs[h:], **lk)])
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([o1, o2], 1), out)
+    # misuse
+    with pytest.raises(L.MicError, match="rowsum2"):
+        ops.gemm(a0.to(dev), b0.to(dev), x, M, K, 64, act=2, rowsum2=st)
+    with pytest.raises(L.MicError, match="folded LayerNorm"):
+        ops.gemm(x, wf, out, M, N, K, ln_stats=st, ln_colsum=cs, ln_width=K, ln_eps=eps)   # bias' missing
