@@ -64,10 +64,16 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A halves | B halves]
   const int tid = threadIdx.x, lane = tid & 63, wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kg = wave_all / NWAVES, wave = wave_all % NWAVES;  // K-group, wave within the group
+  // Persistent launches (PLAIN 256x256 instantiations only — the others have no registers to spare for the loop state; grid <
+  // total_blocks, a multiple of 8): a block walks the tiles bid, bid + grid, ... — no block retirement / dispatch gap between
+  // two tiles of a CU.  Every other instantiation runs the body once.
+  constexpr bool PERSIST = PLAIN && WM == 128 && KG == 1;
+  int bid = blockIdx.x;
+  do {
   // bijective XCD remap: the blocks that land on XCD x (= bid % 8) get a contiguous run of logical block ids
   int lid;
   {
-    const int bid = blockIdx.x, nwg = tab.total_blocks;
+    const int nwg = tab.total_blocks;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
@@ -82,8 +88,8 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
     // split-K with K-range <-> XCD affinity: XCD x owns the K-chunks [x*S, (x+1)*S) and walks them chunk by chunk over ALL
     // output tiles, so the ~32 blocks resident on an XCD read the same K-range of A and B at the same time (one HBM read
     // per operand byte; tile-major order made every block stream private panels: fabric-bound, no gain over no split)
-    const int T = P.tiles_m * P.tiles_n, S = P.nsplit >> 3, j = blockIdx.x >> 3;
-    split = (blockIdx.x & 7) * S + j / T;
+    const int T = P.tiles_m * P.tiles_n, S = P.nsplit >> 3, j = bid >> 3;
+    split = (bid & 7) * S + j / T;
     tile = j % T;
   }
   int tm, tn;
@@ -244,6 +250,11 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
   }
 
   gemm_epilogue<WM, WN, WNW, KG, PLAIN, F8>(acc, P, smem, m0, n0, split, kg, wave, lane, tid);
+  if constexpr (!PERSIST) break;
+  bid += gridDim.x;
+  if (bid >= tab.total_blocks) break;
+  __syncthreads();  // the next tile's prologue rewrites the LDS the epilogue restaged through
+  } while (true);
 }
 
 // ------------------------------------------------------------------------------------------------ f32
@@ -359,7 +370,11 @@ static void launch_cfg_p(const LaunchTable& tab, int akm, int bkm, hipStream_t s
   const size_t red = (size_t)(KG - 1) * 2 * WNW * (WM / 32) * (WN / 32) * 16 * 64 * 4;  // K-group partial sums
   if (epi > lds) lds = epi;
   if (red > lds) lds = red;
-  dim3 grid(tab.total_blocks), block(128 * WNW * KG);
+  // 256x256 tiles hold a CU alone (128 KiB LDS): launches with more tiles than CUs run as 256 persistent blocks
+  static const int persist = [] { const char* e = getenv("MIC_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
+  int nblk = tab.total_blocks;
+  if (persist && BM == 256 && PLAIN && KG == 1 && nblk > 256) nblk = 256;
+  dim3 grid(nblk), block(128 * WNW * KG);
 #define LAUNCH(AKM, BKMM)                                                                                                  \
   do {                                                                                                                     \
     static bool attr_set_dev[64] = {}; /* per instantiation AND device (the attribute belongs to the device's code object) */ \
