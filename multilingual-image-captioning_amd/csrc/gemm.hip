@@ -473,7 +473,12 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
   static const int w4 = [] { const char* e = getenv("MIC_GEMM_W4"); return e ? atoi(e) : 0; }();  // opt-in: measured slower
   bool any_rowsum = false;
   for (int i = 0; i < count; ++i) any_rowsum |= args[i].a_rowsum != nullptr;
-  if (bm == 256 && f8 == 0 && w4 && !any_rowsum) launch_gemm_w4(tab, args[0].a_kmajor, args[0].b_kmajor, table_is_plain(tab), s);  // 4 waves, 128x128 wave tiles
+  bool fits32 = true;  // the v2 kernel addresses its operands through 32-bit buffer offsets
+  for (int i = 0; i < count; ++i)
+    fits32 &= (size_t)tab.p[i].M * tab.p[i].lda * 2 < 0xFFFFFFFFull && (size_t)tab.p[i].N * tab.p[i].ldb * 2 < 0xFFFFFFFFull;
+  if (bm == 256 && f8 == 0 && w4 == 2 && !any_rowsum && !args[0].a_kmajor && !args[0].b_kmajor && fits32)
+    launch_gemm_w4v2(tab, table_is_plain(tab), s);
+  else if (bm == 256 && f8 == 0 && w4 == 1 && !any_rowsum) launch_gemm_w4(tab, args[0].a_kmajor, args[0].b_kmajor, table_is_plain(tab), s);  // 4 waves, 128x128 wave tiles
   else if (bm == 256 && f8 == 0 && phased) launch_gemm_phased(tab, args[0].a_kmajor, args[0].b_kmajor, table_is_plain(tab), s);  // LDS-DMA, phased
   else if (bm == 256) launch_cfg<128, 64, 4, 64>(tab, args[0].a_kmajor, args[0].b_kmajor, s, f8);     // 256x256x64, 8 waves
   else if (bm == 128) {  // 128x128x64, 8 waves (measured better than the 4-wave 64x64 wave tile at every tile count);

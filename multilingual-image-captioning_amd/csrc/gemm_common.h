@@ -23,6 +23,7 @@ struct LaunchTable { int count; int total_blocks; Problem p[MAX_PROBLEMS]; };
 void launch_gemm_phased(const LaunchTable& tab, int akm, int bkm, bool plain, hipStream_t s);
 // gemm_w4.hip: 256x256 tiles on four waves (wave tile 128x128, accumulators in AGPRs), hand-pipelined K-tile (bf16, no row sums)
 void launch_gemm_w4(const LaunchTable& tab, int akm, int bkm, bool plain, hipStream_t s);
+void launch_gemm_w4v2(const LaunchTable& tab, bool plain, hipStream_t s);  // NT only: two K-tiles in flight, buffer loads
 
 // --- stage one operand image (ROWS x BKT k, or BKT k x ROWS x; ROWS = 128 or 64) HBM/L2 -> registers -> LDS.
 //     Measured on gfx950: a global_load_lds (LDS-DMA) instruction costs ~100 cycles of issue time in the issuing wave's

@@ -187,6 +187,164 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(LaunchTable tab) {
   gemm_epilogue<WM, WN, WNW, 1, PLAIN, 0>(acc, P, smem, m0, n0, split, 0, wave, lane, tid);
 }
 
+// ---------------------------------------------------------------------------------------------------------------- v2 (NT only)
+// Same tiling, but what the v1 ablations asked for: TWO K-tiles in flight (two register sets X / Y, 128 VGPRs: tile t+1 is
+// written to LDS from one set while tile t+2 is still landing in the other, and each piece's register is reloaded with tile
+// t+3 right behind its ds_write — a load has two full K-tiles to arrive), the 16 ds_writes of a K-tile spread over k-steps
+// 0..2 (6 / 6 / 4) instead of packed into two, and addressing that costs no registers: buffer_load_dwordx4 with one per-lane
+// byte offset per operand + a uniform per-piece offset (rows past M fall outside the descriptor and read as zero),
+// ds_write / ds_read with per-lane bases and immediate offsets.  K-loop unrolled by two (X / Y and the LDS stages alternate).
+// MEASURED (MIC_GEMM_W4=2): the ISA is exactly this schedule (256 VGPR + 256 AGPR, no scratch, `M r vmcnt(31) w G` with 32
+// loads in flight, a handful of VALU instructions per K-tile), results bit-identical — head forward 1520 us against 1467 us
+// (v1) and 1158 us (8-wave kernel) on the same box.  So operand latency was not what v1 lacked.  What both versions share:
+// per k-step the four waves put 4 x (8 ds_read_b128 + 6..8 ds_write_b128) = 4 x (8 x 4.2 + 6 x 13.3) ~ 450 cycles of LDS-pipe
+// work into a 512-cycle MFMA window (tools/bench_lds_rw.hip: 241 and 77 B/clk/CU), LDS operations retire in order, and the
+// lgkmcnt wait in front of every MFMA therefore sits behind 13-cycle writes; with ONE instruction stream per SIMD each such wait
+// idles the matrix pipe (the 8-wave kernel has the same LDS load but a second wave to issue MFMAs meanwhile).  The tiling
+// needs fewer LDS WRITE bytes per MFMA — one operand straight from L1/L2 into registers in MFMA layout, which for
+// k-contiguous bf16 rows and 32x32x16 fragments means 32-B segments per lane pair — a different kernel, not a schedule.
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+template <bool PLAIN>
+__global__ __launch_bounds__(256, 1) void gemm_w4v2_kernel(LaunchTable tab) {
+  constexpr int WM = 128, WN = 128, WNW = 2, BM = 256, BN = 256, BKT = 64, AI = 4, NJ = 4;
+  constexpr int HALF = 128 * BKT * 2, STAGE = 4 * HALF;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int lid;
+  {
+    const int bid = blockIdx.x, nwg = tab.total_blocks;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_PROBLEMS; ++i)
+    if (i < tab.count && lid >= tab.p[i].block_begin) pi = i;
+  const Problem P = tab.p[pi];
+  const int local = lid - P.block_begin;
+  int tile = local / P.nsplit, split = local - tile * P.nsplit;
+  if (tab.count == 1 && P.nsplit > 1 && (P.nsplit & 7) == 0) {
+    const int T = P.tiles_m * P.tiles_n, S = P.nsplit >> 3, j = blockIdx.x >> 3;
+    split = (blockIdx.x & 7) * S + j / T;
+    tile = j % T;
+  }
+  int tm, tn;
+  tile_coords(tile, P.tiles_m, P.tiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int wr = wave / WNW, wc = wave % WNW;
+
+  f32x16 acc[AI][NJ];
+#pragma unroll
+  for (int i = 0; i < AI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int nk_total = P.K / BKT;
+  const int nk_per = (nk_total + P.nsplit - 1) / P.nsplit;
+  const int kt0 = split * nk_per, kt1 = min(nk_total, kt0 + nk_per);
+  const int nk = max(kt1 - kt0, 0);
+
+  // ---- global side: piece p = 4 h + i of an operand covers rows h*128 + (wave*4 + i)*8 + (lane >> 3), 16-B chunk lane & 7
+  const __amdgpu_buffer_rsrc_t ra_rs = __builtin_amdgcn_make_buffer_rsrc((void*)P.A, 0, (int)((size_t)P.M * P.lda * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb_rs = __builtin_amdgcn_make_buffer_rsrc((void*)P.B, 0, (int)((size_t)P.N * P.ldb * 2), 0x00020000);
+  const int l3 = lane >> 3, c8 = lane & 7;
+  const unsigned va = (unsigned)((m0 + wave * 32 + l3) * P.lda + c8 * 8) * 2u;   // + (h*128 + i*8) * lda * 2 per piece (uniform)
+  const unsigned vb = (unsigned)((n0 + wave * 32 + l3) * P.ldb + c8 * 8) * 2u;
+  const unsigned pa = (unsigned)P.lda * 16u, pb = (unsigned)P.ldb * 16u;          // 8 rows
+  auto gload = [&](u32x4v& r, bool isA, int p, int t) __attribute__((always_inline)) {
+    const int tt = kt0 + (t < nk ? t : nk - 1);
+    const unsigned rows8 = (unsigned)((p >> 2) * 16 + (p & 3));                    // (h*128 + i*8) / 8
+    if (isA) r = __builtin_amdgcn_raw_buffer_load_b128(ra_rs, va + rows8 * pa, tt * (BKT * 2), 0);
+    else r = __builtin_amdgcn_raw_buffer_load_b128(rb_rs, vb + rows8 * pb, tt * (BKT * 2), 0);
+  };
+  // ---- LDS side: image row R = (wave*4 + i)*8 + l3 of half h: 128-B row, chunk c8 ^ ((R >> 1) & 7) = c8 ^ (l3 >> 1) ^ 4 (i & 1)
+  const int wbase = wave * 4096 + l3 * 128 + ((c8 ^ (l3 >> 1)) << 4);
+  auto lstore = [&](const u32x4v& r, char* stage, bool isA, int p) __attribute__((always_inline)) {
+    const int off = (isA ? 0 : 2 * HALF) + (p >> 2) * HALF + (p & 3) * 1024;
+    *reinterpret_cast<u32x4v*>(stage + off + (wbase ^ ((p & 1) << 6))) = r;
+  };
+  bf16x8 af[2][AI], bfr[2][NJ];
+  const int fr = lane & 31, sw = (fr >> 1) & 7, hi = lane >> 5;
+  const int rbaseA = wr * HALF + fr * 128, rbaseB = (2 + wc) * HALF + fr * 128;
+  auto read1 = [&](const char* stage, int kk, int slot, int n) __attribute__((always_inline)) {
+    const int ch = (((kk * 2) ^ (sw & 6)) | (hi ^ (sw & 1))) << 4;
+    if (n < 4) af[slot][n] = *reinterpret_cast<const bf16x8*>(stage + rbaseA + n * 4096 + ch);
+    else bfr[slot][n - 4] = *reinterpret_cast<const bf16x8*>(stage + rbaseB + (n - 4) * 4096 + ch);
+  };
+  auto mfmas = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[slot][i], bfr[slot][j], acc[i][j], 0, 0, 0);
+  };
+  u32x4v X[16], Y[16];  // [0..7] A pieces, [8..15] B pieces
+  // one K-tile: multiply tile t from `cur`, write tile t+1 (in S) to `nxt`, reload S with tile t+3
+  auto ktile = [&](int t, char* cur, char* nxt, u32x4v (&S)[16]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {
+      const int w0 = kk * 6, w1 = kk == 2 ? 16 : w0 + 6;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        read1(cur, kk + 1, (kk + 1) & 1, j);
+        const int p = w0 + j;
+        if (p < w1) {
+          lstore(S[p], nxt, p < 8, p & 7);
+          gload(S[p], p < 8, p & 7, t + 3);
+        }
+      }
+      mfmas(kk & 1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        W4_SGB(SG_MFMA, 1); W4_SGB(SG_DS_RD, 1);
+        if (w0 + j < w1) { W4_SGB(SG_DS_WR, 1); W4_SGB(SG_VMEM_RD, 1); }
+        W4_SGB(SG_MFMA, 1);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) read1(nxt, 0, 0, j);
+    mfmas(1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { W4_SGB(SG_MFMA, 1); W4_SGB(SG_DS_RD, 1); W4_SGB(SG_MFMA, 1); }
+  };
+
+  if (nk > 0) {
+#pragma unroll
+    for (int p = 0; p < 16; ++p) gload(X[p], p < 8, p & 7, 0);
+#pragma unroll
+    for (int p = 0; p < 16; ++p) lstore(X[p], smem, p < 8, p & 7);
+#pragma unroll
+    for (int p = 0; p < 16; ++p) { gload(X[p], p < 8, p & 7, 1); gload(Y[p], p < 8, p & 7, 2); }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) read1(smem, 0, 0, j);
+  }
+  int t = 0;
+  for (; t + 2 <= nk; t += 2) {
+    ktile(t, smem, smem + STAGE, X);
+    ktile(t + 1, smem + STAGE, smem, Y);
+  }
+  if (t < nk) ktile(t, smem, smem + STAGE, X);
+  __syncthreads();
+  gemm_epilogue<WM, WN, WNW, 1, PLAIN, 0>(acc, P, smem, m0, n0, split, 0, wave, lane, tid);
+}
+
+template <bool PLAIN>
+void launch_v2(const LaunchTable& tab, hipStream_t s) {
+  constexpr int LDS = 2 * 4 * 128 * 64 * 2;
+  static bool attr_set_dev[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  bool& attr_set = attr_set_dev[dev & 63];
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4v2_kernel<PLAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_w4v2_kernel<PLAIN>), dim3(tab.total_blocks), dim3(256), LDS, s, tab);
+}
+
 template <bool AK, bool BKM, bool PLAIN>
 void launch_one(const LaunchTable& tab, hipStream_t s) {
   constexpr int LDS = 2 * 4 * 128 * 64 * 2;  // two stages of four 16-KiB images = the epilogue's 4 x (64 x 128) fp32 regions
@@ -202,6 +360,11 @@ void launch_one(const LaunchTable& tab, hipStream_t s) {
 }
 
 }  // namespace
+
+void launch_gemm_w4v2(const LaunchTable& tab, bool plain, hipStream_t s) {
+  if (plain) launch_v2<true>(tab, s);
+  else launch_v2<false>(tab, s);
+}
 
 void launch_gemm_w4(const LaunchTable& tab, int akm, int bkm, bool plain, hipStream_t s) {
 #define W4_LAUNCH(A_, B_)                         \
