@@ -151,6 +151,45 @@ def test_decode_plan_graph_replay_matches_oracle(dev, monkeypatch):
     assert len(model._decode_plans) == 2
 
 
+def test_decode_layernorm_fold_matches_explicit_layernorms(dev):
+    """bfloat16 decoder steps with the LayerNorms folded around the GEMMs (default) against the explicit LayerNorm kernels
+    (engine.decode_ln_fold = False): same cache protocol, logits equal up to the one bf16 rounding the fold skips (the
+    normalised activations are never rounded) — 2e-2 of the logit scale over 6 cached steps, and the same greedy tokens
+    wherever the explicit path's top-2 margin exceeds that error.  float32 mode never folds (bit-exact tests above)."""
+    rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6, d_layers=3)
+    eng = model.engine
+    assert eng.decode_ln_fold
+    B, L = 5, 8
+    px, *_ = batch(rc, B, 12, seed=61)
+    enc = model.encode(px.numpy())
+    g = torch.Generator().manual_seed(5)
+    toks = torch.randint(4, rc.vocab_size - 20, (L, B, 1), generator=g).numpy().astype(np.int32)
+    outs = {}
+    for fold in (True, False):
+        eng.decode_ln_fold = fold
+        cache = model.init_cache(B, L, enc)
+        logits = []
+        for t in range(6):
+            pos = np.full((B, 1), t, dtype=np.int32)
+            o = model.decode(toks[t], enc, decoder_position_ids=pos, past_key_values=cache)
+            cache = o.past_key_values
+            logits.append(torch.as_tensor(o.logits).float().cpu().reshape(B, -1))
+        outs[fold] = torch.stack(logits)
+    eng.decode_ln_fold = True
+    a, b = outs[True], outs[False]
+    scale = b.abs().max().item()
+    err = (a - b).abs().max().item()
+    assert err < 2e-2 * scale, (err, scale)
+    top2 = b.topk(2, dim=-1).values
+    decisive = (top2[..., 0] - top2[..., 1]) > 2 * err
+    assert decisive.float().mean().item() > 0.5   # the comparison below is not vacuous
+    assert torch.equal(a.argmax(-1)[decisive], b.argmax(-1)[decisive])
+    # the fold's operands follow the weights: after a parameter update the folded copies are rebuilt
+    v0 = model.store.version
+    model.invalidate_params_cache()
+    assert model.store.version == v0 + 1
+
+
 def _rule_batch(rc, classes, T=12, n=8):
     """synthetic captioning task with a learnable, deterministic answer: the image is a constant colour that encodes a class c,
     the caption is lang, s_1 = 100 + c, s_{t+1} = 100 + (3 (s_t - 100) + c + 1) mod 200, ..., eos"""
