@@ -23,6 +23,11 @@ struct LaunchTable { int count; int total_blocks; Problem p[MAX_PROBLEMS]; };
 void launch_gemm_phased(const LaunchTable& tab, int akm, int bkm, bool plain, hipStream_t s);
 // gemm_w4.hip: 256x256 tiles on four waves (wave tile 128x128, accumulators in AGPRs), hand-pipelined K-tile (bf16, no row sums)
 void launch_gemm_w4(const LaunchTable& tab, int akm, int bkm, bool plain, hipStream_t s);
+// one translation unit per tile configuration of the main kernel (gemm_kernel.h): 256x256 / 128x128 (K-groups 1, 2) / 64x64 (1, 2, 4)
+bool table_is_plain(const LaunchTable& t);
+void launch_gemm_t256(const LaunchTable& tab, int akm, int bkm, hipStream_t s, int f8);
+void launch_gemm_t128(const LaunchTable& tab, int akm, int bkm, hipStream_t s, int f8, int kgroups);
+void launch_gemm_t64(const LaunchTable& tab, int akm, int bkm, hipStream_t s, int f8, int kgroups);
 void launch_gemm_w4v2(const LaunchTable& tab, bool plain, hipStream_t s);  // NT only: two K-tiles in flight, buffer loads
 
 // --- stage one operand image (ROWS x BKT k, or BKT k x ROWS x; ROWS = 128 or 64) HBM/L2 -> registers -> LDS.
