@@ -1,4 +1,7 @@
-// gemm.hip — MFMA GEMMs with fused epilogues (mic_gemm / mic_gemm_grouped).
+// gemm.hip — MFMA GEMMs with fused epilogues (mic_gemm / mic_gemm_grouped): argument checks, launch-table construction and the
+// choice of tile configuration.  The bf16 / fp8 kernel template itself is gemm_kernel.h, instantiated in gemm_t256.hip /
+// gemm_t128.hip / gemm_t64.hip (one translation unit per tile configuration, so they compile in parallel); the fp32 kernel
+// is below.
 //
 // bf16 kernel: ONE template, table-driven (a launch carries up to 8 problems), three tile configurations chosen per launch:
 //   256x256 tile, 8 waves (2x4), wave tile 128x64 (4x2 v_mfma_f32_32x32x16_bf16 accumulators), 128 KiB LDS, 1 block/CU
