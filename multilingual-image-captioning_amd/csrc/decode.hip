@@ -200,53 +200,96 @@ extern "C" int mic_row_lse_topk(int dtype, int R, int V, const void* logits, int
 
 // ------------------------------------------------------------------ per-row lse + top-k from the head GEMM's tile partials
 // The LM-head GEMM can emit, per row and 64-column granule, (max, sum exp(x - max)) of the logits it stores
-// (mic_gemm_args.rowstat).  Merging the ceil(V / 64) partials of a row gives its log-sum-exp without touching the logits,
-// and the k-th largest granule maximum is a lower bound tau on the row's k-th best logit (k distinct granules each hold an
-// element >= their maximum), so only the few granules whose maximum reaches tau can hold a top-k entry: the kernel reads 3908
-// float2 and ~k x 64 logits per row instead of streaming 250 054 logits twice.  Results are those of row_lse_topk_kernel: candidates
-// ordered (processed value desc, index asc) on the same fp32 arithmetic (x = (v - max) - log sum + bias).
+// (mic_gemm_args.rowstat).  Merging the ceil(V / 64) partials of a row gives its log-sum-exp without touching the logits.
+// For the top-k let f(x) = ((x - max) - log sum) + bias be the processed value (monotone in x, the arithmetic of
+// row_lse_topk_kernel) and tau the kk-th largest granule maximum (kk = k, + 1 when the EOS column — possibly a granule's
+// maximum — is not eligible).  At least k eligible elements have f >= f(tau), so the row's top-k (value desc, index asc) is
+//   * every element with f > f(tau): all of them sit in the granules A = {f(granule max) > f(tau)}, |A| < kk, and then
+//   * elements with f == f(tau) in index order: they sit in A or in E = {f(granule max) == f(tau)}, and since every E granule
+//     (but the EOS one) holds at least one, the FIRST kk granules of E by index hold the lowest-indexed k of them.
+// So at most 2 kk - 1 granules (<= 33 x 64 logits) are read per row however many granule maxima tie — a randomly
+// initialised model's bf16 logits tie in hundreds of granules, which made the "every granule >= tau" scan of the first
+// version re-read most of the row k times (113 us in situ against 37 us on spread-out logits).
+__device__ __forceinline__ void wave_best(float& v, int& i) {  // all lanes end with the wave's best (value, index)
+#define MIC_BEST_STEP(X)                                                          \
+  {                                                                               \
+    const float ov = X(v);                                                        \
+    const int oi = __builtin_bit_cast(int, X(__builtin_bit_cast(float, i)));      \
+    if (better(ov, oi, v, i)) { v = ov; i = oi; }                                 \
+  }
+  MIC_BEST_STEP(dpp_f<DPP_HALF_MIRROR>)
+  MIC_BEST_STEP(dpp_f<DPP_XOR1>)
+  MIC_BEST_STEP(dpp_f<DPP_XOR2>)
+  MIC_BEST_STEP(dpp_f<DPP_ROR8>)
+  MIC_BEST_STEP(lane_xor16)
+  MIC_BEST_STEP(lane_xor32)
+#undef MIC_BEST_STEP
+}
 template <typename T>
 __global__ __launch_bounds__(256) void row_topk_tiles_kernel(int V, const T* __restrict__ logits, int ld, const float2* __restrict__ stat,
                                                             int stat_ld, int ntiles, int k, int suppress_eos, int eos, int raw,
                                                             const float* __restrict__ row_bias, float* __restrict__ top_val,
                                                             int32_t* __restrict__ top_idx) {
-  constexpr int TPT = 16;  // granules per thread: up to 4096 granules of 64 columns (V <= 262 144)
-  __shared__ float sm[256], ss[256];
-  __shared__ int si[256];
-  __shared__ int cand[256];
-  __shared__ int ncand;
-  const int row = blockIdx.x, tid = threadIdx.x;
+  constexpr int TPT = 16;                     // granules per thread: up to 4096 granules of 64 columns (V <= 262 144)
+  constexpr int NCAND = 2 * (TOPK_MAX + 1);   // >= 2 kk - 1 candidate granules
+  constexpr int CPT = (NCAND + 3) / 4;        // candidate granules per wave
+  __shared__ float rv[2][4];
+  __shared__ int ri[2][4];
+  __shared__ int ecnt[TPT * 4], ebase[TPT * 4 + 1];
+  __shared__ int cand[NCAND];
+  __shared__ int nA;
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const float2* sr = stat + (size_t)row * stat_ld;
   const T* lr = logits + (size_t)row * ld;
   const float bias = row_bias ? row_bias[row] : 0.f;
-  float tm[TPT];
-  float m = -INFINITY, s = 0.f;
-#pragma unroll
-  for (int u = 0; u < TPT; ++u) {
-    const int t = tid + u * 256;
-    tm[u] = -INFINITY;
-    if (t < ntiles) {
-      const float2 p = sr[t];
-      tm[u] = p.x;
-      const float mn = fmaxf(m, p.x);
-      s = (mn == -INFINITY) ? 0.f : s * __expf(m - mn) + p.y * __expf(p.x - mn);
-      m = mn;
-    }
-  }
-  sm[tid] = m; ss[tid] = s;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o) {
-      const float m1 = sm[tid], m2 = sm[tid + o], mn = fmaxf(m1, m2);
-      ss[tid] = mn == -INFINITY ? 0.f : ss[tid] * __expf(m1 - mn) + ss[tid + o] * __expf(m2 - mn);
-      sm[tid] = mn;
-    }
+  if (tid == 0) nA = 0;
+  // one barrier per block-wide reduction: partials of the four waves in a slot that alternates between reductions
+  int par = 0;
+  auto block_best = [&](float& v, int& i) __attribute__((always_inline)) {
+    wave_best(v, i);
+    if (lane == 0) { rv[par][wv] = v; ri[par][wv] = i; }
     __syncthreads();
+    v = rv[par][0]; i = ri[par][0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (better(rv[par][w], ri[par][w], v, i)) { v = rv[par][w]; i = ri[par][w]; }
+    par ^= 1;
+  };
+  float tm[TPT], ts[TPT];
+#pragma unroll
+  for (int u = 0; u < TPT; ++u) {  // 16 independent 8-byte loads in flight per thread
+    const int t = tid + u * 256;
+    float2 p = make_float2(-INFINITY, 0.f);
+    if (t < ntiles) p = sr[t];
+    tm[u] = p.x; ts[u] = p.y;
   }
-  const float mx = raw ? 0.f : sm[0];
-  const float logsum = raw ? 0.f : logf(ss[0]);
-  __syncthreads();
-  // tau = the kk-th largest tile maximum (one more when the EOS column, which may be a tile's maximum, is not eligible)
+  float mx = 0.f, logsum = 0.f;
+  if (!raw) {
+    float m = tm[0];
+#pragma unroll
+    for (int u = 1; u < TPT; ++u) m = fmaxf(m, tm[u]);
+    m = wave_max(m);
+    if (lane == 0) rv[par][wv] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(rv[par][0], rv[par][1]), fmaxf(rv[par][2], rv[par][3]));
+    par ^= 1;
+    float sum = 0.f;
+    if (m > -INFINITY) {
+#pragma unroll
+      for (int u = 0; u < TPT; ++u) sum += ts[u] * __expf(tm[u] - m);
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) rv[par][wv] = sum;
+    __syncthreads();
+    sum = (rv[par][0] + rv[par][1]) + (rv[par][2] + rv[par][3]);
+    par ^= 1;
+    mx = m; logsum = logf(sum);
+  }
+  auto proc = [&](float x) __attribute__((always_inline)) -> float {  // row_lse_topk_kernel's arithmetic, in its order
+    x = raw ? x : (x - mx) - logsum;
+    return x + bias;
+  };
+  // tau = the kk-th largest granule maximum
   const int kk = k + (suppress_eos ? 1 : 0);
   float tau = INFINITY;
   {
@@ -254,69 +297,87 @@ __global__ __launch_bounds__(256) void row_topk_tiles_kernel(int V, const T* __r
 #pragma unroll
     for (int u = 0; u < TPT; ++u) mine[u] = tm[u];
     for (int round = 0; round < kk; ++round) {
-      float best = -INFINITY;
-      int bu = 0;
+      float bv = mine[0];
+      int bi = tid;
 #pragma unroll
-      for (int u = 0; u < TPT; ++u) if (mine[u] > best) { best = mine[u]; bu = u; }
-      sm[tid] = best; si[tid] = tid;
-      __syncthreads();
-      for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o && better(sm[tid + o], si[tid + o], sm[tid], si[tid])) { sm[tid] = sm[tid + o]; si[tid] = si[tid + o]; }
-        __syncthreads();
-      }
-      tau = sm[0];
-      if (tid == si[0]) {
+      for (int u = 1; u < TPT; ++u)
+        if (mine[u] > bv) { bv = mine[u]; bi = tid + u * 256; }
+      block_best(bv, bi);
+      tau = bv;
+      if ((bi & 255) == tid) {
 #pragma unroll
-        for (int u = 0; u < TPT; ++u) if (u == bu) mine[u] = -INFINITY;
+        for (int u = 0; u < TPT; ++u) if (u == (bi >> 8)) mine[u] = -INFINITY;
       }
-      __syncthreads();
     }
   }
-  // tiles that can hold a top-k entry: maximum >= tau minus a margin that covers distinct logits collapsing to one fp32
-  // processed value (the same margin row_lse_topk_kernel uses)
-  const float t_safe = tau > -INFINITY ? tau - 1e-5f * (fabsf(tau) + fabsf(bias) + fabsf(logsum) + fabsf(mx) + 1.0f) : -INFINITY;
-  if (tid == 0) ncand = 0;
+  const float ftau = proc(tau);
+  // E granules ranked by index = (u, thread) order: counts per (u, wave), exclusive prefix by wave 0, rank by ballot
+#pragma unroll
+  for (int u = 0; u < TPT; ++u) {
+    const bool isE = tid + u * 256 < ntiles && proc(tm[u]) == ftau;
+    const unsigned long long em = __ballot(isE);
+    if (lane == 0) ecnt[u * 4 + wv] = __popcll(em);
+  }
   __syncthreads();
+  if (wv == 0) {
+    const int c = ecnt[lane];
+    int inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int n = __shfl_up(inc, o);
+      if (lane >= o) inc += n;
+    }
+    ebase[lane] = inc - c;
+    if (lane == 63) ebase[64] = inc;
+  }
+  __syncthreads();
+  const int nE = min(ebase[64], kk);
 #pragma unroll
   for (int u = 0; u < TPT; ++u) {
     const int t = tid + u * 256;
-    if (t < ntiles && tm[u] >= t_safe) {
-      const int slot = atomicAdd(&ncand, 1);
-      if (slot < 256) cand[slot] = t;
+    const float fm = proc(tm[u]);
+    const bool isE = t < ntiles && fm == ftau;
+    const unsigned long long em = __ballot(isE);
+    if (isE) {
+      const int rank = ebase[u * 4 + wv] + __popcll(em & ((1ull << lane) - 1ull));
+      if (rank < kk) cand[rank] = t;
+    }
+    if (t < ntiles && fm > ftau) {  // fewer than kk of these
+      const int slot = nE + atomicAdd(&nA, 1);
+      if (slot < NCAND) cand[slot] = t;
     }
   }
   __syncthreads();
-  const int nc = ncand;
+  const int nc = min(nE + nA, NCAND);
+  // candidate values: granule q of the list belongs to wave q % 4; every load of a thread is issued before the first use
+  float xv[CPT];
+  int xc[CPT];
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) {
+    const int q = wv + 4 * j;
+    const int c = q < nc ? cand[q] * 64 + lane : V;
+    xc[j] = c;
+    float x = -INFINITY;
+    if (c < V) {
+      x = proc(ElemT<T>::ld(lr + c));
+      if (suppress_eos && c == eos) x = -INFINITY + bias;
+    }
+    xv[j] = x;
+  }
   // k rounds: the best (processed value, index) that comes after the previous winner in the order (value desc, index asc)
   float pv = INFINITY;
   int pidx = -1;
   for (int round = 0; round < k; ++round) {
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    auto consider = [&](int t) __attribute__((always_inline)) {  // this thread's element of granule t
-      const int c = t * 64 + (tid & 63);
-      if (c >= V) return;
-      float x = ElemT<T>::ld(lr + c);
-      x = raw ? x : (x - mx) - logsum;
-      if (suppress_eos && c == eos) x = -INFINITY;
-      x += bias;
-      const bool after = x < pv || (x == pv && c > pidx);  // strictly behind the previous winner
-      if (after && better(x, c, bv, bi)) { bv = x; bi = c; }
-    };
-    if (nc <= 256) {  // four granules per sweep (one per wave)
-      for (int q = tid >> 6; q < nc; q += 4) consider(cand[q]);
-    } else {  // pathological ties (more than 256 granules at the maximum): every granule is a candidate
-      for (int t = tid >> 6; t < ntiles; t += 4) consider(t);
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      const bool after = xv[j] < pv || (xv[j] == pv && xc[j] > pidx);  // strictly behind the previous winner
+      if (xc[j] < V && after && better(xv[j], xc[j], bv, bi)) { bv = xv[j]; bi = xc[j]; }
     }
-    sm[tid] = bv; si[tid] = bi;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (tid < o && better(sm[tid + o], si[tid + o], sm[tid], si[tid])) { sm[tid] = sm[tid + o]; si[tid] = si[tid + o]; }
-      __syncthreads();
-    }
-    pv = sm[0]; pidx = si[0];
+    block_best(bv, bi);
+    pv = bv; pidx = bi;
     if (tid == 0) { top_val[(size_t)row * k + round] = pv; top_idx[(size_t)row * k + round] = pidx; }
-    __syncthreads();
   }
 }
 extern "C" int mic_row_topk_tiles(int dtype, int R, int V, const void* logits, int ld, const float* rowstat, int stat_ld, int k,
