@@ -150,6 +150,11 @@ bool table_is_plain(const LaunchTable& t) {
   }
   return true;
 }
+static bool any_rowsum_early(const mic_gemm_args* args, int count) {
+  for (int i = 0; i < count; ++i)
+    if (args[i].a_rowsum) return true;
+  return false;
+}
 static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
   LaunchTable tab;
   tab.count = count;
@@ -198,7 +203,10 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
   tab.total_blocks = blocks;
   for (int i = 0; i < count; ++i)
     MIC_CHECK(!args[i].rowsum2 || table_is_plain(tab), "mic_gemm_grouped: rowsum2 needs every problem of the launch on the bare / residual epilogue");
-  static const int phased = [] { const char* e = getenv("MIC_GEMM_PHASED"); return e ? atoi(e) : 0; }();  // opt-in: measured slower
+  // LDS-DMA four-phase 256x256 kernel: 1 = every 256x256 launch (measured slower over the train step), 0 = never, default 2 = the
+  // NT launches only (both operands k-contiguous: LM-head forward, FFN-in forward), where its deeper operand prefetch wins
+  static const int phased_env = [] { const char* e = getenv("MIC_GEMM_PHASED"); return e ? atoi(e) : 2; }();
+  const bool phased = phased_env == 1 || (phased_env == 2 && !args[0].a_kmajor && !args[0].b_kmajor && count == 1 && !any_rowsum_early(args, count));
   static const int w4 = [] { const char* e = getenv("MIC_GEMM_W4"); return e ? atoi(e) : 0; }();  // opt-in: measured slower
   bool any_rowsum = false;
   for (int i = 0; i < count; ++i) any_rowsum |= args[i].a_rowsum != nullptr;
