@@ -289,6 +289,12 @@ class Trainer:
         # sharded optimizer (data parallel only): reduce-scatter / AdamW on 1/world of every bucket / all-gather the weights
         self.sharded = bool(sharded_optimizer) and self.world > 1
         self.buckets = plan_buckets(st.numel, int(bucket_mb * 1024 * 1024 / 4), bounds, granule=self.world * 64 if self.sharded else 1)
+        # MIC_OPT_OVERLAP=0: AdamW as one launch after backward (profiling aid: per-bucket AdamW on its own stream shares HBM with
+        # the backward kernels it overlaps, so their individual durations read longer than the kernels are)
+        import os
+
+        if os.environ.get("MIC_OPT_OVERLAP", "1") == "0" and not self.sharded:
+            overlap_optimizer = False
         self.overlap_optimizer = overlap_optimizer or self.sharded
         sh = st.segs["shared"]
         self.reducer = GradReducer(st.grad, self.buckets, group, on_ready=self._adamw_slice if self.overlap_optimizer else None,

@@ -7,8 +7,9 @@ from collections import defaultdict
 
 
 def short(name):
-    name = re.sub(r"\(.*", "", name)
     name = re.sub(r"^void ", "", name)
+    name = name.replace("(anonymous namespace)::", "")
+    name = re.sub(r"\(.*", "", name)
     return name[:100]
 
 
