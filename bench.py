@@ -252,6 +252,12 @@ def bench_generate(model, cfg, dev, batch=256, langs=(250004, 250008, 250003, 25
                        "ms_per_step": round(at / nst * 1e3, 3), "algorithmic_MB_per_launch": round(ab / an / 1e6, 2),
                        "note": "algorithmic bytes = K and V of every valid cache slot once (cross K/V once per image, shared by "
                                "its beams) + q + output; HIP events around every launch of one untimed generate call"}
+    pmc = os.path.join(ROOT, "profiles", "r2_generate_pmc_hbm_traffic.json")
+    if batch == 256 and os.path.exists(pmc):  # HBM-side bytes per launch from separate rocprofv3 --pmc passes over this leg (committed)
+        t = json.load(open(pmc))
+        res["roofline"]["traffic"] = t["bytes_per_launch"]
+        res["roofline"]["traffic_unit"] = "HBM-side bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, avg over the 24 decode-attention launches of a step; beams that share a prefix hit L2 for the shared slots, hence below the algorithmic figure)"
+        res["roofline"]["traffic_source"] = t["summary"] + " (commit " + t.get("commit", "?") + ")"
     res["roofline_gemm"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
                             "head": {"achieved": round(hf / ht / 1e12, 1), "frac": round(hf / ht / 1e12 / PEAK_TFLOPS["bf16"], 4),
                                      "ms_per_step": round(ht / nst * 1e3, 3), "launches_per_step": round(hn / nst, 1)},
