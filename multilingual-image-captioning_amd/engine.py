@@ -70,7 +70,10 @@ class Engine:
         tensor: amax, then quantise).  scaling="delayed" (default; the usual production recipe): the scale comes from the
         amax the same tensor had in the previous pass, the quantiser records the new amax on the way (one pass); values
         that outgrow the old amax saturate at +-FMAX for that one pass.  A tensor seen for the first time is scaled by its
-        current amax.  Weights are always re-quantised with their current amax, once per optimizer step."""
+        current amax.  Weights are re-quantised once per optimizer step — with their current amax ("current"), or ("delayed")
+        with the amax of the previous step's weights, recorded by the previous quantiser pass: an optimizer step moves a weight
+        by ~lr, so the one-step-old maximum is the current one to fp8 precision and the amax pass over 246 M parameters goes;
+        weights that arrive any other way (params setter, checkpoint restore) start again from their current amax."""
         if name in (None, "bf16", "bfloat16", "f32", "float32"):
             self.fp8 = False
             return
@@ -92,6 +95,8 @@ class Engine:
                            torch.empty((K, N), dtype=torch.float8_e4m3fn, device=self.dev),   # [in][out]: dX = dy W
                            self._w8_state[i])
         self._w8_stale = True
+        self._w8_part = torch.zeros((len(names), ops.fp8_amax_partials()), dtype=torch.float32, device=self.dev) if scaling == "delayed" else None
+        self._w8_seen = False  # delayed scaling: _w8_state carries the amax recorded by the previous quantiser pass
         # one (amax, 1/scale) slot per quantised activation / gradient tensor; delayed scaling: + its table of partial maxima
         self._a8_state = torch.zeros((1024, 2), dtype=torch.float32, device=self.dev)
         self._a8_part = torch.zeros((1024, ops.fp8_amax_partials()), dtype=torch.float32, device=self.dev) if scaling == "delayed" else None
@@ -100,8 +105,10 @@ class Engine:
         self._a8_cache: Dict = {}
         self._dw8_queue = []
 
-    def fp8_weights_changed(self):
+    def fp8_weights_changed(self, by_optimizer: bool = False):
         self._w8_stale = True
+        if not by_optimizer:
+            self._w8_seen = False
 
     def _fp8_begin_pass(self):
         """start of a forward(+backward) pass: re-quantise the weights if the optimizer moved them; current scaling: clear the
@@ -109,10 +116,18 @@ class Engine:
         if not self.fp8:
             return
         if self._w8_stale:
-            ops.zero(self._w8_state)
             P = self.P
-            items = [ops.fp8_item(P.w(n + ".w"), q.shape[0], q.shape[1], st, torch.float8_e4m3fn, q=q, qT=qT) for n, (q, qT, st) in self._w8.items()]
-            ops.fp8_quantize(items)
+            delayed = self.fp8_scaling == "delayed"
+            if delayed and self._w8_seen:
+                ops.fp8_roll_amax(self._w8_state, self._w8_part, len(self._w8))
+            else:
+                ops.zero(self._w8_state)
+                if delayed:
+                    ops.zero(self._w8_part)
+            items = [ops.fp8_item(P.w(n + ".w"), q.shape[0], q.shape[1], st, torch.float8_e4m3fn, q=q, qT=qT,
+                                  amax_next=self._w8_part[i] if delayed else None) for i, (n, (q, qT, st)) in enumerate(self._w8.items())]
+            ops.fp8_quantize(items, amax_pass=not (delayed and self._w8_seen))
+            self._w8_seen = delayed
             self._w8_stale = False
         n = len(self._a8_slots)
         if self.fp8_scaling == "delayed":

@@ -129,11 +129,11 @@ class FlaxCLIPVisionMBartPreTrainedModel(FlaxCLIPVisionMBartGenerationMixin):
         if self.engine.fp8:
             self.engine.fp8_weights_changed()
 
-    def invalidate_params_cache(self):
+    def invalidate_params_cache(self, by_optimizer: bool = False):
         self._params_cache = None
         self.store.version = getattr(self.store, "version", 0) + 1
         if self.engine.fp8:
-            self.engine.fp8_weights_changed()
+            self.engine.fp8_weights_changed(by_optimizer=by_optimizer)
 
     def _use_params(self, params):
         if params is not None and params is not self._params_cache:

@@ -386,7 +386,7 @@ class Trainer:
         if not self.overlap_optimizer:
             ops.adamw(st.master, st.m, st.v, st.grad, None if st.lp is st.master else st.lp, self.hyper, self.b1, self.b2, self.eps,
                       self.wd, grad_scale=1.0 / self.world)
-        m.invalidate_params_cache()
+        m.invalidate_params_cache(by_optimizer=True)
         self._state_dirty = True
         self.step += 1
         self.metrics_buf[0:1].copy_(loss)
