@@ -605,6 +605,18 @@ extern "C" int mic_attn_bwd(int dtype, int B, int H, int Tq, int Tk, const void*
   return MIC_OK;
 }
 
+// 8 cache elements as they arrive from memory (converted at use: a load in flight costs 4 registers in bf16)
+template <typename T> struct Raw8;
+template <> struct Raw8<uint16_t> {
+  u32x4 v;
+  __device__ __forceinline__ void load(const uint16_t* p) { v = *reinterpret_cast<const u32x4*>(p); }
+  __device__ __forceinline__ void get(float* o) const { unpack8(v, o); }
+};
+template <> struct Raw8<float> {
+  float4 a, b;
+  __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
+  __device__ __forceinline__ void get(float* o) const { o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w; }
+};
 // ------------------------------------------------------------------ decode-time attention (K9d): one wave per (row, head)
 // Latency-bound (measured ~15 us at one slot, 46 us at 63: dependent round trips x two residency rounds of the 16k waves;
 // re-mapping blocks so an image's beams share a CU, issuing V together with K, and LDS-free reductions all measured +-0).
@@ -635,14 +647,27 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(int R, int H, int max_
     float sc[8];
     int srow[8];
 #pragma unroll
+    for (int it = 0; it < 8; ++it) {  // slot ownership first: every K / V address of the chunk depends on it
+      const int slot = c0 + it * 8 + grp;
+      srow[it] = 0;
+      if (slot < n) srow[it] = src_row ? src_row[(size_t)r * max_len + slot] : r / row_div;
+    }
+    Raw8<T> kraw[8], vraw[8];  // K and V of the chunk requested together: one round trip instead of K -> softmax -> V
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int slot = c0 + it * 8 + grp;
+      if (slot < n) {
+        kraw[it].load(kc + ((size_t)srow[it] * max_len + slot) * ldc + h * 64 + sub * 8);
+        vraw[it].load(vc + ((size_t)srow[it] * max_len + slot) * ldc + h * 64 + sub * 8);
+      }
+    }
+#pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int slot = c0 + it * 8 + grp;
       float acc = 0.f;
-      srow[it] = 0;
       if (slot < n) {
-        srow[it] = src_row ? src_row[(size_t)r * max_len + slot] : r / row_div;
         float kv[8];
-        ld8(kc + ((size_t)srow[it] * max_len + slot) * ldc + h * 64 + sub * 8, kv);
+        kraw[it].get(kv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc += qv[e] * kv[e];
       }
@@ -672,7 +697,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(int R, int H, int max_
       const int slot = c0 + it * 8 + grp;
       if (slot < n) {
         float vv[8];
-        ld8(vc + ((size_t)srow[it] * max_len + slot) * ldc + h * 64 + sub * 8, vv);
+        vraw[it].get(vv);
         const float p = sc[it];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] += p * vv[e];
@@ -710,12 +735,23 @@ __global__ __launch_bounds__(256) void attn_decode_group_kernel(int NI, int H, i
     for (int e = 0; e < 8; ++e) qv[g][e] *= SCALE;
   }
   const int n = min(cur + 1, max_len);
+  // K and V of all this lane's slots are requested up front (raw 16-B registers): one memory round trip for the wave instead
+  // of K -> softmax -> V
+  Raw8<T> kraw[8], vraw[8];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int slot = it * 8 + grp;
+    if (slot < n) {
+      kraw[it].load(kc + ((size_t)img * max_len + slot) * ldc + h * 64 + sub * 8);
+      vraw[it].load(vc + ((size_t)img * max_len + slot) * ldc + h * 64 + sub * 8);
+    }
+  }
   float sc[G][8];
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     const int slot = it * 8 + grp;
     float kv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (slot < n) ld8(kc + ((size_t)img * max_len + slot) * ldc + h * 64 + sub * 8, kv);
+    if (slot < n) kraw[it].get(kv);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       float acc = 0.f;
@@ -747,7 +783,7 @@ __global__ __launch_bounds__(256) void attn_decode_group_kernel(int NI, int H, i
     const int slot = it * 8 + grp;
     if (slot < n) {
       float vv[8];
-      ld8(vc + ((size_t)img * max_len + slot) * ldc + h * 64 + sub * 8, vv);
+      vraw[it].get(vv);
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const float p = sc[g][it] * inv[g];
