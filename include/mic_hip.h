@@ -79,7 +79,7 @@ typedef struct {
   long long split_stride;  /* split_k > 1 only.  0: partial sums are atomically added into C (above).  > 0: split s stores its
                               partial tile plainly at C + s * split_stride (elements; C = fp32 workspace of split_k slabs),
                               to be summed by mic_sum_slabs — no atomics, no zero-fill, deterministic */
-  float* a_rowsum;         /* optional (bf16 only): a_rowsum[m] += sum over k < rowsum_k of A(m,k), fp32 atomics into a
+  float* a_rowsum;         /* optional (bf16, a_kmajor launches only): a_rowsum[m] += sum over k < rowsum_k of A(m,k), fp32 atomics into a
                               caller-zeroed vector.  With A = dy^T (a_kmajor, the weight-gradient GEMM dW = dy^T x) this is
                               the bias gradient colsum(dy) (nn.Dense bias; main.py:696 grads) from operand fragments the
                               kernel holds anyway — no extra pass over dy */

@@ -195,6 +195,7 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
     MIC_CHECK(args[i].split_stride >= 0 && (args[i].split_stride == 0 || args[i].split_stride >= (long long)(p.M - 1) * args[i].ldc + p.N),
               "mic_gemm: split_stride must cover one M x N slab");
     MIC_CHECK(p.split_stride == 0 || p.nsplit == args[i].split_k, "mic_gemm: split_k exceeds K/64 with a slab workspace");
+    MIC_CHECK(!args[i].a_rowsum || args[i].a_kmajor, "mic_gemm: a_rowsum needs a_kmajor (A = dy^T of the weight-gradient GEMM)");
     p.a_rowsum = args[i].a_rowsum;
     p.rowsum_k = args[i].rowsum_k > 0 ? args[i].rowsum_k : p.K;
     p.block_begin = blocks;

@@ -81,10 +81,13 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
 
   // optional row sums of A (bias gradient when A = dy^T): the K-tiles are dealt round-robin to the tile columns tn and the
   // k-steps to the wave columns wc, so every wave adds 8 fragment values on 1/(tiles_n*WNW) of its k-steps
+  // (compiled only into the A-k-major instantiations — the bias gradient rides on dW = dy^T x; the NT / NN kernels run at the
+  // 256-VGPR limit and have no registers for code they never execute)
+  constexpr bool RS = AK && F8 == 0;
   float bsum[AI];
 #pragma unroll
   for (int i = 0; i < AI; ++i) bsum[i] = 0.0f;
-  const bool do_rowsum = P.a_rowsum != nullptr;
+  const bool do_rowsum = RS && P.a_rowsum != nullptr;
   const int rs_tiles_n = P.tiles_n, rs_k = P.rowsum_k;  // registers: a kernarg load inside the K loop also waits on the LDS reads
 
   const int nk_total = P.K / BKT;
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
         for (int i = 0; i < AI; ++i) af[i] = read_frag<AK, BKT, UA>(At, a_off + i * 32, kk, lane);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) bfr[j] = read_frag<BKM, BKT, UB>(Bt, b_off + j * 32, kk, lane);
-        if (rs_tile && (kk % WNW) == wc) {
+        if constexpr (RS) if (rs_tile && (kk % WNW) == wc) {
           const int kb = (kt0 + t) * BKT + kk * 16 + 8 * (lane >> 5);  // this lane's 8 consecutive k
 #pragma unroll
           for (int i = 0; i < AI; ++i) {
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
     __syncthreads();
   }
 
-  if (do_rowsum) {
+  if constexpr (RS) if (do_rowsum) {
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const float v = bsum[i] + __shfl_xor(bsum[i], 32, 64);  // the two k-halves of the fragment
