@@ -146,43 +146,52 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
               acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i], b8[j], acc[i][j], F8 == 2 ? 1 : 0, 0, 0, 0x7f7f7f7f, 0,
                                                                           0x7f7f7f7f);  // cbsz/blgp: 0 = e4m3, 1 = e5m2; scales 2^0
         }
-      } else if constexpr (WM == 32) {
-        // 32 x 32 wave tile: one MFMA per k-step, all on the same accumulator — the K-tile's eight fragment reads go out together
-        // (the compiler otherwise issues k-step kk+1's reads behind MFMA kk and waits a full LDS latency in every k-step; these
-        // launches are latency chains, not throughput)
+      } else if constexpr (WM == 32 || (WM == 64 && !AK)) {
+        // small wave tiles (32 x 32: one MFMA per k-step on one accumulator; 64 x 32: two): the K-tile's fragment reads all go
+        // out together, then the MFMAs (the compiler otherwise issues k-step kk+1's reads behind the MFMAs of kk and waits a full
+        // LDS latency in every k-step; these launches are latency chains, not throughput)
         if (t + 1 < nk) {
           write_lds(gsm + ((t + 1) & 1) * STAGE);
           if (t + 2 < nk) load_regs(t + 2);
         }
-        bf16x8 af[KSTEPS], bfr[KSTEPS];
+        bf16x8 af[KSTEPS][AI], bfr[KSTEPS][NJ];
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
-          af[kk] = read_frag<AK, BKT, UA>(At, a_off, kk, lane);
-          bfr[kk] = read_frag<BKM, BKT, UB>(Bt, b_off, kk, lane);
+#pragma unroll
+          for (int i = 0; i < AI; ++i) af[kk][i] = read_frag<AK, BKT, UA>(At, a_off + i * 32, kk, lane);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) bfr[kk][j] = read_frag<BKM, BKT, UB>(Bt, b_off + j * 32, kk, lane);
         }
         if constexpr (RS) {
           if (rs_tile) {
 #pragma unroll
             for (int kk = 0; kk < KSTEPS; ++kk) {
               if ((kk % WNW) != wc) continue;
-              const int kb = (kt0 + t) * BKT + kk * 16 + 8 * (lane >> 5);
-              const u32x4 u = __builtin_bit_cast(u32x4, af[kk]);
-              const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-              float sacc = 0.0f;
+              const int kb = (kt0 + t) * BKT + kk * 16 + 8 * (lane >> 5);  // this lane's 8 consecutive k
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const float lo = __uint_as_float(w[q] << 16), hi = __uint_as_float(w[q] & 0xffff0000u);
-                sacc += (kb + 2 * q < rs_k ? lo : 0.0f) + (kb + 2 * q + 1 < rs_k ? hi : 0.0f);
+              for (int i = 0; i < AI; ++i) {
+                const u32x4 u = __builtin_bit_cast(u32x4, af[kk][i]);
+                const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+                float sacc = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const float lo = __uint_as_float(w[q] << 16), hi = __uint_as_float(w[q] & 0xffff0000u);
+                  sacc += (kb + 2 * q < rs_k ? lo : 0.0f) + (kb + 2 * q + 1 < rs_k ? hi : 0.0f);
+                }
+                bsum[i] += sacc;
               }
-              bsum[0] += sacc;
             }
           }
         }
 #pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk], bfr[kk], acc[0][0], 0, 0, 0);
+        for (int kk = 0; kk < KSTEPS; ++kk)
+#pragma unroll
+          for (int i = 0; i < AI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
         // pin the order (the scheduler otherwise sinks every read next to its MFMA): all DS reads, then the MFMAs
-        __builtin_amdgcn_sched_group_barrier(0x100, (AK ? 2 : 1) * KSTEPS + (BKM ? 2 : 1) * KSTEPS, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, KSTEPS, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, ((AK ? 2 : 1) * AI + (BKM ? 2 : 1) * NJ) * KSTEPS, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, KSTEPS * AI * NJ, 0);
       } else {
 #pragma unroll
       for (int kk = 0; kk < KSTEPS; ++kk) {
