@@ -53,9 +53,18 @@ template <> struct Tile<uint16_t> {
   // (non-KM B tile is stored [j][k]).
   template <bool AKM, bool BKM>
   static __device__ __forceinline__ void mma(f32x16& acc, const char* At, int a0, const char* Bt, int b0, int lane) {
+    // the four k-steps accumulate into ONE block: all fragment reads go out first, pinned in front of the MFMAs (the scheduler
+    // otherwise sinks each pair of reads next to its MFMA and waits an LDS round trip per k-step)
+    bf16x8 a[4], b[4];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag<AKM>(At, a0, kk, lane), frag<BKM>(Bt, b0, kk, lane), acc, 0, 0, 0);
+    for (int kk = 0; kk < 4; ++kk) {
+      a[kk] = frag<AKM>(At, a0, kk, lane);
+      b[kk] = frag<BKM>(Bt, b0, kk, lane);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk], b[kk], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, ((AKM ? 2 : 1) + (BKM ? 2 : 1)) * 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
   }
   static __device__ __forceinline__ void store4(char* t, int row, int col0, const float* v) {
     uint2 o;
