@@ -486,6 +486,19 @@ def test_gemm_a_rowsum_is_the_bias_gradient(dev, Mo, No, K, kvalid):
     assert (db3 - dy.float().sum(0)).abs().max().item() < 2e-3 * max(1.0, dy.float().sum(0).abs().max().item())
 
 
+def test_gemm_a_rowsum_needs_a_kmajor(dev):
+    """the row-sum code exists only in the A-k-major kernels (include/mic_hip.h: a_rowsum): any other layout is refused, not ignored"""
+    from mic_amd import ops
+    from mic_amd._lib import MicError
+
+    a = torch.zeros(256, 128, dtype=torch.bfloat16, device=dev)
+    w = torch.zeros(256, 128, dtype=torch.bfloat16, device=dev)
+    c = torch.empty(256, 256, dtype=torch.float32, device=dev)
+    rs = torch.zeros(256, dtype=torch.float32, device=dev)
+    with pytest.raises(MicError):
+        ops.gemm(a, w, c, 256, 256, 128, a_rowsum=rs)
+
+
 def test_gemm_split_k_slabs_and_sum(dev):
     """split_k with split_stride: every split stores its partial tile into its own fp32 slab (no atomics, no zero-fill);
     mic_sum_slabs adds the slabs and rounds once.  Same result as the un-split GEMM; deterministic run to run."""
