@@ -127,7 +127,31 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
       const char* cur = gsm + (t & 1) * STAGE;
       const char* At = cur + a_half * HALF_A;
       const char* Bt = cur + NHA * HALF_A + b_half * HALF_B;
-      if constexpr (F8 != 0) {
+      if constexpr (F8 != 0 && WM <= 64) {
+        // fp8, small wave tiles: both halves' fragment reads in front of the MFMAs (as for bf16 below)
+        if (t + 1 < nk) {
+          write_lds(gsm + ((t + 1) & 1) * STAGE);
+          if (t + 2 < nk) load_regs(t + 2);
+        }
+        i32x8 a8[2][AI], b8[2][NJ];
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) {
+#pragma unroll
+          for (int i = 0; i < AI; ++i) a8[mm][i] = read_frag8(At, a_off + i * 32, mm, lane);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) b8[mm][j] = read_frag8(Bt, b_off + j * 32, mm, lane);
+        }
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+          for (int i = 0; i < AI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[mm][i], b8[mm][j], acc[i][j], F8 == 2 ? 1 : 0, 0, 0, 0x7f7f7f7f, 0,
+                                                                          0x7f7f7f7f);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * 2 * (AI + NJ), 0);  // two 16-B reads per fragment
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * AI * NJ, 0);
+      } else if constexpr (F8 != 0) {
 #pragma unroll
         for (int mm = 0; mm < 2; ++mm) {  // two K = 64 MFMAs per 128-byte stage
           if (mm == 0 && t + 1 < nk) {
