@@ -1,4 +1,6 @@
-"""Generates tests/golden/twin_small_decode_grads.npz — run ONLY in the build container (needs transformers 5.x).
+"""Generates tests/golden/twin_small_decode_grads.npz and twin_small_default_decode_grads.npz — run ONLY in the build
+container (needs transformers 5.x).  One file per switch setting of make_golden.VARIANTS ("" = the twin as shipped: erf GELU /
+eps 1e-5; "_default" = the product defaults: tanh GELU / eps 1e-6).
 
 Second fixture of the PyTorch twins (same reduced config, seed and weights as make_golden.py):
   * KV-cached decoding: the twin's `MBartDecoder(use_cache=True)` fed one token per step with its own `past_key_values`
@@ -21,7 +23,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
-from make_golden import SEED, SMALL, load_into_twin  # noqa: E402
+from make_golden import SEED, VARIANTS, load_into_twin, variant_cfg  # noqa: E402
 
 from oracle import model_ref as M  # noqa: E402
 from oracle import train_ref  # noqa: E402
@@ -50,8 +52,8 @@ def sub(a):
     return a[:: max(1, -(-a.size // 6000))].copy()
 
 
-def main():
-    cfg = M.RefConfig(**SMALL)
+def main(suffix=""):
+    cfg = variant_cfg(suffix)
     p = M.init_params(cfg, seed=SEED, perturb_ln=True)
     vit, dec = load_into_twin(cfg, p)
     g = torch.Generator().manual_seed(4321)
@@ -113,8 +115,9 @@ def main():
         out[f"grad_{tag}|model/visual_projection/kernel"] = sub(vp_k.grad.numpy())
         out[f"grad_{tag}|model/visual_projection/bias"] = sub(vp_b.grad.numpy())
         out[f"grad_{tag}|final_logits_bias"] = sub(flb.grad.numpy())
-    out.update(g_pixels=pixels.numpy(), g_labels=labels.numpy(), g_mask=mask.numpy(), g_dec_in=dec_in.numpy(), seed=np.int64(SEED))
-    path = os.path.join(HERE, "twin_small_decode_grads.npz")
+    out.update(g_pixels=pixels.numpy(), g_labels=labels.numpy(), g_mask=mask.numpy(), g_dec_in=dec_in.numpy(), seed=np.int64(SEED),
+               gelu=np.array(cfg.gelu), decoder_ln_eps=np.float64(cfg.decoder_ln_eps))
+    path = os.path.join(HERE, f"twin_small{suffix}_decode_grads.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
     # immediate self-check of the oracle
@@ -145,4 +148,5 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    for sfx in VARIANTS:
+        main(sfx)

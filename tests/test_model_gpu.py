@@ -17,6 +17,14 @@ from util_small import SEED, batch, make_pair
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "twin_small.npz")
+# fixture sets (tests/golden/make_golden.py): "" = the twin as transformers ships it (erf GELU, eps 1e-5); "_default" = the twin
+# driven at the product-default switch settings (tanh GELU, eps 1e-6) — the settings engine.py runs when nothing is configured
+VARIANTS = ["", "_default"]
+
+
+def _fixture(path, variant):
+    g = np.load(path.replace("twin_small", "twin_small" + variant))
+    return g, dict(gelu=str(g["gelu"]), decoder_ln_eps=float(g["decoder_ln_eps"]))
 
 
 def scale_err(got, ref):
@@ -26,10 +34,15 @@ def scale_err(got, ref):
     return (d.max() / s).item(), (d.mean() / s).item()
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_logits_match_golden_twin(dev, dtype):
-    g = np.load(GOLD)
-    rc, p, model = make_pair(dtype, dev)
+def test_logits_match_golden_twin(dev, dtype, variant):
+    g, sw = _fixture(GOLD, variant)
+    rc, p, model = make_pair(dtype, dev, **sw)
+    if variant == "_default":  # nothing configured = these settings
+        from mic_amd import CLIPVisionMBartConfig
+        mc = CLIPVisionMBartConfig().mbart_config
+        assert (mc.gelu_variant, mc.decoder_ln_eps) == (sw["gelu"], sw["decoder_ln_eps"])
     assert int(g["seed"]) == SEED
     out = model(g["pixels"], g["ids"], g["mask"])
     logits = out[0]
@@ -40,6 +53,11 @@ def test_logits_match_golden_twin(dev, dtype):
         assert mx < 2e-4, (mx, mean)
     else:
         assert mx < 3e-2 and mean < 4e-3, (mx, mean)
+    if dtype == torch.float32:
+        # the other switch setting's fixture lies 5e-6 of the scale away: further than this path's own distance to ITS fixture
+        other, _ = _fixture(GOLD, "_default" if variant == "" else "")
+        mx_o, _ = scale_err(logits[valid.to(dev)], torch.from_numpy(other["logits"])[valid])
+        assert mx < mx_o, (mx, mx_o)
     enc = model.encode(g["pixels"], _int32_cast=False)
     mx, mean = scale_err(enc.last_hidden_state, torch.from_numpy(g["ehs"]))
     assert mx < (2e-4 if dtype == torch.float32 else 3e-2), (mx, mean)
@@ -176,11 +194,12 @@ def _sub(a):
     return a[:: max(1, -(-a.size // 6000))]
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_cached_decode_matches_twin_golden(dev, dtype):
+def test_cached_decode_matches_twin_golden(dev, dtype, variant):
     """decode() with past_key_values on the HIP path vs the twin's own `use_cache=True` logits (committed golden)."""
-    g = np.load(GOLD2)
-    rc, p, model = make_pair(dtype, dev)
+    g, sw = _fixture(GOLD2, variant)
+    rc, p, model = make_pair(dtype, dev, **sw)
     assert int(g["seed"]) == SEED
     enc = model.encode(g["dec_pixels"], _int32_cast=False)
     ids = g["dec_step_ids"]
@@ -193,12 +212,13 @@ def test_cached_decode_matches_twin_golden(dev, dtype):
         assert (mx < 2e-4) if dtype == torch.float32 else (mx < 3e-2 and mean < 4e-3), (t, mx, mean)
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("ls", [0.0, 0.1])
-def test_gradients_match_twin_autograd_golden(dev, ls):
+def test_gradients_match_twin_autograd_golden(dev, ls, variant):
     """The hand-derived HIP backward (float32 mode) against the twin's autograd gradients from the committed golden —
     not via the oracle."""
-    g = np.load(GOLD2)
-    rc, p, model = make_pair(torch.float32, dev)
+    g, sw = _fixture(GOLD2, variant)
+    rc, p, model = make_pair(torch.float32, dev, **sw)
     d = model._dev
     labels, mask, dec_in = g["g_labels"], g["g_mask"], g["g_dec_in"]
     B, T = labels.shape

@@ -11,13 +11,24 @@ import torch
 from util_small import ref_config
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "twin_small.npz")
+GDIR = os.path.dirname(GOLD)
+# fixture sets: "" = the twin as transformers ships it (erf GELU, eps 1e-5); "_default" = the twin driven at the product defaults
+# (tanh GELU, eps 1e-6) — tests/golden/make_golden.py
+VARIANTS = ["", "_default"]
 
 
-def test_oracle_matches_twin_golden():
+def _fixture(name, variant):
+    g = np.load(os.path.join(GDIR, name.replace("twin_small", "twin_small" + variant)))
+    rc = ref_config(str(g["gelu"]), float(g["decoder_ln_eps"]))
+    assert (rc.gelu, rc.decoder_ln_eps) == (("erf", 1e-5) if variant == "" else ("tanh", 1e-6))
+    return g, rc
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_oracle_matches_twin_golden(variant):
     from oracle import model_ref as M
 
-    g = np.load(GOLD)
-    rc = ref_config("erf", 1e-5)
+    g, rc = _fixture("twin_small.npz", variant)
     p = M.init_params(rc, seed=int(g["seed"]), perturb_ln=True)
     px, ids, mask = torch.from_numpy(g["pixels"]), torch.from_numpy(g["ids"]), torch.from_numpy(g["mask"])
     with torch.no_grad():
@@ -29,8 +40,22 @@ def test_oracle_matches_twin_golden():
     assert np.abs(last.numpy() - g["enc_last"]).max() < 2e-5
     assert np.abs(pooled.numpy() - g["pooled"]).max() < 2e-5
     assert np.abs(ehs.numpy() - g["ehs"]).max() < 2e-5
+    # 3e-6: the two switch settings differ by 1.4e-5 on these logits, so each fixture only passes at ITS setting
     assert np.abs(h.numpy() - g["dec_hidden"])[valid].max() < 2e-5
-    assert np.abs(logits.numpy() - g["logits"])[valid].max() < 2e-5
+    assert np.abs(logits.numpy() - g["logits"])[valid].max() < 3e-6
+
+
+def test_twin_fixtures_tell_the_switch_settings_apart():
+    """the oracle at the WRONG switch setting misses either fixture's logits by more than the tolerance above"""
+    from oracle import model_ref as M
+
+    for variant, wrong in (("", ("tanh", 1e-6)), ("_default", ("erf", 1e-5))):
+        g, _ = _fixture("twin_small.npz", variant)
+        rc = ref_config(*wrong)
+        p = M.init_params(rc, seed=int(g["seed"]), perturb_ln=True)
+        with torch.no_grad():
+            logits = M.forward_logits(rc, p, torch.from_numpy(g["pixels"]), torch.from_numpy(g["ids"]), torch.from_numpy(g["mask"]))
+        assert np.abs(logits.numpy() - g["logits"])[g["mask"].astype(bool)].max() > 6e-6
 
 
 GOLD2 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "twin_small_decode_grads.npz")
@@ -41,13 +66,13 @@ def _sub(a):
     return a[:: max(1, -(-a.size // 6000))]
 
 
-def test_oracle_cached_decode_matches_twin_golden():
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_oracle_cached_decode_matches_twin_golden(variant):
     """The oracle's static-cache decode_step against the twin's own `use_cache=True` decoding (golden made by
     tests/golden/make_golden_decode_grads.py): pins the cache path to something other than the oracle itself."""
     from oracle import model_ref as M
 
-    g = np.load(GOLD2)
-    rc = ref_config("erf", 1e-5)
+    g, rc = _fixture("twin_small_decode_grads.npz", variant)
     p = M.init_params(rc, seed=int(g["seed"]), perturb_ln=True)
     ids, ehs = torch.from_numpy(g["dec_step_ids"]), torch.from_numpy(g["dec_ehs"])
     B, S = ids.shape
@@ -57,19 +82,19 @@ def test_oracle_cached_decode_matches_twin_golden():
         st = M.DecodeState(rc, B, S + 3)
         for t in range(S):
             lg = M.decode_step(rc, p, st, ids[:, t:t + 1], torch.full((B, 1), t), ehs)
-            assert np.abs(lg[:, 0].numpy() - g["dec_step_logits"][:, t]).max() < 2e-5, t
+            assert np.abs(lg[:, 0].numpy() - g["dec_step_logits"][:, t]).max() < 3e-6, t
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("ls", [0.0, 0.1])
-def test_oracle_gradients_match_twin_autograd_golden(ls):
+def test_oracle_gradients_match_twin_autograd_golden(ls, variant):
     """value_and_grad of the masked (label-smoothed) cross-entropy: the oracle (autograd over oracle.model_ref) against the
     twin's autograd over ITS forward, leaves from every part of the graph.  The twin's nn.Embedding(padding_idx) drops the
     input-embedding gradient of the pad row, flax nn.Embed does not: that row is excluded."""
     from oracle import model_ref as M
     from oracle import train_ref
 
-    g = np.load(GOLD2)
-    rc = ref_config("erf", 1e-5)
+    g, rc = _fixture("twin_small_decode_grads.npz", variant)
     p = M.init_params(rc, seed=int(g["seed"]), perturb_ln=True)
     t = lambda k: torch.from_numpy(g[k])
     loss, gr = train_ref.loss_and_grads(rc, p, t("g_pixels"), t("g_labels"), t("g_mask"), t("g_dec_in"), label_smoothing_factor=ls)
