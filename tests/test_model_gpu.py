@@ -41,7 +41,7 @@ def test_logits_match_golden_twin(dev, dtype, variant):
     rc, p, model = make_pair(dtype, dev, **sw)
     if variant == "_default":  # nothing configured = these settings
         from mic_amd import CLIPVisionMBartConfig
-        mc = CLIPVisionMBartConfig().mbart_config
+        mc = CLIPVisionMBartConfig(mbart_config={}, clip_vision_config={}).mbart_config
         assert (mc.gelu_variant, mc.decoder_ln_eps) == (sw["gelu"], sw["decoder_ln_eps"])
     assert int(g["seed"]) == SEED
     out = model(g["pixels"], g["ids"], g["mask"])
