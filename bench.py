@@ -207,7 +207,7 @@ def bench_generate(model, cfg, dev, batch=256, langs=(250004, 250008, 250003, 25
         return res
     # one more, untimed call with every decode-attention and GEMM launch bracketed by HIP events on the launch stream
     recs = []
-    orig_attn, orig_gemm = ops.attn_decode, ops.gemm
+    orig_attn, orig_gemm, orig_grouped = ops.attn_decode, ops.gemm, ops.gemm_grouped
     es = 2 if model.dtype == torch.bfloat16 else 4
 
     def ev():
@@ -232,12 +232,20 @@ def bench_generate(model, cfg, dev, batch=256, langs=(250004, 250008, 250003, 25
         recs.append(("head" if N == st.Vpad else "gemm", 2.0 * M * N * K, e0, e1))
         return r
 
-    ops.attn_decode, ops.gemm = timed_attn, timed_gemm
+    def timed_grouped(arg_list):  # the fused q/k/v projection of a decoder layer: one launch, three problems
+        e0, e1 = ev()
+        e0.record()
+        r = orig_grouped(arg_list)
+        e1.record()
+        recs.append(("gemm", sum(2.0 * g.M * g.N * g.K for g in arg_list), e0, e1))
+        return r
+
+    ops.attn_decode, ops.gemm, ops.gemm_grouped = timed_attn, timed_gemm, timed_grouped
     try:
         model.generate(px, forced_bos_token_id=langs[0], num_beams=4, max_length=max_length)
         torch.cuda.synchronize()
     finally:
-        ops.attn_decode, ops.gemm = orig_attn, orig_gemm
+        ops.attn_decode, ops.gemm, ops.gemm_grouped = orig_attn, orig_gemm, orig_grouped
 
     def agg(kind):
         sel = [r for r in recs if r[0] == kind]
@@ -247,22 +255,42 @@ def bench_generate(model, cfg, dev, batch=256, langs=(250004, 250008, 250003, 25
     hf, ht, hn = agg("head")
     gf, gt, gn = agg("gemm")
     nst = max_length - 1
-    res["roofline"] = {"bound": "hbm", "kernel": "attn_decode_kernel", "achieved": round(ab / at / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                       "frac": round(ab / at / 1e9 / PEAK_HBM_GBS, 4), "traffic": None, "launches_per_step": round(an / nst, 1),
-                       "ms_per_step": round(at / nst * 1e3, 3), "algorithmic_MB_per_launch": round(ab / an / 1e6, 2),
-                       "note": "algorithmic bytes = K and V of every valid cache slot once (cross K/V once per image, shared by "
-                               "its beams) + q + output; HIP events around every launch of one untimed generate call"}
-    pmc = os.path.join(ROOT, "profiles", "r2_generate_pmc_hbm_traffic.json")
-    if batch == 256 and os.path.exists(pmc):  # HBM-side bytes per launch from separate rocprofv3 --pmc passes over this leg (committed)
-        t = json.load(open(pmc))
-        res["roofline"]["traffic"] = t["bytes_per_launch"]
-        res["roofline"]["traffic_unit"] = "HBM-side bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, avg over the 24 decode-attention launches of a step; beams that share a prefix hit L2 for the shared slots, hence below the algorithmic figure)"
-        res["roofline"]["traffic_source"] = t["summary"] + " (commit " + t.get("commit", "?") + ")"
-    res["roofline_gemm"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
-                            "head": {"achieved": round(hf / ht / 1e12, 1), "frac": round(hf / ht / 1e12 / PEAK_TFLOPS["bf16"], 4),
-                                     "ms_per_step": round(ht / nst * 1e3, 3), "launches_per_step": round(hn / nst, 1)},
-                            "layers": {"achieved": round(gf / gt / 1e12, 1), "frac": round(gf / gt / 1e12 / PEAK_TFLOPS["bf16"], 4),
-                                       "ms_per_step": round(gt / nst * 1e3, 3), "launches_per_step": round(gn / nst, 1)}}
+    # the dominant kernel class of a decoder step BY TIME is the MFMA GEMM (LM head + the layers' projections): that is the
+    # leg's `roofline`; the decode attention (HBM-bound) and the whole step are reported beside it
+    peak = PEAK_TFLOPS["bf16"] if model.dtype == torch.bfloat16 else PEAK_TFLOPS["f32"]
+    res["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel + gemm_phased_kernel (every GEMM launch of a decoder step: LM head + layer projections)",
+                       "achieved": round((hf + gf) / (ht + gt) / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
+                       "frac": round((hf + gf) / (ht + gt) / 1e12 / peak, 4), "traffic": None,
+                       "ms_per_step": round((ht + gt) / nst * 1e3, 3), "launches_per_step": round((hn + gn) / nst, 1),
+                       "gflop_per_step": round((hf + gf) / nst / 1e9, 1),
+                       "head": {"achieved": round(hf / ht / 1e12, 1), "frac": round(hf / ht / 1e12 / peak, 4),
+                                "ms_per_step": round(ht / nst * 1e3, 3), "launches_per_step": round(hn / nst, 1)},
+                       "layers": {"achieved": round(gf / gt / 1e12, 1), "frac": round(gf / gt / 1e12 / peak, 4),
+                                  "ms_per_step": round(gt / nst * 1e3, 3), "launches_per_step": round(gn / nst, 1)},
+                       "note": "HIP events around every GEMM launch (plain and grouped) of one untimed generate call; flops = sum of 2MNK"}
+    res["roofline_attention"] = {"bound": "hbm", "kernel": "attn_decode_kernel + attn_decode_group_kernel", "achieved": round(ab / at / 1e9, 1),
+                                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ab / at / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+                                 "launches_per_step": round(an / nst, 1), "ms_per_step": round(at / nst * 1e3, 3),
+                                 "algorithmic_MB_per_launch": round(ab / an / 1e6, 2),
+                                 "note": "algorithmic bytes = K and V of every valid cache slot once (cross K/V once per image, shared by "
+                                         "its beams) + q + output; HIP events around every launch of one untimed generate call"}
+    for name in ("r3_generate_pmc_hbm_traffic.json", "r2_generate_pmc_hbm_traffic.json"):
+        pmc = os.path.join(ROOT, "profiles", name)
+        if batch == 256 and os.path.exists(pmc):  # HBM-side bytes per launch from separate rocprofv3 --pmc passes over this leg (committed)
+            t = json.load(open(pmc))
+            src = t["summary"] + " (commit " + t.get("commit", "?") + ")"
+            ra = res["roofline_attention"]
+            att = t.get("attention", t)  # r2 file: attention figures at the top level
+            ra["traffic"] = att["bytes_per_launch"]
+            ra["frac_on_counter_bytes"] = round(att["bytes_per_launch"] * an / at / 1e9 / PEAK_HBM_GBS, 4)
+            ra["traffic_unit"] = ("HBM-side bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, avg over the decode-attention launches of a step; beams "
+                                  "that share a prefix hit L2 for the shared slots, hence below the algorithmic figure)")
+            ra["traffic_source"] = src
+            if "gemm" in t:
+                res["roofline"]["traffic"] = t["gemm"]["bytes_per_launch"]
+                res["roofline"]["traffic_unit"] = "HBM-side bytes per GEMM launch (PMC FETCH_SIZE x2 + WRITE_SIZE, avg over a decoder step's GEMM launches)"
+                res["roofline"]["traffic_source"] = src
+            break
     scale = batch * 4 / 1024.0  # SURVEY's step figures are for 1024 rows
     res["step_vs_roofline"] = {"mfma_frac": round(DECODE_STEP_TFLOP * scale / (ms_step * 1e-3) / PEAK_TFLOPS["bf16"], 4),
                                "hbm_frac": round(DECODE_STEP_GB * scale / (ms_step * 1e-3) / PEAK_HBM_GBS, 4),
@@ -280,11 +308,22 @@ def pmc_traffic(argv, kernel_prefix="gemm_"):
     import tempfile
 
     tot, launches = 0.0, 0
+    # the child is a fresh single-GPU process: no launcher variables (it must not try to join this job's rendezvous), no --gpus
+    drop = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE")
+    child_argv, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
+        elif a in ("--gpus", "--steps", "--warmup"):
+            skip = True
+        elif a != "--pmc-traffic" and not a.startswith(("--gpus=", "--steps=", "--warmup=")):
+            child_argv.append(a)
     for ctr, factor in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
         d = tempfile.mkdtemp(prefix="mic_pmc_", dir="/tmp")
-        env = dict(os.environ, TMPDIR="/tmp")
+        env = {k: v for k, v in os.environ.items() if k not in drop and not k.startswith(("MASTER_", "TORCHELASTIC_"))}
+        env["TMPDIR"] = "/tmp"
         cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__)] + \
-              [a for a in argv if a != "--pmc-traffic"] + ["--steps", "1", "--warmup", "1", "--no-roofline", "--no-generate", "--no-cpu-baseline"]
+              child_argv + ["--steps", "1", "--warmup", "1", "--no-roofline", "--no-generate", "--no-cpu-baseline", "--no-dense-leg"]
         subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
         n = 0
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -294,7 +333,8 @@ def pmc_traffic(argv, kernel_prefix="gemm_"):
                     n += 1
         launches = max(launches, n)
         shutil.rmtree(d, ignore_errors=True)
-    return (tot / 2.0 / launches, launches / 2) if launches else (None, 0)  # 2 steps (1 warm-up + 1) per pass
+    # `tot` and `launches` both run over the pass's 2 steps (1 warm-up + 1): bytes per launch = tot / launches
+    return (tot / launches, launches / 2) if launches else (None, 0)
 
 
 def main():
@@ -313,6 +353,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-generate", action="store_true", help="skip the beam-4 captions/sec leg")
+    ap.add_argument("--no-dense-leg", action="store_true", help="skip the short dense-caption timing reported beside the headline")
     ap.add_argument("--gen-batch", type=int, default=256)
     ap.add_argument("--generate-only", action="store_true", help="profiling aid: only the beam-4 leg")
     ap.add_argument("--pmc-traffic", action="store_true", help="measure roofline.traffic now (two rocprofv3 child passes, ~2 min)")
@@ -404,6 +445,36 @@ def main():
         dt = float(tmax.item())
     images_per_sec = world * B * args.steps / dt
 
+    # the same step on dense captions (every caption 62 tokens: no padded label positions, the configuration BASELINE.md §4's
+    # "padding not discounted" FLOP count describes) — a second, shorter timed region on every rank, reported beside the headline
+    dense = None
+    if not args.dense_captions and not args.no_dense_leg and not args.small:
+        dsteps = max(2, min(args.steps, 6))
+        db2 = []
+        for i in range(2):
+            b = synth_batch(B, T, V, img, 4321 + rank * 100 + i, dense=True)
+            d2 = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
+            idx, rl = loss_rows(b["attention_mask"], b["input_ids"])
+            d2["loss_rows"] = (torch.from_numpy(idx).to(dev), torch.from_numpy(rl).to(dev))
+            db2.append(d2)
+        for i in range(2):
+            tr.train_step(db2[i % 2])
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(dsteps):
+            tr.train_step(db2[i % 2])
+        barrier()
+        ddt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([ddt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            ddt = float(tmax.item())
+        dense = {"ms_per_step": round(ddt / dsteps * 1e3, 3), "images_per_sec": round(world * B * dsteps / ddt, 1), "steps": dsteps,
+                 "model_tflops_per_gpu": round(TRAIN_GFLOP_PER_SAMPLE * B * dsteps / ddt / 1e3, 1),
+                 "note": "every caption 62 tokens + language id + eos: all 64 positions carry loss, the LM head runs on every row; "
+                         "201.3 GFLOP per sample are executed in full"}
+        del db2
+
     if rank == 0:
         note(f"{images_per_sec:.1f} images/s; roofline step")
     roofline = None
@@ -436,8 +507,6 @@ def main():
             recs.append((sum(2.0 * g.M * g.N * g.K for g in arg_list), e0, e1, "grouped"))
             return r
 
-        ops.gemm = timed_gemm
-        ops.gemm_grouped = timed_grouped
         # the instrumented step keeps the weight-gradient GEMMs on the main stream: on their own stream (the default) they overlap
         # the next layer's kernels and an event pair would time two kernels sharing the chip, not the kernel
         # ... and AdamW as one launch after backward: per bucket on its own stream (the default) it shares HBM with the GEMMs it overlaps
@@ -449,14 +518,16 @@ def main():
         # an un-instrumented step goes first WITHOUT a sync in between: the host then issues the instrumented step while the GPU
         # is still busy, so no event pair contains the host's issue time of its kernel (two event records + a ctypes launch cost
         # about as much host time as a 25-us GEMM runs)
-        ops.gemm, ops.gemm_grouped = orig, orig_g
-        tr.train_step(dbatches[1])
-        ops.gemm, ops.gemm_grouped = timed_gemm, timed_grouped
-        tr.train_step(dbatches[0])
-        torch.cuda.synchronize()
-        eng.dw_overlap = overlap
-        tr.overlap_optimizer, tr.reducer.on_ready = opt_overlap, on_ready
-        ops.gemm, ops.gemm_grouped = orig, orig_g
+        try:
+            ops.gemm, ops.gemm_grouped = orig, orig_g
+            tr.train_step(dbatches[1])
+            ops.gemm, ops.gemm_grouped = timed_gemm, timed_grouped
+            tr.train_step(dbatches[0])
+            torch.cuda.synchronize()
+        finally:  # an exception must not leave the trainer or the ops module patched for the beam-4 leg
+            eng.dw_overlap = overlap
+            tr.overlap_optimizer, tr.reducer.on_ready = opt_overlap, on_ready
+            ops.gemm, ops.gemm_grouped = orig, orig_g
         flops = sum(r[0] for r in recs)
         ms = sum(r[1].elapsed_time(r[2]) for r in recs)
         ach = flops / (ms * 1e-3) / 1e12
@@ -471,7 +542,9 @@ def main():
                 roofline["fp8_gemms"] = {"achieved": round(f8f / f8t / 1e12, 1), "frac_of_fp8_peak": round(f8f / f8t / 1e12 / PEAK_TFLOPS["fp8"], 4),
                                          "launches_per_step": len(f8), "ms_per_step": round(f8t * 1e3, 3)}
             roofline["note"] = "peak = dense fp8 MFMA peak; only the QKV/FFN GEMMs run in fp8 (configs[4]), the rest in bf16"
-        if args.pmc_traffic:
+        if args.pmc_traffic and world > 1:
+            note("--pmc-traffic is a single-GPU measurement (rocprofv3 child passes of this command); skipped under a launcher")
+        if args.pmc_traffic and world == 1:
             tb, nl = pmc_traffic(sys.argv[1:])
             roofline["traffic"] = None if tb is None else int(tb)
             roofline["traffic_unit"] = "HBM bytes per GEMM launch (PMC FETCH_SIZE x2 + WRITE_SIZE, x1024 B), measured now by two rocprofv3 child passes"
@@ -516,7 +589,11 @@ def main():
                 gen["cpu_baseline"] = {"value": None, "unit": "captions/sec", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
 
     if rank == 0:
-        step_flops = TRAIN_GFLOP_PER_SAMPLE * 1e9 * B
+        # executed work: the LM head (forward, dE, dX: 3 x 2 x rows x V x d) runs only on the label positions that carry loss
+        n_loss = sum(int(b["attention_mask"].sum()) for b in batches) / len(batches)
+        d_model = cfg.mbart_config.d_model
+        dense_flops = TRAIN_GFLOP_PER_SAMPLE * 1e9 * B if not args.small else float("nan")
+        step_flops = dense_flops - 6.0 * (B * T - n_loss) * V * d_model
         head = ("logits/CE on all label positions (dense captions: every position carries loss)" if args.dense_captions else
                 "logits/CE on the label positions with loss mask 1 only (exact; ragged captions n~U{8..62})")
         line = {
@@ -531,6 +608,11 @@ def main():
                        "grad_allreduce": f"{args.grad_comm} flat buckets, RCCL, side stream",
                        "lm_head": head, "gemm_dtype": "fp8 e4m3 (fwd) / e5m2 (grads) for QKV+FFN, bf16 elsewhere" if args.dtype == "fp8" else args.dtype},
             "model_tflops_per_gpu": round(step_flops * args.steps / dt / 1e12, 1),
+            "model_tflops_note": f"EXECUTED model FLOPs per step ({step_flops / 1e12:.2f} TF: dense {dense_flops / 1e12:.2f} TF of SURVEY 8d minus the LM-head work on the "
+                                 f"{B * T - n_loss:.0f} padded label positions, whose loss weight is 0) / ms_per_step; dense_equivalent divides the full dense count "
+                                 "by the same time (NOT executed work); dense_captions is the measured step when every position carries loss",
+            "dense_equivalent_tflops_per_gpu": round(dense_flops * args.steps / dt / 1e12, 1),
+            "dense_captions": dense,
             "final_loss": round(loss, 4),
             "roofline": roofline, "cpu_baseline": cpu, "beam4_generate": gen,
         }

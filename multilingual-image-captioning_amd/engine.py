@@ -105,6 +105,22 @@ class Engine:
         self._a8_cache: Dict = {}
         self._dw8_queue = []
 
+    def storage_dtype_gemms(self):
+        """context: every Linear runs in the storage dtype (bf16) even when the trainer switched the projections to fp8 — the
+        inference entry points (`encode`, `decode`, `generate`) are not part of a train / eval pass: nothing re-quantises the
+        weights for them or rolls the activation scales, so fp8 launches there would read stale (or never written) copies"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            keep = self.fp8
+            self.fp8 = False
+            try:
+                yield
+            finally:
+                self.fp8 = keep
+        return ctx()
+
     def fp8_weights_changed(self, by_optimizer: bool = False):
         self._w8_stale = True
         if not by_optimizer:

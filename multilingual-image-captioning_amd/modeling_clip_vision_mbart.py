@@ -218,7 +218,8 @@ class FlaxCLIPVisionMBartForConditionalGeneration(FlaxCLIPVisionMBartPreTrainedM
         self._check_pixels(px)
         B = px.shape[0]
         # modeling:330 — `jnp.array(pixel_values, dtype="i4")`: truncation toward zero, reproduced inside im2col
-        last, ehs = self.engine.vit_forward(px, save=False, trunc_int32=_int32_cast)
+        with self.engine.storage_dtype_gemms():  # inference stays in the storage dtype (fp8 copies belong to train / eval passes)
+            last, ehs = self.engine.vit_forward(px, save=False, trunc_int32=_int32_cast)
         S, d = self.store.S, self.store.d
         pooled = self.engine.vit_pooler(last, B)
         out = ModelOutput(last_hidden_state=ehs[: B * S].reshape(B, S, d).clone(), pooler_output=pooled)
@@ -252,7 +253,8 @@ class FlaxCLIPVisionMBartForConditionalGeneration(FlaxCLIPVisionMBartPreTrainedM
         mask = torch.ones_like(ids) if decoder_attention_mask is None else self._dev(decoder_attention_mask, torch.int32)
         ehs_buf = self.engine.buf("v.ehs", R * S, d)
         ehs_buf[: R * S].copy_(ehs.reshape(R * S, d))
-        hf = self.engine.decoder_forward(ids.reshape(-1), pos.reshape(-1), mask, ehs_buf, R, T, save=False, seed=None)
+        with self.engine.storage_dtype_gemms():
+            hf = self.engine.decoder_forward(ids.reshape(-1), pos.reshape(-1), mask, ehs_buf, R, T, save=False, seed=None)
         logits = self.engine.head_logits(hf, R * T)
         out = ModelOutput(logits=logits[: R * T, :V].reshape(R, T, V))
         return out if return_dict is not False else out.to_tuple()

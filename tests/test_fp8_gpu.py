@@ -207,6 +207,39 @@ def test_fp8_trainer_learns_and_eval_matches(dev):
         m32.engine.set_gemm_dtype("fp8")
 
 
+def test_fp8_trainer_inference_entry_points_stay_in_the_storage_dtype(dev):
+    """`encode` / `decode` / `generate` beside an fp8 trainer run bf16 GEMMs: identical to a bf16 engine holding the same weights,
+    (i) directly after Trainer construction, when no pass has quantised the fp8 weight copies yet, and (ii) directly after a
+    train_step, when those copies are one optimizer step stale."""
+    from mic_amd import Trainer, create_learning_rate_fn
+
+    rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.0)
+    _, _, plain = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.0)
+    tr = Trainer(model, create_learning_rate_fn(64, 2, 4, 2, 1e-3), gemm_dtype="fp8")
+    tp = Trainer(plain, create_learning_rate_fn(64, 2, 4, 2, 1e-3))
+    assert model.engine.fp8 and not plain.engine.fp8
+    px, labels, mask, dec_in = batch(rc, 2, 12, seed=4)
+
+    def check(tag):
+        a, b = model.encode(px.numpy()), plain.encode(px.numpy())
+        assert torch.equal(a.last_hidden_state, b.last_hidden_state), tag
+        assert torch.isfinite(a.last_hidden_state.float()).all()
+        la = model.decode(dec_in.numpy(), a, decoder_attention_mask=mask.numpy()).logits
+        lb = plain.decode(dec_in.numpy(), b, decoder_attention_mask=mask.numpy()).logits
+        assert torch.equal(la, lb), tag
+        sa = model.generate(px.numpy(), num_beams=2, max_length=6)
+        sb = plain.generate(px.numpy(), num_beams=2, max_length=6)
+        assert torch.equal(sa.sequences, sb.sequences) and torch.equal(sa.scores, sb.scores), tag
+        assert model.engine.fp8  # the switch is restored behind every entry point
+
+    check("after construction")
+    b = {"pixel_values": px.numpy(), "input_ids": labels.numpy(), "attention_mask": mask.numpy(), "decoder_input_ids": dec_in.numpy()}
+    tr.train_step(b)
+    # give the bf16 model the fp8 trainer's updated weights (its own step would differ by the fp8 gradients)
+    plain.params = model.params
+    check("after a train step")
+
+
 # ---------------------------------------------------------------------------------------------- delayed scaling
 @pytest.mark.parametrize("fmt", [torch.float8_e4m3fn, torch.float8_e5m2])
 @pytest.mark.parametrize("rows,cols", [(200, 136), (4096, 1024), (3, 8)])

@@ -79,6 +79,65 @@ def test_forward_matches_oracle_switches(dev, dtype, gelu, eps):
     assert (mx < 2e-4) if dtype == torch.float32 else (mx < 3e-2 and mean < 4e-3), (mx, mean)
 
 
+# ---------------------------------------------------------------- north-star "logits within 1e-3 (bf16)": against the bf16-storage oracle
+# oracle/model_ref_bf16.py rounds every tensor to bf16 exactly where engine.py stores one, so the storage format cancels in
+# the comparison and what is left is kernel arithmetic.  Asserted on the STORED logits: each lies within half a bf16 ulp (its
+# own final rounding) + 1e-3 * max|logit| of the oracle's unrounded value.
+BF16_KERNEL_TOL = 1e-3
+
+
+@pytest.mark.parametrize("gelu,eps", [("tanh", 1e-6), ("erf", 1e-5)])
+def test_bf16_logits_within_1e3_of_bf16_storage_oracle(dev, gelu, eps):
+    from oracle import model_ref_bf16 as E
+
+    rc, p, model = make_pair(torch.bfloat16, dev, gelu=gelu, decoder_ln_eps=eps)
+    px, labels, mask, dec_in = batch(rc, 4, 12, seed=3)
+    with torch.no_grad():
+        ref = E.forward_logits(rc, p, px, dec_in, mask)
+    got = model(px.numpy(), dec_in.numpy(), mask.numpy())[0]
+    assert got.dtype == torch.bfloat16
+    valid = mask.bool()
+    mx, mean = E.stored_error(got[valid.to(dev)].cpu(), ref[valid])
+    assert mx < BF16_KERNEL_TOL and mean < 1e-4, (mx, mean)
+    # and the plain distance between the stored values and the oracle's stored values: at most a rounding flip
+    raw_mx, raw_mean = scale_err(got[valid.to(dev)], E.rb(ref[valid]))
+    assert raw_mx < 4e-3 + BF16_KERNEL_TOL and raw_mean < 3e-4, (raw_mx, raw_mean)
+
+
+@pytest.mark.parametrize("fold", [False, True])
+def test_bf16_cached_decode_within_1e3_of_bf16_storage_oracle(dev, fold, monkeypatch):
+    """cached decoder steps of the bf16 mode, explicit-LayerNorm launches and LayerNorm-folded GEMMs separately, each against
+    the restatement of ITS arithmetic"""
+    from oracle import model_ref_bf16 as E
+
+    rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6)
+    model.engine.decode_ln_fold = fold
+    px, *_ = batch(rc, 3, 12, seed=8)
+    g = torch.Generator().manual_seed(2)
+    ids = torch.randint(4, rc.vocab_size, (3, 7), generator=g)
+    pc = E.compute_copy(p)
+    with torch.no_grad():
+        ehs = E.encode(rc, pc, px, int32_cast=False)
+    enc = model.encode(px.numpy(), _int32_cast=False)
+    mx, _ = E.stored_error(enc.last_hidden_state.cpu(), ehs)
+    assert mx < BF16_KERNEL_TOL, mx
+    B, S = ids.shape
+    cache = model.init_cache(B, S + 2, enc)
+    st = E.DecodeState(rc, B, S + 2)
+    # the oracle continues from the encoder states the HIP path produced (so encoder rounding flips do not leak into this check)
+    ehs_hip = enc.last_hidden_state.float().cpu()
+    ckv = E.cross_kv(rc, pc, ehs_hip)
+    worst = 0.0
+    for t in range(S):
+        out = model.decode(ids[:, t:t + 1].numpy(), enc, decoder_position_ids=np.full((B, 1), t), past_key_values=cache)
+        cache = out.past_key_values
+        with torch.no_grad():
+            ref = E.decode_step(rc, pc, st, ids[:, t:t + 1], torch.full((B, 1), t), ehs_hip, ln_fold=fold, cross_kv=ckv)
+        mx, mean = E.stored_error(out.logits[:, 0].cpu(), ref[:, 0])
+        worst = max(worst, mx)
+        assert mx < BF16_KERNEL_TOL and mean < 1e-4, (t, mx, mean)
+
+
 def test_encode_int32_cast_and_shapes(dev):
     """encode() truncates pixel values toward zero (modeling:330); __call__ does not (modeling:501)."""
     from oracle import model_ref as M

@@ -402,3 +402,60 @@ def test_sample_loop_reference_bug_and_fixed_mode():
     freq = np.bincount(idx, minlength=4) / 20000
     sm = np.exp(logits[0]) / np.exp(logits[0]).sum()
     assert np.abs(freq - sm).max() < 0.012
+
+
+# ---------------------------------------------------------------- bf16-storage restatement (oracle/model_ref_bf16.py)
+def test_bf16_storage_oracle_is_the_fp32_oracle_up_to_storage_rounding():
+    """rounding every stored tensor to bf16 moves the logits by the format's resolution and no more; without any rounding
+    (rb = identity) the restatement IS oracle.model_ref"""
+    from oracle import model_ref as M
+    from oracle import model_ref_bf16 as E
+
+    rc = ref_config("tanh", 1e-6)
+    p = M.init_params(rc, seed=5, perturb_ln=True)
+    px, labels, mask, dec_in = __import__("util_small").batch(rc, 3, 12, seed=2)
+    with torch.no_grad():
+        ref = M.forward_logits(rc, p, px, dec_in, mask)
+        emu = E.forward_logits(rc, p, px, dec_in, mask)
+        keep = E.rb
+        try:
+            E.rb = lambda x: x
+            same = E.forward_logits(rc, p, px, dec_in, mask)
+        finally:
+            E.rb = keep
+    valid = mask.bool()
+    s = ref[valid].abs().max()
+    assert ((same - ref)[valid].abs().max() / s).item() < 2e-6
+    d = (emu - ref)[valid].abs()
+    assert 1e-4 < (d.max() / s).item() < 3e-2 and (d.mean() / s).item() < 4e-3
+
+
+def test_bf16_storage_oracle_decode_paths_agree():
+    """cached decode of the bf16-storage oracle: the explicit-LayerNorm step follows the teacher-forced pass (different
+    attention rounding only), the LayerNorm-folded step follows the explicit one to bf16 rounding"""
+    from oracle import model_ref as M
+    from oracle import model_ref_bf16 as E
+
+    rc = ref_config("tanh", 1e-6)
+    p = M.init_params(rc, seed=6, perturb_ln=True)
+    pc = E.compute_copy(p)
+    assert torch.equal(pc["model/shared/embedding"], E.rb(p["model/shared/embedding"]))
+    assert pc["final_logits_bias"] is p["final_logits_bias"]
+    B, T = 2, 6
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(4, rc.vocab_size, (B, T), generator=g)
+    ehs = E.rb(torch.randn(B, rc.v_seq, rc.d_model, generator=g))
+    with torch.no_grad():
+        full = E.lm_head(rc, pc, E.decoder_forward(rc, pc, ids, torch.ones_like(ids), torch.arange(T)[None].expand(B, T), ehs))
+        sa, sb = E.DecodeState(rc, B, 8), E.DecodeState(rc, B, 8)
+        ckv = E.cross_kv(rc, pc, ehs)
+        s = full.abs().max()
+        for t in range(T):
+            a = E.decode_step(rc, pc, sa, ids[:, t:t + 1], torch.full((B, 1), t), ehs, ln_fold=False)
+            b = E.decode_step(rc, pc, sb, ids[:, t:t + 1], torch.full((B, 1), t), ehs, ln_fold=True, cross_kv=ckv)
+            assert ((a[:, 0] - full[:, t]).abs().max() / s).item() < 2e-2
+            assert ((a[:, 0] - b[:, 0]).abs().max() / s).item() < 2e-2
+    x = torch.randn(1000) * 7
+    assert E.stored_error(E.rb(x).to(torch.bfloat16), x) == (0.0, 0.0)
+    mx, _ = E.stored_error(E.rb(x + 0.5).to(torch.bfloat16), x)
+    assert mx > 1e-2
