@@ -55,20 +55,35 @@ def _ln(x, p, name, eps):
     return rb(M.layer_norm(x, p[name + "/scale"], p[name + "/bias"], eps))
 
 
+ACC64 = False  # True: every Linear / LM-head contraction accumulates in float64 — an fp32-ulp-sized perturbation of each
+#                pre-rounding value, used by the tests to measure how far two VALID evaluation orders of the same bf16 arithmetic
+#                drift apart through the rounding points of a deep stack (see tests/test_fullsize_gpu.py)
+
+
+def _mm(x, w):
+    return (x.double() @ w.double()).float() if ACC64 else x @ w
+
+
 def _lin(x, p, name):
     """fp32 accumulate + fp32 bias, NOT yet rounded (the caller rounds once, after residual / at the store)"""
-    return M.dense(x, p, name)
+    y = _mm(x, p[name + "/kernel"])
+    b = p.get(name + "/bias")
+    return y + b if b is not None else y
 
 
-def _attn_train(q, k, v, bias):
-    """attn_fwd_kernel: s = (q.k) / 8 in fp32; p = exp(s - max) rounded to bf16 for P.V, row sum over the unrounded p"""
+def attn_train_unrounded(q, k, v, bias):
+    """attn_fwd_kernel: s = (q.k) / 8 in fp32; p = exp(s - max) rounded to bf16 for P.V, row sum over the unrounded p; the
+    context BEFORE its store"""
     d = q.shape[-1]
     s = torch.einsum("bthd,bshd->bhts", q, k) / math.sqrt(d)
     if bias is not None:
         s = s + bias
     e = torch.exp(s - s.max(dim=-1, keepdim=True).values)
-    o = torch.einsum("bhts,bshd->bthd", rb(e), v) / e.sum(-1).permute(0, 2, 1)[..., None]
-    return rb(o)
+    return torch.einsum("bhts,bshd->bthd", rb(e), v) / e.sum(-1).permute(0, 2, 1)[..., None]
+
+
+def _attn_train(q, k, v, bias):
+    return rb(attn_train_unrounded(q, k, v, bias))
 
 
 def vit_encoder(cfg: M.RefConfig, pc: Params, pixels_nhwc: torch.Tensor) -> torch.Tensor:
@@ -77,7 +92,7 @@ def vit_encoder(cfg: M.RefConfig, pc: Params, pixels_nhwc: torch.Tensor) -> torc
     ps, g = cfg.patch_size, cfg.image_size // cfg.patch_size
     H, Dh = cfg.v_heads, cfg.v_hidden // cfg.v_heads
     x = rb(pixels_nhwc).reshape(B, g, ps, g, ps, 3).permute(0, 1, 3, 2, 4, 5).reshape(B, g * g, ps * ps * 3)
-    pe = rb(x @ pc[V + "embeddings/patch_embedding/kernel"].reshape(ps * ps * 3, cfg.v_hidden))
+    pe = rb(_mm(x, pc[V + "embeddings/patch_embedding/kernel"].reshape(ps * ps * 3, cfg.v_hidden)))
     cls = pc[V + "embeddings/class_embedding"].reshape(1, 1, -1).expand(B, 1, cfg.v_hidden)
     x = rb(torch.cat([cls, pe], dim=1) + pc[V + "embeddings/position_embedding/embedding"][None, : cfg.v_seq])
     x = _ln(x, pc, V + "pre_layrnorm", cfg.v_ln_eps)
@@ -137,7 +152,7 @@ def decoder_forward(cfg: M.RefConfig, pc: Params, ids, attention_mask, position_
 
 def lm_head(cfg, pc, h):
     """fp32 logits BEFORE the final bf16 rounding of the store"""
-    return h @ pc["model/shared/embedding"].T + pc["final_logits_bias"]
+    return _mm(h, pc["model/shared/embedding"].T) + pc["final_logits_bias"]
 
 
 def forward_logits(cfg: M.RefConfig, p: Params, pixel_values, decoder_input_ids, decoder_attention_mask=None) -> torch.Tensor:
@@ -180,7 +195,7 @@ def _ln_folded_lin(x, fold, eps):
     mu = (x.double().sum(-1, keepdim=True) / n).float()
     var = ((x.double() ** 2).sum(-1, keepdim=True) / n).float() - mu * mu
     rstd = torch.rsqrt(var.clamp_min(0.0) + eps)
-    return rstd * (x @ wf - mu * g) + b
+    return rstd * (_mm(x, wf) - mu * g) + b
 
 
 def decode_step(cfg: M.RefConfig, pc: Params, state: DecodeState, ids, position_ids, ehs, ln_fold: bool,
@@ -228,6 +243,11 @@ def cross_kv(cfg: M.RefConfig, pc: Params, ehs: torch.Tensor):
     """cross-attention K/V projected once per image (`_decode_set_encoder`)"""
     H = cfg.d_heads
     return [tuple(M._split(rb(_lin(ehs, pc, f"{D_}layers/{i}/encoder_attn/{n}_proj")), H) for n in ("k", "v")) for i in range(cfg.d_layers)]
+
+
+def flips(got_bf16: torch.Tensor, ref_unrounded: torch.Tensor) -> float:
+    """fraction of stored values that differ from the rounding of the reference's unrounded value"""
+    return (got_bf16.to(torch.float32) != rb(ref_unrounded.to(torch.float32))).float().mean().item()
 
 
 def stored_error(got_bf16: torch.Tensor, ref_unrounded: torch.Tensor) -> Tuple[float, float]:

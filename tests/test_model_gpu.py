@@ -99,9 +99,25 @@ def test_bf16_logits_within_1e3_of_bf16_storage_oracle(dev, gelu, eps):
     valid = mask.bool()
     mx, mean = E.stored_error(got[valid.to(dev)].cpu(), ref[valid])
     assert mx < BF16_KERNEL_TOL and mean < 1e-4, (mx, mean)
-    # and the plain distance between the stored values and the oracle's stored values: at most a rounding flip
+    # and the plain distance between the stored values and the oracle's stored values: at most one rounding flip (one bf16 ulp,
+    # 2^-7 of the value just above a power of two) on a few elements
     raw_mx, raw_mean = scale_err(got[valid.to(dev)], E.rb(ref[valid]))
-    assert raw_mx < 4e-3 + BF16_KERNEL_TOL and raw_mean < 3e-4, (raw_mx, raw_mean)
+    assert raw_mx < 2.0 ** -7 + BF16_KERNEL_TOL and raw_mean < 3e-4, (raw_mx, raw_mean)
+
+
+@pytest.mark.parametrize("gelu,eps", [("tanh", 1e-6), ("erf", 1e-5)])
+def test_bf16_every_stage_within_1e3_of_bf16_storage_oracle(dev, gelu, eps):
+    """every stored tensor of the bf16 forward pass against the oracle's restatement of the stage that produced it, evaluated on
+    the pass's own stored inputs (tests/util_bf16_stages.py: why stage by stage)"""
+    from util_bf16_stages import report, run_stages
+
+    rc, p, model = make_pair(torch.bfloat16, dev, gelu=gelu, decoder_ln_eps=eps)
+    px, labels, mask, dec_in = batch(rc, 4, 12, seed=3)
+    stages = run_stages(model, rc, p, px, dec_in, mask)
+    msg, bad = report(stages, BF16_KERNEL_TOL)
+    print("[bf16 stages, reduced model]", msg)
+    assert len(stages) == 4 + 8 * rc.v_layers + 1 + 2 + 13 * rc.d_layers + 2 and not bad, (msg, bad[:5])
+    assert max(s[3] for s in stages) < 0.02  # rounding flips: a fraction of a percent of the elements at most
 
 
 @pytest.mark.parametrize("fold", [False, True])
@@ -116,11 +132,7 @@ def test_bf16_cached_decode_within_1e3_of_bf16_storage_oracle(dev, fold, monkeyp
     g = torch.Generator().manual_seed(2)
     ids = torch.randint(4, rc.vocab_size, (3, 7), generator=g)
     pc = E.compute_copy(p)
-    with torch.no_grad():
-        ehs = E.encode(rc, pc, px, int32_cast=False)
     enc = model.encode(px.numpy(), _int32_cast=False)
-    mx, _ = E.stored_error(enc.last_hidden_state.cpu(), ehs)
-    assert mx < BF16_KERNEL_TOL, mx
     B, S = ids.shape
     cache = model.init_cache(B, S + 2, enc)
     st = E.DecodeState(rc, B, S + 2)

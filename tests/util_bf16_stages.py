@@ -1,0 +1,141 @@
+"""Stage-by-stage check of the bf16 forward pass against the bf16-storage oracle (oracle/model_ref_bf16.py).
+
+Why stage by stage: a deep stack of bf16 roundings amplifies ANY fp32-ulp-sized difference between two evaluation orders of
+the same arithmetic — a pre-rounding value that moves by d relative flips its bf16 rounding with probability d / ulp and then
+moves by a whole ulp, so the rms perturbation after one rounding point is sqrt(d * ulp) >> d, and after a handful of rounding
+points it sits at the ulp level whatever d was (the oracle run twice, once with float64 accumulation, differs from itself by
+3.7e-3 of the logit scale at 12 + 12 layers: tests/test_oracle_cpu.py::test_bf16_rounding_cascade...).  End to end, "within
+1e-3 of a bf16 oracle" is therefore not a property any implementation can have.  What CAN be asserted at 1e-3 — and is, here —
+is every kernel on its own: each stored tensor of the HIP pass is compared with the oracle's restatement of the stage that
+produced it, evaluated on the HIP pass's OWN stored inputs, so that no earlier flip leaks in.  `stored_error` removes the
+stored value's own final rounding; what remains is kernel arithmetic (accumulation order, exp / rcp / rsqrt approximations).
+"""
+import math
+
+import torch
+
+
+def run_stages(model, rc, p, px, dec_in, mask):
+    """Runs the bf16 HIP forward pass (teacher forced, eval) keeping every per-layer activation, then walks its stages.
+    Returns [(stage name, kernel err max, kernel err mean, fraction of rounding flips)] in execution order."""
+    from oracle import model_ref as M
+    from oracle import model_ref_bf16 as E
+
+    eng, st = model.engine, model.store
+    dev = model.device
+    B, T = dec_in.shape
+    S, vd, vf, vH = st.S, st.vd, st.vffn, st.vH
+    d, f, H = st.d, st.ffn, st.H
+    Mv, Mp, Md = B * S, B * (S - 1), B * T
+    dv = model._dev
+    pos = torch.arange(T, dtype=torch.int32, device=dev)[None].expand(B, T).contiguous()
+    logits, _ = eng.forward_logits(dv(px, torch.float32), dv(dec_in, torch.int32).reshape(-1), pos.reshape(-1), dv(mask, torch.int32), B, T,
+                                   save=True, seed=None)
+    torch.cuda.synchronize()
+    pc = E.compute_copy(p)
+    out = []
+
+    def hb(name, rows, cols):
+        return eng.buf(name, rows, cols)[:rows].float().cpu()
+
+    def cmp(name, got, ref):
+        mx, mean = E.stored_error(got, ref.reshape(got.shape))
+        out.append((name, mx, mean, E.flips(got, ref.reshape(got.shape))))
+
+    def ln(x, name, eps):
+        return M.layer_norm(x, pc[name + "/scale"], pc[name + "/bias"], eps)
+
+    def qkv_lin(a, L, blk):
+        return torch.cat([E._lin(a, pc, L + f"{blk}/{n}_proj") for n in ("q", "k", "v")], dim=-1)
+
+    with torch.no_grad():
+        # ---------------------------------------------------------------- ViT
+        ps, g = rc.patch_size, rc.image_size // rc.patch_size
+        pk = ps * ps * 3
+        patches = hb("v.patches", Mp, pk)
+        cmp("vit.im2col", patches, px.reshape(B, g, ps, g, ps, 3).permute(0, 1, 3, 2, 4, 5).reshape(Mp, pk))
+        pe = hb("v.pe", Mp, vd)
+        cmp("vit.patch_gemm", pe, patches @ pc[E.V + "embeddings/patch_embedding/kernel"].reshape(pk, vd))
+        emb = hb("v.emb", Mv, vd)
+        cls = pc[E.V + "embeddings/class_embedding"].reshape(1, 1, -1).expand(B, 1, vd)
+        cmp("vit.assemble", emb, torch.cat([cls, pe.reshape(B, S - 1, vd)], 1) + pc[E.V + "embeddings/position_embedding/embedding"][None, :S])
+        x = hb("v.x0", Mv, vd)
+        cmp("vit.pre_ln", x, ln(emb, E.V + "pre_layrnorm", rc.v_ln_eps))
+        for l in range(rc.v_layers):
+            L, tag = f"{E.V}encoder/layers/{l}/", f"v{l}."
+            a1 = hb(tag + "a1", Mv, vd)
+            cmp(tag + "ln1", a1, ln(x, L + "layer_norm1", rc.v_ln_eps))
+            qkv = hb(tag + "qkv", Mv, 3 * vd)
+            cmp(tag + "qkv", qkv, qkv_lin(a1, L, "self_attn"))
+            ctx = hb(tag + "ctx", Mv, vd)
+            q, k, v = (qkv[:, i * vd:(i + 1) * vd].reshape(B, S, vH, vd // vH) for i in range(3))
+            cmp(tag + "attn", ctx, E.attn_train_unrounded(q, k, v, None).reshape(Mv, vd))
+            xm = hb(tag + "xm", Mv, vd)
+            cmp(tag + "out_proj+res", xm, E._lin(ctx, pc, L + "self_attn/out_proj") + x)
+            a2 = hb(tag + "a2", Mv, vd)
+            cmp(tag + "ln2", a2, ln(xm, L + "layer_norm2", rc.v_ln_eps))
+            z, u = hb(tag + "z", Mv, vf), hb(tag + "u", Mv, vf)
+            cmp(tag + "fc1", z, E._lin(a2, pc, L + "mlp/fc1"))
+            cmp(tag + "quick_gelu", u, M.quick_gelu(z))
+            xo = hb(tag + "xo", Mv, vd)
+            cmp(tag + "fc2+res", xo, E._lin(u, pc, L + "mlp/fc2") + xm)
+            x = xo
+        ehs = hb("v.ehs", Mv, d)
+        cmp("visual_projection", ehs, E._lin(x, pc, "model/visual_projection"))
+        # ---------------------------------------------------------------- decoder
+        ids = dec_in.to(torch.int64)
+        causal = torch.tril(torch.ones(T, T, dtype=torch.int32))[None, None]
+        bias = M.mask_to_bias(causal * mask.to(torch.int32)[:, None, None, :])
+        h0 = hb("d.h0", Md, d)
+        scale = math.sqrt(rc.d_model) if rc.scale_embedding else 1.0
+        pid = torch.arange(T)[None].expand(B, T)
+        cmp("dec.embed", h0, (pc["model/shared/embedding"][ids] * scale + pc[E.D_ + "embed_positions/embedding"][pid + 2]))
+        x = hb("d.x0", Md, d)
+        eps = rc.decoder_ln_eps
+        cmp("dec.ln_emb", x, ln(h0, E.D_ + "layernorm_embedding", eps))
+        e3 = ehs.reshape(B, S, d)
+        for l in range(rc.d_layers):
+            L, tag = f"{E.D_}layers/{l}/", f"d{l}."
+            a = hb(tag + "a_sa", Md, d)
+            cmp(tag + "ln_sa", a, ln(x, L + "self_attn_layer_norm", eps))
+            qkv = hb(tag + "qkv", Md, 3 * d)
+            cmp(tag + "qkv", qkv, qkv_lin(a, L, "self_attn"))
+            ctx = hb(tag + "ctx", Md, d)
+            q, k, v = (qkv[:, i * d:(i + 1) * d].reshape(B, T, H, d // H) for i in range(3))
+            cmp(tag + "self_attn", ctx, E.attn_train_unrounded(q, k, v, bias).reshape(Md, d))
+            x1 = hb(tag + "x1", Md, d)
+            cmp(tag + "so+res", x1, E._lin(ctx, pc, L + "self_attn/out_proj") + x)
+            a = hb(tag + "a_ca", Md, d)
+            cmp(tag + "ln_ca", a, ln(x1, L + "encoder_attn_layer_norm", eps))
+            cq = hb(tag + "cq", Md, d)
+            cmp(tag + "cq", cq, E._lin(a, pc, L + "encoder_attn/q_proj"))
+            ckv = hb(tag + "ckv", Mv, 2 * d)
+            cmp(tag + "ckv", ckv, torch.cat([E._lin(ehs, pc, L + f"encoder_attn/{n}_proj") for n in ("k", "v")], -1))
+            cctx = hb(tag + "cctx", Md, d)
+            cmp(tag + "cross_attn", cctx, E.attn_train_unrounded(cq.reshape(B, T, H, d // H), ckv[:, :d].reshape(B, S, H, d // H),
+                                                                 ckv[:, d:].reshape(B, S, H, d // H), None).reshape(Md, d))
+            x2 = hb(tag + "x2", Md, d)
+            cmp(tag + "co+res", x2, E._lin(cctx, pc, L + "encoder_attn/out_proj") + x1)
+            a = hb(tag + "a_ff", Md, d)
+            cmp(tag + "ln_ff", a, ln(x2, L + "final_layer_norm", eps))
+            z, u = hb(tag + "z", Md, f), hb(tag + "u", Md, f)
+            cmp(tag + "fc1", z, E._lin(a, pc, L + "fc1"))
+            cmp(tag + "gelu", u, M.gelu(z, rc.gelu))
+            x3 = hb(tag + "x3", Md, d)
+            cmp(tag + "fc2+res", x3, E._lin(u, pc, L + "fc2") + x2)
+            x = x3
+        hf = hb("d.hf", Md, d)
+        cmp("dec.ln_f", hf, ln(x, E.D_ + "layer_norm", eps))
+        V = rc.vocab_size
+        got = logits[:Md, :V].float().cpu()
+        cmp("lm_head", got, E.lm_head(rc, pc, hf))
+    return out
+
+
+def report(stages, tol):
+    worst = max(stages, key=lambda s: s[1])
+    flips = max(stages, key=lambda s: s[3])
+    msg = (f"{len(stages)} stages; worst kernel error {worst[1]:.2e} of the stage's scale at {worst[0]} (mean {worst[2]:.2e}); "
+           f"most rounding flips {flips[3]:.2e} of the elements at {flips[0]}")
+    bad = [s for s in stages if not (s[1] < tol)]
+    return msg, bad
