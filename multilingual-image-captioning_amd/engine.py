@@ -44,6 +44,7 @@ class Engine:
         self.embed_rows = None     # (ids, dh0 buffer, M) of the last backward when deferred
         self._dw_queue = []
         self._cs_queue = []
+        self.on_free = []  # callables run by free_buffers() before the buffers go (decode plans drop their captured graphs)
         self.fp8 = False
         import os
         self.use_head_stats = os.environ.get("MIC_HEAD_STATS", "1") != "0"  # softmax partials out of the LM-head GEMM (A/B switch)
@@ -217,7 +218,13 @@ class Engine:
         return t
 
     def free_buffers(self):
+        """drop every scratch / activation buffer.  Captured decoder-step graphs hold raw pointers into these buffers (and into
+        the LayerNorm-folded weights): whoever captured them registered a callback in `on_free` and is told first."""
+        for cb in list(self.on_free):
+            cb()
         self._bufs.clear()
+        self._lnf = {}
+        self._lnf_version = -1
 
     # ------------------------------------------------------------------ small helpers
     def linear(self, x, wname, out, M, *, act=0, zout=None, residual=None, drop_seed=None, bias=True, save_tag=None, fp8=True,

@@ -35,6 +35,7 @@ from . import ops
 NEG = -1.0e7
 _POLL = 8          # decoder steps between two looks at the device-side stop flag
 _MAX_PLANS = 2     # decode plans kept per model (each owns a KV cache: 24 x rows x max_length x d_model elements)
+_AUTO_SLICES = 1   # MIC_DECODE_SLICES=auto
 
 
 class _DecodePlan:
@@ -45,6 +46,8 @@ class _DecodePlan:
         self.graphs = {}     # cur_len -> torch.cuda.CUDAGraph
         self.calls = 0
         self.stream = None   # capture stream
+        self.subs = []       # beam search: one sub-plan (state tensors + KV cache) per image slice
+        self.streams = []    # ... and the streams their chains run on
 
     def run_step(self, cur_len: int, fn, use_graphs: bool):
         """fn() issues the launches of decoder step `cur_len` on the current stream.  First call of a plan: eager.  Later calls:
@@ -67,10 +70,16 @@ class _DecodePlan:
         g.replay()
 
 
-def _graphs_enabled(dev) -> bool:
+def _graphs_enabled(dev, slices: int = 1) -> bool:
+    """per-step hipGraphs: opt-in for a single chain (a replayed chain costs what the eager launches cost), ON for a sliced beam
+    search — there the graph is what makes the slices' chains parallel branches of one launch (issuing them eagerly would cost
+    the host `slices` x 1.4 ms per step); MIC_DECODE_GRAPHS=0|1 forces either"""
     import os
 
-    return dev.type == "cuda" and os.environ.get("MIC_DECODE_GRAPHS", "0") == "1"
+    want = os.environ.get("MIC_DECODE_GRAPHS", "auto")
+    if dev.type != "cuda" or want == "0":
+        return False
+    return want == "1" or slices > 1
 
 
 class FlaxCLIPVisionMBartGenerationMixin:
@@ -262,86 +271,144 @@ class FlaxCLIPVisionMBartGenerationMixin:
         return ModelOutput(sequences=sequences)
 
     # ------------------------------------------------------------------ gen:665-990
+    def _decode_slices(self, B: int, K: int) -> int:
+        """Number of independent image slices a beam search is cut into.  Images never interact in beam search (gen:665-990 is
+        vmapped over the batch), and a decoder step is a chain of ~110 dependent launches most of which leave the chip idle
+        (one 64x64 tile per CU, latency-bound) or use one resource only (decode attention: HBM; GEMMs: MFMA + LDS).  Slices run
+        the same chain on their own streams — as parallel branches of the step's hipGraph — so one slice's latency chain and
+        HBM-bound kernels overlap another's.  MIC_DECODE_SLICES=n forces n (1 = off)."""
+        import os
+
+        want = os.environ.get("MIC_DECODE_SLICES", "auto")
+        if self.device.type != "cuda":
+            return 1
+        n = int(want) if want != "auto" else _AUTO_SLICES
+        # auto: a slice keeps at least 256 decoder rows (below that a chain is pure launch latency and slicing only adds launches)
+        while n > 1 and (B % n != 0 or (want == "auto" and (B // n) * K < 256)):
+            n -= 1
+        return max(n, 1)
+
     def _beam_search(self, ehs, B, K, start_token, max_length, pad_token_id, eos_token_id, length_penalty, early_stopping, procs):
         from .modeling_clip_vision_mbart import ModelOutput
 
         if 2 * K > 16:
             raise NotImplementedError("num_beams > 8 needs a wider per-row top-k than this build ships (k = 2*num_beams <= 16)")
         dev, st = self.device, self.store
-        R = B * K
+        NS = self._decode_slices(B, K)
+        Bs = B // NS          # images per slice
+        R = Bs * K            # decoder rows per slice
 
-        def build(plan):
-            t = plan.t
-            t["running_seq"] = torch.empty((B, K, max_length), dtype=torch.int32, device=dev)
-            t["seq"] = torch.empty((B, K, max_length), dtype=torch.int32, device=dev)
-            t["finished"] = torch.empty((B, K), dtype=torch.int32, device=dev)
-            t["running_scores"] = torch.empty((B, K), dtype=torch.float32, device=dev)
-            t["scores"] = torch.empty((B, K), dtype=torch.float32, device=dev)
+        def build_slice(sub):
+            t = sub.t
+            t["running_seq"] = torch.empty((Bs, K, max_length), dtype=torch.int32, device=dev)
+            t["seq"] = torch.empty((Bs, K, max_length), dtype=torch.int32, device=dev)
+            t["finished"] = torch.empty((Bs, K), dtype=torch.int32, device=dev)
+            t["running_scores"] = torch.empty((Bs, K), dtype=torch.float32, device=dev)
+            t["scores"] = torch.empty((Bs, K), dtype=torch.float32, device=dev)
             t["next_token"] = torch.empty((R,), dtype=torch.int32, device=dev)
             t["src_row"] = torch.empty((R, max_length), dtype=torch.int32, device=dev)
-            t["flags"] = torch.empty((B, 2), dtype=torch.int32, device=dev)
+            t["flags"] = torch.empty((Bs, 2), dtype=torch.int32, device=dev)
             t["cand_val"] = torch.empty((R, 2 * K), dtype=torch.float32, device=dev)
             t["cand_idx"] = torch.empty((R, 2 * K), dtype=torch.int32, device=dev)
             t["pos_all"] = torch.arange(max_length, dtype=torch.int32, device=dev).repeat_interleave(R)  # position ids of every step
             t["gstate"] = torch.empty(8, dtype=torch.int32, device=dev)
-            t["score0"] = torch.tensor([0.0] + [NEG] * (K - 1), dtype=torch.float32, device=dev).repeat(B, 1).contiguous()
+            t["score0"] = torch.tensor([0.0] + [NEG] * (K - 1), dtype=torch.float32, device=dev).repeat(Bs, 1).contiguous()
             t["rows"] = torch.arange(R, dtype=torch.int32, device=dev)
 
-        plan = self._decode_plan(("beam", B, K, max_length, pad_token_id, eos_token_id, float(length_penalty), bool(early_stopping),
+        def build(plan):
+            plan.subs = [_DecodePlan() for _ in range(NS)]
+            for sub in plan.subs:
+                build_slice(sub)
+            plan.streams = [torch.cuda.Stream(device=dev) for _ in range(NS)] if NS > 1 else []
+
+        plan = self._decode_plan(("beam", B, K, NS, max_length, pad_token_id, eos_token_id, float(length_penalty), bool(early_stopping),
                                   procs["min_length"], procs["forced_eos"], self.dtype), build)
-        t = plan.t
-        running_seq, seq, finished, running_scores, scores = t["running_seq"], t["seq"], t["finished"], t["running_scores"], t["scores"]
-        next_token, src_row, flags, cand_val, cand_idx, pos_all, gstate = (t[k] for k in ("next_token", "src_row", "flags", "cand_val",
-                                                                                          "cand_idx", "pos_all", "gstate"))
-        running_seq.fill_(pad_token_id)  # gen:751-757
-        running_seq[:, :, 0] = start_token
-        seq.fill_(pad_token_id)
-        finished.zero_()  # gen:760
-        running_scores.copy_(t["score0"])  # gen:763-765
-        scores.fill_(NEG)  # gen:766
-        next_token.fill_(start_token)
-        src_row.zero_()
-        src_row[:, 0] = t["rows"]
-        flags.zero_()
-        cache = self._plan_cache(plan, R, max_length)
-        cache["src_row"] = src_row
-        # encoder states are shared by an image's K beams (gen:299-307 broadcasts them; here: row r reads image r // K)
-        self._decode_set_encoder(cache, ehs.reshape(B * st.S, st.d), B, K)
-        # beam_search_cond_fn (gen:798-820) lives on the device: mic_beam_step evaluates it on the new state, and once it says
-        # stop every later mic_beam_step launch is a no-op.  The host therefore enqueues decoder steps (graph replays once the
-        # plan is warm) without waiting and looks at the flag only every _POLL steps.
-        gstate.zero_()
-        use_graphs = _graphs_enabled(dev)
+        ehs = ehs.reshape(B, st.S * st.d)
+        steps_fn = []
+        for i, sub in enumerate(plan.subs):
+            t = sub.t
+            t["running_seq"].fill_(pad_token_id)  # gen:751-757
+            t["running_seq"][:, :, 0] = start_token
+            t["seq"].fill_(pad_token_id)
+            t["finished"].zero_()  # gen:760
+            t["running_scores"].copy_(t["score0"])  # gen:763-765
+            t["scores"].fill_(NEG)  # gen:766
+            t["next_token"].fill_(start_token)
+            t["src_row"].zero_()
+            t["src_row"][:, 0] = t["rows"]
+            t["flags"].zero_()
+            cache = self._plan_cache(sub, R, max_length)
+            cache["src_row"] = t["src_row"]
+            cache["ns"] = f"s{i}." if NS > 1 else ""
+            # encoder states are shared by an image's K beams (gen:299-307 broadcasts them; here: row r reads image r // K)
+            self._decode_set_encoder(cache, ehs[i * Bs:(i + 1) * Bs].reshape(Bs * st.S, st.d), Bs, K)
+            # beam_search_cond_fn (gen:798-820) lives on the device: mic_beam_step evaluates it on the new state, and once it says
+            # stop every later mic_beam_step launch is a no-op.  The host therefore enqueues decoder steps (graph replays once the
+            # plan is warm) without waiting and looks at the flag only every _POLL steps.
+            t["gstate"].zero_()
+            steps_fn.append(self._beam_step_fn(cache, t, Bs, K, max_length, pad_token_id, eos_token_id, length_penalty, early_stopping, procs))
+        use_graphs = _graphs_enabled(dev, NS)
 
         def step(cur_len):
+            if NS == 1:
+                return lambda: steps_fn[0](cur_len)
+
             def fn():
-                with ops.pinned_stream():
-                    cache["cache_index"] = cur_len - 1
-                    logits, stat = self._decode_step(cache, next_token, pos_all[(cur_len - 1) * R: cur_len * R], stats=True)  # gen:830-840
-                    forced, suppress = self._proc_args(procs, cur_len, max_length, eos_token_id)
-                    if stat is not None and forced < 0:
-                        # log-softmax + top-2K from the head GEMM's per-granule partials: 3908 pairs and a few 64-column granules
-                        # per row instead of two passes over the 250 054 logits (same candidates, same order, same fp32 arithmetic)
-                        ops.row_topk_tiles(logits, logits.stride(0), st.V, stat, 2 * K, cand_val, cand_idx, R, suppress_eos=suppress,
-                                           eos_token_id=eos_token_id, row_bias=running_scores.reshape(-1))
-                    else:
-                        ops.row_lse_topk(logits, logits.stride(0), st.V, 2 * K, cand_val, cand_idx, R, forced_token=forced,
-                                         suppress_eos=suppress, eos_token_id=eos_token_id, row_bias=running_scores.reshape(-1))  # gen:850-873
-                    ops.beam_step(B, K, max_length, st.V, cur_len, eos_token_id, pad_token_id, length_penalty, early_stopping, cand_val,
-                                  cand_idx, running_seq, running_scores, seq, scores, finished, src_row, next_token, flags, gstate=gstate)  # gen:872-966
+                # fork: every slice's chain on its own stream behind what the current stream has enqueued; join: the current
+                # stream waits for all of them (inside a capture these are the graph's parallel branches)
+                cur = torch.cuda.current_stream()
+                fork = torch.cuda.Event()
+                fork.record(cur)
+                for i, s_ in enumerate(plan.streams):
+                    s_.wait_event(fork)
+                    with torch.cuda.stream(s_):
+                        steps_fn[i](cur_len)
+                        done = torch.cuda.Event()
+                        done.record(s_)
+                    cur.wait_event(done)
             return fn
 
+        gstates = [sub.t["gstate"] for sub in plan.subs]
         cur_len = 1
         while cur_len < max_length:
             plan.run_step(cur_len, step(cur_len), use_graphs and cur_len > 1)  # step 1 carries the call's forced-BOS id: never captured
             cur_len += 1
-            if cur_len < max_length and (cur_len - 1) % _POLL == 0 and int(gstate[3].item()) != 0:
+            if cur_len < max_length and (cur_len - 1) % _POLL == 0 and all(int(g[3].item()) != 0 for g in gstates):
                 break
         plan.calls += 1
-        steps = int(gstate[4].item())
-        any_fin = finished.bool().any(dim=1)  # gen:980
-        out_seq = torch.where(any_fin[:, None, None], seq, running_seq)  # gen:981-983
-        out_scores = torch.where(any_fin[:, None], scores, running_scores)  # gen:984
-        out = ModelOutput(sequences=out_seq[:, -1].contiguous(), scores=out_scores[:, -1].contiguous())  # gen:987-990
+        steps = max(int(g[4].item()) for g in gstates)
+        outs = []
+        for sub in plan.subs:
+            t = sub.t
+            any_fin = t["finished"].bool().any(dim=1)  # gen:980
+            out_seq = torch.where(any_fin[:, None, None], t["seq"], t["running_seq"])  # gen:981-983
+            out_scores = torch.where(any_fin[:, None], t["scores"], t["running_scores"])  # gen:984
+            outs.append((out_seq[:, -1], out_scores[:, -1]))  # gen:987-990
+        out = ModelOutput(sequences=torch.cat([o[0] for o in outs]).contiguous(), scores=torch.cat([o[1] for o in outs]).contiguous())
         out["steps"] = steps
         return out
+
+    def _beam_step_fn(self, cache, t, B, K, max_length, pad_token_id, eos_token_id, length_penalty, early_stopping, procs):
+        """the launches of one beam-search step (gen:822-966) of one slice of B images: step(cur_len)"""
+        st = self.store
+        R = B * K
+        running_seq, seq, finished, running_scores, scores = t["running_seq"], t["seq"], t["finished"], t["running_scores"], t["scores"]
+        next_token, src_row, flags, cand_val, cand_idx, pos_all, gstate = (t[k] for k in ("next_token", "src_row", "flags", "cand_val",
+                                                                                          "cand_idx", "pos_all", "gstate"))
+
+        def step(cur_len):
+            with ops.pinned_stream():
+                cache["cache_index"] = cur_len - 1
+                logits, stat = self._decode_step(cache, next_token, pos_all[(cur_len - 1) * R: cur_len * R], stats=True)  # gen:830-840
+                forced, suppress = self._proc_args(procs, cur_len, max_length, eos_token_id)
+                if stat is not None and forced < 0:
+                    # log-softmax + top-2K from the head GEMM's per-granule partials: 3908 pairs and a few 64-column granules
+                    # per row instead of two passes over the 250 054 logits (same candidates, same order, same fp32 arithmetic)
+                    ops.row_topk_tiles(logits, logits.stride(0), st.V, stat, 2 * K, cand_val, cand_idx, R, suppress_eos=suppress,
+                                       eos_token_id=eos_token_id, row_bias=running_scores.reshape(-1))
+                else:
+                    ops.row_lse_topk(logits, logits.stride(0), st.V, 2 * K, cand_val, cand_idx, R, forced_token=forced,
+                                     suppress_eos=suppress, eos_token_id=eos_token_id, row_bias=running_scores.reshape(-1))  # gen:850-873
+                ops.beam_step(B, K, max_length, st.V, cur_len, eos_token_id, pad_token_id, length_penalty, early_stopping, cand_val,
+                              cand_idx, running_seq, running_scores, seq, scores, finished, src_row, next_token, flags, gstate=gstate)  # gen:872-966
+        return step

@@ -90,6 +90,7 @@ class FlaxCLIPVisionMBartPreTrainedModel(FlaxCLIPVisionMBartGenerationMixin):
         self.device = torch.device(device)
         self.store = ParamStore(config, self.dtype, self.device)
         self.engine = Engine(self.store)
+        self.engine.on_free.append(self.release_decode_plans)  # captured decoder steps point into the engine's buffers
         self._required_params = set(tuple(k.split("/")) for k in self.store.flax_shapes())  # utils:78
         self._params_cache = None
         self._state_sync = None  # set by a Trainer with a sharded optimizer: all-gathers the master weights before an export
@@ -295,11 +296,12 @@ class FlaxCLIPVisionMBartForConditionalGeneration(FlaxCLIPVisionMBartPreTrainedM
         them every step; same values).  ehs_rows: [n_img*S, d]."""
         eng, st = self.engine, self.store
         S, d = st.S, st.d
-        ehs_b = eng.buf("g.ehs", n_img * S, d)
+        ns = cache.get("ns", "")  # scratch-buffer namespace of a decode slice (slices of equal size must not share buffers)
+        ehs_b = eng.buf(ns + "g.ehs", n_img * S, d)
         ehs_b[: n_img * S].copy_(ehs_rows)
         cross = []
         for l in range(st.L):
-            kv = eng.buf(f"g.ckv{l}", n_img * S, 2 * d)
+            kv = eng.buf(f"{ns}g.ckv{l}", n_img * S, 2 * d)
             eng.linear(ehs_b, f"dec{l}.ckv", kv, n_img * S, fp8=False)  # generation stays in the storage dtype
             cross.append(kv)
         cache["cross"], cache["row_div"] = cross, row_div
@@ -324,16 +326,17 @@ class FlaxCLIPVisionMBartForConditionalGeneration(FlaxCLIPVisionMBartPreTrainedM
         R, Lmax, cur = cache["rows"], cache["max_length"], cache["cache_index"]
         d, f, H, S = st.d, st.ffn, st.H, st.S
         fold = eng.decode_ln_fold and self.dtype == torch.bfloat16
-        h0 = eng.buf("g.h0", R, d)
+        ns = cache.get("ns", "")
+        h0 = eng.buf(ns + "g.h0", R, d)
         ops.embed_fwd(tokens, pos, P.w("shared"), P.f32("dec.pos"), eng.embed_scale, h0, R, d)
-        x = eng.buf("g.x", R, d)
+        x = eng.buf(ns + "g.x", R, d)
         ops.layernorm_fwd(h0, P.f32("dec.ln_emb.g"), P.f32("dec.ln_emb.b"), eng.dec_eps, x, rows=R)
-        a, ctx = eng.buf("g.a", R, d), eng.buf("g.ctx", R, d)
-        x1, x2, q = eng.buf("g.x1", R, d), eng.buf("g.x2", R, d), eng.buf("g.q", R, d)
-        u = eng.buf("g.u", R, f)
+        a, ctx = eng.buf(ns + "g.a", R, d), eng.buf(ns + "g.ctx", R, d)
+        x1, x2, q = eng.buf(ns + "g.x1", R, d), eng.buf(ns + "g.x2", R, d), eng.buf(ns + "g.q", R, d)
+        u = eng.buf(ns + "g.u", R, f)
         if fold:
             # (sum, sum of squares) per row of x (layer input; layer 0's comes from an explicit LayerNorm), x1, x2 — zeroed once per step
-            lnst = eng.buf("g.lnstats", st.L * 3 * R, 2, torch.int64)[: st.L * 3 * R].view(st.L, 3, R, 2)  # 2^20 fixed point
+            lnst = eng.buf(ns + "g.lnstats", st.L * 3 * R, 2, torch.int64)[: st.L * 3 * R].view(st.L, 3, R, 2)  # 2^20 fixed point
             ops.zero(lnst)
         eps = eng.dec_eps
         for l in range(st.L):
@@ -375,10 +378,10 @@ class FlaxCLIPVisionMBartForConditionalGeneration(FlaxCLIPVisionMBartPreTrainedM
                 ops.layernorm_fwd(x2, P.f32(p + "ln_ff.g"), P.f32(p + "ln_ff.b"), eps, a, rows=R)
                 eng.linear(a, p + "fc1", u, R, act=eng.gelu, fp8=False)
                 eng.linear(u, p + "fc2", x, R, residual=x2, fp8=False)
-        hf = eng.buf("g.hf", R, d)
+        hf = eng.buf(ns + "g.hf", R, d)
         ops.layernorm_fwd(x, P.f32("dec.ln_f.g"), P.f32("dec.ln_f.b"), eng.dec_eps, hf, rows=R)
         cache["cache_index"] = cur + 1
-        return eng.head_logits(hf, R, name="g.logits", stats=stats)
+        return eng.head_logits(hf, R, name=ns + "g.logits", stats=stats)
 
     # ------------------------------------------------------------------ construction (modeling:703-773)
     @classmethod

@@ -151,6 +151,56 @@ def test_decode_plan_graph_replay_matches_oracle(dev, monkeypatch):
     assert len(model._decode_plans) == 2
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ns", [2, 4])
+def test_sliced_beam_search_equals_the_single_chain(dev, monkeypatch, dtype, ns):
+    """MIC_DECODE_SLICES=n cuts the images of a beam search into n slices whose decoder-step chains run as parallel branches of
+    the step's hipGraph (own streams, state, KV cache and scratch buffers).  Images never interact (gen:665-990 is per batch
+    item), so ids, scores and the step count must be those of the single chain and of the oracle — on the eager first call, the
+    capturing second call and the replaying third; with beams of ONE slice finishing early while the other keeps going; and
+    after Engine.free_buffers() dropped everything the captured graphs pointed at."""
+    from mic_amd.params import unflatten_tree
+
+    rc, p, model = make_pair(dtype, dev, gelu="tanh", decoder_ln_eps=1e-6)
+    B, K = 8, 4
+    p = dict(p)
+    flb = p["final_logits_bias"].clone()
+    flb[0, rc.eos_token_id] = 5.0   # some beams finish early
+    p["final_logits_bias"] = flb
+    model.params = unflatten_tree({k: v.numpy() for k, v in p.items()})
+    kw = dict(max_length=14, num_beams=K)
+    for call, (seed, bos) in enumerate([(51, 996), (52, 995), (53, 994)]):
+        px, *_ = batch(rc, B, 12, seed=seed)
+        k2 = dict(kw, forced_bos_token_id=bos)
+        monkeypatch.setenv("MIC_DECODE_SLICES", "1")
+        one = model.generate(px.numpy(), **k2)
+        monkeypatch.setenv("MIC_DECODE_SLICES", str(ns))
+        cut = model.generate(px.numpy(), **k2)
+        plan = [v for k, v in model._decode_plans.items() if k[3] == ns][0]
+        assert len(plan.subs) == ns and plan.calls == call + 1
+        if call >= 1:
+            assert len(plan.graphs) > 0  # sliced chains are graph branches by default
+        assert torch.equal(one.sequences, cut.sequences), (call, ns)
+        assert torch.equal(one.scores, cut.scores) and one["steps"] == cut["steps"]
+        if dtype == torch.float32:
+            ref = _oracle_gen(rc, p, px, B, **k2)
+            assert np.array_equal(cut.sequences.cpu().numpy(), ref.sequences) and cut["steps"] == ref.steps
+            assert np.allclose(cut.scores.cpu().numpy(), ref.scores, rtol=1e-4, atol=1e-4)
+    # only the first half of the images finishes early: the stop flags of the slices differ, the loop ends when ALL have stopped
+    px2 = px.clone()
+    px2[B // 2:] = px[: B // 2].flip(0) * 0.3
+    monkeypatch.setenv("MIC_DECODE_SLICES", "1")
+    one = model.generate(px2.numpy(), **k2)
+    monkeypatch.setenv("MIC_DECODE_SLICES", str(ns))
+    cut = model.generate(px2.numpy(), **k2)
+    assert torch.equal(one.sequences, cut.sequences) and torch.equal(one.scores, cut.scores) and one["steps"] == cut["steps"]
+    # free_buffers() drops the plans (their graphs point into the engine's buffers); the next call rebuilds everything
+    model.engine.free_buffers()
+    assert not getattr(model, "_decode_plans", None)
+    again = model.generate(px2.numpy(), **k2)
+    assert torch.equal(again.sequences, cut.sequences) and torch.equal(again.scores, cut.scores)
+
+
 def test_decode_layernorm_fold_matches_explicit_layernorms(dev):
     """bfloat16 decoder steps with the LayerNorms folded around the GEMMs (default) against the explicit LayerNorm kernels
     (engine.decode_ln_fold = False): same cache protocol, logits equal up to the one bf16 rounding the fold skips (the
