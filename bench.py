@@ -382,10 +382,24 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        try:
+            if share:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                # the first collective creates the RCCL communicator (ring / tree set-up over xGMI): fail here, with the cause, not
+                # somewhere inside the first train step
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                assert int(probe.item()) == world, f"all-reduce probe returned {probe.item()} for world {world}"
+        except Exception as e:  # name the cause and leave with a non-zero code (the launcher then ends the other ranks)
+            print(f"bench.py rank {rank}/{world} (device {local_rank}): torch.distributed / RCCL initialisation failed: {type(e).__name__}: {e}\n"
+                  f"  MASTER_ADDR={os.environ.get('MASTER_ADDR')} MASTER_PORT={os.environ.get('MASTER_PORT')} "
+                  f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')} visible GPUs={torch.cuda.device_count()}\n"
+                  "  (RCCL needs one distinct GPU per rank and dmabuf IPC: HSA_ENABLE_IPC_MODE_LEGACY=0; NCCL_DEBUG=INFO prints its own log)",
+                  file=sys.stderr, flush=True)
+            sys.exit(3)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import mic_amd  # noqa: F401

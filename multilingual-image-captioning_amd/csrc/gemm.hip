@@ -204,20 +204,12 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
   tab.total_blocks = blocks;
   for (int i = 0; i < count; ++i)
     MIC_CHECK(!args[i].rowsum2 || table_is_plain(tab), "mic_gemm_grouped: rowsum2 needs every problem of the launch on the bare / residual epilogue");
-  // LDS-DMA four-phase 256x256 kernel: 1 = every 256x256 launch (measured slower over the train step), 0 = never, default 2 = the
-  // NT launches only (both operands k-contiguous: LM-head forward, FFN-in forward), where its deeper operand prefetch wins
+  // LDS-DMA four-phase 256x256 kernel for the single-problem NT launches (both operands k-contiguous: LM-head forward, FFN-in
+  // forward), where its deeper operand prefetch wins; MIC_GEMM_PHASED=0 switches it off (A/B).  On every 256x256 launch it
+  // measured +1.6 ms per train step: that mode is gone.
   static const int phased_env = [] { const char* e = getenv("MIC_GEMM_PHASED"); return e ? atoi(e) : 2; }();
-  const bool phased = phased_env == 1 || (phased_env == 2 && !args[0].a_kmajor && !args[0].b_kmajor && count == 1 && !any_rowsum_early(args, count));
-  static const int w4 = [] { const char* e = getenv("MIC_GEMM_W4"); return e ? atoi(e) : 0; }();  // opt-in: measured slower
-  bool any_rowsum = false;
-  for (int i = 0; i < count; ++i) any_rowsum |= args[i].a_rowsum != nullptr;
-  bool fits32 = true;  // the v2 kernel addresses its operands through 32-bit buffer offsets
-  for (int i = 0; i < count; ++i)
-    fits32 &= (size_t)tab.p[i].M * tab.p[i].lda * 2 < 0xFFFFFFFFull && (size_t)tab.p[i].N * tab.p[i].ldb * 2 < 0xFFFFFFFFull;
-  if (bm == 256 && f8 == 0 && w4 == 2 && !any_rowsum && !args[0].a_kmajor && !args[0].b_kmajor && fits32)
-    launch_gemm_w4v2(tab, table_is_plain(tab), s);
-  else if (bm == 256 && f8 == 0 && w4 == 1 && !any_rowsum && !args[0].a_kmajor && !args[0].b_kmajor) launch_gemm_w4(tab, args[0].a_kmajor, args[0].b_kmajor, table_is_plain(tab), s);  // 4 waves, 128x128 wave tiles
-  else if (bm == 256 && f8 == 0 && phased) launch_gemm_phased(tab, args[0].a_kmajor, args[0].b_kmajor, table_is_plain(tab), s);  // LDS-DMA, phased
+  const bool phased = phased_env != 0 && !args[0].a_kmajor && !args[0].b_kmajor && count == 1 && !any_rowsum_early(args, count);
+  if (bm == 256 && f8 == 0 && phased) launch_gemm_phased(tab, args[0].a_kmajor, args[0].b_kmajor, table_is_plain(tab), s);  // LDS-DMA, phased
   else if (bm == 256) launch_gemm_t256(tab, args[0].a_kmajor, args[0].b_kmajor, s, f8);     // 256x256x64, 8 waves
   else if (bm == 128) {  // 128x128x64, 8 waves (measured better than the 4-wave 64x64 wave tile at every tile count);
                          // two K-groups (16 waves) when the launch is a single round of at most one block per CU

@@ -21,14 +21,11 @@ struct Problem {
 struct LaunchTable { int count; int total_blocks; Problem p[MAX_PROBLEMS]; };
 // gemm_phased.hip: 256x256 tiles, LDS-DMA operands, four-phase K-tile schedule (bf16 operands, no K-groups)
 void launch_gemm_phased(const LaunchTable& tab, int akm, int bkm, bool plain, hipStream_t s);
-// gemm_w4.hip: 256x256 tiles on four waves (wave tile 128x128, accumulators in AGPRs), hand-pipelined K-tile (bf16, no row sums)
-void launch_gemm_w4(const LaunchTable& tab, int akm, int bkm, bool plain, hipStream_t s);
 // one translation unit per tile configuration of the main kernel (gemm_kernel.h): 256x256 / 128x128 (K-groups 1, 2) / 64x64 (1, 2, 4)
 bool table_is_plain(const LaunchTable& t);
 void launch_gemm_t256(const LaunchTable& tab, int akm, int bkm, hipStream_t s, int f8);
 void launch_gemm_t128(const LaunchTable& tab, int akm, int bkm, hipStream_t s, int f8, int kgroups);
 void launch_gemm_t64(const LaunchTable& tab, int akm, int bkm, hipStream_t s, int f8, int kgroups);
-void launch_gemm_w4v2(const LaunchTable& tab, bool plain, hipStream_t s);  // NT only: two K-tiles in flight, buffer loads
 
 // --- stage one operand image (ROWS x BKT k, or BKT k x ROWS x; ROWS = 128 or 64) HBM/L2 -> registers -> LDS.
 //     Measured on gfx950: a global_load_lds (LDS-DMA) instruction costs ~100 cycles of issue time in the issuing wave's
@@ -68,31 +65,6 @@ struct HalfStager {
       }
       r[i] = *reinterpret_cast<const u32x4*>(g);
     }
-  }
-  // single pieces (gemm_w4.hip interleaves them with its fragment reads by hand)
-  static __device__ __forceinline__ void load1(u32x4& r, const uint16_t* __restrict__ src, int ld, int x0, int k0, int lim, int q, int lane) {
-    int row, c;
-    coords(q, lane, row, c);
-    const uint16_t* g;
-    if (!KMAJOR) {
-      int gr = x0 + row;
-      gr = gr < lim ? gr : lim - 1;
-      g = src + (size_t)gr * ld + k0 + c * 8;
-    } else {
-      int gx = x0 + c * 8;
-      gx = gx < lim ? gx : 0;
-      g = src + (size_t)(k0 + row) * ld + gx;
-    }
-    r = *reinterpret_cast<const u32x4*>(g);
-  }
-  static __device__ __forceinline__ void store1(const u32x4& r, char* lds_tile, int q, int lane) {
-    int row, c;
-    coords(q, lane, row, c);
-    int off;
-    if (!KMAJOR) off = BKT == 64 ? row * 128 + ((c ^ ((row >> 1) & 7)) << 4) : row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
-    else if (ROWS == 128) off = row * 256 + ((c ^ ((row & 3) << 2)) << 4);
-    else off = row * 128 + ((c ^ (((row >> 1) & 1) << 2)) << 4);
-    *reinterpret_cast<u32x4*>(lds_tile + off) = r;
   }
   static __device__ __forceinline__ void store(const u32x4 (&r)[PER], char* lds_tile, int wave, int lane) {
 #pragma unroll

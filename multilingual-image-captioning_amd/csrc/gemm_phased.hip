@@ -253,15 +253,10 @@ void launch_one(const LaunchTable& tab, hipStream_t s) {
 
 }  // namespace
 
+// NT launches only (both operands k-contiguous): the dispatcher takes this kernel for the single-problem NT 256x256 launches, where
+// it measured faster than the register-staged kernel; on the k-major layouts it lost, those instantiations are not built.
 void launch_gemm_phased(const LaunchTable& tab, int akm, int bkm, bool plain, hipStream_t s) {
-#define PH_LAUNCH(A_, B_)                         \
-  do {                                            \
-    if (plain) launch_one<A_, B_, true>(tab, s);  \
-    else launch_one<A_, B_, false>(tab, s);       \
-  } while (0)
-  if (!akm && !bkm) PH_LAUNCH(false, false);
-  else if (!akm && bkm) PH_LAUNCH(false, true);
-  else if (akm && bkm) PH_LAUNCH(true, true);
-  else PH_LAUNCH(true, false);
-#undef PH_LAUNCH
+  if (akm || bkm) { mic_set_error("launch_gemm_phased: NT launches only"); return; }
+  if (plain) launch_one<false, false, true>(tab, s);
+  else launch_one<false, false, false>(tab, s);
 }

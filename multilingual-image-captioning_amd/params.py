@@ -67,7 +67,8 @@ D_ = "model/decoder/"
 
 
 class ParamStore:
-    def __init__(self, config, dtype: torch.dtype, device):
+    def __init__(self, config, dtype: torch.dtype, device, allocate: bool = True):
+        """allocate=False: the segment layout only (offsets / shapes / order), no buffers — what the bucket planner needs"""
         self.cfg, self.dtype, self.device = config, dtype, device
         mc, vc = config.mbart_config, config.clip_vision_config
         self.d, self.ffn, self.L, self.H = mc.d_model, mc.decoder_ffn_dim, mc.decoder_layers, mc.decoder_attention_heads
@@ -125,6 +126,10 @@ class ParamStore:
         add("vit.pos", (self.S, vd))
         add("vit.cls", (vd,))
         self.numel = _rup(off, 256)
+        if not allocate:
+            self.master = self.lp = None
+            self.grad = self.m = self.v = None
+            return
         self.master = torch.zeros(self.numel, dtype=torch.float32, device=device)
         self.lp = self.master if dtype == torch.float32 else torch.zeros(self.numel, dtype=dtype, device=device)
         self.grad = None

@@ -71,6 +71,24 @@ def plan_buckets(numel: int, bucket_elems: int, boundaries: List[int], granule: 
     return cuts
 
 
+def bucket_plan(store, bucket_mb: float = 64.0, world: int = 1, sharded: bool = False) -> List[Tuple[int, int]]:
+    """the gradient-exchange buckets of a ParamStore layout (a store built with allocate=False is enough)"""
+    bounds = [s.offset for s in store.segs.values()]
+    return plan_buckets(store.numel, int(bucket_mb * 1024 * 1024 / 4), bounds, granule=world * 64 if sharded else 1)
+
+
+def describe_buckets(store, buckets: List[Tuple[int, int]], comm_bytes: int = 4) -> List[Dict]:
+    """per bucket: first / last segment it covers, elements and bytes on the wire per rank and exchange (logged by rank 0 at
+    Trainer construction; the order is the order backward completes them)"""
+    segs = sorted(store.segs.values(), key=lambda s: s.offset)
+    out = []
+    for i, (b, e) in enumerate(buckets):
+        inside = [s.name for s in segs if s.offset < e and s.offset + s.numel > b]
+        out.append({"bucket": i, "begin": b, "end": e, "elements": e - b, "MB": round((e - b) * comm_bytes / 1e6, 1),
+                    "first": inside[0], "last": inside[-1], "segments": len(inside)})
+    return out
+
+
 class GradReducer:
     """Bucketed all-reduce(mean) of the flat gradient buffer on a side stream (C1 of SURVEY §2.3), optionally followed —
     still on the side stream — by a per-bucket callback (the fused AdamW of that slice): HBM-bound optimizer traffic then
@@ -285,10 +303,19 @@ class Trainer:
         if gemm_dtype is not None:
             model.engine.set_gemm_dtype(gemm_dtype, scaling=fp8_scaling)
         self.hyper = torch.zeros(2, dtype=torch.float32, device=model.device)
-        bounds = [s.offset for s in st.segs.values()]
         # sharded optimizer (data parallel only): reduce-scatter / AdamW on 1/world of every bucket / all-gather the weights
         self.sharded = bool(sharded_optimizer) and self.world > 1
-        self.buckets = plan_buckets(st.numel, int(bucket_mb * 1024 * 1024 / 4), bounds, granule=self.world * 64 if self.sharded else 1)
+        self.buckets = bucket_plan(st, bucket_mb, self.world, self.sharded)
+        if self.world > 1 and self.rank == 0:
+            import sys
+
+            cb = 2 if grad_comm_dtype in (torch.bfloat16, torch.float16) else 4
+            desc = describe_buckets(st, self.buckets, cb)
+            print(f"[mic_amd.Trainer] data parallel over {self.world} ranks: {len(desc)} gradient buckets in backward-completion order, "
+                  f"{sum(d['MB'] for d in desc):.0f} MB per exchange in {'bf16' if cb == 2 else 'fp32'} "
+                  f"({'reduce-scatter + all-gather, sharded optimizer' if self.sharded else 'all-reduce'}); first: "
+                  f"{desc[0]['first']}..{desc[0]['last']} {desc[0]['MB']:.0f} MB, last: {desc[-1]['first']}..{desc[-1]['last']} {desc[-1]['MB']:.0f} MB; "
+                  f"sizes MB {[d['MB'] for d in desc]}", file=sys.stderr, flush=True)
         # MIC_OPT_OVERLAP=0: AdamW as one launch after backward (profiling aid: per-bucket AdamW on its own stream shares HBM with
         # the backward kernels it overlaps, so their individual durations read longer than the kernels are)
         import os
@@ -303,7 +330,15 @@ class Trainer:
         self.metrics_buf = torch.zeros(2, dtype=torch.float32, device=model.device)
         self._state_dirty = False
         if self.sharded:
-            model._state_sync = self.sync_full_state  # params export / checkpoints need every rank's master + moments
+            # params export / checkpoints need every rank's master weights + moments.  The all-gather is a COLLECTIVE: it is only
+            # ever started explicitly (`sync_full_state()` / `save_checkpoint()` on every rank); `model.params` on stale state
+            # raises instead of starting one on whichever rank happened to ask (a rank-0-only access would deadlock RCCL)
+            model._state_sync = self._require_synced_state
+
+    def _require_synced_state(self):
+        if self.sharded and self._state_dirty:
+            raise RuntimeError("sharded optimizer: the fp32 master weights of this rank are current only on its own shard; call "
+                               "Trainer.sync_full_state() on EVERY rank (a collective) before reading model.params / save_pretrained")
 
     def sync_full_state(self):
         """Sharded optimizer: the fp32 master weights and AdamW moments of a bucket are current only on the rank that owns the

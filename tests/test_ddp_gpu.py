@@ -135,8 +135,16 @@ def _sharded_worker(rank, world, port, q):
                                          "decoder_input_ids": dec_in.numpy()})
                 torch.cuda.synchronize()
                 lp = model.store.lp.float().clone()            # the weights the next forward would use
-                full = flatten_tree(model.params)              # collective in sharded mode (all-gathers the master shards)
+                if mode == "sharded":
+                    # the all-gather of the master shards is an explicit collective; reading params on stale state raises
+                    # (it used to start the collective implicitly: a rank-0-only access would have deadlocked)
+                    try:
+                        model.params
+                        raise AssertionError("model.params on unsynced sharded state must raise")
+                    except RuntimeError as e:
+                        assert "sync_full_state" in str(e)
                 tr.sync_full_state()
+                full = flatten_tree(model.params)
                 results[(mode, dtype)] = (float(out["loss"]), lp, full, model.store.m.clone(), model.store.v.clone())
         # float32: the two optimizers must agree to rounding (the embedding scatter accumulates duplicate rows with fp32 atomics
         # whose order varies, hence not bit-for-bit).  bfloat16: two separate runs already differ in the last gradient bits, and

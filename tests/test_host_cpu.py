@@ -138,6 +138,38 @@ def test_plan_buckets():
     assert [e for _, e in g[:-1]] == [(x // 128) * 128 for x in (21_013, 45_777, 70_001, 99_990)]
 
 
+def test_bucket_plan_full_size_world8():
+    """configs[2] (8 ranks, 547 M parameters): the exchange buckets of the real layout, computed without allocating it.  They
+    follow backward: the first bucket is the dense LM-head half of the tied embedding (+ the logits bias) — complete right
+    after the head's weight-gradient GEMM, 1 GB in fp32, on the wire for the whole of backward — then the decoder layers top
+    down, the projection, the ViT layers top down; the region accumulated by atomics (biases, LayerNorm, position tables) is last."""
+    from mic_amd import CLIPVisionMBartConfig
+    from mic_amd.params import ParamStore
+    from mic_amd.train import bucket_plan, describe_buckets
+
+    st = ParamStore(CLIPVisionMBartConfig(mbart_config={}, clip_vision_config={}), torch.bfloat16, "cpu", allocate=False)
+    assert st.numel == 547_223_040 and st.master is None
+    for world, sharded in ((8, False), (8, True), (2, False)):
+        b = bucket_plan(st, 64.0, world, sharded)
+        d = describe_buckets(st, b)
+        assert b[0][0] == 0 and b[-1][1] == st.numel and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+        assert all(x["elements"] * 4 >= 64 * 1024 * 1024 for x in d[:-1])
+        # bucket 0 = flb + shared: the first gradients backward completes
+        sh = st.segs["shared"]
+        assert d[0]["first"] == "flb" and d[0]["last"] == "shared" and abs(b[0][1] - (sh.offset + sh.numel)) < 8 * 64
+        assert 1.0e3 < d[0]["MB"] < 1.1e3
+        # then decoder layers 11 -> 0 (each 16.8 M elements = 67 MB: one bucket per layer), projection + ViT, atomics region last
+        firsts = [x["first"] for x in d]
+        dec = [f for f in firsts if f.startswith("dec") and f.endswith(".w")]
+        assert dec == sorted(dec, key=lambda n: -int(n[3:].split(".")[0])) and dec[0].startswith("dec11.") and len(dec) == 12
+        assert d[-1]["last"] == "vit.cls"
+        vit_first = next(i for i, f in enumerate(firsts) if f.startswith("vit") or f == "vp.w")
+        assert all(not f.startswith("dec") or not f.endswith(".w") for f in firsts[vit_first:])
+        if sharded:
+            assert all(e % (world * 64) == 0 for _, e in b[:-1])
+        assert 14 <= len(b) <= 24, len(b)
+
+
 def _ddp_worker(rank, world, port, q):
     import torch.distributed as dist
 
