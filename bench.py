@@ -606,8 +606,8 @@ def main():
         # executed work: the LM head (forward, dE, dX: 3 x 2 x rows x V x d) runs only on the label positions that carry loss
         n_loss = sum(int(b["attention_mask"].sum()) for b in batches) / len(batches)
         d_model = cfg.mbart_config.d_model
-        dense_flops = TRAIN_GFLOP_PER_SAMPLE * 1e9 * B if not args.small else float("nan")
-        step_flops = dense_flops - 6.0 * (B * T - n_loss) * V * d_model
+        dense_flops = TRAIN_GFLOP_PER_SAMPLE * 1e9 * B if not args.small else 0.0  # (the FLOP model is for the full-size network)
+        step_flops = max(dense_flops - 6.0 * (B * T - n_loss) * V * d_model, 0.0)
         head = ("logits/CE on all label positions (dense captions: every position carries loss)" if args.dense_captions else
                 "logits/CE on the label positions with loss mask 1 only (exact; ragged captions n~U{8..62})")
         line = {

@@ -55,6 +55,7 @@ class Engine:
         self.dw_overlap = self.dev.type == "cuda" and os.environ.get("MIC_DW_OVERLAP", "1") != "0"
         # decoder-step LayerNorms folded around the GEMMs (bfloat16 generate path): A/B switch
         self.decode_ln_fold = self.dev.type == "cuda" and os.environ.get("MIC_DECODE_LNFOLD", "1") != "0"
+        self._ckv_hoist = os.environ.get("MIC_CKV_HOIST", "1") != "0"
         self._lnf = {}
         self._lnf_version = -1
         self._dw_stream = None
@@ -484,6 +485,7 @@ class Engine:
         ste = self.buf("d.emb.stats", 2, _rup(M, ROWPAD), torch.float32)
         ops.layernorm_fwd(h0, P.f32("dec.ln_emb.g"), P.f32("dec.ln_emb.b"), self.dec_eps, x, ste[0], ste[1], rows=M,
                           dropout_p=self.p_drop if drop else 0.0, dropout_seed=sd(1) or 0)
+        kvcat = self.cross_kv_all(ehs, Mv, "d." if save else "d_.") if self.ckv_hoisted() else None
         for l in range(P.L):
             tag = f"d{l}." if save else "d_."
             p = f"dec{l}."
@@ -502,11 +504,14 @@ class Engine:
             ops.layernorm_fwd(x1, P.f32(p + "ln_ca.g"), P.f32(p + "ln_ca.b"), self.dec_eps, a, stats[2], stats[3], rows=M)
             q = self.buf(tag + "cq", M, d)
             self.linear(a, p + "cq", q, M, save_tag=tag if save else None)
-            kv = self.buf(tag + "ckv", Mv, 2 * d)
-            self.linear(ehs, p + "ckv", kv, Mv, save_tag="d.ehs." if save else None, stable_input=True)
+            if kvcat is not None:
+                kv, ldkv = kvcat[:, l * 2 * d:], kvcat.stride(0)
+            else:
+                kv, ldkv = self.buf(tag + "ckv", Mv, 2 * d), 2 * d
+                self.linear(ehs, p + "ckv", kv, Mv, save_tag="d.ehs." if save else None, stable_input=True)
             cctx = self.buf(tag + "cctx", M, d)
             clse = self.vec(tag + "clse", B * H * T)
-            ops.attn_fwd(q, kv, kv[:, d:], cctx, B, H, T, S, ldq=d, ldk=2 * d, ldv=2 * d, ldo=d, lse=clse)
+            ops.attn_fwd(q, kv, kv[:, d:], cctx, B, H, T, S, ldq=d, ldk=ldkv, ldv=ldkv, ldo=d, lse=clse)
             x2 = self.buf(tag + "x2", M, d)
             self.linear(cctx, p + "co", x2, M, residual=x1, drop_seed=sd(11 + 3 * l))
             a = self.buf(tag + "a_ff", M, d)
@@ -520,6 +525,23 @@ class Engine:
         stf = self.buf("d.f.stats", 2, _rup(M, ROWPAD), torch.float32)
         ops.layernorm_fwd(x, P.f32("dec.ln_f.g"), P.f32("dec.ln_f.b"), self.dec_eps, hf, stf[0], stf[1], rows=M)
         return hf
+
+    # ------------------------------------------------------------------ cross-attention k/v of all layers as one GEMM
+    def ckv_hoisted(self) -> bool:
+        """the cross-attention k/v projections of all decoder layers run as ONE GEMM each way (forward, dX, dW): they read the
+        same encoder states and their weights sit side by side (ParamStore.ckv_cat).  L one-round launches (3200 x 2048 x 1024:
+        400 tiles of 128x128) become one with 1248 tiles of 256x256; the dX sum over the layers becomes a K = L*2d contraction
+        with one rounding instead of L bf16 accumulations.  fp8 mode keeps the per-layer launches (per-tensor scales);
+        MIC_CKV_HOIST=0 switches back (A/B)."""
+        return self._ckv_hoist and not self.fp8
+
+    def cross_kv_all(self, ehs, Mv: int, tag: str):
+        """[Mv][L*2d]: layer l's (k | v) in columns [l*2d, (l+1)*2d)"""
+        P = self.P
+        w, b = P.ckv_cat("w")
+        kvcat = self.buf(tag + "ckvcat", Mv, P.L * 2 * P.d)
+        ops.gemm(ehs, w, kvcat, Mv, P.L * 2 * P.d, P.d, bias=b)
+        return kvcat
 
     def head_logits(self, hf, M: int, name: str = "d.logits", stats: bool = False):
         """Tied head (modeling:170-178): logits[M, Vpad] = hf @ shared^T + final_logits_bias (compute dtype).
@@ -586,12 +608,15 @@ class Engine:
         ops.layernorm_bwd(x_last, P.f32("dec.ln_f.g"), stf[0], stf[1], dhf, dx, P.g("dec.ln_f.g"), P.g("dec.ln_f.b"), rows=M,
                           dxm=dxm, dropout_p=pd, dropout_seed=sd(12 + 3 * (P.L - 1)))
         dehs = self.buf("db.dehs", Mv, d)
+        hoist = self.ckv_hoisted()
+        kvcat = self.buf("d.ckvcat", Mv, P.L * 2 * d) if hoist else None
+        dkvcat = self.buf("db.dkvcat", Mv, P.L * 2 * d) if hoist else None
         for l in reversed(range(P.L)):
             tag, p = f"d{l}.", f"dec{l}."
             stats = self.buf(tag + "stats", 6, _rup(M, ROWPAD), torch.float32)
             a_sa, qkv, ctx, x1 = (self.buf(tag + n, M, c) for n, c in (("a_sa", d), ("qkv", 3 * d), ("ctx", d), ("x1", d)))
             a_ca, cq, cctx, x2 = (self.buf(tag + n, M, d) for n in ("a_ca", "cq", "cctx", "x2"))
-            ckv = self.buf(tag + "ckv", Mv, 2 * d)
+            ckv, ldkv = (kvcat[:, l * 2 * d:], kvcat.stride(0)) if hoist else (self.buf(tag + "ckv", Mv, 2 * d), 2 * d)
             a_ff, z, u = self.buf(tag + "a_ff", M, d), self.buf(tag + "z", M, f), self.buf(tag + "u", M, f)
             lse, clse = self.vec(tag + "lse", B * H * T), self.vec(tag + "clse", B * H * T)
             x_in = self.buf(f"d{l - 1}.x3", M, d) if l > 0 else self.buf("d.x0", M, d)
@@ -608,11 +633,12 @@ class Engine:
             dctx = self.buf("db.dctx", M, d)
             self.linear_bwd(p + "co", cctx, dxm_b, M, dx=dctx, defer=True)
             dq = self.dyb("db.dq", l, M, d)
-            dkv = self.dyb("db.dkv", l, Mv, 2 * d)
-            ops.attn_bwd(cq, ckv, ckv[:, d:], cctx, dctx, clse, dq, dkv, dkv[:, d:], B, H, T, S, ldq=d, ldk=2 * d, ldv=2 * d, ldo=d,
-                         lddo=d, lddq=d, lddk=2 * d, lddv=2 * d)
+            dkv = dkvcat[:, l * 2 * d:] if hoist else self.dyb("db.dkv", l, Mv, 2 * d)
+            ops.attn_bwd(cq, ckv, ckv[:, d:], cctx, dctx, clse, dq, dkv, dkv[:, d:], B, H, T, S, ldq=d, ldk=ldkv, ldv=ldkv, ldo=d,
+                         lddo=d, lddq=d, lddk=ldkv, lddv=ldkv)
             self.linear_bwd(p + "cq", a_ca, dq, M, dx=da, defer=True)
-            self.linear_bwd(p + "ckv", ehs, dkv, Mv, dx=dehs, dx_accumulate=(l != P.L - 1), defer=True)
+            if not hoist:
+                self.linear_bwd(p + "ckv", ehs, dkv, Mv, dx=dehs, dx_accumulate=(l != P.L - 1), defer=True)
             dx1 = self.buf("db.dx1", M, d)
             ops.layernorm_bwd(x1, P.f32(p + "ln_ca.g"), stats[2], stats[3], da, dx1, P.g(p + "ln_ca.g"), P.g(p + "ln_ca.b"), rows=M,
                               dres=dx2, dxm=dxm_c, dropout_p=pd, dropout_seed=sd(10 + 3 * l))
@@ -630,6 +656,30 @@ class Engine:
             else:
                 ops.layernorm_bwd(x_in, P.f32(p + "ln_sa.g"), stats[0], stats[1], da, dx, P.g(p + "ln_sa.g"), P.g(p + "ln_sa.b"), rows=M,
                                   dres=dx1)
+        if hoist:
+            # the cross-attention k/v projections of all layers at once: dW (+ bias row sums) = dkv^T ehs as one [L*2d][d] weight
+            # gradient (on the dW stream), dehs = dkv W as one contraction over K = L*2d (split over K into fp32 slabs: 52 output
+            # tiles of 256x256 cannot fill the chip)
+            wcat, _ = P.ckv_cat("w")
+            gw, gb = P.ckv_cat("g")
+            N = P.L * 2 * d
+            Mvp = _rup(Mv, ROWPAD)
+            fuse = self.dt == torch.bfloat16
+            rs = dict(a_rowsum=gb, rowsum_k=Mv) if fuse else {}
+            # dX first: it READS the weights, and reporting their gradients final (flush_dw -> _done) lets the per-bucket optimizer
+            # rewrite them; the dW stream's launch waits for everything enqueued here, so the bucket's event covers this GEMM too
+            if self.dt == torch.bfloat16:
+                nsp = 8
+                slab = Mvp * d
+                d32 = self.buf("db.dehs32", nsp * Mvp, d, torch.float32)
+                ops.gemm(dkvcat, wcat, d32, Mv, d, N, b_kmajor=True, split_k=nsp, split_stride=slab)
+                ops.sum_slabs(d32, nsp, slab, dehs, Mv, d, d32.stride(0), dehs.stride(0))
+            else:
+                ops.gemm(dkvcat, wcat, dehs, Mv, d, N, b_kmajor=True)
+            self._dw_queue.append((ops.gemm_args(dkvcat, ehs, gw, N, d, Mvp, a_kmajor=True, b_kmajor=True, **rs), f"dec{P.L - 1}.ckv", True))
+            if not fuse:
+                self._cs_queue.append((dkvcat, gb, Mv, N, dkvcat.stride(0)))
+            self.flush_dw()
         # embedding LayerNorm (+ its dropout) and the token/position embedding scatter
         h0 = self.buf("d.h0", M, d)
         ste = self.buf("d.emb.stats", 2, _rup(M, ROWPAD), torch.float32)

@@ -92,11 +92,16 @@ class ParamStore:
         add("flb", (self.Vpad,))
         add("shared", (self.Vpad, d))  # LM-head part is final right after the head dW GEMM; the sparse input-embedding rows are
         #                                added after the dense all-reduce (see Trainer / Engine.defer_embed)
-        dec_lin = (("fc2", (d, f)), ("fc1", (f, d)), ("co", (d, d)), ("cq", (d, d)), ("ckv", (2 * d, d)), ("so", (d, d)), ("qkv", (3 * d, d)))
+        # the cross-attention k/v projections of ALL layers read the same encoder states and nothing inside the decoder feeds
+        # them: they sit side by side ([L*2d][d], layer 0 first) so that forward (ehs W^T), dX (sum over layers) and dW are ONE
+        # GEMM each instead of L; their gradients complete with the end of decoder backward, hence behind layer 0's segments
+        dec_lin = (("fc2", (d, f)), ("fc1", (f, d)), ("co", (d, d)), ("cq", (d, d)), ("so", (d, d)), ("qkv", (3 * d, d)))
         vit_lin = (("fc2", (vd, vf)), ("fc1", (vf, vd)), ("o", (vd, vd)), ("qkv", (3 * vd, vd)))
         for l in reversed(range(self.L)):
             for n, shp in dec_lin:
                 add(f"dec{l}.{n}.w", shp)
+        for l in range(self.L):
+            add(f"dec{l}.ckv.w", (2 * d, d))
         add("vp.w", (d, vd))
         for l in reversed(range(self.vL)):
             for n, shp in vit_lin:
@@ -108,6 +113,8 @@ class ParamStore:
         for l in reversed(range(self.L)):
             for n, shp in dec_lin:
                 add(f"dec{l}.{n}.b", (shp[0],))
+        for l in range(self.L):
+            add(f"dec{l}.ckv.b", (2 * d,))
         add("vp.b", (d,))
         for l in reversed(range(self.vL)):
             for n, shp in vit_lin:
@@ -149,6 +156,16 @@ class ParamStore:
     def g(self, name: str) -> torch.Tensor:
         s = self.segs[name]
         return self.grad[s.offset: s.offset + s.numel].view(s.shape)
+
+    def ckv_cat(self, which: str = "w"):
+        """(weights [L*2d][d], biases [L*2d]) of the cross-attention k/v projections of all layers as ONE matrix: `which` = "w"
+        (compute copy + fp32 bias) or "g" (gradients)"""
+        a, b = self.segs["dec0.ckv.w"], self.segs[f"dec{self.L - 1}.ckv.w"]
+        ba, bb = self.segs["dec0.ckv.b"], self.segs[f"dec{self.L - 1}.ckv.b"]
+        n = self.L * 2 * self.d
+        assert b.offset + b.numel - a.offset == n * self.d and bb.offset + bb.numel - ba.offset == n, "ckv segments are not contiguous"
+        wbuf, bbuf = (self.lp, self.master) if which == "w" else (self.grad, self.grad)
+        return wbuf[a.offset: a.offset + n * self.d].view(n, self.d), bbuf[ba.offset: ba.offset + n]
 
     def ensure_grads(self):
         if self.grad is None:

@@ -93,7 +93,8 @@ def run_stages(model, rc, p, px, dec_in, mask):
         x = hb("d.x0", Md, d)
         eps = rc.decoder_ln_eps
         cmp("dec.ln_emb", x, ln(h0, E.D_ + "layernorm_embedding", eps))
-        e3 = ehs.reshape(B, S, d)
+        hoist = eng.ckv_hoisted()  # the cross-attention k/v projections of all layers as one GEMM: [Mv][L*2d]
+        ckvcat = hb("d.ckvcat", Mv, rc.d_layers * 2 * d) if hoist else None
         for l in range(rc.d_layers):
             L, tag = f"{E.D_}layers/{l}/", f"d{l}."
             a = hb(tag + "a_sa", Md, d)
@@ -109,7 +110,7 @@ def run_stages(model, rc, p, px, dec_in, mask):
             cmp(tag + "ln_ca", a, ln(x1, L + "encoder_attn_layer_norm", eps))
             cq = hb(tag + "cq", Md, d)
             cmp(tag + "cq", cq, E._lin(a, pc, L + "encoder_attn/q_proj"))
-            ckv = hb(tag + "ckv", Mv, 2 * d)
+            ckv = ckvcat[:, l * 2 * d:(l + 1) * 2 * d] if hoist else hb(tag + "ckv", Mv, 2 * d)
             cmp(tag + "ckv", ckv, torch.cat([E._lin(ehs, pc, L + f"encoder_attn/{n}_proj") for n in ("k", "v")], -1))
             cctx = hb(tag + "cctx", Md, d)
             cmp(tag + "cross_attn", cctx, E.attn_train_unrounded(cq.reshape(B, T, H, d // H), ckv[:, :d].reshape(B, S, H, d // H),
