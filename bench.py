@@ -425,11 +425,19 @@ def main():
     batches = [synth_batch(B, T, V, img, 1234 + rank * 100 + i, dense=args.dense_captions) for i in range(2)]
     # inputs resident in HBM before the timed region
     dbatches = [{k: torch.from_numpy(v).to(dev) for k, v in b.items()} for b in batches]
-    from mic_amd import loss_rows
+    from mic_amd import loss_rows, packed_rows
 
-    for b, db in zip(batches, dbatches):  # collate-side: positions that carry loss (the LM head runs only there)
+    def collate_extras(b, db):
+        """collate-side: positions that carry loss (the LM head runs only there) and the packed-row description of the batch (the
+        decoder runs only on the valid caption positions); host work, outside the timed region like the reference's collate_fn"""
         idx, rl = loss_rows(b["attention_mask"], b["input_ids"])
         db["loss_rows"] = (torch.from_numpy(idx).to(dev), torch.from_numpy(rl).to(dev))
+        pk = packed_rows(b["attention_mask"], b["decoder_input_ids"])
+        if pk is not None:
+            db["packed_rows"] = tuple(torch.from_numpy(t).to(dev) for t in pk)
+
+    for b, db in zip(batches, dbatches):
+        collate_extras(b, db)
 
     def barrier():
         if world > 1:
@@ -468,8 +476,7 @@ def main():
         for i in range(2):
             b = synth_batch(B, T, V, img, 4321 + rank * 100 + i, dense=True)
             d2 = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
-            idx, rl = loss_rows(b["attention_mask"], b["input_ids"])
-            d2["loss_rows"] = (torch.from_numpy(idx).to(dev), torch.from_numpy(rl).to(dev))
+            collate_extras(b, d2)
             db2.append(d2)
         for i in range(2):
             tr.train_step(db2[i % 2])
@@ -608,6 +615,9 @@ def main():
         d_model = cfg.mbart_config.d_model
         dense_flops = TRAIN_GFLOP_PER_SAMPLE * 1e9 * B if not args.small else 0.0  # (the FLOP model is for the full-size network)
         step_flops = max(dense_flops - 6.0 * (B * T - n_loss) * V * d_model, 0.0)
+        packed = tr.pack_rows and args.dtype == "bf16" and not args.dense_captions
+        if packed:  # the decoder layers run on the valid rows only: 14 d^2 multiply-adds per row and layer (qkv 3, so 1, cq 1, co 1, fc1 4, fc2 4), x3 for fwd + bwd
+            step_flops = max(step_flops - 6.0 * 14.0 * d_model * d_model * cfg.mbart_config.decoder_layers * (B * T - n_loss), 0.0)
         head = ("logits/CE on all label positions (dense captions: every position carries loss)" if args.dense_captions else
                 "logits/CE on the label positions with loss mask 1 only (exact; ragged captions n~U{8..62})")
         line = {
@@ -620,10 +630,13 @@ def main():
                                    + (" [ALL RANKS SHARE cuda:0 OVER gloo: functional check, not a benchmark]" if share and world > 1 else ""),
                        "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}" + ("+sharded-optimizer" if args.sharded_optimizer else ""),
                        "grad_allreduce": f"{args.grad_comm} flat buckets, RCCL, side stream",
+                       "decoder_rows": ("valid caption positions only (packed rows: padded positions neither carry loss nor are attended to — exact; "
+                                        f"{n_loss:.0f} of {B * T} rows per step)" if (tr.pack_rows and args.dtype == "bf16" and not args.dense_captions) else f"all {B * T} positions"),
                        "lm_head": head, "gemm_dtype": "fp8 e4m3 (fwd) / e5m2 (grads) for QKV+FFN, bf16 elsewhere" if args.dtype == "fp8" else args.dtype},
             "model_tflops_per_gpu": round(step_flops * args.steps / dt / 1e12, 1),
-            "model_tflops_note": f"EXECUTED model FLOPs per step ({step_flops / 1e12:.2f} TF: dense {dense_flops / 1e12:.2f} TF of SURVEY 8d minus the LM-head work on the "
-                                 f"{B * T - n_loss:.0f} padded label positions, whose loss weight is 0) / ms_per_step; dense_equivalent divides the full dense count "
+            "model_tflops_note": f"EXECUTED model FLOPs per step ({step_flops / 1e12:.2f} TF: dense {dense_flops / 1e12:.2f} TF of SURVEY 8d minus the LM-head "
+                                 + ("and decoder-layer " if packed else "") + f"work on the {B * T - n_loss:.0f} padded label positions, whose loss weight is 0"
+                                 + (" and which no valid position attends to" if packed else "") + ") / ms_per_step; dense_equivalent divides the full dense count "
                                  "by the same time (NOT executed work); dense_captions is the measured step when every position carries loss",
             "dense_equivalent_tflops_per_gpu": round(dense_flops * args.steps / dt / 1e12, 1),
             "dense_captions": dense,

@@ -109,6 +109,10 @@ typedef struct {
    * disappears.  N % 128 == 0, bare or residual epilogue. */
   const long long* a_ln_stats; const float* a_ln_colsum; int a_ln_width; float a_ln_eps;
   long long* rowsum2;
+  /* bf16, a_kmajor && b_kmajor launches (weight gradients dW = dy^T x, reduction over the ROWS of dy and x): rows k >= k_valid of
+   * both operands count as zero (0 = all K rows are valid).  K stays a multiple of 64; the buffers need not keep their rows
+   * [k_valid, K) zeroed — with variable-length (packed) batches the number of valid rows changes from step to step. */
+  int k_valid;
 } mic_gemm_args;
 int mic_gemm(const mic_gemm_args* a, void* stream);
 /* dst[r][c] (dst_dtype) = sum over s < n_slabs of src[s * slab_stride + r * ld_src + c] (fp32): the second half of a
@@ -180,6 +184,19 @@ int mic_attn_bwd(int dtype, int B, int H, int Tq, int Tk, const void* q, int ldq
                  const void* v, int ldv, const void* out, int ldo, const void* dout, int lddo, const float* lse,
                  const int32_t* key_mask, int causal, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv,
                  void* stream);
+
+/* The same cores on variable-length ("packed") rows: sequence b owns the q rows [q_off[b], q_off[b] + q_len[b]) of a packed
+ * [sum q_len][ld] matrix — padded positions have no rows at all (their loss weight is 0 and no valid position attends to them,
+ * main.py:678, 692: every gradient they would contribute is exactly 0).  kv_packed = 1: keys / values are the same packed rows
+ * (decoder self-attention: key j allowed iff j <= i, all within q_len[b]); kv_packed = 0: every sequence has its Tk dense rows
+ * [b*Tk, (b+1)*Tk) (cross-attention over the encoder states).  q_len[b] <= Tq_max <= 64, Tk <= 64; lse [B][H][Tq_max]. */
+int mic_attn_fwd_packed(int dtype, int B, int H, int Tq_max, int Tk, const int32_t* q_off, const int32_t* q_len, int kv_packed,
+                        const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int causal,
+                        float* lse, void* stream);
+int mic_attn_bwd_packed(int dtype, int B, int H, int Tq_max, int Tk, const int32_t* q_off, const int32_t* q_len, int kv_packed,
+                        const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* out, int ldo,
+                        const void* dout, int lddo, const float* lse, int causal, void* dq, int lddq, void* dk, int lddk,
+                        void* dv, int lddv, void* stream);
 
 /* Decode-time self-attention over the static max_len-slot cache (3P _concatenate_to_cache; modeling:249-282;
  * SURVEY App. B7): one query per row, validity slot <= cur (cache_index).  The cache is NOT physically

@@ -8,7 +8,7 @@ from . import _lib  # noqa: F401
 from .configuration_clip_vision_mbart import CLIPVisionMBartConfig  # noqa: F401
 from .modeling_clip_vision_mbart import FlaxCLIPVisionMBartForConditionalGeneration  # noqa: F401
 from .image_transform import Transform  # noqa: F401
-from .train import Trainer, create_learning_rate_fn, loss_rows, shift_tokens_right  # noqa: F401
+from .train import Trainer, create_learning_rate_fn, loss_rows, packed_rows, shift_tokens_right  # noqa: F401
 
 __all__ = ["CLIPVisionMBartConfig", "FlaxCLIPVisionMBartForConditionalGeneration", "Trainer", "Transform", "create_learning_rate_fn",
-           "loss_rows", "shift_tokens_right"]
+           "loss_rows", "packed_rows", "shift_tokens_right"]

@@ -32,7 +32,7 @@ class GemmArgs(C.Structure):
         ("a_fmt", C.c_int), ("b_fmt", C.c_int), ("a_scale_inv", C.c_void_p), ("b_scale_inv", C.c_void_p),
         ("rowstat", C.c_void_p), ("rowstat_ld", C.c_int), ("rowstat_nvalid", C.c_int),
         ("a_ln_stats", C.c_void_p), ("a_ln_colsum", C.c_void_p), ("a_ln_width", C.c_int), ("a_ln_eps", C.c_float),
-        ("rowsum2", C.c_void_p),
+        ("rowsum2", C.c_void_p), ("k_valid", C.c_int),
     ]
 
 
@@ -76,6 +76,8 @@ _SIGS = {
     "mic_layernorm_bwd": ([_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _u32, _f, _u32, _p], C.c_int),
     "mic_attn_fwd": ([_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p], C.c_int),
     "mic_attn_bwd": ([_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p], C.c_int),
+    "mic_attn_fwd_packed": ([_i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _p, _p], C.c_int),
+    "mic_attn_bwd_packed": ([_i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p], C.c_int),
     "mic_attn_decode": ([_i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p], C.c_int),
     "mic_kv_append": ([_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p], C.c_int),
     "mic_im2col": ([_i, _i, _i, _i, _p, _p, _i, _i, _p], C.c_int),

@@ -118,15 +118,20 @@ __device__ __forceinline__ unsigned long long load_key_mask(const int32_t* key_m
   return __ballot(mv != 0);
 }
 
+// Variable-length ("packed") rows: sequence b owns the q rows [q_off[b], q_off[b] + q_len[b]) of a packed [sum q_len][ld] matrix
+// (no rows for padded positions at all).  kv_packed: keys / values are the same packed rows (self-attention) — otherwise every
+// sequence has its Tk dense rows [b*Tk, (b+1)*Tk) (cross-attention over the encoder states).  q_off == nullptr: dense rows.
+struct PackedRows { const int32_t* q_off; const int32_t* q_len; int kv_packed; };
+
 // ------------------------------------------------------------------ forward
 // 256 threads = 4 waves share one (batch, head) problem.  Phase 1: wave w owns the (ib, jb) = (w>>1, w&1) quadrant of
 // S^T = K Q^T (lane <-> query): quadrant max -> LDS, barrier, p = exp(s - rowmax) written UNnormalised to the P tile,
 // quadrant row sums -> LDS.  Phase 2: wave w owns output block (ib, db) of O = P V and scales each row by 1/rowsum.
 template <typename T>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(int H, int Tq, int Tk, const T* __restrict__ q, int ldq,
+__global__ __launch_bounds__(256) void attn_fwd_kernel(int H, int Tq_max, int Tk_max, const T* __restrict__ q, int ldq,
                                                        const T* __restrict__ k, int ldk, const T* __restrict__ v, int ldv,
                                                        T* __restrict__ out, int ldo, const int32_t* __restrict__ key_mask,
-                                                       int causal, float* __restrict__ lse_out) {
+                                                       int causal, float* __restrict__ lse_out, PackedRows pk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TB = Tile<T>::BYTES;
   char* Qt = smem;
@@ -137,9 +142,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int H, int Tq, int Tk, co
   float* psum = pmax + 128;                               // [2 jb][64 queries]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / H, h = blockIdx.x % H;
-  Tile<T>::template stage<256>(Qt, q + (size_t)b * Tq * ldq + h * 64, ldq, Tq, tid);
-  Tile<T>::template stage<256>(Kt, k + (size_t)b * Tk * ldk + h * 64, ldk, Tk, tid);
-  Tile<T>::template stage<256>(Vt, v + (size_t)b * Tk * ldv + h * 64, ldv, Tk, tid);
+  int Tq = Tq_max, Tk = Tk_max;
+  size_t q0 = (size_t)b * Tq_max, k0 = (size_t)b * Tk_max;
+  if (pk.q_off) {
+    q0 = pk.q_off[b]; Tq = pk.q_len[b];
+    if (pk.kv_packed) { k0 = q0; Tk = Tq; }
+  }
+  Tile<T>::template stage<256>(Qt, q + q0 * ldq + h * 64, ldq, Tq, tid);
+  Tile<T>::template stage<256>(Kt, k + k0 * ldk + h * 64, ldk, Tk, tid);
+  Tile<T>::template stage<256>(Vt, v + k0 * ldv + h * 64, ldv, Tk, tid);
   const unsigned long long km = load_key_mask(key_mask, b, Tk, lane);
   __syncthreads();
   const int nib = (Tq + 31) >> 5, njb = (Tk + 31) >> 5;
@@ -177,7 +188,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int H, int Tq, int Tk, co
   l += __shfl_xor(l, 32, 64);
   if (lane < 32) psum[jb * 64 + i] = l;
   __syncthreads();
-  if (jb == 0 && lane < 32 && i < Tq && lse_out) lse_out[((size_t)b * H + h) * Tq + i] = mrow + logf(psum[i] + psum[64 + i]);
+  if (jb == 0 && lane < 32 && i < Tq && lse_out) lse_out[((size_t)b * H + h) * Tq_max + i] = mrow + logf(psum[i] + psum[64 + i]);
   {
     const int db = wave & 1;  // output block (ib, db)
     if (ib < nib) {
@@ -188,7 +199,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int H, int Tq, int Tk, co
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int qi = ib * 32 + acc_row(r, lane);
-        if (qi < Tq) ElemT<T>::st(out + ((size_t)b * Tq + qi) * ldo + h * 64 + d, o[r] / (psum[qi] + psum[64 + qi]));
+        if (qi < Tq) ElemT<T>::st(out + (q0 + qi) * ldo + h * 64 + d, o[r] / (psum[qi] + psum[64 + qi]));
       }
     }
   }
@@ -200,35 +211,44 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int H, int Tq, int Tk, co
 // quadrant of S^T / dP^T and writes its quadrant of the P and dS tiles.  Phase 2: wave w owns output block
 // (w>>1, w&1) of dQ, dK and dV.
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(int H, int Tq, int Tk, const T* __restrict__ q, int ldq,
+__global__ __launch_bounds__(256) void attn_bwd_kernel(int H, int Tq_max, int Tk_max, const T* __restrict__ q, int ldq,
                                                        const T* __restrict__ k, int ldk, const T* __restrict__ v, int ldv,
                                                        const T* __restrict__ out, int ldo, const T* __restrict__ dout, int lddo,
                                                        const float* __restrict__ lse_in, const int32_t* __restrict__ key_mask,
                                                        int causal, T* __restrict__ dq, int lddq, T* __restrict__ dk, int lddk,
-                                                       T* __restrict__ dv, int lddv) {
+                                                       T* __restrict__ dv, int lddv, PackedRows pk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TB = Tile<T>::BYTES;
+  // five tiles (40 KiB in bf16: FOUR workgroups per CU, so the 1024 (batch, head) problems of a decoder layer at batch 64 are one
+  // residency round instead of 768 + 256): V is dead once dP^T = V dO^T is in the accumulators, so the P tile takes its place
+  // (one extra barrier), and the 512 B of per-query lse / delta live in the head of the dS tile until dS itself is written
   char* Qt = smem;
   char* Kt = smem + TB;
   char* Vt = smem + 2 * TB;
   char* dOt = smem + 3 * TB;
-  char* Pt = smem + 4 * TB;
-  char* dSt = smem + 5 * TB;
-  float* lse_s = reinterpret_cast<float*>(smem + 6 * TB);
+  char* dSt = smem + 4 * TB;
+  char* Pt = Vt;
+  float* lse_s = reinterpret_cast<float*>(dSt);
   float* delta_s = lse_s + 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / H, h = blockIdx.x % H;
-  Tile<T>::template stage<256>(Qt, q + (size_t)b * Tq * ldq + h * 64, ldq, Tq, tid);
-  Tile<T>::template stage<256>(Kt, k + (size_t)b * Tk * ldk + h * 64, ldk, Tk, tid);
-  Tile<T>::template stage<256>(Vt, v + (size_t)b * Tk * ldv + h * 64, ldv, Tk, tid);
-  Tile<T>::template stage<256>(dOt, dout + (size_t)b * Tq * lddo + h * 64, lddo, Tq, tid);
+  int Tq = Tq_max, Tk = Tk_max;
+  size_t q0 = (size_t)b * Tq_max, k0 = (size_t)b * Tk_max;
+  if (pk.q_off) {
+    q0 = pk.q_off[b]; Tq = pk.q_len[b];
+    if (pk.kv_packed) { k0 = q0; Tk = Tq; }
+  }
+  Tile<T>::template stage<256>(Qt, q + q0 * ldq + h * 64, ldq, Tq, tid);
+  Tile<T>::template stage<256>(Kt, k + k0 * ldk + h * 64, ldk, Tk, tid);
+  Tile<T>::template stage<256>(Vt, v + k0 * ldv + h * 64, ldv, Tk, tid);
+  Tile<T>::template stage<256>(dOt, dout + q0 * lddo + h * 64, lddo, Tq, tid);
   {
     // delta_i = dO_i . O_i : thread t covers 16 of the 64 dims of row t>>2
     const int row = tid >> 2, part = tid & 3;
     float dl = 0.f;
     if (row < Tq) {
-      const T* orow = out + ((size_t)b * Tq + row) * ldo + h * 64 + part * 16;
-      const T* drow = dout + ((size_t)b * Tq + row) * lddo + h * 64 + part * 16;
+      const T* orow = out + (q0 + row) * ldo + h * 64 + part * 16;
+      const T* drow = dout + (q0 + row) * lddo + h * 64 + part * 16;
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         float a[8], g[8];
@@ -241,7 +261,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(int H, int Tq, int Tk, co
     dl += __shfl_xor(dl, 1, 64);
     dl += __shfl_xor(dl, 2, 64);
     if (part == 0) delta_s[row] = dl;
-    if (tid < 64) lse_s[tid] = tid < Tq ? lse_in[((size_t)b * H + h) * Tq + tid] : 0.f;
+    if (tid < 64) lse_s[tid] = tid < Tq ? lse_in[((size_t)b * H + h) * Tq_max + tid] : 0.f;
   }
   const unsigned long long km = load_key_mask(key_mask, b, Tk, lane);
   __syncthreads();
@@ -258,6 +278,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(int H, int Tq, int Tk, co
       Tile<T>::template mma<false, false>(sacc, Kt, jb * 32, Qt, ib * 32, lane);
       Tile<T>::template mma<false, false>(dp, Vt, jb * 32, dOt, ib * 32, lane);
     }
+    __syncthreads();  // every wave has read V (-> P) and lse / delta (-> dS) before those regions are overwritten
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       float pv[4], dsv[4];
@@ -285,7 +306,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(int H, int Tq, int Tk, co
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = xb * 32 + acc_row(r, lane);
-        if (i < Tq) ElemT<T>::st(dq + ((size_t)b * Tq + i) * lddq + h * 64 + d, a[r]);
+        if (i < Tq) ElemT<T>::st(dq + (q0 + i) * lddq + h * 64 + d, a[r]);
       }
     }
     if (xb < njb) {
@@ -297,8 +318,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(int H, int Tq, int Tk, co
       for (int r = 0; r < 16; ++r) {
         const int j = xb * 32 + acc_row(r, lane);
         if (j < Tk) {
-          ElemT<T>::st(dk + ((size_t)b * Tk + j) * lddk + h * 64 + d, a[r]);
-          ElemT<T>::st(dv + ((size_t)b * Tk + j) * lddv + h * 64 + d, c[r]);
+          ElemT<T>::st(dk + (k0 + j) * lddk + h * 64 + d, a[r]);
+          ElemT<T>::st(dv + (k0 + j) * lddv + h * 64 + d, c[r]);
         }
       }
     }
@@ -566,11 +587,11 @@ extern "C" int mic_attn_fwd(int dtype, int B, int H, int Tq, int Tk, const void*
   }
   dim3 grid(B * H), block(256);
   if (dtype == MIC_BF16) {
-    hipLaunchKernelGGL(attn_fwd_kernel<uint16_t>, grid, block, 4 * Tile<uint16_t>::BYTES + 1024, (hipStream_t)stream, H, Tq, Tk, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk, (const uint16_t*)v, ldv, (uint16_t*)out, ldo, key_mask, causal, lse);
+    hipLaunchKernelGGL(attn_fwd_kernel<uint16_t>, grid, block, 4 * Tile<uint16_t>::BYTES + 1024, (hipStream_t)stream, H, Tq, Tk, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk, (const uint16_t*)v, ldv, (uint16_t*)out, ldo, key_mask, causal, lse, PackedRows{nullptr, nullptr, 0});
   } else if (dtype == MIC_F32) {
     const size_t lds = 4 * Tile<float>::BYTES + 1024;
     if (int rc = set_lds(attn_fwd_kernel<float>, lds)) return rc;
-    hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, block, lds, (hipStream_t)stream, H, Tq, Tk, (const float*)q, ldq, (const float*)k, ldk, (const float*)v, ldv, (float*)out, ldo, key_mask, causal, lse);
+    hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, block, lds, (hipStream_t)stream, H, Tq, Tk, (const float*)q, ldq, (const float*)k, ldk, (const float*)v, ldv, (float*)out, ldo, key_mask, causal, lse, PackedRows{nullptr, nullptr, 0});
   } else MIC_CHECK(false, "mic_attn_fwd: bad dtype");
   MIC_LAUNCH_CHECK();
   return MIC_OK;
@@ -603,13 +624,55 @@ extern "C" int mic_attn_bwd(int dtype, int B, int H, int Tq, int Tk, const void*
   }
   dim3 grid(B * H), block(256);
   if (dtype == MIC_BF16) {
-    const size_t lds = 6 * Tile<uint16_t>::BYTES + 512;
-    hipLaunchKernelGGL(attn_bwd_kernel<uint16_t>, grid, block, lds, (hipStream_t)stream, H, Tq, Tk, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk, (const uint16_t*)v, ldv, (const uint16_t*)out, ldo, (const uint16_t*)dout, lddo, lse, key_mask, causal, (uint16_t*)dq, lddq, (uint16_t*)dk, lddk, (uint16_t*)dv, lddv);
+    const size_t lds = 5 * Tile<uint16_t>::BYTES;
+    hipLaunchKernelGGL(attn_bwd_kernel<uint16_t>, grid, block, lds, (hipStream_t)stream, H, Tq, Tk, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk, (const uint16_t*)v, ldv, (const uint16_t*)out, ldo, (const uint16_t*)dout, lddo, lse, key_mask, causal, (uint16_t*)dq, lddq, (uint16_t*)dk, lddk, (uint16_t*)dv, lddv, PackedRows{nullptr, nullptr, 0});
   } else if (dtype == MIC_F32) {
-    const size_t lds = 6 * Tile<float>::BYTES + 512;
+    const size_t lds = 5 * Tile<float>::BYTES;
     if (int rc = set_lds(attn_bwd_kernel<float>, lds)) return rc;
-    hipLaunchKernelGGL(attn_bwd_kernel<float>, grid, block, lds, (hipStream_t)stream, H, Tq, Tk, (const float*)q, ldq, (const float*)k, ldk, (const float*)v, ldv, (const float*)out, ldo, (const float*)dout, lddo, lse, key_mask, causal, (float*)dq, lddq, (float*)dk, lddk, (float*)dv, lddv);
+    hipLaunchKernelGGL(attn_bwd_kernel<float>, grid, block, lds, (hipStream_t)stream, H, Tq, Tk, (const float*)q, ldq, (const float*)k, ldk, (const float*)v, ldv, (const float*)out, ldo, (const float*)dout, lddo, lse, key_mask, causal, (float*)dq, lddq, (float*)dk, lddk, (float*)dv, lddv, PackedRows{nullptr, nullptr, 0});
   } else MIC_CHECK(false, "mic_attn_bwd: bad dtype");
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}
+
+// ------------------------------------------------------------------ packed (variable-length) rows, one 64x64 tile per sequence
+extern "C" int mic_attn_fwd_packed(int dtype, int B, int H, int Tq_max, int Tk, const int32_t* q_off, const int32_t* q_len, int kv_packed,
+                                   const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo,
+                                   int causal, float* lse, void* stream) {
+  MIC_CHECK(B > 0 && H > 0 && Tq_max > 0 && Tq_max <= 64 && Tk > 0 && Tk <= 64, "mic_attn_fwd_packed: one 64x64 tile per sequence (Tq_max=%d Tk=%d)", Tq_max, Tk);
+  MIC_CHECK(q && k && v && out && q_off && q_len, "mic_attn_fwd_packed: null pointer");
+  const int align = dtype == MIC_BF16 ? 8 : 4;
+  MIC_CHECK(ldq % align == 0 && ldk % align == 0 && ldv % align == 0, "mic_attn_fwd_packed: row strides must keep 16-B alignment");
+  const PackedRows pk{q_off, q_len, kv_packed};
+  dim3 grid(B * H), block(256);
+  if (dtype == MIC_BF16) {
+    hipLaunchKernelGGL(attn_fwd_kernel<uint16_t>, grid, block, 4 * Tile<uint16_t>::BYTES + 1024, (hipStream_t)stream, H, Tq_max, Tk, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk, (const uint16_t*)v, ldv, (uint16_t*)out, ldo, nullptr, causal, lse, pk);
+  } else if (dtype == MIC_F32) {
+    const size_t lds = 4 * Tile<float>::BYTES + 1024;
+    if (int rc = set_lds(attn_fwd_kernel<float>, lds)) return rc;
+    hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, block, lds, (hipStream_t)stream, H, Tq_max, Tk, (const float*)q, ldq, (const float*)k, ldk, (const float*)v, ldv, (float*)out, ldo, nullptr, causal, lse, pk);
+  } else MIC_CHECK(false, "mic_attn_fwd_packed: bad dtype");
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}
+extern "C" int mic_attn_bwd_packed(int dtype, int B, int H, int Tq_max, int Tk, const int32_t* q_off, const int32_t* q_len, int kv_packed,
+                                   const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* out, int ldo,
+                                   const void* dout, int lddo, const float* lse, int causal, void* dq, int lddq, void* dk, int lddk,
+                                   void* dv, int lddv, void* stream) {
+  MIC_CHECK(B > 0 && H > 0 && Tq_max > 0 && Tq_max <= 64 && Tk > 0 && Tk <= 64, "mic_attn_bwd_packed: one 64x64 tile per sequence (Tq_max=%d Tk=%d)", Tq_max, Tk);
+  MIC_CHECK(q && k && v && out && dout && lse && dq && dk && dv && q_off && q_len, "mic_attn_bwd_packed: null pointer");
+  const int align = dtype == MIC_BF16 ? 8 : 4;
+  MIC_CHECK(ldq % align == 0 && ldk % align == 0 && ldv % align == 0 && ldo % align == 0 && lddo % align == 0, "mic_attn_bwd_packed: row strides must keep 16-B alignment");
+  const PackedRows pk{q_off, q_len, kv_packed};
+  dim3 grid(B * H), block(256);
+  if (dtype == MIC_BF16) {
+    const size_t lds = 5 * Tile<uint16_t>::BYTES;
+    hipLaunchKernelGGL(attn_bwd_kernel<uint16_t>, grid, block, lds, (hipStream_t)stream, H, Tq_max, Tk, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk, (const uint16_t*)v, ldv, (const uint16_t*)out, ldo, (const uint16_t*)dout, lddo, lse, nullptr, causal, (uint16_t*)dq, lddq, (uint16_t*)dk, lddk, (uint16_t*)dv, lddv, pk);
+  } else if (dtype == MIC_F32) {
+    const size_t lds = 5 * Tile<float>::BYTES;
+    if (int rc = set_lds(attn_bwd_kernel<float>, lds)) return rc;
+    hipLaunchKernelGGL(attn_bwd_kernel<float>, grid, block, lds, (hipStream_t)stream, H, Tq_max, Tk, (const float*)q, ldq, (const float*)k, ldk, (const float*)v, ldv, (const float*)out, ldo, (const float*)dout, lddo, lse, nullptr, causal, (float*)dq, lddq, (float*)dk, lddk, (float*)dv, lddv, pk);
+  } else MIC_CHECK(false, "mic_attn_bwd_packed: bad dtype");
   MIC_LAUNCH_CHECK();
   return MIC_OK;
 }

@@ -198,6 +198,9 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
     MIC_CHECK(!args[i].a_rowsum || args[i].a_kmajor, "mic_gemm: a_rowsum needs a_kmajor (A = dy^T of the weight-gradient GEMM)");
     p.a_rowsum = args[i].a_rowsum;
     p.rowsum_k = args[i].rowsum_k > 0 ? args[i].rowsum_k : p.K;
+    MIC_CHECK(args[i].k_valid >= 0 && (args[i].k_valid == 0 || (args[i].a_kmajor && args[i].b_kmajor && !f8)),
+              "mic_gemm: k_valid is a feature of the bf16 k-major x k-major (weight-gradient) launches");
+    p.k_valid = args[i].k_valid > 0 ? args[i].k_valid : 0x7fffffff;
     p.block_begin = blocks;
     blocks += p.tiles_m * p.tiles_n * p.nsplit;
   }
@@ -239,6 +242,7 @@ extern "C" int mic_gemm(const mic_gemm_args* a, void* stream) {
   if (int rc = fill_epi(a, e)) return rc;
   MIC_CHECK(a->split_k <= 1, "mic_gemm(f32): split_k is a bf16-path feature");
   MIC_CHECK(!a->a_rowsum, "mic_gemm(f32): a_rowsum is a bf16-path feature (use mic_colsum)");
+  MIC_CHECK(a->k_valid == 0, "mic_gemm(f32): k_valid is a bf16-path feature");
   dim3 grid((a->N + 63) / 64, (a->M + 63) / 64), block(256);
   const long sam = a->a_kmajor ? 1 : a->lda, sak = a->a_kmajor ? a->lda : 1;
   const long sbk = a->b_kmajor ? a->ldb : 1, sbn = a->b_kmajor ? 1 : a->ldb;

@@ -14,6 +14,7 @@ struct Problem {
   int lda, ldb, M, N, K;
   int tiles_m, tiles_n, block_begin, nsplit;
   float* a_rowsum; int rowsum_k;
+  int k_valid;  // k-major operands: rows k >= k_valid read as zero (packed batches leave stale rows behind the valid ones)
   long long split_stride;
   const float* sa; const float* sb;  // fp8: device scalars, the operands' dequantisation factors (1 / quantisation scale)
   EpiArgs epi;
@@ -66,7 +67,9 @@ struct HalfStager {
       r[i] = *reinterpret_cast<const u32x4*>(g);
     }
   }
-  static __device__ __forceinline__ void store(const u32x4 (&r)[PER], char* lds_tile, int wave, int lane) {
+  // k_rows_valid (k-major images only): rows k >= k_rows_valid of this K-tile are written as zeros — the mask sits on the LDS
+  // write, where the loaded registers are consumed anyway (masking behind the load would wait for it on the spot)
+  static __device__ __forceinline__ void store(const u32x4 (&r)[PER], char* lds_tile, int wave, int lane, int k_rows_valid = 0x7fffffff) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       int row, c;
@@ -75,7 +78,9 @@ struct HalfStager {
       if (!KMAJOR) off = BKT == 64 ? row * 128 + ((c ^ ((row >> 1) & 7)) << 4) : row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
       else if (ROWS == 128) off = row * 256 + ((c ^ ((row & 3) << 2)) << 4);
       else off = row * 128 + ((c ^ (((row >> 1) & 1) << 2)) << 4);
-      *reinterpret_cast<u32x4*>(lds_tile + off) = r[i];
+      u32x4 v = r[i];
+      if (KMAJOR && row >= k_rows_valid) v = u32x4{0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(lds_tile + off) = v;
     }
   }
 };

@@ -105,11 +105,16 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
 #pragma unroll
     for (int h = 0; h < NHB; ++h) SB::load(rb[h], B, ldb, n0 + h * UB, (kt0 + t) * BKT, N, wave, lane);
   };
-  auto write_lds = [&](char* buf) __attribute__((always_inline)) {
+  // weight-gradient launches (both operands k-major, see mic_gemm_args.k_valid): reduction rows k >= k_valid are written to LDS
+  // as zeros; `t` = the K-tile being written
+  constexpr bool KV = AK && BKM && F8 == 0;
+  const int k_valid = KV ? P.k_valid : 0x7fffffff;
+  auto write_lds = [&](char* buf, int t) __attribute__((always_inline)) {
+    const int kr = KV ? k_valid - (kt0 + t) * BKT : 0x7fffffff;  // valid rows of this K-tile (>= BKT: all)
 #pragma unroll
-    for (int h = 0; h < NHA; ++h) SA::store(ra[h], buf + h * HALF_A, wave, lane);
+    for (int h = 0; h < NHA; ++h) SA::store(ra[h], buf + h * HALF_A, wave, lane, kr);
 #pragma unroll
-    for (int h = 0; h < NHB; ++h) SB::store(rb[h], buf + NHA * HALF_A + h * HALF_B, wave, lane);
+    for (int h = 0; h < NHB; ++h) SB::store(rb[h], buf + NHA * HALF_A + h * HALF_B, wave, lane, kr);
   };
   // this wave's operand sub-images
   const int a_half = (wr * WM) / UA, a_off = (wr * WM) % UA;
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
 
   if (nk > 0) {
     load_regs(0);
-    write_lds(gsm);
+    write_lds(gsm, 0);
     if (nk > 1) load_regs(1);
   }
   if (nk_loop > 0) __syncthreads();
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
       if constexpr (F8 != 0 && WM <= 64) {
         // fp8, small wave tiles: both halves' fragment reads in front of the MFMAs (as for bf16 below)
         if (t + 1 < nk) {
-          write_lds(gsm + ((t + 1) & 1) * STAGE);
+          write_lds(gsm + ((t + 1) & 1) * STAGE, t + 1);
           if (t + 2 < nk) load_regs(t + 2);
         }
         i32x8 a8[2][AI], b8[2][NJ];
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
 #pragma unroll
         for (int mm = 0; mm < 2; ++mm) {  // two K = 64 MFMAs per 128-byte stage
           if (mm == 0 && t + 1 < nk) {
-            write_lds(gsm + ((t + 1) & 1) * STAGE);
+            write_lds(gsm + ((t + 1) & 1) * STAGE, t + 1);
             if (t + 2 < nk) load_regs(t + 2);
           }
           i32x8 a8[AI], b8[NJ];
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
         // out together, then the MFMAs (the compiler otherwise issues k-step kk+1's reads behind the MFMAs of kk and waits a full
         // LDS latency in every k-step; these launches are latency chains, not throughput)
         if (t + 1 < nk) {
-          write_lds(gsm + ((t + 1) & 1) * STAGE);
+          write_lds(gsm + ((t + 1) & 1) * STAGE, t + 1);
           if (t + 2 < nk) load_regs(t + 2);
         }
         bf16x8 af[KSTEPS][AI], bfr[KSTEPS][NJ];
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
 #pragma unroll
       for (int kk = 0; kk < KSTEPS; ++kk) {
         if (kk == STAGE_AT && t + 1 < nk) {
-          write_lds(gsm + ((t + 1) & 1) * STAGE);  // its buffer was last read in iteration t-1 (barrier below)
+          write_lds(gsm + ((t + 1) & 1) * STAGE, t + 1);  // its buffer was last read in iteration t-1 (barrier below)
           if (t + 2 < nk) load_regs(t + 2);        // a full iteration of MFMAs to land
         }
         bf16x8 af[AI], bfr[NJ];

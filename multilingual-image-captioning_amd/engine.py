@@ -282,6 +282,8 @@ class Engine:
         # kernel already holds; fp32 atomics into the pre-zeroed atomic region).  fp32 mode keeps the separate column sum.
         fuse = bias and self.dt == torch.bfloat16
         rs = dict(a_rowsum=P.g(wname + ".b"), rowsum_k=M) if fuse else {}
+        if self.dt == torch.bfloat16:
+            rs["k_valid"] = M  # reduction rows behind the M valid ones count as zero (packed batches: M changes from step to step)
         if defer:
             self._dw_queue.append((ops.gemm_args(dy, x, P.g(wname + ".w"), N, K, Mp, a_kmajor=True, b_kmajor=True, **rs), wname, bias))
         else:
@@ -469,60 +471,75 @@ class Engine:
         self._done("patch.w")
 
     # ------------------------------------------------------------------ decoder (teacher forced)
-    def decoder_forward(self, ids, pos_ids, key_mask, ehs, B: int, T: int, save: bool, seed: Optional[int]):
-        """ids/pos_ids/key_mask int32 [B*T]/[B*T]/[B,T]; ehs [B*S,d].  Returns final-layer-normed hidden [B*T,d]."""
+    def decoder_forward(self, ids, pos_ids, key_mask, ehs, B: int, T: int, save: bool, seed: Optional[int], pack=None):
+        """ids/pos_ids/key_mask int32 [B*T]/[B*T]/[B,T]; ehs [B*S,d].  Returns final-layer-normed hidden [B*T,d].
+
+        pack = (q_off int32 [B], q_len int32 [B], rows): PACKED rows — the decoder runs on the `rows` = sum(q_len) valid positions
+        only (sequence b = rows [q_off[b], q_off[b] + q_len[b]); ids / pos_ids are then the packed arrays, key_mask is unused:
+        every position of a sequence is valid).  Padded positions carry no loss (main.py:678) and no valid position attends to
+        them (main.py:692: the labels' attention mask is the decoder's key mask), so everything they would compute or receive as
+        gradient is exactly zero: leaving them out changes no result.  Buffers keep their [B*T] capacity."""
         P = self.P
         d, f, H, S = P.d, P.ffn, P.H, P.S
-        M, Mv = B * T, B * S
+        Mcap, Mv = B * T, B * S
+        M = pack[2] if pack is not None else Mcap  # rows the kernels process
         drop = seed is not None and self.p_drop > 0
 
         def sd(site):
             return _mix(seed, site) if drop else None
 
-        h0 = self.buf("d.h0", M, d)
+        h0 = self.buf("d.h0", Mcap, d)
         ops.embed_fwd(ids, pos_ids, P.w("shared"), P.f32("dec.pos"), self.embed_scale, h0, M, d)
-        x = self.buf("d.x0", M, d)
-        ste = self.buf("d.emb.stats", 2, _rup(M, ROWPAD), torch.float32)
+        x = self.buf("d.x0", Mcap, d)
+        ste = self.buf("d.emb.stats", 2, _rup(Mcap, ROWPAD), torch.float32)
         ops.layernorm_fwd(h0, P.f32("dec.ln_emb.g"), P.f32("dec.ln_emb.b"), self.dec_eps, x, ste[0], ste[1], rows=M,
                           dropout_p=self.p_drop if drop else 0.0, dropout_seed=sd(1) or 0)
         kvcat = self.cross_kv_all(ehs, Mv, "d." if save else "d_.") if self.ckv_hoisted() else None
         for l in range(P.L):
             tag = f"d{l}." if save else "d_."
             p = f"dec{l}."
-            stats = self.buf(tag + "stats", 6, _rup(M, ROWPAD), torch.float32)
-            a = self.buf(tag + "a_sa", M, d)
+            stats = self.buf(tag + "stats", 6, _rup(Mcap, ROWPAD), torch.float32)
+            a = self.buf(tag + "a_sa", Mcap, d)
             ops.layernorm_fwd(x, P.f32(p + "ln_sa.g"), P.f32(p + "ln_sa.b"), self.dec_eps, a, stats[0], stats[1], rows=M)
-            qkv = self.buf(tag + "qkv", M, 3 * d)
+            qkv = self.buf(tag + "qkv", Mcap, 3 * d)
             self.linear(a, p + "qkv", qkv, M, save_tag=tag if save else None)
-            ctx = self.buf(tag + "ctx", M, d)
+            ctx = self.buf(tag + "ctx", Mcap, d)
             lse = self.vec(tag + "lse", B * H * T)
-            ops.attn_fwd(qkv, qkv[:, d:], qkv[:, 2 * d:], ctx, B, H, T, T, ldq=3 * d, ldk=3 * d, ldv=3 * d, ldo=d, key_mask=key_mask,
-                         causal=True, lse=lse)
-            x1 = self.buf(tag + "x1", M, d)
+            if pack is not None:
+                ops.attn_fwd_packed(qkv, qkv[:, d:], qkv[:, 2 * d:], ctx, B, H, T, T, pack[0], pack[1], kv_packed=True, ldq=3 * d, ldk=3 * d,
+                                    ldv=3 * d, ldo=d, causal=True, lse=lse)
+            else:
+                ops.attn_fwd(qkv, qkv[:, d:], qkv[:, 2 * d:], ctx, B, H, T, T, ldq=3 * d, ldk=3 * d, ldv=3 * d, ldo=d, key_mask=key_mask,
+                             causal=True, lse=lse)
+            x1 = self.buf(tag + "x1", Mcap, d)
             self.linear(ctx, p + "so", x1, M, residual=x, drop_seed=sd(10 + 3 * l))
-            a = self.buf(tag + "a_ca", M, d)
+            a = self.buf(tag + "a_ca", Mcap, d)
             ops.layernorm_fwd(x1, P.f32(p + "ln_ca.g"), P.f32(p + "ln_ca.b"), self.dec_eps, a, stats[2], stats[3], rows=M)
-            q = self.buf(tag + "cq", M, d)
+            q = self.buf(tag + "cq", Mcap, d)
             self.linear(a, p + "cq", q, M, save_tag=tag if save else None)
             if kvcat is not None:
                 kv, ldkv = kvcat[:, l * 2 * d:], kvcat.stride(0)
             else:
                 kv, ldkv = self.buf(tag + "ckv", Mv, 2 * d), 2 * d
                 self.linear(ehs, p + "ckv", kv, Mv, save_tag="d.ehs." if save else None, stable_input=True)
-            cctx = self.buf(tag + "cctx", M, d)
+            cctx = self.buf(tag + "cctx", Mcap, d)
             clse = self.vec(tag + "clse", B * H * T)
-            ops.attn_fwd(q, kv, kv[:, d:], cctx, B, H, T, S, ldq=d, ldk=ldkv, ldv=ldkv, ldo=d, lse=clse)
-            x2 = self.buf(tag + "x2", M, d)
+            if pack is not None:
+                ops.attn_fwd_packed(q, kv, kv[:, d:], cctx, B, H, T, S, pack[0], pack[1], kv_packed=False, ldq=d, ldk=ldkv, ldv=ldkv, ldo=d,
+                                    lse=clse)
+            else:
+                ops.attn_fwd(q, kv, kv[:, d:], cctx, B, H, T, S, ldq=d, ldk=ldkv, ldv=ldkv, ldo=d, lse=clse)
+            x2 = self.buf(tag + "x2", Mcap, d)
             self.linear(cctx, p + "co", x2, M, residual=x1, drop_seed=sd(11 + 3 * l))
-            a = self.buf(tag + "a_ff", M, d)
+            a = self.buf(tag + "a_ff", Mcap, d)
             ops.layernorm_fwd(x2, P.f32(p + "ln_ff.g"), P.f32(p + "ln_ff.b"), self.dec_eps, a, stats[4], stats[5], rows=M)
-            z, u = self.buf(tag + "z", M, f), self.buf(tag + "u", M, f)
+            z, u = self.buf(tag + "z", Mcap, f), self.buf(tag + "u", Mcap, f)
             self.linear(a, p + "fc1", u, M, act=self.gelu, zout=z, save_tag=tag if save else None)
-            x3 = self.buf(f"d{l}.x3" if save else f"d_.x3{l & 1}", M, d)
+            x3 = self.buf(f"d{l}.x3" if save else f"d_.x3{l & 1}", Mcap, d)
             self.linear(u, p + "fc2", x3, M, residual=x2, drop_seed=sd(12 + 3 * l), save_tag=tag if save else None)
             x = x3
-        hf = self.buf("d.hf", M, d)
-        stf = self.buf("d.f.stats", 2, _rup(M, ROWPAD), torch.float32)
+        hf = self.buf("d.hf", Mcap, d)
+        stf = self.buf("d.f.stats", 2, _rup(Mcap, ROWPAD), torch.float32)
         ops.layernorm_fwd(x, P.f32("dec.ln_f.g"), P.f32("dec.ln_f.b"), self.dec_eps, hf, stf[0], stf[1], rows=M)
         return hf
 
@@ -558,24 +575,26 @@ class Engine:
             return None  # the fp32 (parity) GEMM kernel has no by-products: its consumers stream the logits
         return self.buf(name + ".stat", M, 2 * (self.P.Vpad // 64), torch.float32)  # (max, sum exp) per 64-column granule
 
-    def decoder_backward(self, B: int, T: int, ids, pos_ids, key_mask, ehs, dlogits, seed: Optional[int], rows=None):
+    def decoder_backward(self, B: int, T: int, ids, pos_ids, key_mask, ehs, dlogits, seed: Optional[int], rows=None, pack=None):
         """Consumes dlogits [M,Vpad] (or [Mc,Vpad] for the compacted head: rows = (idx int32 [Mc], Mc)); writes all
-        decoder/embedding/head grads; returns dehs [B*S,d]."""
+        decoder/embedding/head grads; returns dehs [B*S,d].  pack: see decoder_forward (the compacted head's rows ARE the packed
+        rows then: no gather / scatter between the head and the decoder)."""
         P = self.P
         d, f, H, S = P.d, P.ffn, P.H, P.S
-        M, Mv = B * T, B * S
+        Mcap, Mv = B * T, B * S
+        M = pack[2] if pack is not None else Mcap
         drop = seed is not None and self.p_drop > 0
         pd = self.p_drop if drop else 0.0
 
         def sd(site):
             return _mix(seed, site) if drop else 0
 
-        dhf = self.buf("db.dhf", M, d)
+        dhf = self.buf("db.dhf", Mcap, d)
         if rows is None:
-            hf = self.buf("d.hf", M, d)
+            hf = self.buf("d.hf", Mcap, d)
             Mh = M
         else:
-            hf = self.buf("d.hfc", M, d)  # compacted final hidden states (pad rows zero)
+            hf = self.buf("d.hf" if pack is not None else "d.hfc", Mcap, d)  # compacted final hidden states (pad rows zero)
             Mh = rows[1]
         Mhp = _rup(Mh, 64)
         if self.dt == torch.bfloat16:  # final_logits_bias gradient = row sums of dlogits^T, fused into the dE GEMM
@@ -585,26 +604,26 @@ class Engine:
             ops.colsum(dlogits, P.g("flb"), Mh, P.Vpad, dlogits.stride(0))
             ops.gemm(dlogits, hf, P.g("shared"), P.Vpad, d, Mhp, a_kmajor=True, b_kmajor=True)
         self._done("shared")  # dense (LM head) part of the tied embedding gradient: first thing backward completes
-        dhc = dhf if rows is None else self.buf("db.dhfc", M, d)
+        dhc = dhf if (rows is None or pack is not None) else self.buf("db.dhfc", Mcap, d)
         if self.dt == torch.bfloat16 and P.Vpad >= 16384:
             # [Mh, d] output, reduction over the whole vocabulary: far too few tiles to fill 256 CUs.  Split-K 32 with K-range
             # <-> XCD affinity (gemm.hip) into per-split fp32 slabs (no atomics), summed and rounded to bf16 once.
             nsp = 32  # 16..64 measure the same (+-0.1 ms/step); the gain over the atomic variant is the absence of atomics
-            d32 = self.buf("db.dhf32", nsp * _rup(M, ROWPAD), d, torch.float32)  # one fp32 slab per split, summed below
-            slab = _rup(M, ROWPAD) * d
+            d32 = self.buf("db.dhf32", nsp * _rup(Mcap, ROWPAD), d, torch.float32)  # one fp32 slab per split, summed below
+            slab = _rup(Mcap, ROWPAD) * d
             ops.gemm(dlogits, P.w("shared"), d32, Mh, d, P.Vpad, b_kmajor=True, split_k=nsp, split_stride=slab)
             ops.sum_slabs(d32, nsp, slab, dhc, Mh, d, d32.stride(0), dhc.stride(0))
         else:
             ops.gemm(dlogits, P.w("shared"), dhc, Mh, d, P.Vpad, b_kmajor=True)
-        if rows is not None:
+        if rows is not None and pack is None:
             ops.zero(dhf[:M])  # masked-out positions receive exactly zero gradient from the loss
             ops.copy_rows(dhc, dhf, Mh, d, dst_idx=rows[0])
-        dx = self.buf("db.dx", M, d)
+        dx = self.buf("db.dx", Mcap, d)
         # masked gradients entering the FFN / cross-attention / self-attention branches and the other operands of the deferred
         # weight-gradient GEMMs come from dyb(): one buffer per layer parity while dW runs on its own stream
-        dxm = self.dyb("db.dxm_a", P.L - 1, M, d)
-        stf = self.buf("d.f.stats", 2, _rup(M, ROWPAD), torch.float32)
-        x_last = self.buf(f"d{P.L - 1}.x3", M, d)
+        dxm = self.dyb("db.dxm_a", P.L - 1, Mcap, d)
+        stf = self.buf("d.f.stats", 2, _rup(Mcap, ROWPAD), torch.float32)
+        x_last = self.buf(f"d{P.L - 1}.x3", Mcap, d)
         ops.layernorm_bwd(x_last, P.f32("dec.ln_f.g"), stf[0], stf[1], dhf, dx, P.g("dec.ln_f.g"), P.g("dec.ln_f.b"), rows=M,
                           dxm=dxm, dropout_p=pd, dropout_seed=sd(12 + 3 * (P.L - 1)))
         dehs = self.buf("db.dehs", Mv, d)
@@ -613,43 +632,52 @@ class Engine:
         dkvcat = self.buf("db.dkvcat", Mv, P.L * 2 * d) if hoist else None
         for l in reversed(range(P.L)):
             tag, p = f"d{l}.", f"dec{l}."
-            stats = self.buf(tag + "stats", 6, _rup(M, ROWPAD), torch.float32)
-            a_sa, qkv, ctx, x1 = (self.buf(tag + n, M, c) for n, c in (("a_sa", d), ("qkv", 3 * d), ("ctx", d), ("x1", d)))
-            a_ca, cq, cctx, x2 = (self.buf(tag + n, M, d) for n in ("a_ca", "cq", "cctx", "x2"))
+            stats = self.buf(tag + "stats", 6, _rup(Mcap, ROWPAD), torch.float32)
+            a_sa, qkv, ctx, x1 = (self.buf(tag + n, Mcap, c) for n, c in (("a_sa", d), ("qkv", 3 * d), ("ctx", d), ("x1", d)))
+            a_ca, cq, cctx, x2 = (self.buf(tag + n, Mcap, d) for n in ("a_ca", "cq", "cctx", "x2"))
             ckv, ldkv = (kvcat[:, l * 2 * d:], kvcat.stride(0)) if hoist else (self.buf(tag + "ckv", Mv, 2 * d), 2 * d)
-            a_ff, z, u = self.buf(tag + "a_ff", M, d), self.buf(tag + "z", M, f), self.buf(tag + "u", M, f)
+            a_ff, z, u = self.buf(tag + "a_ff", Mcap, d), self.buf(tag + "z", Mcap, f), self.buf(tag + "u", Mcap, f)
             lse, clse = self.vec(tag + "lse", B * H * T), self.vec(tag + "clse", B * H * T)
-            x_in = self.buf(f"d{l - 1}.x3", M, d) if l > 0 else self.buf("d.x0", M, d)
+            x_in = self.buf(f"d{l - 1}.x3", Mcap, d) if l > 0 else self.buf("d.x0", Mcap, d)
             # --- FFN branch: x3 = x2 + drop(fc2(gelu(fc1(LN(x2)))));  dxm = dropout-masked dx3
-            dxm_b, dxm_c = self.dyb("db.dxm_b", l, M, d), self.dyb("db.dxm_c", l, M, d)
-            dz = self.dyb("db.dz", l, M, f)
+            dxm_b, dxm_c = self.dyb("db.dxm_b", l, Mcap, d), self.dyb("db.dxm_c", l, Mcap, d)
+            dz = self.dyb("db.dz", l, Mcap, f)
             self.linear_bwd(p + "fc2", u, dxm, M, dx=dz, zin=z, dact=self.gelu, defer=True)
-            da = self.buf("db.da", M, d)
+            da = self.buf("db.da", Mcap, d)
             self.linear_bwd(p + "fc1", a_ff, dz, M, dx=da, defer=True)
-            dx2 = self.buf("db.dx2", M, d)
+            dx2 = self.buf("db.dx2", Mcap, d)
             ops.layernorm_bwd(x2, P.f32(p + "ln_ff.g"), stats[4], stats[5], da, dx2, P.g(p + "ln_ff.g"), P.g(p + "ln_ff.b"), rows=M,
                               dres=dx, dxm=dxm_b, dropout_p=pd, dropout_seed=sd(11 + 3 * l))
             # --- cross-attention branch
-            dctx = self.buf("db.dctx", M, d)
+            dctx = self.buf("db.dctx", Mcap, d)
             self.linear_bwd(p + "co", cctx, dxm_b, M, dx=dctx, defer=True)
-            dq = self.dyb("db.dq", l, M, d)
+            dq = self.dyb("db.dq", l, Mcap, d)
             dkv = dkvcat[:, l * 2 * d:] if hoist else self.dyb("db.dkv", l, Mv, 2 * d)
-            ops.attn_bwd(cq, ckv, ckv[:, d:], cctx, dctx, clse, dq, dkv, dkv[:, d:], B, H, T, S, ldq=d, ldk=ldkv, ldv=ldkv, ldo=d,
-                         lddo=d, lddq=d, lddk=ldkv, lddv=ldkv)
+            if pack is not None:
+                ops.attn_bwd_packed(cq, ckv, ckv[:, d:], cctx, dctx, clse, dq, dkv, dkv[:, d:], B, H, T, S, pack[0], pack[1], kv_packed=False,
+                                    ldq=d, ldk=ldkv, ldv=ldkv, ldo=d, lddo=d, lddq=d, lddk=ldkv, lddv=ldkv)
+            else:
+                ops.attn_bwd(cq, ckv, ckv[:, d:], cctx, dctx, clse, dq, dkv, dkv[:, d:], B, H, T, S, ldq=d, ldk=ldkv, ldv=ldkv, ldo=d,
+                             lddo=d, lddq=d, lddk=ldkv, lddv=ldkv)
             self.linear_bwd(p + "cq", a_ca, dq, M, dx=da, defer=True)
             if not hoist:
                 self.linear_bwd(p + "ckv", ehs, dkv, Mv, dx=dehs, dx_accumulate=(l != P.L - 1), defer=True)
-            dx1 = self.buf("db.dx1", M, d)
+            dx1 = self.buf("db.dx1", Mcap, d)
             ops.layernorm_bwd(x1, P.f32(p + "ln_ca.g"), stats[2], stats[3], da, dx1, P.g(p + "ln_ca.g"), P.g(p + "ln_ca.b"), rows=M,
                               dres=dx2, dxm=dxm_c, dropout_p=pd, dropout_seed=sd(10 + 3 * l))
             # --- self-attention branch
             self.linear_bwd(p + "so", ctx, dxm_c, M, dx=dctx, defer=True)
-            dqkv = self.dyb("db.dqkv", l, M, 3 * d)
-            ops.attn_bwd(qkv, qkv[:, d:], qkv[:, 2 * d:], ctx, dctx, lse, dqkv, dqkv[:, d:], dqkv[:, 2 * d:], B, H, T, T, ldq=3 * d,
-                         ldk=3 * d, ldv=3 * d, ldo=d, lddo=d, lddq=3 * d, lddk=3 * d, lddv=3 * d, key_mask=key_mask, causal=True)
+            dqkv = self.dyb("db.dqkv", l, Mcap, 3 * d)
+            if pack is not None:
+                ops.attn_bwd_packed(qkv, qkv[:, d:], qkv[:, 2 * d:], ctx, dctx, lse, dqkv, dqkv[:, d:], dqkv[:, 2 * d:], B, H, T, T, pack[0],
+                                    pack[1], kv_packed=True, ldq=3 * d, ldk=3 * d, ldv=3 * d, ldo=d, lddo=d, lddq=3 * d, lddk=3 * d,
+                                    lddv=3 * d, causal=True)
+            else:
+                ops.attn_bwd(qkv, qkv[:, d:], qkv[:, 2 * d:], ctx, dctx, lse, dqkv, dqkv[:, d:], dqkv[:, 2 * d:], B, H, T, T, ldq=3 * d,
+                             ldk=3 * d, ldv=3 * d, ldo=d, lddo=d, lddq=3 * d, lddk=3 * d, lddv=3 * d, key_mask=key_mask, causal=True)
             self.linear_bwd(p + "qkv", a_sa, dqkv, M, dx=da, defer=True)
             self.flush_dw()  # the layer's 7 weight-gradient GEMMs as one grouped launch (before dxm_a is rewritten)
-            dxm = self.dyb("db.dxm_a", l - 1, M, d)
+            dxm = self.dyb("db.dxm_a", l - 1, Mcap, d)
             if l > 0:
                 ops.layernorm_bwd(x_in, P.f32(p + "ln_sa.g"), stats[0], stats[1], da, dx, P.g(p + "ln_sa.g"), P.g(p + "ln_sa.b"), rows=M,
                                   dres=dx1, dxm=dxm, dropout_p=pd, dropout_seed=sd(12 + 3 * (l - 1)))
@@ -681,14 +709,18 @@ class Engine:
                 self._cs_queue.append((dkvcat, gb, Mv, N, dkvcat.stride(0)))
             self.flush_dw()
         # embedding LayerNorm (+ its dropout) and the token/position embedding scatter
-        h0 = self.buf("d.h0", M, d)
-        ste = self.buf("d.emb.stats", 2, _rup(M, ROWPAD), torch.float32)
-        dh0 = self.buf("db.dh0", M, d)
+        h0 = self.buf("d.h0", Mcap, d)
+        ste = self.buf("d.emb.stats", 2, _rup(Mcap, ROWPAD), torch.float32)
+        dh0 = self.buf("db.dh0", Mcap, d)
         ops.layernorm_bwd(h0, P.f32("dec.ln_emb.g"), ste[0], ste[1], dx, dh0, P.g("dec.ln_emb.g"), P.g("dec.ln_emb.b"), rows=M,
                           in_dropout_p=pd, in_dropout_seed=sd(1))
         if self.defer_embed:
             ops.embed_bwd(ids, pos_ids, dh0, self.embed_scale, None, P.g("dec.pos"), M, d)
-            self.embed_rows = (ids, dh0, M)
+            if pack is not None and M < Mcap:
+                # the ranks exchange a FIXED number of (id, dh0) rows: rows behind this rank's valid ones carry id 0 (packed ids are
+                # zero-padded to B*T by the caller) and must add nothing
+                ops.zero(dh0[M:Mcap])
+            self.embed_rows = (ids, dh0, Mcap if pack is not None else M)
         else:
             # single process: the scatter lands before the optimizer touches the segment (Trainer holds that bucket)
             ops.embed_bwd(ids, pos_ids, dh0, self.embed_scale, P.g("shared"), P.g("dec.pos"), M, d)
@@ -718,14 +750,18 @@ class Engine:
             return logits, ehs, stat
         return self.head_logits(hf, B * T), ehs
 
-    def compact_head(self, hf, M: int, rows):
+    def compact_head(self, hf, M: int, rows, packed: bool = False):
         """LM head on the loss-relevant rows only: gather hf[idx] -> [Mc, d] (zero pad to a multiple of 64 rows) and
-        project.  Exact: loss_fn multiplies every other position by 0 (main.py:678)."""
+        project.  Exact: loss_fn multiplies every other position by 0 (main.py:678).  packed: hf already holds exactly those
+        rows, in that order (the decoder ran on them only): no gather."""
         P = self.P
         idx, Mc = rows
         Mcp = _rup(Mc, 64)
-        hfc = self.buf("d.hfc", M, P.d)
-        ops.copy_rows(hf, hfc, Mc, P.d, src_idx=idx)
+        if packed:
+            hfc = hf
+        else:
+            hfc = self.buf("d.hfc", M, P.d)
+            ops.copy_rows(hf, hfc, Mc, P.d, src_idx=idx)
         if Mcp > Mc:
             ops.zero(hfc[Mc:Mcp])
         logits = self.buf("d.logits", M, P.Vpad)
@@ -735,17 +771,28 @@ class Engine:
             ops.zero(logits[Mc:Mcp])  # reduction padding of the dE GEMM (rows of an earlier, longer batch may linger here)
         return logits, stat
 
-    def loss_only(self, pixels, ids, pos_ids, key_mask, labels, B, T, *, label_smoothing=0.0, rows=None, row_labels=None):
+    def loss_only(self, pixels, ids, pos_ids, key_mask, labels, B, T, *, label_smoothing=0.0, rows=None, row_labels=None, pack=None):
         """eval_step's forward + loss (main.py:710-716)."""
         M = B * T
+        pack = self._check_pack(pack, rows, T)
         if rows is None:
             logits, _, stat = self.forward_logits(pixels, ids, pos_ids, key_mask, B, T, save=False, seed=None, stats=True)
             return self.loss_and_dlogits(logits, labels, key_mask.reshape(-1), M, label_smoothing, backward=False, stat=stat)
         self._fp8_begin_pass()
         _, ehs = self.vit_forward(pixels, False)
-        hf = self.decoder_forward(ids, pos_ids, key_mask, ehs, B, T, False, None)
-        logits, stat = self.compact_head(hf, M, rows)
+        hf = self.decoder_forward(ids, pos_ids, key_mask, ehs, B, T, False, None, pack=pack)
+        logits, stat = self.compact_head(hf, M, rows, packed=pack is not None)
         return self.loss_and_dlogits(logits, row_labels, self.ones_i32(rows[1]), rows[1], label_smoothing, backward=False, stat=stat)
+
+    def _check_pack(self, pack, rows, T: int):
+        """packed rows need the bf16 (non-fp8) kernels, one attention tile per sequence, and the compacted head on the same rows"""
+        if pack is None:
+            return None
+        if rows is None or rows[1] != pack[2]:
+            raise ValueError("packed decoder rows go with the compacted LM head on the same rows (rows=(idx, n) with n == pack rows)")
+        if self.dt != torch.bfloat16 or self.fp8 or T > 64 or self.P.S > 64:
+            raise ValueError("packed decoder rows: bfloat16 mode (not fp8), seq_len <= 64 and at most 64 encoder positions")
+        return pack
 
     def ones_i32(self, n: int):
         key = f"ones_i32:{n}"
@@ -756,7 +803,7 @@ class Engine:
         return t
 
     def loss_and_grads(self, pixels, ids, pos_ids, key_mask, labels, B, T, *, label_smoothing=0.0, seed=None, rows=None,
-                       row_labels=None):
+                       row_labels=None, pack=None):
         """value_and_grad(compute_loss) of train_step (main.py:688-697): grads land in ParamStore.grad.
         rows = (idx int32 [Mc] of the positions with loss mask 1, Mc) and row_labels = labels[idx] switch the LM head,
         the cross-entropy and their backward to those rows only (identical loss and gradients, ~(1 - Mc/M) less head work)."""
@@ -764,16 +811,17 @@ class Engine:
         P.ensure_grads()
         ops.zero(P.grad[P.atomic_begin:])
         M = B * T
+        pack = self._check_pack(pack, rows, T)
         if rows is None:
             logits, ehs, stat = self.forward_logits(pixels, ids, pos_ids, key_mask, B, T, save=True, seed=seed, stats=True)
             loss = self.loss_and_dlogits(logits, labels, key_mask.reshape(-1), M, label_smoothing, backward=True, stat=stat)
         else:
             self._fp8_begin_pass()
             _, ehs = self.vit_forward(pixels, True)
-            hf = self.decoder_forward(ids, pos_ids, key_mask, ehs, B, T, True, seed)
-            logits, stat = self.compact_head(hf, M, rows)
+            hf = self.decoder_forward(ids, pos_ids, key_mask, ehs, B, T, True, seed, pack=pack)
+            logits, stat = self.compact_head(hf, M, rows, packed=pack is not None)
             loss = self.loss_and_dlogits(logits, row_labels, self.ones_i32(rows[1]), rows[1], label_smoothing, backward=True, stat=stat)
-        dehs = self.decoder_backward(B, T, ids, pos_ids, key_mask, ehs, logits, seed, rows=rows)
+        dehs = self.decoder_backward(B, T, ids, pos_ids, key_mask, ehs, logits, seed, rows=rows, pack=pack)
         self.vit_backward(B, dehs)
         self.dw_join()
         return loss

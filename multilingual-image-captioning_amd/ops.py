@@ -61,7 +61,7 @@ def gemm_args(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: in
               bias=None, act=0, zout=None, zin=None, dact=0, residual=None, accumulate=False, dropout_p=0.0, dropout_seed=0,
               alpha=1.0, lda=None, ldb=None, ldc=None, ldz=None, ldr=None, split_k=0, split_stride=0, a_rowsum=None, rowsum_k=0,
               a_scale_inv=None, b_scale_inv=None, rowstat=None, rowstat_nvalid=0, ln_stats=None, ln_colsum=None, ln_width=0,
-              ln_eps=0.0, rowsum2=None) -> "L.GemmArgs":
+              ln_eps=0.0, rowsum2=None, k_valid=0) -> "L.GemmArgs":
     """fp8 operands: `a` / `b` are torch.float8_e4m3fn / float8_e5m2 tensors (k-contiguous), `a_scale_inv` / `b_scale_inv` the
     device scalars mic_fp8_quantize wrote for them."""
     g = L.GemmArgs()
@@ -87,6 +87,7 @@ def gemm_args(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: in
     if ln_stats is not None:  # LayerNorm folded around the GEMM: b = gamma o W, bias = bias' (ln_fold_weight), stats of the A rows
         g.a_ln_stats, g.a_ln_colsum, g.a_ln_width, g.a_ln_eps = _p(ln_stats), _p(ln_colsum), int(ln_width), float(ln_eps)
     g.rowsum2 = _p(rowsum2)  # int64 [M][2]: (sum, sum of squares) x 2^20 of the stored output rows, accumulated
+    g.k_valid = int(k_valid)  # k-major x k-major launches: operand rows k >= k_valid count as zero (0 = all)
     return g
 
 
@@ -168,6 +169,20 @@ def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, Tq, Tk, *, ldq, ldk, ldv
              causal=False):
     L.check(L.lib().mic_attn_bwd(_dt(q), B, H, Tq, Tk, _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), ldo, _p(dout), lddo, _p(lse),
                                  _p(key_mask), int(causal), _p(dq), lddq, _p(dk), lddk, _p(dv), lddv, _stream()), "mic_attn_bwd")
+
+
+def attn_fwd_packed(q, k, v, out, B, H, Tq_max, Tk, q_off, q_len, *, kv_packed, ldq, ldk, ldv, ldo, causal=False, lse=None):
+    """attention cores on packed (variable-length) rows: sequence b = rows [q_off[b], q_off[b] + q_len[b])"""
+    L.check(L.lib().mic_attn_fwd_packed(_dt(q), B, H, Tq_max, Tk, _p(q_off), _p(q_len), int(kv_packed), _p(q), ldq, _p(k), ldk, _p(v), ldv,
+                                        _p(out), ldo, int(causal), _p(lse), _stream()), "mic_attn_fwd_packed")
+    return out
+
+
+def attn_bwd_packed(q, k, v, out, dout, lse, dq, dk, dv, B, H, Tq_max, Tk, q_off, q_len, *, kv_packed, ldq, ldk, ldv, ldo, lddo, lddq,
+                    lddk, lddv, causal=False):
+    L.check(L.lib().mic_attn_bwd_packed(_dt(q), B, H, Tq_max, Tk, _p(q_off), _p(q_len), int(kv_packed), _p(q), ldq, _p(k), ldk, _p(v), ldv,
+                                        _p(out), ldo, _p(dout), lddo, _p(lse), int(causal), _p(dq), lddq, _p(dk), lddk, _p(dv), lddv,
+                                        _stream()), "mic_attn_bwd_packed")
 
 
 def attn_decode(q, kc, vc, out, R, H, max_len, cur, *, ldq, ldo, ldc=None, src_row=None, row_div=1):

@@ -56,6 +56,27 @@ def loss_rows(attention_mask, labels):
     return idx, np.asarray(labels).reshape(-1)[idx].astype(np.int32)
 
 
+def packed_rows(attention_mask, decoder_input_ids):
+    """Collate-side helper for the packed decoder: when every row of the [B,T] loss / attention mask is a PREFIX of ones (what
+    the tokenizer's `padding="max_length"` produces, main.py:513-523), the decoder can run on the sum(len_b) valid positions
+    only — sequence b = packed rows [q_off[b], q_off[b] + q_len[b]), in the same order as `loss_rows`' indices.  Returns
+    (q_off int32 [B], q_len int32 [B], ids int32 [B*T], pos int32 [B*T]) — decoder input ids and position ids of the packed
+    rows, zero-padded to B*T — or None when some row is not a prefix (the padded path is used then)."""
+    m = np.asarray(attention_mask)
+    B, T = m.shape
+    ln = m.astype(bool).sum(1).astype(np.int32)
+    if not np.array_equal(m.astype(bool), np.arange(T)[None, :] < ln[:, None]):
+        return None
+    off = np.zeros(B, dtype=np.int32)
+    off[1:] = np.cumsum(ln)[:-1]
+    idx = np.nonzero(m.reshape(-1))[0]
+    ids = np.zeros(B * T, dtype=np.int32)
+    pos = np.zeros(B * T, dtype=np.int32)
+    ids[: idx.size] = np.asarray(decoder_input_ids).reshape(-1)[idx]
+    pos[: idx.size] = (idx % T).astype(np.int32)  # default position ids arange(T) (modeling:490-494)
+    return off, ln, ids, pos
+
+
 def plan_buckets(numel: int, bucket_elems: int, boundaries: List[int], granule: int = 1) -> List[Tuple[int, int]]:
     """Contiguous [begin, end) slices of the flat gradient buffer, cut at segment boundaries, each >= bucket_elems
     (except the last).  `granule` > 1 (sharded optimizer: world * 64) rounds every interior cut DOWN to a multiple of it,
@@ -286,12 +307,18 @@ class Trainer:
     def __init__(self, model, learning_rate_fn: Callable[[int], float], b1=0.9, b2=0.999, eps=1e-8, weight_decay=0.0,
                  label_smoothing_factor=0.0, seed: int = 42, bucket_mb: float = 64.0, group=None, compact_head: bool = True,
                  overlap_optimizer: bool = True, grad_comm_dtype: Optional[torch.dtype] = None, sharded_optimizer: bool = False,
-                 gemm_dtype: Optional[str] = None, fp8_scaling: str = "delayed"):
+                 gemm_dtype: Optional[str] = None, fp8_scaling: str = "delayed", pack_rows: bool = True):
+        """pack_rows (bfloat16 mode, with compact_head): the decoder runs on the valid caption positions only (`packed_rows`);
+        exact — padded positions neither carry loss nor are attended to — and ~1/3 fewer decoder rows on ragged captions.  Needs
+        prefix-shaped masks available on the host: a numpy / CPU `attention_mask`, or `batch["packed_rows"]` from the collate
+        function; otherwise the step runs padded.  MIC_PACK_ROWS=0 switches it off."""
         import torch.distributed as dist
 
         self.model, self.lr_fn = model, learning_rate_fn
         self.b1, self.b2, self.eps, self.wd, self.ls = b1, b2, eps, weight_decay, label_smoothing_factor
         self.compact_head = compact_head
+        import os as _os
+        self.pack_rows = bool(pack_rows) and compact_head and _os.environ.get("MIC_PACK_ROWS", "1") != "0"
         self.step = 0  # state.step
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -386,6 +413,7 @@ class Trainer:
         B, T = labels.shape
         pos = torch.arange(T, dtype=torch.int32, device=m.device)[None].expand(B, T).contiguous()
         rows = row_labels = None
+        pk = batch.get("packed_rows") if self.pack_rows else None
         if self.compact_head:
             if "loss_rows" in batch:  # precomputed by the collate function (no device->host sync in the step)
                 idx, rl = batch["loss_rows"]
@@ -397,8 +425,17 @@ class Trainer:
                 lb = lb.cpu().numpy() if isinstance(lb, torch.Tensor) else np.asarray(lb)
                 idx, rl = loss_rows(am, lb)
                 idx, rl = m._dev(idx, torch.int32), m._dev(rl, torch.int32)
+                if self.pack_rows and pk is None:
+                    di = batch["decoder_input_ids"]
+                    pk = packed_rows(am, di.cpu().numpy() if isinstance(di, torch.Tensor) else np.asarray(di))
             if 0 < idx.numel() < B * T:
                 rows, row_labels = (idx, int(idx.numel())), rl
+        # packed decoder rows: bf16 (not fp8) kernels, one attention tile per sequence, compacted head on the same rows
+        self._pack = None
+        eng = m.engine
+        if pk is not None and rows is not None and eng.dt == torch.bfloat16 and not eng.fp8 and T <= 64 and m.store.S <= 64:
+            q_off, q_len, ids_p, pos_p = (m._dev(t, torch.int32) for t in pk)
+            self._pack = ((q_off, q_len, rows[1]), ids_p, pos_p)
         self._rows, self._row_labels = rows, row_labels
         return px, labels, mask, dec_in, pos, B, T
 
@@ -413,8 +450,13 @@ class Trainer:
         eng.grad_progress = self.reducer.progress if self.reducer.active else None
         eng.defer_embed = self.world > 1
         with ops.pinned_stream():
-            loss = eng.loss_and_grads(px, dec_in.reshape(-1), pos.reshape(-1), mask, labels.reshape(-1), B, T,
-                                      label_smoothing=self.ls, seed=seed, rows=self._rows, row_labels=self._row_labels)
+            if self._pack is not None:  # the decoder sees the valid positions only
+                pack, ids_p, pos_p = self._pack
+                loss = eng.loss_and_grads(px, ids_p, pos_p, None, labels.reshape(-1), B, T, label_smoothing=self.ls, seed=seed,
+                                          rows=self._rows, row_labels=self._row_labels, pack=pack)
+            else:
+                loss = eng.loss_and_grads(px, dec_in.reshape(-1), pos.reshape(-1), mask, labels.reshape(-1), B, T,
+                                          label_smoothing=self.ls, seed=seed, rows=self._rows, row_labels=self._row_labels)
         self.reducer.progress(st.numel)  # everything is final now: remaining buckets go out
         self.reducer.release_held(self._scatter_embedding_rows if self.world > 1 else None)
         self.reducer.finish()  # pmean(grad) (main.py:698): SUM here, 1/world folded into AdamW's grad_scale
@@ -432,8 +474,13 @@ class Trainer:
         """main.py:710-721 (train=False, no dropout)."""
         m, eng = self.model, self.model.engine
         px, labels, mask, dec_in, pos, B, T = self._prep(batch)
-        loss = eng.loss_only(px, dec_in.reshape(-1), pos.reshape(-1), mask, labels.reshape(-1), B, T, label_smoothing=self.ls,
-                             rows=self._rows, row_labels=self._row_labels)
+        if self._pack is not None:
+            pack, ids_p, pos_p = self._pack
+            loss = eng.loss_only(px, ids_p, pos_p, None, labels.reshape(-1), B, T, label_smoothing=self.ls, rows=self._rows,
+                                 row_labels=self._row_labels, pack=pack)
+        else:
+            loss = eng.loss_only(px, dec_in.reshape(-1), pos.reshape(-1), mask, labels.reshape(-1), B, T, label_smoothing=self.ls,
+                                 rows=self._rows, row_labels=self._row_labels)
         self.metrics_buf[0:1].copy_(loss)
         self.metrics_buf[1] = 0.0
         out = self._pmean_metrics()

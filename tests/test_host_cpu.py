@@ -138,6 +138,20 @@ def test_plan_buckets():
     assert [e for _, e in g[:-1]] == [(x // 128) * 128 for x in (21_013, 45_777, 70_001, 99_990)]
 
 
+def test_packed_rows_helper():
+    from mic_amd import loss_rows, packed_rows
+
+    mask = np.array([[1, 1, 1, 0, 0], [1, 1, 1, 1, 1], [1, 0, 0, 0, 0]])
+    dec_in = np.arange(15).reshape(3, 5) + 100
+    q_off, q_len, ids, pos = packed_rows(mask, dec_in)
+    assert q_off.tolist() == [0, 3, 8] and q_len.tolist() == [3, 5, 1] and ids.shape == (15,) and ids.dtype == np.int32
+    assert ids[:9].tolist() == [100, 101, 102, 105, 106, 107, 108, 109, 110] and ids[9:].tolist() == [0] * 6
+    assert pos[:9].tolist() == [0, 1, 2, 0, 1, 2, 3, 4, 0]
+    idx, _ = loss_rows(mask, dec_in)
+    assert np.array_equal(dec_in.reshape(-1)[idx], ids[: len(idx)])      # same order as the compacted LM head's rows
+    assert packed_rows(np.array([[1, 0, 1]]), np.zeros((1, 3))) is None  # not a prefix of ones: the padded path is used
+
+
 def test_bucket_plan_full_size_world8():
     """configs[2] (8 ranks, 547 M parameters): the exchange buckets of the real layout, computed without allocating it.  They
     follow backward: the first bucket is the dense LM-head half of the tied embedding (+ the logits bias) — complete right

@@ -378,3 +378,69 @@ def test_weight_gradient_stream_gives_the_same_gradients(dev, dtype):
         assert abs(la - lb) <= 1e-6 * abs(lb)
         scale = gb.abs().max().item()
         assert (ga - gb).abs().max().item() <= 1e-5 * scale, ((ga - gb).abs().max().item(), scale)
+
+
+# ---------------------------------------------------------------- packed decoder rows (Trainer(pack_rows=True), the default in bf16)
+def test_packed_decoder_rows_change_nothing(dev):
+    """The decoder on the valid caption positions only (packed rows) against the padded [B*T] rows: padded positions carry no loss
+    and no valid position attends to them, so the loss is the SAME number (every valid row goes through the same per-row
+    arithmetic) and every gradient agrees up to the summation order of the weight-gradient reductions; also after a packed step
+    that left stale rows behind a shorter batch's valid ones."""
+    from mic_amd import loss_rows, packed_rows
+
+    rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.0)
+    d = model._dev
+    B, T = 6, 16
+    pos = torch.arange(T, dtype=torch.int32, device=dev)[None].expand(B, T).contiguous()
+
+    def run(seed, packed):
+        px, labels, mask, dec_in = batch(rc, B, T, seed=seed)
+        idx, rl = loss_rows(mask.numpy(), labels.numpy())
+        rows = (d(idx, torch.int32), len(idx))
+        kw = dict(rows=rows, row_labels=d(rl, torch.int32))
+        if packed:
+            q_off, q_len, ids_p, pos_p = (d(t, torch.int32) for t in packed_rows(mask.numpy(), dec_in.numpy()))
+            assert int(q_len.sum()) == len(idx) < B * T
+            loss = model.engine.loss_and_grads(d(px, torch.float32), ids_p, pos_p, None, d(labels, torch.int32).reshape(-1), B, T,
+                                               pack=(q_off, q_len, len(idx)), **kw)
+        else:
+            loss = model.engine.loss_and_grads(d(px, torch.float32), d(dec_in, torch.int32).reshape(-1), pos.reshape(-1), d(mask, torch.int32),
+                                               d(labels, torch.int32).reshape(-1), B, T, **kw)
+        torch.cuda.synchronize()
+        return float(loss), {k: v.copy() for k, v in model.store.export_flat("grad").items()}
+
+    for seed in (21, 22, 23):  # different numbers of valid rows from step to step: stale rows behind the valid ones must not count
+        lp, gp = run(seed, True)
+        lr, gr = run(seed, False)
+        assert lp == lr, (lp, lr)
+        for k in gr:
+            sc = max(np.abs(gr[k]).max(), 1e-12)
+            assert np.abs(gp[k] - gr[k]).max() <= 2e-4 * sc, (seed, k, np.abs(gp[k] - gr[k]).max() / sc)
+
+
+def test_trainer_packs_rows_by_default_and_matches_the_padded_trainer(dev):
+    from mic_amd import Trainer, create_learning_rate_fn
+    from mic_amd.params import flatten_tree
+
+    res = {}
+    for pack in (True, False):
+        rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.0)
+        tr = Trainer(model, create_learning_rate_fn(64, 2, 4, 0, 1e-3), pack_rows=pack)
+        losses = []
+        for s in range(3):
+            px, labels, mask, dec_in = batch(rc, 4, 12, seed=70 + s)
+            b = {"pixel_values": px.numpy(), "input_ids": labels.numpy(), "attention_mask": mask.numpy(), "decoder_input_ids": dec_in.numpy()}
+            losses.append(float(tr.train_step(b)["loss"]))
+            assert (tr._pack is not None) == pack
+        ev = float(tr.eval_step(b)["loss"])
+        res[pack] = (losses, ev, flatten_tree(model.params))
+    assert res[True][0][0] == res[False][0][0]                       # first step: same weights, same loss bit for bit
+    assert np.allclose(res[True][0], res[False][0], rtol=2e-3) and abs(res[True][1] - res[False][1]) < 2e-3 * abs(res[False][1])
+    # a mask that is not a prefix of ones falls back to the padded rows
+    rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.0)
+    tr = Trainer(model, create_learning_rate_fn(64, 2, 4, 0, 1e-3))
+    px, labels, mask, dec_in = batch(rc, 4, 12, seed=70)
+    mask = mask.clone()
+    mask[1, 0] = 0
+    tr.train_step({"pixel_values": px.numpy(), "input_ids": labels.numpy(), "attention_mask": mask.numpy(), "decoder_input_ids": dec_in.numpy()})
+    assert tr._pack is None
