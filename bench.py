@@ -615,7 +615,7 @@ def main():
         d_model = cfg.mbart_config.d_model
         dense_flops = TRAIN_GFLOP_PER_SAMPLE * 1e9 * B if not args.small else 0.0  # (the FLOP model is for the full-size network)
         step_flops = max(dense_flops - 6.0 * (B * T - n_loss) * V * d_model, 0.0)
-        packed = tr.pack_rows and args.dtype == "bf16" and not args.dense_captions
+        packed = tr.pack_rows and args.dtype in ("bf16", "fp8") and not args.dense_captions
         if packed:  # the decoder layers run on the valid rows only: 14 d^2 multiply-adds per row and layer (qkv 3, so 1, cq 1, co 1, fc1 4, fc2 4), x3 for fwd + bwd
             step_flops = max(step_flops - 6.0 * 14.0 * d_model * d_model * cfg.mbart_config.decoder_layers * (B * T - n_loss), 0.0)
         head = ("logits/CE on all label positions (dense captions: every position carries loss)" if args.dense_captions else
@@ -631,7 +631,7 @@ def main():
                        "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}" + ("+sharded-optimizer" if args.sharded_optimizer else ""),
                        "grad_allreduce": f"{args.grad_comm} flat buckets, RCCL, side stream",
                        "decoder_rows": ("valid caption positions only (packed rows: padded positions neither carry loss nor are attended to — exact; "
-                                        f"{n_loss:.0f} of {B * T} rows per step)" if (tr.pack_rows and args.dtype == "bf16" and not args.dense_captions) else f"all {B * T} positions"),
+                                        f"{n_loss:.0f} of {B * T} rows per step)" if (tr.pack_rows and args.dtype in ("bf16", "fp8") and not args.dense_captions) else f"all {B * T} positions"),
                        "lm_head": head, "gemm_dtype": "fp8 e4m3 (fwd) / e5m2 (grads) for QKV+FFN, bf16 elsewhere" if args.dtype == "fp8" else args.dtype},
             "model_tflops_per_gpu": round(step_flops * args.steps / dt / 1e12, 1),
             "model_tflops_note": f"EXECUTED model FLOPs per step ({step_flops / 1e12:.2f} TF: dense {dense_flops / 1e12:.2f} TF of SURVEY 8d minus the LM-head "

@@ -785,13 +785,14 @@ class Engine:
         return self.loss_and_dlogits(logits, row_labels, self.ones_i32(rows[1]), rows[1], label_smoothing, backward=False, stat=stat)
 
     def _check_pack(self, pack, rows, T: int):
-        """packed rows need the bf16 (non-fp8) kernels, one attention tile per sequence, and the compacted head on the same rows"""
+        """packed rows need the bf16-storage kernels (bf16 or fp8 GEMMs), one attention tile per sequence, and the compacted head on
+        the same rows"""
         if pack is None:
             return None
         if rows is None or rows[1] != pack[2]:
             raise ValueError("packed decoder rows go with the compacted LM head on the same rows (rows=(idx, n) with n == pack rows)")
-        if self.dt != torch.bfloat16 or self.fp8 or T > 64 or self.P.S > 64:
-            raise ValueError("packed decoder rows: bfloat16 mode (not fp8), seq_len <= 64 and at most 64 encoder positions")
+        if self.dt != torch.bfloat16 or T > 64 or self.P.S > 64:
+            raise ValueError("packed decoder rows: bfloat16 storage mode, seq_len <= 64 and at most 64 encoder positions")
         return pack
 
     def ones_i32(self, n: int):

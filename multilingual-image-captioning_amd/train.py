@@ -430,10 +430,10 @@ class Trainer:
                     pk = packed_rows(am, di.cpu().numpy() if isinstance(di, torch.Tensor) else np.asarray(di))
             if 0 < idx.numel() < B * T:
                 rows, row_labels = (idx, int(idx.numel())), rl
-        # packed decoder rows: bf16 (not fp8) kernels, one attention tile per sequence, compacted head on the same rows
+        # packed decoder rows: bf16-storage kernels, one attention tile per sequence, compacted head on the same rows
         self._pack = None
         eng = m.engine
-        if pk is not None and rows is not None and eng.dt == torch.bfloat16 and not eng.fp8 and T <= 64 and m.store.S <= 64:
+        if pk is not None and rows is not None and eng.dt == torch.bfloat16 and T <= 64 and m.store.S <= 64:
             q_off, q_len, ids_p, pos_p = (m._dev(t, torch.int32) for t in pk)
             self._pack = ((q_off, q_len, rows[1]), ids_p, pos_p)
         self._rows, self._row_labels = rows, row_labels

@@ -148,13 +148,59 @@ def test_fullsize_bf16_cached_decode_as_close_to_the_bf16_storage_oracle_as_the_
         model.engine.decode_ln_fold = keep
 
 
+_REF = {}
+
+
+def _ref_loss_and_grads(full):
+    """the fp32 oracle's loss and gradients on the fixture batch (autograd over oracle.model_ref at full size: computed once)"""
+    from oracle import train_ref
+
+    if "g" not in _REF:
+        rc, p, models, (px, labels, mask, dec_in), _ = full
+        _REF["g"] = train_ref.loss_and_grads(rc, p, px, labels, mask, dec_in)
+    return _REF["g"]
+
+
+def test_fullsize_fp8_train_step_against_fp32_oracle(full):
+    """BASELINE configs[4] at ViT-B/32 + mBART-large-50 size: the QKV / FFN projections of both towers as e4m3 / e5m2 GEMMs
+    (forward, dX, dW; per-tensor scaling, first pass = current amax) against the fp32 oracle — loss within 3e-2, every large
+    gradient leaf with cosine > 0.9, all leaves together > 0.97 (the tolerances of the reduced-size test, tests/test_fp8_gpu.py)."""
+    from mic_amd import loss_rows
+
+    rc, p, models, (px, labels, mask, dec_in), _ = full
+    ref_loss, ref_g = _ref_loss_and_grads(full)
+    model = models[torch.bfloat16]
+    eng = model.engine
+    eng.set_gemm_dtype("fp8")
+    try:
+        d = model._dev
+        B, T = labels.shape
+        pos = torch.arange(T, dtype=torch.int32, device=model.device)[None].expand(B, T).contiguous()
+        idx, rl = loss_rows(mask.numpy(), labels.numpy())
+        loss = eng.loss_and_grads(d(px, torch.float32), d(dec_in, torch.int32).reshape(-1), pos.reshape(-1), d(mask, torch.int32),
+                                  d(labels, torch.int32).reshape(-1), B, T, rows=(d(idx, torch.int32), len(idx)), row_labels=d(rl, torch.int32))
+        torch.cuda.synchronize()
+        assert abs(loss.item() - ref_loss.item()) < 3e-2 * abs(ref_loss.item()), (loss.item(), ref_loss.item())
+        got = model.store.export_flat("grad")
+        cos = lambda a, b: torch.nn.functional.cosine_similarity(a.reshape(-1).double(), b.reshape(-1).double(), dim=0).item()
+        worst = {k: cos(torch.from_numpy(got[k]).reshape(rg.shape), rg) for k, rg in ref_g.items() if rg.abs().max().item() > 1e-5 and rg.numel() >= 4096}
+        bad = {k: v for k, v in worst.items() if v < 0.9}
+        allc = cos(torch.cat([torch.from_numpy(got[k]).reshape(-1) for k in ref_g]), torch.cat([v.reshape(-1) for v in ref_g.values()]))
+        print(f"[fullsize fp8] loss {loss.item():.4f} vs {ref_loss.item():.4f}; worst leaf cosine {min(worst.values()):.3f} over {len(worst)} leaves; all leaves {allc:.4f}")
+        assert not bad, sorted(bad.items(), key=lambda kv: kv[1])[:6]
+        assert allc > 0.97, allc
+        assert eng._w8["dec11.fc1"][0].dtype == torch.float8_e4m3fn and float(eng._w8["dec11.fc1"][2][1]) > 0  # the fp8 copies carry a scale
+    finally:
+        eng.set_gemm_dtype(None)
+        eng.free_buffers()
+
+
 def test_fullsize_loss_and_gradients_f32(full):
     from mic_amd import loss_rows
-    from oracle import train_ref
 
     rc, p, models, (px, labels, mask, dec_in), _ = full
     model = models[torch.float32]
-    ref_loss, ref_g = train_ref.loss_and_grads(rc, p, px, labels, mask, dec_in)
+    ref_loss, ref_g = _ref_loss_and_grads(full)
     d = model._dev
     B, T = labels.shape
     pos = torch.arange(T, dtype=torch.int32, device=model.device)[None].expand(B, T).contiguous()
