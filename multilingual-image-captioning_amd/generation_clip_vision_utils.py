@@ -21,8 +21,10 @@ processor switches are baked-in launch arguments) and from then on a step is ONE
 the loop except for a stop-flag poll every 8 steps (`lax.while_loop` in the reference has no host in it either, gen:976).
 MEASURED (MI355X, ROCm 7.2, tools/decode_host_probe.py, ms per decoder step, graphs vs eager): batch 256 x 4 beams 2.71 vs
 2.70 (GPU-bound either way), batch 32: 1.61 vs 1.62, batch 4: 1.47 vs 1.57 — a replayed 140-node graph costs what 140
-back-to-back launches cost (~10 us per dependent kernel on this stack), so the graphs are correct (tests) but buy nothing
-here and stay opt-in; fewer, fatter kernels per step are what would move small-batch latency.
+back-to-back launches cost: the ~10 us per dependent kernel are the kernels' own durations (a chain of first-tile miss, K loop,
+reduction and epilogue), not launch overhead, so the graphs are correct (tests) but buy nothing for a single chain and stay
+opt-in there; fewer, fatter kernels per step are what would move small-batch latency.  A beam search cut into image slices
+(MIC_DECODE_SLICES) uses the graphs to run the slices' chains as parallel branches.
 """
 from __future__ import annotations
 
