@@ -573,7 +573,7 @@ def main():
         else:
             # HBM bytes per launch come from separate rocprofv3 --pmc passes (a profiler cannot wrap this very process); the
             # committed summary of the last such passes over this same command is reported with the commit it was taken at.
-            for name in ("r2_train_pmc_hbm_traffic.json", "r1_train_pmc_hbm_traffic.json"):
+            for name in ("r3_train_pmc_hbm_traffic.json", "r2_train_pmc_hbm_traffic.json", "r1_train_pmc_hbm_traffic.json"):
                 pmc = os.path.join(ROOT, "profiles", name)
                 if args.dtype == "bf16" and B == 64 and not args.small and not args.dense_captions and os.path.exists(pmc):
                     t = json.load(open(pmc))

@@ -37,9 +37,11 @@ for k in sorted(set(f) | set(w), key=lambda k: -(f[k][1] * 2 + w[k][1])):
         print(f"{k:72s} {n / steps:10.2f} {fb / steps / 1e6:14.2f} {wb / steps / 1e6:14.2f} {(fb + wb) / n / 1e6:10.2f}")
 print(f"{'TOTAL':72s} {'':10s} {tf / steps / 1e6:14.2f} {tw / steps / 1e6:14.2f}")
 if len(sys.argv) > 4:
-    att = [v for k, v in rows.items() if k.startswith("attn_decode")]
-    n = sum(v[0] for v in att)
-    json.dump({"kernel": "attn_decode_kernel + attn_decode_group_kernel", "launches_per_step": n / steps,
-               "bytes_per_launch": int(sum(v[1] + v[2] for v in att) / n),
-               "fetch_MB_per_step": round(sum(v[1] for v in att) / steps / 1e6, 2), "write_MB_per_step": round(sum(v[2] for v in att) / steps / 1e6, 2),
+    def group(pred):
+        sel = [v for k, v in rows.items() if pred(k)]
+        n = sum(v[0] for v in sel)
+        return {"launches_per_step": round(n / steps, 2), "bytes_per_launch": int(sum(v[1] + v[2] for v in sel) / max(n, 1)),
+                "fetch_MB_per_step": round(sum(v[1] for v in sel) / steps / 1e6, 2), "write_MB_per_step": round(sum(v[2] for v in sel) / steps / 1e6, 2)}
+    json.dump({"attention": dict(kernel="attn_decode_kernel + attn_decode_group_kernel", **group(lambda k: k.startswith("attn_decode"))),
+               "gemm": dict(kernel="gemm_bf16_kernel + gemm_phased_kernel", **group(lambda k: k.startswith("gemm_"))),
                "total_GB_per_decoder_step": round((tf + tw) / steps / 1e9, 3)}, open(sys.argv[4], "w"), indent=1)
