@@ -15,8 +15,8 @@ def load(path):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt, dur, seen = collections.Counter(), collections.defaultdict(float), set()
     for r in csv.DictReader(open(path)):
-        k = r["Kernel_Name"]
-        k = (k[:k.index("(")] if "(" in k else k).replace("void ", "")[:58]
+        k = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")
+        k = (k[:k.index("(")] if "(" in k else k)[:58]
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Dispatch_Id"] not in seen:
             seen.add(r["Dispatch_Id"])
