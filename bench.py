@@ -278,7 +278,7 @@ def bench_generate(model, cfg, dev, batch=256, langs=(250004, 250008, 250003, 25
         pmc = os.path.join(ROOT, "profiles", name)
         if batch == 256 and os.path.exists(pmc):  # HBM-side bytes per launch from separate rocprofv3 --pmc passes over this leg (committed)
             t = json.load(open(pmc))
-            src = t["summary"] + " (commit " + t.get("commit", "?") + ")"
+            src = t.get("summary", "profiles/" + name.replace(".json", ".txt")) + " (commit " + t.get("commit", "<see git log of the file>") + ")"
             ra = res["roofline_attention"]
             att = t.get("attention", t)  # r2 file: attention figures at the top level
             ra["traffic"] = att["bytes_per_launch"]
@@ -579,7 +579,8 @@ def main():
                     t = json.load(open(pmc))
                     roofline["traffic"] = t["bytes_per_launch"]
                     roofline["traffic_unit"] = "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, avg over the step's GEMM launches)"
-                    roofline["traffic_source"] = t["summary"] + " (committed counter passes of this command at commit " + t.get("commit", "0a85f1c, round 1") + "; --pmc-traffic re-measures)"
+                    roofline["traffic_source"] = (t.get("summary", "profiles/" + name.replace(".json", ".txt")) + " (committed counter passes of this command at commit "
+                                                  + t.get("commit", "<see git log of the file>") + "; --pmc-traffic re-measures)")
                     break
     if world > 1:
         dist.barrier()
