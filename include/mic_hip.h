@@ -287,7 +287,7 @@ int mic_adamw(int64_t n, float* p, float* m, float* v, const float* g, void* p_l
 
 /* ---------------------------------------------------------------------------------------------
  * Generation epilogues
- *   mic_row_lse_topk: per row of logits [R][ld] (dtype): lse over V and the top-k (k <= 16) of
+ *   mic_row_lse_topk: per row of logits [R][ld] (dtype): lse over V and the top-k (k <= 32) of
  *       processed log-probs (forced_token >= 0: everything -inf except forced_token := 0; min-length: eos := -inf
  *       when suppress_eos), plus row_bias[row] (the beam's running score, gen:857) — candidates ordered
  *       (value desc, index asc), i.e. lax.top_k (gen:850-873).  raw_logits = 1: no log-softmax (greedy, gen:497-499).

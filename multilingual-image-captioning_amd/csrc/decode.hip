@@ -3,7 +3,8 @@
 // (K18) — a [rows][max_len] slot-ownership table is updated instead (see attention.hip / mic_attn_decode).
 #include "common.h"
 
-#define TOPK_MAX 16  // widest per-row top-k (= 2 * num_beams): num_beams <= 8; k <= 8 runs the 8-wide build
+#define TOPK_MAX 16   // widest top-k of the partials-based kernel (row_topk_tiles: k = 2 * num_beams <= 16, its candidate set lives in registers)
+#define TOPK_WIDE 32  // widest top-k of the streaming kernel and of the beam bookkeeping: num_beams <= 16
 #define NEG_BIG (-1.0e7f)
 
 __device__ __forceinline__ bool better(float av, int ai, float bv, int bi) { return av > bv || (av == bv && ai < bi); }
@@ -187,11 +188,11 @@ __global__ __launch_bounds__(256) void row_lse_topk_kernel(int V, const T* __res
 extern "C" int mic_row_lse_topk(int dtype, int R, int V, const void* logits, int ld, int k, int forced_token,
                                 int suppress_eos, int eos_token_id, int raw_logits, const float* row_bias, float* top_val,
                                 int32_t* top_idx, void* stream) {
-  MIC_CHECK(R > 0 && V > 0 && ld >= V && ld % 8 == 0 && k >= 1 && k <= TOPK_MAX && logits && top_val && top_idx, "mic_row_lse_topk: bad args");
+  MIC_CHECK(R > 0 && V > 0 && ld >= V && ld % 8 == 0 && k >= 1 && k <= TOPK_WIDE && logits && top_val && top_idx, "mic_row_lse_topk: bad args (k <= 32)");
   dim3 grid(R), block(256);
 #define TOPK_LAUNCH(TT, KM) hipLaunchKernelGGL((row_lse_topk_kernel<TT, KM>), grid, block, 0, (hipStream_t)stream, V, (const TT*)logits, ld, k, forced_token, suppress_eos, eos_token_id, raw_logits, row_bias, top_val, top_idx)
-  if (dtype == MIC_BF16) { if (k <= 8) TOPK_LAUNCH(uint16_t, 8); else TOPK_LAUNCH(uint16_t, 16); }
-  else if (dtype == MIC_F32) { if (k <= 8) TOPK_LAUNCH(float, 8); else TOPK_LAUNCH(float, 16); }
+  if (dtype == MIC_BF16) { if (k <= 8) TOPK_LAUNCH(uint16_t, 8); else if (k <= 16) TOPK_LAUNCH(uint16_t, 16); else TOPK_LAUNCH(uint16_t, 32); }
+  else if (dtype == MIC_F32) { if (k <= 8) TOPK_LAUNCH(float, 8); else if (k <= 16) TOPK_LAUNCH(float, 16); else TOPK_LAUNCH(float, 32); }
   else MIC_CHECK(false, "mic_row_lse_topk: bad dtype");
 #undef TOPK_LAUNCH
   MIC_LAUNCH_CHECK();
@@ -397,9 +398,9 @@ extern "C" int mic_row_topk_tiles(int dtype, int R, int V, const void* logits, i
 }
 
 // ------------------------------------------------------------------ one beam_search_body_fn iteration (gen:857-966)
-// One 128-thread block per batch item; K <= 8 beams (2K*K <= 128 candidates).  All arithmetic is fp32 in
-// the reference's operation order so scores are bit-identical to the oracle.
-__global__ __launch_bounds__(128) void beam_step_kernel(mic_beam_step_args a) {
+// One block per batch item, one thread per (beam, candidate) pair: 128 threads up to K = 8 beams (2K*K <= 128 candidates), 512 up
+// to K = 16.  All arithmetic is fp32 in the reference's operation order so scores are bit-identical to the oracle.
+__global__ __launch_bounds__(512) void beam_step_kernel(mic_beam_step_args a) {
   extern __shared__ int32_t lds_i[];
   const int K = a.K, C = 2 * K, L = a.max_len, V = a.V;
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(128) void beam_step_kernel(mic_beam_step_args a) {
   // loop-condition inputs on the NEW state (gen:798-820), per item
   if (tid == 0) {
     int all_fin = 1; float mn = INFINITY;
-    float ns[TOPK_MAX]; int nf[TOPK_MAX];
+    float ns[TOPK_WIDE / 2]; int nf[TOPK_WIDE / 2];
     for (int kx = 0; kx < K; ++kx) {
       const int mi = mrg_pick[kx];
       ns[kx] = mi < K ? old_scores[mi] : fin_score[mi - K];
@@ -538,12 +539,13 @@ __global__ __launch_bounds__(128) void beam_step_kernel(mic_beam_step_args a) {
   }
 }
 extern "C" int mic_beam_step(const mic_beam_step_args* a, void* stream) {
-  MIC_CHECK(a && a->B > 0 && a->K >= 1 && a->K <= TOPK_MAX / 2 * 2 && 2 * a->K <= TOPK_MAX && a->max_len > 1 && a->cur_len >= 1 && a->cur_len < a->max_len,
-            "mic_beam_step: bad shape (K <= 8 supported: per-row candidates come from mic_row_lse_topk with k = 2K <= 16)");
+  MIC_CHECK(a && a->B > 0 && a->K >= 1 && 2 * a->K <= TOPK_WIDE && a->max_len > 1 && a->cur_len >= 1 && a->cur_len < a->max_len,
+            "mic_beam_step: bad shape (K <= 16 supported: per-row candidates come from mic_row_lse_topk with k = 2K <= 32)");
   MIC_CHECK(a->cand_val && a->cand_idx && a->running_seq && a->running_scores && a->seq && a->scores && a->finished && a->src_row && a->next_token && a->flags, "mic_beam_step: null pointer");
   const size_t lds = (size_t)(3 * a->K * a->max_len + 8 * 2 * a->K + 8 * a->K) * 4;
   MIC_CHECK(lds <= 65536, "mic_beam_step: max_len too large for the LDS staging");
-  hipLaunchKernelGGL(beam_step_kernel, dim3(a->B), dim3(128), lds, (hipStream_t)stream, *a);
+  const int threads = 2 * a->K * a->K <= 128 ? 128 : 512;  // one thread per (beam, candidate) pair
+  hipLaunchKernelGGL(beam_step_kernel, dim3(a->B), dim3(threads), lds, (hipStream_t)stream, *a);
   MIC_LAUNCH_CHECK();
   return MIC_OK;
 }

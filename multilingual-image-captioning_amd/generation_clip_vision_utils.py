@@ -293,8 +293,8 @@ class FlaxCLIPVisionMBartGenerationMixin:
     def _beam_search(self, ehs, B, K, start_token, max_length, pad_token_id, eos_token_id, length_penalty, early_stopping, procs):
         from .modeling_clip_vision_mbart import ModelOutput
 
-        if 2 * K > 16:
-            raise NotImplementedError("num_beams > 8 needs a wider per-row top-k than this build ships (k = 2*num_beams <= 16)")
+        if 2 * K > 32:
+            raise NotImplementedError("num_beams > 16 needs a wider per-row top-k than this build ships (k = 2*num_beams <= 32)")
         dev, st = self.device, self.store
         NS = self._decode_slices(B, K)
         Bs = B // NS          # images per slice
@@ -403,7 +403,7 @@ class FlaxCLIPVisionMBartGenerationMixin:
                 cache["cache_index"] = cur_len - 1
                 logits, stat = self._decode_step(cache, next_token, pos_all[(cur_len - 1) * R: cur_len * R], stats=True)  # gen:830-840
                 forced, suppress = self._proc_args(procs, cur_len, max_length, eos_token_id)
-                if stat is not None and forced < 0:
+                if stat is not None and forced < 0 and 2 * K <= 16:
                     # log-softmax + top-2K from the head GEMM's per-granule partials: 3908 pairs and a few 64-column granules
                     # per row instead of two passes over the 250 054 logits (same candidates, same order, same fp32 arithmetic)
                     ops.row_topk_tiles(logits, logits.stride(0), st.V, stat, 2 * K, cand_val, cand_idx, R, suppress_eos=suppress,
