@@ -204,12 +204,32 @@ class FlaxCLIPVisionMBartForConditionalGeneration(FlaxCLIPVisionMBartPreTrainedM
         else:
             pos = self._dev(decoder_position_ids, torch.int32)
         seed = _seed_from(dropout_rng) if train else None  # deterministic = not train (508)
-        logits, _ = self.engine.forward_logits(px, ids.reshape(-1), pos.reshape(-1), mask, B, T, save=False, seed=seed)
+        output_hidden_states = output_hidden_states if output_hidden_states is not None else getattr(self.config, "output_hidden_states", False)
+        output_attentions = output_attentions if output_attentions is not None else getattr(self.config, "output_attentions", False)
+        if output_attentions:
+            # modeling:499-510 forwards the flag to the Flax modules, which return the softmax weights of every layer; the fused
+            # attention kernels here never materialise them
+            raise NotImplementedError("output_attentions=True: the attention kernels do not materialise the attention weights")
+        logits, ehs = self.engine.forward_logits(px, ids.reshape(-1), pos.reshape(-1), mask, B, T, save=bool(output_hidden_states), seed=seed)
         V = self.store.V
         out = logits[: B * T, :V].reshape(B, T, V)
-        if return_dict is False:
-            return (out,)
-        return ModelOutput(logits=out)
+        if not output_hidden_states:
+            if return_dict is False:
+                return (out,)
+            return ModelOutput(logits=out)
+        # FlaxSeq2SeqLMOutput fields of the reference's module output (modeling:176-192): the per-layer activations the forward
+        # pass kept (`save=True`), copied out of the engine's buffers.  Decoder: the embedding output (after layernorm_embedding)
+        # and every layer's output — the last one before the final layer_norm, as the Flax decoder collects them; encoder: the
+        # pre-layernormed embeddings and every layer's output.
+        eng, st = self.engine, self.store
+        S, d, vd = st.S, st.d, st.vd
+        dec = [eng.buf("d.x0", B * T, d)] + [eng.buf(f"d{l}.x3", B * T, d) for l in range(st.L)]
+        enc = [eng.buf("v.x0", B * S, vd)] + [eng.buf(f"v{l}.xo", B * S, vd) for l in range(st.vL)]
+        res = ModelOutput(logits=out,
+                          decoder_hidden_states=tuple(t[: B * T].reshape(B, T, d).clone() for t in dec),
+                          encoder_last_hidden_state=ehs[: B * S].reshape(B, S, d).clone(),
+                          encoder_hidden_states=tuple(t[: B * S].reshape(B, S, vd).clone() for t in enc))
+        return res if return_dict is not False else res.to_tuple()
 
     # ------------------------------------------------------------------ encode (modeling:284-337)
     def encode(self, pixel_values, output_attentions=None, output_hidden_states=None, return_dict=None, train: bool = False,

@@ -238,3 +238,41 @@ def test_evaluate_loop(dev):
     # generation really starts from the language code (main.py:820)
     g = model.generate(loaders["fr_XX"][0]["pixel_values"], max_length=10, num_beams=2, decoder_start_token_id=codes["fr_XX"])
     assert (g.sequences[:, 0] == codes["fr_XX"]).all()
+
+
+def test_output_hidden_states_match_oracle(dev):
+    """`output_hidden_states=True` (modeling:499-510 forwards it to the modules): decoder and encoder per-layer states of the
+    forward pass against the oracle's; `output_attentions=True` is refused (the fused kernels keep no attention weights)."""
+    import numpy as np
+
+    from oracle import model_ref as M
+    from util_small import batch, make_pair
+
+    rc, p, model = make_pair(torch.float32, dev, gelu="tanh", decoder_ln_eps=1e-6)
+    px, labels, mask, dec_in = batch(rc, 3, 12, seed=9)
+    out = model(px.numpy(), dec_in.numpy(), mask.numpy(), output_hidden_states=True)
+    plain = model(px.numpy(), dec_in.numpy(), mask.numpy())
+    assert torch.equal(out.logits, plain.logits) and set(plain.keys()) == {"logits"}
+    with torch.no_grad():
+        x = M.layer_norm(M.vision_embeddings(rc, p, px), p[M.V + "pre_layrnorm/scale"], p[M.V + "pre_layrnorm/bias"], rc.v_ln_eps)
+        enc = [x]
+        for i in range(rc.v_layers):
+            x = M.vit_layer(rc, p, x, i)
+            enc.append(x)
+        ehs = M.dense(x, p, "model/visual_projection")
+        B, T = dec_in.shape
+        pos = torch.arange(T)[None].expand(B, T)
+        _, layers = M.decoder_forward(rc, p, dec_in, mask, pos, ehs, return_layers=True)
+        dec = [M.decoder_embed(rc, p, dec_in, pos)] + layers
+    assert len(out.decoder_hidden_states) == rc.d_layers + 1 and len(out.encoder_hidden_states) == rc.v_layers + 1
+    valid = mask.bool()
+    for got, ref in zip(out.encoder_hidden_states, enc):
+        assert (got.cpu() - ref).abs().max().item() < 2e-4 * ref.abs().max().item()
+    for got, ref in zip(out.decoder_hidden_states, dec):
+        assert (got.cpu() - ref)[valid].abs().max().item() < 2e-4 * ref[valid].abs().max().item()
+    assert (out.encoder_last_hidden_state.cpu() - ehs).abs().max().item() < 2e-4 * ehs.abs().max().item()
+    assert len(model(px.numpy(), dec_in.numpy(), mask.numpy(), output_hidden_states=True, return_dict=False)) == 4
+    import pytest
+
+    with pytest.raises(NotImplementedError, match="attention weights"):
+        model(px.numpy(), dec_in.numpy(), mask.numpy(), output_attentions=True)
