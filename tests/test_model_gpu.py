@@ -418,6 +418,42 @@ def test_packed_decoder_rows_change_nothing(dev):
             assert np.abs(gp[k] - gr[k]).max() <= 2e-4 * sc, (seed, k, np.abs(gp[k] - gr[k]).max() / sc)
 
 
+@pytest.mark.parametrize("lens", [[1, 16, 2, 15, 16, 1, 3], [16, 16], [1], [5, 1, 1, 1, 1, 1, 1, 1, 9]])
+def test_packed_decoder_rows_edge_lengths(dev, lens):
+    """packed rows with one-token captions, full-length captions, a single sequence and row counts that are not multiples of
+    anything: same loss as the padded rows, gradients within the summation-order tolerance"""
+    from mic_amd import loss_rows, packed_rows
+
+    rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.0)
+    d = model._dev
+    B, T = len(lens), 16
+    g = torch.Generator().manual_seed(sum(lens))
+    px = torch.randn(B, rc.image_size, rc.image_size, 3, generator=g).clamp(-1.8, 2.2)
+    labels = torch.full((B, T), rc.pad_token_id, dtype=torch.int64)
+    mask = torch.zeros((B, T), dtype=torch.int64)
+    for b, n in enumerate(lens):
+        labels[b, :n] = torch.randint(4, rc.vocab_size - 20, (n,), generator=g)
+        mask[b, :n] = 1
+    dec_in = torch.full_like(labels, rc.pad_token_id)
+    dec_in[:, 1:] = labels[:, :-1]
+    pos = torch.arange(T, dtype=torch.int32, device=dev)[None].expand(B, T).contiguous()
+    idx, rl = loss_rows(mask.numpy(), labels.numpy())
+    if len(idx) == B * T:
+        pytest.skip("every position valid: nothing to pack (Trainer runs the dense path)")
+    kw = dict(rows=(d(idx, torch.int32), len(idx)), row_labels=d(rl, torch.int32))
+    q_off, q_len, ids_p, pos_p = (d(t, torch.int32) for t in packed_rows(mask.numpy(), dec_in.numpy()))
+    lp = float(model.engine.loss_and_grads(d(px, torch.float32), ids_p, pos_p, None, d(labels, torch.int32).reshape(-1), B, T,
+                                           pack=(q_off, q_len, len(idx)), **kw))
+    gp = {k: v.copy() for k, v in model.store.export_flat("grad").items()}
+    lr = float(model.engine.loss_and_grads(d(px, torch.float32), d(dec_in, torch.int32).reshape(-1), pos.reshape(-1), d(mask, torch.int32),
+                                           d(labels, torch.int32).reshape(-1), B, T, **kw))
+    gr = model.store.export_flat("grad")
+    assert lp == lr and np.isfinite(lp), (lp, lr)
+    for k in gr:
+        sc = max(np.abs(gr[k]).max(), 1e-12)
+        assert np.abs(gp[k] - gr[k]).max() <= 2e-4 * sc, (k, np.abs(gp[k] - gr[k]).max() / sc)
+
+
 def test_trainer_packs_rows_by_default_and_matches_the_padded_trainer(dev):
     from mic_amd import Trainer, create_learning_rate_fn
     from mic_amd.params import flatten_tree
