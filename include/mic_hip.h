@@ -113,13 +113,6 @@ typedef struct {
    * both operands count as zero (0 = all K rows are valid).  K stays a multiple of 64; the buffers need not keep their rows
    * [k_valid, K) zeroed — with variable-length (packed) batches the number of valid rows changes from step to step. */
   int k_valid;
-  /* bf16, single-problem launches with 256 x 256 tiles whose A operand is the LM head's LOGITS (the two head gradient GEMMs of
-   * main.py:658-680's backward: dE = dlogits^T hf with a_kmajor = b_kmajor = 1, dX = dlogits E with b_kmajor = 1): the cross-entropy
-   * backward is applied to A on its way from memory to LDS,
-   *     dlogit(r, c) = ce_lw[r].y * (exp(logit(r, c) - ce_lw[r].x) - (c == ce_label[r] ? ce_conf : ce_low))   for c < ce_V, r < ce_rows,  0 otherwise
-   * — exactly mic_ce_bwd's arithmetic, without its pass over the [rows][250 112] logits.  ce_lw = (row lse, loss weight
-   * mask / denom) from mic_ce_rowparams; NULL = off.  A is never written. */
-  const float* ce_lw; const int32_t* ce_label; int ce_V; int ce_rows; float ce_conf, ce_low;
 } mic_gemm_args;
 int mic_gemm(const mic_gemm_args* a, void* stream);
 /* dst[r][c] (dst_dtype) = sum over s < n_slabs of src[s * slab_stride + r * ld_src + c] (fp32): the second half of a
@@ -304,9 +297,6 @@ int mic_adamw(int64_t n, float* p, float* m, float* v, const float* g, void* p_l
 int mic_row_lse_topk(int dtype, int R, int V, const void* logits, int ld, int k, int forced_token,
                      int suppress_eos, int eos_token_id, int raw_logits, const float* row_bias, float* top_val,
                      int32_t* top_idx, void* stream);
-
-/* per-row operands of the fused cross-entropy backward (mic_gemm_args.ce_lw): lw[r] = (row_lse[r], mask[r] ? loss_scale / denom[0] : 0) */
-int mic_ce_rowparams(int rows, const float* row_lse, const int32_t* mask, const float* denom, float loss_scale, float* lw, void* stream);
 
 /* mic_row_lse_topk's results (no forced token) from the head GEMM's per-granule partials: lse by merging ceil(V / 64) pairs, the
  * top-k by scanning only the 64-column granules whose maximum reaches the k-th largest granule maximum (gen:850-873 without

@@ -33,7 +33,6 @@ class GemmArgs(C.Structure):
         ("rowstat", C.c_void_p), ("rowstat_ld", C.c_int), ("rowstat_nvalid", C.c_int),
         ("a_ln_stats", C.c_void_p), ("a_ln_colsum", C.c_void_p), ("a_ln_width", C.c_int), ("a_ln_eps", C.c_float),
         ("rowsum2", C.c_void_p), ("k_valid", C.c_int),
-        ("ce_lw", C.c_void_p), ("ce_label", C.c_void_p), ("ce_V", C.c_int), ("ce_rows", C.c_int), ("ce_conf", C.c_float), ("ce_low", C.c_float),
     ]
 
 
@@ -90,7 +89,6 @@ _SIGS = {
     "mic_ce_rows_tiles": ([_i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p], C.c_int),
     "mic_row_topk_tiles": ([_i, _i, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p], C.c_int),
     "mic_ce_reduce": ([_i, _p, _p, _p, _p, _p], C.c_int),
-    "mic_ce_rowparams": ([_i, _p, _p, _p, _f, _p, _p], C.c_int),
     "mic_ce_bwd": ([_i, _i, _i, _i, _p, _i, _p, _p, _f, _p, _p, _f, _p], C.c_int),
     "mic_colsum": ([_i, _i, _i, _p, _i, _p, _i, _p], C.c_int),
     "mic_colsum_grouped": ([_i, C.POINTER(ColsumItem), _i, _p], C.c_int),

@@ -266,18 +266,6 @@ extern "C" int mic_ce_reduce(int rows, const float* row_loss, const int32_t* mas
   MIC_LAUNCH_CHECK();
   return MIC_OK;
 }
-__global__ void ce_rowparams_kernel(int rows, const float* __restrict__ row_lse, const int32_t* __restrict__ mask,
-                                    const float* __restrict__ denom, float loss_scale, float2* __restrict__ lw) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < rows) lw[r] = make_float2(row_lse[r], mask[r] ? loss_scale / denom[0] : 0.f);  // the `w` and `lse` of ce_bwd_kernel
-}
-extern "C" int mic_ce_rowparams(int rows, const float* row_lse, const int32_t* mask, const float* denom, float loss_scale, float* lw,
-                                void* stream) {
-  MIC_CHECK(rows > 0 && row_lse && mask && denom && lw && ((uintptr_t)lw & 7) == 0, "mic_ce_rowparams: bad args");
-  hipLaunchKernelGGL(ce_rowparams_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, rows, row_lse, mask, denom, loss_scale, (float2*)lw);
-  MIC_LAUNCH_CHECK();
-  return MIC_OK;
-}
 // dlogits = mask/denom * loss_scale * (softmax - soft_label); soft_label = conf at label, low elsewhere.
 template <typename T>
 __global__ __launch_bounds__(256) void ce_bwd_kernel(int V, int Vpad, T* __restrict__ logits, int ld,

@@ -201,15 +201,6 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
     MIC_CHECK(args[i].k_valid >= 0 && (args[i].k_valid == 0 || (args[i].a_kmajor && args[i].b_kmajor && !f8)),
               "mic_gemm: k_valid is a feature of the bf16 k-major x k-major (weight-gradient) launches");
     p.k_valid = args[i].k_valid > 0 ? args[i].k_valid : 0x7fffffff;
-    p.ce_lw = (const float2*)args[i].ce_lw; p.ce_label = args[i].ce_label; p.ce_V = args[i].ce_V; p.ce_rows = args[i].ce_rows;
-    p.ce_conf = args[i].ce_conf; p.ce_low = args[i].ce_low;
-    if (args[i].ce_lw) {
-      MIC_CHECK(count == 1 && !f8 && args[i].b_kmajor && args[i].ce_label && args[i].ce_V > 1 && args[i].ce_rows > 0 && ((uintptr_t)args[i].ce_lw & 7) == 0,
-                "mic_gemm: the fused cross-entropy backward is a single bf16 problem with b_kmajor, ce_label, ce_V, ce_rows");
-      MIC_CHECK(!args[i].a_kmajor || p.M % 256 == 0, "mic_gemm: fused cross-entropy backward with A k-major (dE): M (the padded vocabulary) must be a multiple of 256");
-      bm = 256;  // the kernel is built for 256 x 256 tiles only; tiles below were counted with bm before this line
-      p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bm - 1) / bm;
-    }
     p.block_begin = blocks;
     blocks += p.tiles_m * p.tiles_n * p.nsplit;
   }
@@ -221,8 +212,7 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
   // measured +1.6 ms per train step: that mode is gone.
   static const int phased_env = [] { const char* e = getenv("MIC_GEMM_PHASED"); return e ? atoi(e) : 2; }();
   const bool phased = phased_env != 0 && !args[0].a_kmajor && !args[0].b_kmajor && count == 1 && !any_rowsum_early(args, count);
-  if (args[0].ce_lw) launch_gemm_t256_ce(tab, args[0].a_kmajor, s);  // head gradient GEMMs with the fused cross-entropy backward
-  else if (bm == 256 && f8 == 0 && phased) launch_gemm_phased(tab, args[0].a_kmajor, args[0].b_kmajor, table_is_plain(tab), s);  // LDS-DMA, phased
+  if (bm == 256 && f8 == 0 && phased) launch_gemm_phased(tab, args[0].a_kmajor, args[0].b_kmajor, table_is_plain(tab), s);  // LDS-DMA, phased
   else if (bm == 256) launch_gemm_t256(tab, args[0].a_kmajor, args[0].b_kmajor, s, f8);     // 256x256x64, 8 waves
   else if (bm == 128) {  // 128x128x64, 8 waves (measured better than the 4-wave 64x64 wave tile at every tile count);
                          // two K-groups (16 waves) when the launch is a single round of at most one block per CU
@@ -253,7 +243,6 @@ extern "C" int mic_gemm(const mic_gemm_args* a, void* stream) {
   MIC_CHECK(a->split_k <= 1, "mic_gemm(f32): split_k is a bf16-path feature");
   MIC_CHECK(!a->a_rowsum, "mic_gemm(f32): a_rowsum is a bf16-path feature (use mic_colsum)");
   MIC_CHECK(a->k_valid == 0, "mic_gemm(f32): k_valid is a bf16-path feature");
-  MIC_CHECK(!a->ce_lw, "mic_gemm(f32): the fused cross-entropy backward is a bf16-path feature (use mic_ce_bwd)");
   dim3 grid((a->N + 63) / 64, (a->M + 63) / 64), block(256);
   const long sam = a->a_kmajor ? 1 : a->lda, sak = a->a_kmajor ? a->lda : 1;
   const long sbk = a->b_kmajor ? a->ldb : 1, sbn = a->b_kmajor ? 1 : a->ldb;

@@ -15,8 +15,6 @@ struct Problem {
   int tiles_m, tiles_n, block_begin, nsplit;
   float* a_rowsum; int rowsum_k;
   int k_valid;  // k-major operands: rows k >= k_valid read as zero (packed batches leave stale rows behind the valid ones)
-  // A = the LM head's logits: cross-entropy backward applied while staging A (mic_gemm_args.ce_lw); CE kernel instantiations only
-  const float2* ce_lw; const int32_t* ce_label; int ce_V, ce_rows; float ce_conf, ce_low;
   long long split_stride;
   const float* sa; const float* sb;  // fp8: device scalars, the operands' dequantisation factors (1 / quantisation scale)
   EpiArgs epi;
@@ -27,7 +25,6 @@ void launch_gemm_phased(const LaunchTable& tab, int akm, int bkm, bool plain, hi
 // one translation unit per tile configuration of the main kernel (gemm_kernel.h): 256x256 / 128x128 (K-groups 1, 2) / 64x64 (1, 2, 4)
 bool table_is_plain(const LaunchTable& t);
 void launch_gemm_t256(const LaunchTable& tab, int akm, int bkm, hipStream_t s, int f8);
-void launch_gemm_t256_ce(const LaunchTable& tab, int akm, hipStream_t s);  // A = logits with the fused cross-entropy backward (b k-major)
 void launch_gemm_t128(const LaunchTable& tab, int akm, int bkm, hipStream_t s, int f8, int kgroups);
 void launch_gemm_t64(const LaunchTable& tab, int akm, int bkm, hipStream_t s, int f8, int kgroups);
 

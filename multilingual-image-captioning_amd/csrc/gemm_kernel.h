@@ -21,14 +21,9 @@
 // F8: 0 = bf16 operands; 1 = fp8 e4m3 x e4m3 (forward); 2 = A e5m2 x B e4m3 (gradients x weights / saved activations).
 //   fp8 launches are NT only (both operands k-contiguous: the quantiser writes a transposed copy where one is needed); all
 //   sizes below stay in 2-byte units (K, lda, ldb = bytes / 2), so the staging code is shared.
-// CE: A is the LM head's logits and the cross-entropy backward (mic_ce_bwd's arithmetic) is applied to every 16-byte piece of A
-//   between its global load and its LDS write — the two head gradient GEMMs then need no dlogits pass over the [rows][250 112]
-//   logits.  Per-row operands (lse, loss weight, label) sit in LDS behind the two stages: the block's 256 rows for the
-//   k-contiguous A of dX (loaded once), the 64 rows of a K-tile for the k-major A of dE (double-buffered, fetched two tiles ahead).
-template <int WM, int WN, int WNW, int BKT, bool AK, bool BKM, int KG = 1, bool PLAIN = false, int F8 = 0, bool CE = false>
+template <int WM, int WN, int WNW, int BKT, bool AK, bool BKM, int KG = 1, bool PLAIN = false, int F8 = 0>
 __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kernel(LaunchTable tab) {
   static_assert(F8 == 0 || (!AK && !BKM && BKT == 64), "fp8: k-contiguous operands, 128-byte stages");
-  static_assert(!CE || (WM == 128 && KG == 1 && F8 == 0 && BKM && BKT == 64), "fused cross-entropy backward: the 256x256 head-gradient launches");
   constexpr int BM = 2 * WM, BN = WN * WNW, NWAVES = 2 * WNW, NTHREADS = 64 * NWAVES * KG;
   constexpr int UA = BM < 128 ? BM : 128, UB = BN < 128 ? BN : 128;  // rows per staged image (128, or 64 for the 64-wide tiles)
   constexpr int HALF_A = UA * BKT * 2, HALF_B = UB * BKT * 2;
@@ -42,7 +37,7 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
   // Persistent launches (PLAIN 256x256 instantiations only — the others have no registers to spare for the loop state; grid <
   // total_blocks, a multiple of 8): a block walks the tiles bid, bid + grid, ... — no block retirement / dispatch gap between
   // two tiles of a CU.  Every other instantiation runs the body once.
-  constexpr bool PERSIST = PLAIN && WM == 128 && KG == 1 && !CE;  // (the CE kernels have no registers for the tile loop's state either)
+  constexpr bool PERSIST = PLAIN && WM == 128 && KG == 1;
   int bid = blockIdx.x;
   do {
   // bijective XCD remap: the blocks that land on XCD x (= bid % 8) get a contiguous run of logical block ids
@@ -112,41 +107,10 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
   };
   // weight-gradient launches (both operands k-major, see mic_gemm_args.k_valid): reduction rows k >= k_valid are written to LDS
   // as zeros; `t` = the K-tile being written
-  constexpr bool KV = AK && BKM && F8 == 0 && !CE;  // (the head's logits keep their pad rows zeroed: no k_valid there)
+  constexpr bool KV = AK && BKM && F8 == 0;
   const int k_valid = KV ? P.k_valid : 0x7fffffff;
-  // fused cross-entropy backward: per-row operands in LDS behind the stages (see the CE note above the kernel)
-  float* const ce_lse = reinterpret_cast<float*>(smem + KG * 2 * STAGE);
-  float* const ce_w = ce_lse + 256;
-  int* const ce_lab = reinterpret_cast<int*>(ce_w + 256);
-  const int ce_V = CE ? P.ce_V : 0;
-  const float ce_conf = CE ? P.ce_conf : 0.f, ce_low = CE ? P.ce_low : 0.f;
   auto write_lds = [&](char* buf, int t) __attribute__((always_inline)) {
     const int kr = KV ? k_valid - (kt0 + t) * BKT : 0x7fffffff;  // valid rows of this K-tile (>= BKT: all)
-    if constexpr (CE) {
-#pragma unroll
-      for (int h = 0; h < NHA; ++h)
-#pragma unroll
-        for (int i = 0; i < SA::PER; ++i) {
-          int row, c;
-          SA::coords(wave * SA::PER + i, lane, row, c);
-          // dX (A k-contiguous): piece = logit row (h*UA + row) of the block, vocabulary columns of this K-tile;
-          // dE (A k-major): piece = logit row `row` of this K-tile, vocabulary columns m0 + h*UA + c*8 ..
-          const int ti = AK ? ((t & 1) * BKT + row) : (h * UA + row);
-          const int col0 = AK ? (m0 + h * UA + c * 8) : ((kt0 + t) * BKT + c * 8);
-          const float lse = ce_lse[ti], w = ce_w[ti];
-          const int label = ce_lab[ti];
-          float x[8];
-          unpack8(ra[h][i], x);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int cc = col0 + e;
-            const float v = w * (__expf(x[e] - lse) - (cc == label ? ce_conf : ce_low));  // = ce_bwd_kernel
-            x[e] = (cc < ce_V && w != 0.f) ? v : 0.f;
-          }
-          ra[h][i] = u32x4{f2bf_pk(x[0], x[1]), f2bf_pk(x[2], x[3]), f2bf_pk(x[4], x[5]), f2bf_pk(x[6], x[7])};
-          __builtin_amdgcn_sched_barrier(0);  // one piece at a time: interleaved, the four pieces' temporaries spill (the kernel sits at the register limit)
-        }
-    }
 #pragma unroll
     for (int h = 0; h < NHA; ++h) SA::store(ra[h], buf + h * HALF_A, wave, lane, kr);
 #pragma unroll
@@ -156,24 +120,6 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
   const int a_half = (wr * WM) / UA, a_off = (wr * WM) % UA;
   const int b_half = (wc * WN) / UB, b_off = (wc * WN) % UB;
 
-  if constexpr (CE) {
-    if constexpr (!AK) {  // dX: the block's 256 logit rows, once
-      if (tid < BM) {
-        const int r = m0 + tid;
-        const bool ok = r < P.ce_rows;
-        const float2 lw = ok ? P.ce_lw[r] : make_float2(0.f, 0.f);
-        ce_lse[tid] = lw.x; ce_w[tid] = lw.y; ce_lab[tid] = ok ? P.ce_label[r] : -1;
-      }
-    } else {              // dE: the 64 logit rows of K-tiles 0 and 1
-      if (tid < 2 * BKT) {
-        const int r = kt0 * BKT + tid;
-        const bool ok = r < P.ce_rows && tid < nk * BKT;
-        const float2 lw = ok ? P.ce_lw[r] : make_float2(0.f, 0.f);
-        ce_lse[tid] = lw.x; ce_w[tid] = lw.y; ce_lab[tid] = ok ? P.ce_label[r] : -1;
-      }
-    }
-    __syncthreads();
-  }
   if (nk > 0) {
     load_regs(0);
     write_lds(gsm, 0);
@@ -276,20 +222,11 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
         __builtin_amdgcn_sched_group_barrier(0x100, ((AK ? 2 : 1) * AI + (BKM ? 2 : 1) * NJ) * KSTEPS, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, KSTEPS * AI * NJ, 0);
       } else {
-      float2 ce_next_lw = make_float2(0.f, 0.f);
-      int ce_next_lab = -1;
 #pragma unroll
       for (int kk = 0; kk < KSTEPS; ++kk) {
         if (kk == STAGE_AT && t + 1 < nk) {
           write_lds(gsm + ((t + 1) & 1) * STAGE, t + 1);  // its buffer was last read in iteration t-1 (barrier below)
           if (t + 2 < nk) load_regs(t + 2);        // a full iteration of MFMAs to land
-          if constexpr (CE && AK) {
-            // the logit rows of K-tile t+2 take the table half that write_lds(t) read in the previous iteration
-            if (t + 2 < nk && tid < BKT) {
-              const int r = (kt0 + t + 2) * BKT + tid;
-              if (r < P.ce_rows) { ce_next_lw = P.ce_lw[r]; ce_next_lab = P.ce_label[r]; }
-            }
-          }
         }
         bf16x8 af[AI], bfr[NJ];
 #pragma unroll
@@ -317,12 +254,6 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
           for (int j = 0; j < NJ; ++j) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
           }
-      }
-      if constexpr (CE && AK) {
-        if (t + 2 < nk && tid < BKT) {
-          const int ti = (t & 1) * BKT + tid;
-          ce_lse[ti] = ce_next_lw.x; ce_w[ti] = ce_next_lw.y; ce_lab[ti] = ce_next_lab;
-        }
       }
       }
     }
@@ -372,27 +303,6 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
   if (bid >= tab.total_blocks) break;
   __syncthreads();  // the next tile's prologue rewrites the LDS the epilogue restaged through
   } while (true);
-}
-
-// the two head-gradient launches with the fused cross-entropy backward (256x256 tiles, B k-major): dE (A k-major, bare fp32 epilogue)
-// and dX (A k-contiguous, split-K slabs)
-template <bool AKM, bool PLAIN>
-static inline void launch_cfg_ce(const LaunchTable& tab, hipStream_t s) {
-  constexpr int WM = 128, WN = 64, WNW = 4, BKT = 64;
-  const size_t lds = (size_t)2 * (2 * WM + WN * WNW) * BKT * 2 + 4096;  // two stages + the per-row operand table
-  static const int persist = [] { const char* e = getenv("MIC_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
-  int nblk = tab.total_blocks;
-  (void)persist;  // one block per tile: the CE instantiations are not persistent
-  static bool attr_set_dev[64] = {};
-  int dev_ = 0;
-  (void)hipGetDevice(&dev_);
-  bool& attr_set = attr_set_dev[dev_ & 63];
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WN, WNW, BKT, AKM, true, 1, PLAIN, 0, true>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, WNW, BKT, AKM, true, 1, PLAIN, 0, true>), dim3(nblk), dim3(128 * WNW), lds, s, tab);
 }
 
 template <int WM, int WN, int WNW, int BKT, int KG, bool PLAIN, int F8 = 0>

@@ -56,9 +56,6 @@ class Engine:
         # decoder-step LayerNorms folded around the GEMMs (bfloat16 generate path): A/B switch
         self.decode_ln_fold = self.dev.type == "cuda" and os.environ.get("MIC_DECODE_LNFOLD", "1") != "0"
         self._ckv_hoist = os.environ.get("MIC_CKV_HOIST", "1") != "0"
-        # cross-entropy backward applied inside the two LM-head gradient GEMMs' operand load (no dlogits pass over the logits): A/B switch
-        self.fused_ce = os.environ.get("MIC_FUSED_CE", "0") == "1"
-        self._ce_fused = None
         self._lnf = {}
         self._lnf_version = -1
         self._dw_stream = None
@@ -600,12 +597,9 @@ class Engine:
             hf = self.buf("d.hf" if pack is not None else "d.hfc", Mcap, d)  # compacted final hidden states (pad rows zero)
             Mh = rows[1]
         Mhp = _rup(Mh, 64)
-        ce = self._ce_fused  # (lw, labels, V, rows, label_smoothing): `dlogits` still holds the LOGITS, see loss_and_dlogits
-        self._ce_fused = None
-        cekw = dict(ce=ce) if ce is not None else {}
         if self.dt == torch.bfloat16:  # final_logits_bias gradient = row sums of dlogits^T, fused into the dE GEMM
             ops.zero(P.g("flb"))        # (atomics; this segment sits in front of the pre-zeroed atomic region)
-            ops.gemm(dlogits, hf, P.g("shared"), P.Vpad, d, Mhp, a_kmajor=True, b_kmajor=True, a_rowsum=P.g("flb"), rowsum_k=Mh, **cekw)
+            ops.gemm(dlogits, hf, P.g("shared"), P.Vpad, d, Mhp, a_kmajor=True, b_kmajor=True, a_rowsum=P.g("flb"), rowsum_k=Mh)
         else:
             ops.colsum(dlogits, P.g("flb"), Mh, P.Vpad, dlogits.stride(0))
             ops.gemm(dlogits, hf, P.g("shared"), P.Vpad, d, Mhp, a_kmajor=True, b_kmajor=True)
@@ -617,10 +611,10 @@ class Engine:
             nsp = 32  # 16..64 measure the same (+-0.1 ms/step); the gain over the atomic variant is the absence of atomics
             d32 = self.buf("db.dhf32", nsp * _rup(Mcap, ROWPAD), d, torch.float32)  # one fp32 slab per split, summed below
             slab = _rup(Mcap, ROWPAD) * d
-            ops.gemm(dlogits, P.w("shared"), d32, Mh, d, P.Vpad, b_kmajor=True, split_k=nsp, split_stride=slab, **cekw)
+            ops.gemm(dlogits, P.w("shared"), d32, Mh, d, P.Vpad, b_kmajor=True, split_k=nsp, split_stride=slab)
             ops.sum_slabs(d32, nsp, slab, dhc, Mh, d, d32.stride(0), dhc.stride(0))
         else:
-            ops.gemm(dlogits, P.w("shared"), dhc, Mh, d, P.Vpad, b_kmajor=True, **cekw)
+            ops.gemm(dlogits, P.w("shared"), dhc, Mh, d, P.Vpad, b_kmajor=True)
         if rows is not None and pack is None:
             ops.zero(dhf[:M])  # masked-out positions receive exactly zero gradient from the loss
             ops.copy_rows(dhc, dhf, Mh, d, dst_idx=rows[0])
@@ -742,13 +736,7 @@ class Engine:
         else:
             ops.ce_rows(logits, logits.stride(0), P.V, labels, mask, label_smoothing, lse, rl, M)
         ops.ce_reduce(rl, mask, loss, denom, M)
-        self._ce_fused = None
-        if backward and self.fused_ce and self.dt == torch.bfloat16 and P.Vpad % 256 == 0:
-            # the logits stay as they are: decoder_backward's two head GEMMs turn them into dlogits while staging their A operand
-            lw = self.buf("ce.lw", M, 2, torch.float32)
-            ops.ce_rowparams(lse, mask, denom, lw, M)
-            self._ce_fused = (lw, labels, P.V, M, label_smoothing)
-        elif backward:
+        if backward:
             ops.ce_bwd(logits, logits.stride(0), P.V, P.Vpad, labels, mask, label_smoothing, lse, denom, M)
         return loss
 

@@ -61,7 +61,7 @@ def gemm_args(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: in
               bias=None, act=0, zout=None, zin=None, dact=0, residual=None, accumulate=False, dropout_p=0.0, dropout_seed=0,
               alpha=1.0, lda=None, ldb=None, ldc=None, ldz=None, ldr=None, split_k=0, split_stride=0, a_rowsum=None, rowsum_k=0,
               a_scale_inv=None, b_scale_inv=None, rowstat=None, rowstat_nvalid=0, ln_stats=None, ln_colsum=None, ln_width=0,
-              ln_eps=0.0, rowsum2=None, k_valid=0, ce=None) -> "L.GemmArgs":
+              ln_eps=0.0, rowsum2=None, k_valid=0) -> "L.GemmArgs":
     """fp8 operands: `a` / `b` are torch.float8_e4m3fn / float8_e5m2 tensors (k-contiguous), `a_scale_inv` / `b_scale_inv` the
     device scalars mic_fp8_quantize wrote for them."""
     g = L.GemmArgs()
@@ -88,10 +88,6 @@ def gemm_args(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: in
         g.a_ln_stats, g.a_ln_colsum, g.a_ln_width, g.a_ln_eps = _p(ln_stats), _p(ln_colsum), int(ln_width), float(ln_eps)
     g.rowsum2 = _p(rowsum2)  # int64 [M][2]: (sum, sum of squares) x 2^20 of the stored output rows, accumulated
     g.k_valid = int(k_valid)  # k-major x k-major launches: operand rows k >= k_valid count as zero (0 = all)
-    if ce is not None:  # A = the LM head's logits, cross-entropy backward applied in the operand load: (lw, labels, V, rows, label_smoothing)
-        lw, labels, V, rows, ls = ce
-        g.ce_lw, g.ce_label, g.ce_V, g.ce_rows = _p(lw), _p(labels), int(V), int(rows)
-        g.ce_conf, g.ce_low = 1.0 - float(ls), (float(ls) / (V - 1) if ls > 0 else 0.0)
     return g
 
 
@@ -245,12 +241,6 @@ def ce_bwd(logits, ld, V, Vpad, labels, mask, ls, row_lse, denom, rows, loss_sca
 
 def colsum(x, out, rows, cols, ld, accumulate=False):
     L.check(L.lib().mic_colsum(_dt(x), rows, cols, _p(x), ld, _p(out), int(accumulate), _stream()), "mic_colsum")
-
-
-def ce_rowparams(row_lse, mask, denom, lw, rows, loss_scale=1.0):
-    """lw[r] = (row_lse[r], mask[r] ? loss_scale / denom : 0): the per-row operands of the fused cross-entropy backward"""
-    L.check(L.lib().mic_ce_rowparams(rows, _p(row_lse), _p(mask), _p(denom), float(loss_scale), _p(lw), _stream()), "mic_ce_rowparams")
-    return lw
 
 
 def colsum_grouped(items):

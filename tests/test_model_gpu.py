@@ -480,59 +480,3 @@ def test_trainer_packs_rows_by_default_and_matches_the_padded_trainer(dev):
     mask[1, 0] = 0
     tr.train_step({"pixel_values": px.numpy(), "input_ids": labels.numpy(), "attention_mask": mask.numpy(), "decoder_input_ids": dec_in.numpy()})
     assert tr._pack is None
-
-
-# ---------------------------------------------------------------- cross-entropy backward fused into the head gradient GEMMs
-@pytest.mark.parametrize("ls", [0.0, 0.1])
-@pytest.mark.parametrize("mode", ["compact", "dense_masked", "packed"])
-def test_fused_ce_backward_gives_the_same_gradients_bit_for_bit(dev, ls, mode):
-    """Engine.fused_ce: the two LM-head gradient GEMMs turn the logits into dlogits while staging their A operand (mic_gemm_args.ce_lw)
-    instead of reading what mic_ce_bwd wrote over them.  Same arithmetic per element, hence the same bf16 operand values; the fused
-    launches always run 256x256 tiles while the reduced model's plain launches run 64x64 tiles with K-groups, so the fp32 sums
-    differ in their order (at full size both are 256x256 tiles): asserted to 2e-6 of every leaf's scale — with the compacted
-    head, with the dense head on a mask that has zeros (loss weight 0 rows), with packed decoder rows, with and without label
-    smoothing."""
-    from mic_amd import loss_rows, packed_rows
-
-    rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.0)
-    d = model._dev
-    B, T = 5, 16
-    px, labels, mask, dec_in = batch(rc, B, T, seed=31)
-    pos = torch.arange(T, dtype=torch.int32, device=dev)[None].expand(B, T).contiguous()
-    idx, rl = loss_rows(mask.numpy(), labels.numpy())
-
-    model.store.ensure_grads()
-
-    def run(fused):
-        model.engine.fused_ce = fused
-        model.store.grad.zero_()
-        if mode == "dense_masked":
-            loss = model.engine.loss_and_grads(d(px, torch.float32), d(dec_in, torch.int32).reshape(-1), pos.reshape(-1), d(mask, torch.int32),
-                                               d(labels, torch.int32).reshape(-1), B, T, label_smoothing=ls)
-        else:
-            kw = dict(rows=(d(idx, torch.int32), len(idx)), row_labels=d(rl, torch.int32), label_smoothing=ls)
-            if mode == "packed":
-                q_off, q_len, ids_p, pos_p = (d(t, torch.int32) for t in packed_rows(mask.numpy(), dec_in.numpy()))
-                loss = model.engine.loss_and_grads(d(px, torch.float32), ids_p, pos_p, None, d(labels, torch.int32).reshape(-1), B, T,
-                                                   pack=(q_off, q_len, len(idx)), **kw)
-            else:
-                loss = model.engine.loss_and_grads(d(px, torch.float32), d(dec_in, torch.int32).reshape(-1), pos.reshape(-1), d(mask, torch.int32),
-                                                   d(labels, torch.int32).reshape(-1), B, T, **kw)
-        torch.cuda.synchronize()
-        return float(loss), model.store.grad.clone()
-
-    l0, g0 = run(False)
-    l1, g1 = run(True)
-    model.engine.fused_ce = False
-    assert l0 == l1
-    st = model.store
-    for name in ("shared", "dec1.fc2.w", "dec0.qkv.w", "vp.w", "vit0.fc1.w", "patch.w"):
-        sg = st.segs[name]
-        a, b = g0[sg.offset: sg.offset + sg.numel], g1[sg.offset: sg.offset + sg.numel]
-        # dhf (the head's dX) is rounded to bf16 once: a last-bit difference of the fp32 sum can flip that rounding for single elements,
-        # which the layers below then see; the head's own dE is an fp32 sum of identical products
-        tol = 2e-6 if name == "shared" else 2e-3
-        assert (a - b).abs().max() <= tol * a.abs().max(), (name, ((a - b).abs().max() / a.abs().max()).item())
-    sg = st.segs["flb"]  # the logits-bias gradient = row sums of the transformed operand
-    a, b = g0[sg.offset: sg.offset + st.V], g1[sg.offset: sg.offset + st.V]
-    assert (a - b).abs().max() <= 1e-5 * a.abs().max() and a.abs().max() > 0
