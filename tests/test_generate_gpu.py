@@ -313,7 +313,10 @@ def test_generate_bf16_agrees_with_fp32_oracle_on_a_trained_model(dev):
         if K > 1 and whole.any():
             d = np.abs(got16.scores.cpu().numpy() - ref.scores)[whole]
             print(f"   beam scores of identical hypotheses: max |difference| {d.max():.4f} (scores ~ {np.abs(ref.scores).mean():.3f})")
-            assert d.max() < 2e-2, d
+            # a hypothesis whose score carries the reference's -1e7 offset (gen:890, 910: unfinished candidates in the finished list)
+            # has an fp32 ulp of 0.125 at |score| ~ 1.4e6: 2e-2 absolute on ordinary scores, 3 ulp on those
+            lim = 2e-2 + 3 * np.spacing(np.abs(ref.scores[whole]).astype(np.float32))
+            assert (d <= lim).all(), (d, ref.scores[whole])
         if K == 1:
             # teacher-forced on the oracle's own captions: wherever the fp32 decision has a margin, bf16 must make the same one
             ids = torch.from_numpy(ref_seq.astype(np.int64))
