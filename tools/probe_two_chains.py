@@ -89,7 +89,30 @@ def two_chains(n):
             torch.cuda.current_stream().wait_stream(s)
 
 
-for name, fn in (("one chain, batch 64", one_chain), ("two chains, 2 x batch 32", two_chains), ("one chain, batch 64", one_chain), ("two chains, 2 x batch 32", two_chains)):
+def two_chains_threads(n):
+    """the same two chains, each issued by its own host thread (ctypes releases the GIL inside the launches, so the two launch
+    sequences interleave kernel by kernel instead of phase by phase)"""
+    import threading
+
+    def work(eng, p, s):
+        with torch.cuda.stream(s):
+            for i in range(n):
+                e, l = fwd(eng, p, 7 + i)
+                bwd(eng, p, 7 + i, e, l)
+
+    ts = [threading.Thread(target=work, args=a) for a in ((engA, ph[0], sA), (engB, ph[1], sB))]
+    for s in (sA, sB):
+        s.wait_stream(torch.cuda.current_stream())
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for s in (sA, sB):
+        torch.cuda.current_stream().wait_stream(s)
+
+
+for name, fn in (("one chain, batch 64", one_chain), ("two chains, 2 x batch 32", two_chains), ("two chains, two host threads", two_chains_threads),
+                 ("one chain, batch 64", one_chain), ("two chains, 2 x batch 32", two_chains), ("two chains, two host threads", two_chains_threads)):
     fn(2)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
