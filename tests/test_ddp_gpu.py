@@ -198,3 +198,65 @@ def test_two_rank_sharded_optimizer_equals_replicated(dev):
     for pr in procs:
         pr.join(timeout=60)
     assert all(r[1] for r in res), res
+
+
+def _packed_worker(rank, world, port, q):
+    """bf16, two ranks with different numbers of valid caption positions: the data-parallel step with packed decoder rows against
+    the same step on padded rows (same process, same data, fresh model each): same loss, same summed gradients to the summation-order
+    tolerance, on both ranks; the sparse embedding-row exchange carries a FIXED number of rows per rank whatever the rank's valid
+    count."""
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from util_small import batch, make_pair
+
+        import mic_amd  # noqa: F401
+        from mic_amd import Trainer, create_learning_rate_fn
+
+        dev = torch.device("cuda:0")
+        B, T = 3, 16
+        px, labels, mask, dec_in = batch(make_pair(torch.bfloat16, dev, dropout=0.0)[0], B, T, seed=900 + rank)
+        b = {"pixel_values": px.numpy(), "input_ids": labels.numpy(), "attention_mask": mask.numpy(), "decoder_input_ids": dec_in.numpy()}
+        res = {}
+        for pack in (True, False):
+            rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.0)
+            tr = Trainer(model, create_learning_rate_fn(40, 4, 1, 0, 1e-3), seed=42, bucket_mb=0.25, pack_rows=pack)
+            out = tr.train_step(b)
+            torch.cuda.synchronize()
+            assert (tr._pack is not None) == pack
+            res[pack] = (float(out["loss"]), model.store.grad.clone(), model.store.lp.float().clone())
+        ok, msg = True, ""
+        if res[True][0] != res[False][0]:
+            ok, msg = False, f"loss {res[True][0]} vs {res[False][0]}"
+        g1, g0 = res[True][1], res[False][1]
+        e = ((g1 - g0).abs().max() / g0.abs().max()).item()
+        if e > 2e-3:
+            ok, msg = False, f"summed gradients differ: {e}"
+        # every rank ends with the same weights (the all-reduce and the embedding-row exchange are rank-symmetric)
+        lp = res[True][2]
+        gathered = [torch.zeros_like(lp.cpu()) for _ in range(world)]
+        dist.all_gather(gathered, lp.cpu())
+        if not all(torch.equal(gathered[0], t) for t in gathered):
+            ok, msg = False, "ranks ended with different weights"
+        q.put((rank, ok, msg))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_packed_rows_equal_padded_rows(dev):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_packed_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for pr in procs:
+        pr.join(timeout=60)
+    assert all(r[1] for r in res), res
