@@ -696,8 +696,8 @@ class Engine:
             rs = dict(a_rowsum=gb, rowsum_k=Mv) if fuse else {}
             # dX first: it READS the weights, and reporting their gradients final (flush_dw -> _done) lets the per-bucket optimizer
             # rewrite them; the dW stream's launch waits for everything enqueued here, so the bucket's event covers this GEMM too
-            if self.dt == torch.bfloat16:
-                nsp = 8
+            nsp = min(8, N // 64)  # K-tiles of 64: a reduced model may have fewer than 8 of them
+            if self.dt == torch.bfloat16 and nsp > 1:
                 slab = Mvp * d
                 d32 = self.buf("db.dehs32", nsp * Mvp, d, torch.float32)
                 ops.gemm(dkvcat, wcat, d32, Mv, d, N, b_kmajor=True, split_k=nsp, split_stride=slab)
