@@ -330,6 +330,7 @@ class Trainer:
         if gemm_dtype is not None:
             model.engine.set_gemm_dtype(gemm_dtype, scaling=fp8_scaling)
         self.hyper = torch.zeros(2, dtype=torch.float32, device=model.device)
+        self._hyper_pin, self._hyper_ev = None, None
         # sharded optimizer (data parallel only): reduce-scatter / AdamW on 1/world of every bucket / all-gather the weights
         self.sharded = bool(sharded_optimizer) and self.world > 1
         self.buckets = bucket_plan(st, bucket_mb, self.world, self.sharded)
@@ -439,13 +440,33 @@ class Trainer:
         self._rows, self._row_labels = rows, row_labels
         return px, labels, mask, dec_in, pos, B, T
 
+    def _set_hyper(self, lr: float, count: float) -> None:
+        """(lr, bias-correction count) of this step into the device pair AdamW reads.  From PINNED host memory: a host-to-device
+        copy out of pageable memory is carried out by the runtime synchronously behind everything queued on the stream, i.e.
+        it was a full device sync per step (the host could not queue step k+1 under step k)."""
+        if self.hyper.device.type != "cuda":
+            self.hyper.copy_(torch.tensor([lr, count], dtype=torch.float32))
+            return
+        if self._hyper_pin is None:
+            self._hyper_pin = torch.empty((8, 2), dtype=torch.float32).pin_memory()
+            self._hyper_ev = [None] * 8
+        slot = self.step % 8
+        if self._hyper_ev[slot] is not None:
+            self._hyper_ev[slot].synchronize()  # the copy that last read this slot (8 steps ago) has run
+        self._hyper_pin[slot, 0] = lr
+        self._hyper_pin[slot, 1] = count
+        self.hyper.copy_(self._hyper_pin[slot], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._hyper_ev[slot] = ev
+
     def train_step(self, batch: Dict) -> Dict[str, float]:
         """main.py:684-707."""
         m, st, eng = self.model, self.model.store, self.model.engine
         px, labels, mask, dec_in, pos, B, T = self._prep(batch)
         seed = (self.dropout_seed + self.step * 0x9E3779B1) & 0xFFFFFFFF  # split(dropout_rng) per step (main.py:686)
         lr = float(self.lr_fn(self.step))  # schedule at the pre-increment count, bias correction with count+1 (SURVEY B10)
-        self.hyper.copy_(torch.tensor([lr, float(self.step + 1)], dtype=torch.float32), non_blocking=True)
+        self._set_hyper(lr, float(self.step + 1))
         self.reducer.start_step()
         eng.grad_progress = self.reducer.progress if self.reducer.active else None
         eng.defer_embed = self.world > 1
@@ -467,7 +488,7 @@ class Trainer:
         self._state_dirty = True
         self.step += 1
         self.metrics_buf[0:1].copy_(loss)
-        self.metrics_buf[1] = lr
+        self.metrics_buf[1:2].copy_(self.hyper[0:1])  # lr, device to device (a Python scalar assigned into a device tensor syncs)
         return self._pmean_metrics()
 
     def eval_step(self, batch: Dict) -> Dict[str, float]:
