@@ -503,7 +503,7 @@ class Trainer:
             loss = eng.loss_only(px, dec_in.reshape(-1), pos.reshape(-1), mask, labels.reshape(-1), B, T, label_smoothing=self.ls,
                                  rows=self._rows, row_labels=self._row_labels)
         self.metrics_buf[0:1].copy_(loss)
-        self.metrics_buf[1] = 0.0
+        self.metrics_buf[1:2].zero_()
         out = self._pmean_metrics()
         out.pop("learning_rate")
         return out

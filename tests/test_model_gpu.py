@@ -478,3 +478,35 @@ def test_trainer_packs_rows_by_default_and_matches_the_padded_trainer(dev):
     mask[1, 0] = 0
     tr.train_step({"pixel_values": px.numpy(), "input_ids": labels.numpy(), "attention_mask": mask.numpy(), "decoder_input_ids": dec_in.numpy()})
     assert tr._pack is None
+
+
+@pytest.mark.gpu
+def test_train_step_does_not_wait_for_the_device(dev):
+    """Nothing in `train_step` / `eval_step` synchronises with the GPU when the batch is device-resident and carries the collate
+    extras (main.py:684-707 runs as one jitted call: the host returns as soon as the step is queued).  A long spin kernel is queued
+    in front of the step: the step must return while it is still running."""
+    import time
+
+    from mic_amd import Trainer, create_learning_rate_fn, loss_rows, packed_rows
+
+    rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.1)
+    tr = Trainer(model, create_learning_rate_fn(64, 2, 4, 0, 1e-3))
+    px, labels, mask, dec_in = batch(rc, 4, 12, seed=81)
+    b = {"pixel_values": px.to(dev), "input_ids": labels.to(dev), "attention_mask": mask.to(dev), "decoder_input_ids": dec_in.to(dev)}
+    idx, rl = loss_rows(mask.numpy(), labels.numpy())
+    b["loss_rows"] = (torch.from_numpy(idx).to(dev), torch.from_numpy(rl).to(dev))
+    b["packed_rows"] = tuple(torch.from_numpy(t).to(dev) for t in packed_rows(mask.numpy(), dec_in.numpy()))
+    for _ in range(3):
+        out = tr.train_step(b)
+    tr.eval_step(b)
+    torch.cuda.synchronize()
+    for step in (tr.train_step, tr.eval_step):
+        torch.cuda._sleep(1_500_000_000)  # ~0.6 s of GPU time in front of the step
+        t0 = time.perf_counter()
+        out = step(b)
+        host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        total = time.perf_counter() - t0
+        assert total > 0.2, f"the spin kernel ran only {total:.3f} s: nothing to measure against"
+        assert host < 0.5 * total, f"{step.__name__} returned after {host:.3f} s of a {total:.3f} s queue: it waited for the device"
+        assert np.isfinite(float(out["loss"]))
