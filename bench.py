@@ -650,6 +650,8 @@ def main():
                                    + (" [ALL RANKS SHARE cuda:0 OVER gloo: functional check, not a benchmark]" if share and world > 1 else ""),
                        "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}" + ("+sharded-optimizer" if args.sharded_optimizer else ""),
                        "grad_allreduce": f"{args.grad_comm} flat buckets, RCCL, side stream",
+                       "optimizer": ("AdamW per gradient bucket behind backward" + (f", on a stream masked to {os.environ.get('MIC_OPT_CUS', '96')} CUs" if tr.reducer.step_stream is not None else "")
+                                     + ("; tied embedding updated in two row passes (rows without / with sparse gradient)" if tr._split_shared else "")) if tr.overlap_optimizer else "AdamW, one launch after backward",
                        "decoder_rows": ("valid caption positions only (packed rows: padded positions neither carry loss nor are attended to — exact; "
                                         f"{n_loss:.0f} of {B * T} rows per step)" if (tr.pack_rows and args.dtype in ("bf16", "fp8") and not args.dense_captions) else f"all {B * T} positions"),
                        "lm_head": head, "gemm_dtype": "fp8 e4m3 (fwd) / e5m2 (grads) for QKV+FFN, bf16 elsewhere" if args.dtype == "fp8" else args.dtype},

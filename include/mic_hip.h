@@ -267,6 +267,12 @@ int mic_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n
 /* zero-fill `bytes` bytes on `stream` (the per-step clears: atomically accumulated gradients, row padding of compacted
  * buffers, fp8 amax slots) */
 int mic_zero(void* p, int64_t bytes, void* stream);
+/* A HIP stream restricted to bits [first_cu, first_cu + n_cus) of the device's CU mask (MI355X: bit i -> XCD i % 8, so a multiple
+ * of 8 takes the same number of CUs on every XCD); a proper subset of the device's CUs.  Destroy with mic_stream_destroy.  The reference has no counterpart
+ * (XLA schedules the optimizer inside the jitted step, main.py:684-707): this is how the per-bucket AdamW launches get their own
+ * CUs beside backward. */
+int mic_stream_create_cu_masked(int first_cu, int n_cus, void** stream);
+int mic_stream_destroy(void* stream);
 /* row gather/scatter: dst[dst_idx ? dst_idx[i] : i] = src[src_idx ? src_idx[i] : i], i < n.  Used to run the LM head and
  * the cross-entropy only on the label positions whose loss mask is 1 (main.py:678: masked positions contribute exactly 0). */
 int mic_copy_rows(int dtype, int n, int width, const void* src, int ld_src, const int32_t* src_idx, void* dst, int ld_dst,
@@ -284,6 +290,15 @@ int mic_cast2d(int src_dtype, int dst_dtype, int rows, int cols, const void* src
  * ------------------------------------------------------------------------------------------- */
 int mic_adamw(int64_t n, float* p, float* m, float* v, const float* g, void* p_lp, const float* hyper, double b1,
               double b2, double eps, double wd, float grad_scale, void* stream);
+/* The same update on a [rows][width] slice of the flat buffers, restricted to the rows with (row_flag[row] != 0) == (want != 0).
+ * The tied embedding `shared` takes gradient from two places (modeling:37-44 ties the LM head and the decoder's input embedding): the
+ * dense LM-head half is complete right after the head's weight-gradient GEMM, the sparse input-embedding half (the rows of this
+ * step's decoder input ids) only at the very end of backward.  AdamW is elementwise, so the rows outside the step's ids are
+ * updated early (want = 0, beside backward) and the <= B*T flagged rows after the scatter (want = 1): same arithmetic, bit for bit.
+ * mic_row_flags zero-fills flags[n_rows] and sets flags[ids[i]] = 1 (ids outside [0, n_rows) are ignored). */
+int mic_adamw_rows(int64_t rows, int width, const uint8_t* row_flag, int want, float* p, float* m, float* v, const float* g,
+                   void* p_lp, const float* hyper, double b1, double b2, double eps, double wd, float grad_scale, void* stream);
+int mic_row_flags(const int32_t* ids, int n_ids, uint8_t* flags, int n_rows, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Generation epilogues

@@ -95,9 +95,13 @@ _SIGS = {
     "mic_dropout_mask": ([_p, _i64, _f, _u32, _p], C.c_int),
     "mic_cast": ([_i, _i, _p, _p, _i64, _p], C.c_int),
     "mic_zero": ([_p, _i64, _p], C.c_int),
+    "mic_stream_create_cu_masked": ([_i, _i, C.POINTER(C.c_void_p)], C.c_int),
+    "mic_stream_destroy": ([_p], C.c_int),
     "mic_copy_rows": ([_i, _i, _i, _p, _i, _p, _p, _i, _p, _p], C.c_int),
     "mic_cast2d": ([_i, _i, _i, _i, _p, _i, _p, _i, _p], C.c_int),
     "mic_adamw": ([_i64, _p, _p, _p, _p, _p, _p, C.c_double, C.c_double, C.c_double, C.c_double, _f, _p], C.c_int),
+    "mic_adamw_rows": ([_i64, _i, _p, _i, _p, _p, _p, _p, _p, _p, C.c_double, C.c_double, C.c_double, C.c_double, _f, _p], C.c_int),
+    "mic_row_flags": ([_p, _i, _p, _i, _p], C.c_int),
     "mic_row_lse_topk": ([_i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p], C.c_int),
     "mic_beam_step": ([C.POINTER(BeamStepArgs), _p], C.c_int),
     "mic_greedy_step": ([_i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p], C.c_int),

@@ -462,6 +462,33 @@ extern "C" int mic_zero(void* p, int64_t bytes, void* stream) {
   return MIC_OK;
 }
 
+// A stream whose kernels run on bits [first_cu, first_cu + n_cus) of the device's CU mask only.  On MI355X consecutive mask bits go
+// round the 8 XCDs (bit i -> XCD i % 8), so 64 consecutive bits are 8 CUs on every XCD (tools/probe_cu_mask.hip).  The optimizer's per-bucket
+// launches use such a stream: bandwidth-bound work on a few dedicated CUs beside the backward GEMMs, whose blocks own a CU's
+// whole register file and therefore never share one with anything else.
+extern "C" int mic_stream_create_cu_masked(int first_cu, int n_cus, void** stream) {
+  MIC_CHECK(stream != nullptr && first_cu >= 0 && n_cus > 0, "mic_stream_create_cu_masked: bad args");
+  int dev = 0, total = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e == hipSuccess) e = hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, dev);
+  if (e != hipSuccess) { mic_set_error("mic_stream_create_cu_masked: %s", hipGetErrorString(e)); return MIC_ELAUNCH; }
+  MIC_CHECK(first_cu + n_cus <= total && n_cus < total && total <= 1024, "mic_stream_create_cu_masked: CUs [%d, %d) of %d", first_cu, first_cu + n_cus, total);
+  uint32_t mask[32] = {};
+  for (int i = first_cu; i < first_cu + n_cus; ++i) mask[i >> 5] |= 1u << (i & 31);
+  hipStream_t s = nullptr;
+  e = hipExtStreamCreateWithCUMask(&s, (uint32_t)((total + 31) / 32), mask);
+  if (e != hipSuccess) { mic_set_error("mic_stream_create_cu_masked: %s", hipGetErrorString(e)); return MIC_ELAUNCH; }
+  *stream = (void*)s;
+  return MIC_OK;
+}
+
+extern "C" int mic_stream_destroy(void* stream) {
+  MIC_CHECK(stream != nullptr, "mic_stream_destroy: null stream");
+  hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  if (e != hipSuccess) { mic_set_error("mic_stream_destroy: %s", hipGetErrorString(e)); return MIC_ELAUNCH; }
+  return MIC_OK;
+}
+
 extern "C" int mic_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream) {
   MIC_CHECK(n > 0 && n < (1LL << 40), "mic_cast: bad n");
   // split into rows of <= 2^20 so the 2-D kernel's int shape holds
@@ -506,14 +533,26 @@ extern "C" int mic_copy_rows(int dtype, int n, int width, const void* src, int l
 }
 
 // ------------------------------------------------------------------ fused AdamW over the flat parameter buffer (K15)
+// ROWS: the buffer is [rows][width] and only the rows with (row_flag[row] != 0) == want are updated — the tied embedding's
+// AdamW in two passes (mic_adamw_rows): AdamW is elementwise, so the split is exact.
+template <bool ROWS>
 __global__ __launch_bounds__(256) void adamw_kernel(long n, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                     const float* __restrict__ g, uint16_t* __restrict__ p_lp,
                                                     const float* __restrict__ hyper, float b1, float b2, float omb1, float omb2,
-                                                    float eps, float wd, float gscale) {
+                                                    float eps, float wd, float gscale, const uint8_t* __restrict__ row_flag,
+                                                    int row_f4, int want) {
   const float lr = hyper[0], t = hyper[1];
   const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
   const long n4 = n >> 2;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long)gridDim.x * blockDim.x) {
+  // ROWS: a block walks whole rows (one flag test per row and block, uniform), its threads the row's float4s
+  const long outer_n = ROWS ? n4 / row_f4 : n4;
+  const long outer_0 = ROWS ? blockIdx.x : (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long outer_step = ROWS ? gridDim.x : (long)gridDim.x * blockDim.x;
+  for (long o = outer_0; o < outer_n; o += outer_step) {
+    if constexpr (ROWS) {
+      if ((row_flag[o] != 0) != (want != 0)) continue;
+    }
+    for (long e = ROWS ? o * row_f4 + threadIdx.x : o; e < (ROWS ? (o + 1) * row_f4 : o + 1); e += ROWS ? blockDim.x : 1) {
     float4 pp = reinterpret_cast<float4*>(p)[e], mm = reinterpret_cast<float4*>(m)[e], vv = reinterpret_cast<float4*>(v)[e];
     const float4 gg = reinterpret_cast<const float4*>(g)[e];
     float pa[4] = {pp.x, pp.y, pp.z, pp.w}, ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
@@ -529,10 +568,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(long n, float* __restrict__ 
     reinterpret_cast<float4*>(m)[e] = make_float4(ma[0], ma[1], ma[2], ma[3]);
     reinterpret_cast<float4*>(v)[e] = make_float4(va[0], va[1], va[2], va[3]);
     if (p_lp) {
-      uint2 o;
-      o.x = f2bf_pk(pa[0], pa[1]);
-      o.y = f2bf_pk(pa[2], pa[3]);
-      reinterpret_cast<uint2*>(p_lp)[e] = o;
+      uint2 q;
+      q.x = f2bf_pk(pa[0], pa[1]);
+      q.y = f2bf_pk(pa[2], pa[3]);
+      reinterpret_cast<uint2*>(p_lp)[e] = q;
+    }
     }
   }
 }
@@ -540,8 +580,35 @@ extern "C" int mic_adamw(int64_t n, float* p, float* m, float* v, const float* g
                          double b2, double eps, double wd, float grad_scale, void* stream) {
   MIC_CHECK(n > 0 && n % 4 == 0 && p && m && v && g && hyper, "mic_adamw: bad args (n must be a multiple of 4)");
   long nb = (n / 4 + 255) / 256; if (nb > 8192) nb = 8192;
-  hipLaunchKernelGGL(adamw_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, (long)n, p, m, v, g, (uint16_t*)p_lp, hyper, (float)b1, (float)b2,
-                     (float)(1.0 - b1), (float)(1.0 - b2), (float)eps, (float)wd, grad_scale);
+  hipLaunchKernelGGL(adamw_kernel<false>, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, (long)n, p, m, v, g, (uint16_t*)p_lp, hyper, (float)b1, (float)b2,
+                     (float)(1.0 - b1), (float)(1.0 - b2), (float)eps, (float)wd, grad_scale, (const uint8_t*)nullptr, 1, 0);
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}
+
+extern "C" int mic_adamw_rows(int64_t rows, int width, const uint8_t* row_flag, int want, float* p, float* m, float* v, const float* g,
+                              void* p_lp, const float* hyper, double b1, double b2, double eps, double wd, float grad_scale, void* stream) {
+  MIC_CHECK(rows > 0 && width > 0 && width % 4 == 0 && row_flag && p && m && v && g && hyper, "mic_adamw_rows: bad args (width must be a multiple of 4)");
+  const long n = (long)rows * width;
+  long nb = (n / 4 + 255) / 256; if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(adamw_kernel<true>, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, n, p, m, v, g, (uint16_t*)p_lp, hyper, (float)b1, (float)b2,
+                     (float)(1.0 - b1), (float)(1.0 - b2), (float)eps, (float)wd, grad_scale, row_flag, width / 4, want);
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}
+
+__global__ __launch_bounds__(256) void row_flags_kernel(const int32_t* __restrict__ ids, int n_ids, uint8_t* __restrict__ flags, int n_rows) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n_ids) {
+    const int r = ids[i];
+    if (r >= 0 && r < n_rows) flags[r] = 1;
+  }
+}
+extern "C" int mic_row_flags(const int32_t* ids, int n_ids, uint8_t* flags, int n_rows, void* stream) {
+  MIC_CHECK(ids && flags && n_ids > 0 && n_rows > 0, "mic_row_flags: bad args");
+  hipError_t e = hipMemsetAsync(flags, 0, (size_t)n_rows, (hipStream_t)stream);
+  if (e != hipSuccess) { mic_set_error("mic_row_flags: %s", hipGetErrorString(e)); return MIC_ELAUNCH; }
+  hipLaunchKernelGGL(row_flags_kernel, dim3((n_ids + 255) / 256), dim3(256), 0, (hipStream_t)stream, ids, n_ids, flags, n_rows);
   MIC_LAUNCH_CHECK();
   return MIC_OK;
 }

@@ -271,6 +271,17 @@ def zero(t: torch.Tensor):
     return t
 
 
+def cu_masked_stream(first_cu: int, n_cus: int, device) -> "torch.cuda.Stream":
+    """A torch stream over a HIP stream that may use only bits [first_cu, first_cu + n_cus) of the CU mask (mic_stream_create_cu_masked).  The HIP
+    stream lives as long as the process (a handful per Trainer)."""
+    import ctypes
+
+    h = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        L.check(L.lib().mic_stream_create_cu_masked(int(first_cu), int(n_cus), ctypes.byref(h)), "mic_stream_create_cu_masked")
+    return torch.cuda.ExternalStream(h.value, device=device)
+
+
 def sum_slabs(src, n_slabs, slab_stride, dst, rows, cols, ld_src, ld_dst):
     L.check(L.lib().mic_sum_slabs(_dt(dst), n_slabs, int(slab_stride), rows, cols, _p(src), ld_src, _p(dst), ld_dst, _stream()), "mic_sum_slabs")
     return dst
@@ -290,6 +301,17 @@ def adamw(p, m, v, g, p_lp, hyper, b1, b2, eps, wd, grad_scale=1.0, n=None):
     n = n if n is not None else p.numel()
     L.check(L.lib().mic_adamw(n, _p(p), _p(m), _p(v), _p(g), _p(p_lp), _p(hyper), float(b1), float(b2), float(eps), float(wd),
                               float(grad_scale), _stream()), "mic_adamw")
+
+
+def adamw_rows(rows, width, row_flag, want, p, m, v, g, p_lp, hyper, b1, b2, eps, wd, grad_scale=1.0):
+    """AdamW on the rows of a [rows][width] slice whose flag equals `want` (mic_adamw_rows)."""
+    L.check(L.lib().mic_adamw_rows(int(rows), int(width), _p(row_flag), int(want), _p(p), _p(m), _p(v), _p(g), _p(p_lp), _p(hyper), float(b1),
+                                   float(b2), float(eps), float(wd), float(grad_scale), _stream()), "mic_adamw_rows")
+
+
+def row_flags(ids, n_ids, flags):
+    """flags[:] = 0; flags[ids[i]] = 1 for i < n_ids (uint8 flags, int32 ids)"""
+    L.check(L.lib().mic_row_flags(_p(ids), int(n_ids), _p(flags), flags.numel(), _stream()), "mic_row_flags")
 
 
 def row_lse_topk(logits, ld, V, k, top_val, top_idx, R, *, forced_token=-1, suppress_eos=False, eos_token_id=2, raw_logits=False,

@@ -123,16 +123,34 @@ class GradReducer:
     every rank."""
 
     def __init__(self, flat_grad: torch.Tensor, buckets: List[Tuple[int, int]], group=None, on_ready=None, hold=None,
-                 comm_dtype: Optional[torch.dtype] = None, sharded: bool = False, gather: Optional[List[torch.Tensor]] = None):
+                 comm_dtype: Optional[torch.dtype] = None, sharded: bool = False, gather: Optional[List[torch.Tensor]] = None,
+                 late=None, opt_cus: int = 0):
+        """late: called once per step in `release_held`, after `before()` and the postponed slices (the part of the optimizer
+        that needs the end of backward).  opt_cus: CUs of the optimizer stream's mask (0: no mask)."""
         import torch.distributed as dist
 
         self.dist, self.group = dist, group
+        self.late = late
         self.grad, self.buckets = flat_grad, buckets
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.cuda = flat_grad.is_cuda
         self.stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None       # collectives
         self.opt_stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None   # per-bucket optimizer work
+        # ... on CUs of its own (`opt_cus` of them; 0 = no mask): the optimizer is HBM-bound and needs few CUs, while the backward
+        # GEMM blocks own a CU's whole register file and never share one — with a mask the two run side by side instead of taking
+        # turns.  A CU-masked HIP stream is a BLOCKING stream (it synchronises with the null stream, torch's default): the step then
+        # runs on `step_stream`, and the slices postponed to the end of backward on the unmasked `tail_stream`.
+        self.step_stream = self.tail_stream = None
+        if self.cuda and on_ready is not None and opt_cus > 0:
+            try:
+                self.opt_stream = ops.cu_masked_stream(0, opt_cus, flat_grad.device)
+                self.step_stream = torch.cuda.Stream(device=flat_grad.device)
+                self.tail_stream = torch.cuda.Stream(device=flat_grad.device)
+            except Exception as ex:  # the stack refuses CU masks: plain streams, as before
+                import sys
+
+                print(f"[mic_amd.GradReducer] no CU-masked optimizer stream ({ex}); using a plain stream", file=sys.stderr)
         self.sharded = bool(sharded) and self.world > 1
         self.on_ready = on_ready if (self.cuda or self.sharded) else None
         self.gather = list(gather or []) if self.sharded else []
@@ -272,20 +290,30 @@ class GradReducer:
                     self._ready(b, e)
                     self._gather(b, e)
                 self.held = []
+            if self.late is not None:
+                self.late()
             return
-        if not self.held and before is None:
+        if not self.held and before is None and self.late is None:
             return
         ev = torch.cuda.Event()
         ev.record(self.stream if self.world > 1 else torch.cuda.current_stream())
-        with torch.cuda.stream(self.opt_stream):
-            self.opt_stream.wait_event(ev)
-            if self.world == 1:
-                self.opt_stream.wait_stream(torch.cuda.current_stream())
+        # the postponed slices run after backward, with nothing beside them: on the unmasked tail stream when the optimizer
+        # stream is restricted to a few CUs
+        tail = self.tail_stream if self.tail_stream is not None else self.opt_stream
+        with torch.cuda.stream(tail):
+            tail.wait_event(ev)
+            if tail is not self.opt_stream:
+                tail.wait_stream(self.opt_stream)
+            tail.wait_stream(torch.cuda.current_stream())  # the end of backward (the sparse embedding rows come from there)
             with ops.pinned_stream():
                 if before is not None:
                     before()
                 for (b, e) in self.held:
                     self._ready(b, e)
+                if self.late is not None:
+                    self.late()
+        if tail is not self.opt_stream:
+            self.opt_stream.wait_stream(tail)  # finish() and the sharded gather order themselves behind opt_stream
         self._after_ready_gather(self.held)
         self.held = []
 
@@ -299,6 +327,9 @@ class GradReducer:
         else:
             for h in self.handles:
                 h.wait()
+
+
+OPT_CUS_DEFAULT = 96  # CUs of the optimizer stream (12 per XCD of an MI355X): profiles/README.md, round 3 A/B
 
 
 class Trainer:
@@ -352,9 +383,19 @@ class Trainer:
             overlap_optimizer = False
         self.overlap_optimizer = overlap_optimizer or self.sharded
         sh = st.segs["shared"]
+        # The tied embedding's gradient is complete only at the end of backward (its sparse input-embedding rows).  Replicated
+        # optimizer: AdamW runs early on every row this step's decoder ids do not touch and late on the <= world*B*T rows they do
+        # (`_adamw_slice` / `_adamw_shared_late`; MIC_OPT_SPLIT_SHARED=0: the whole segment waits for the end, as the sharded
+        # optimizer does).  MIC_OPT_CUS: CUs of the optimizer stream's mask.
+        self._split_shared = (self.overlap_optimizer and not self.sharded and model.device.type == "cuda"
+                              and _os.environ.get("MIC_OPT_SPLIT_SHARED", "1") != "0" and sh.numel % st.d == 0)
+        self._sh = (sh.offset, sh.offset + sh.numel, st.d)
+        self._row_flag = torch.zeros(sh.numel // st.d, dtype=torch.uint8, device=model.device) if self._split_shared else None
+        opt_cus = int(_os.environ.get("MIC_OPT_CUS", str(OPT_CUS_DEFAULT))) if (model.device.type == "cuda" and self._split_shared) else 0
         self.reducer = GradReducer(st.grad, self.buckets, group, on_ready=self._adamw_slice if self.overlap_optimizer else None,
-                                   hold=(sh.offset, sh.offset + sh.numel), comm_dtype=grad_comm_dtype, sharded=self.sharded,
-                                   gather=[st.lp])
+                                   hold=None if self._split_shared else (sh.offset, sh.offset + sh.numel), comm_dtype=grad_comm_dtype,
+                                   sharded=self.sharded, gather=[st.lp], late=self._adamw_shared_late if self._split_shared else None,
+                                   opt_cus=opt_cus)
         self.metrics_buf = torch.zeros(2, dtype=torch.float32, device=model.device)
         self._state_dirty = False
         if self.sharded:
@@ -386,10 +427,42 @@ class Trainer:
         self._state_dirty = False
 
     def _adamw_slice(self, b: int, e: int):
-        """AdamW on flat slice [b, e) — runs on the reducer's side stream right after that bucket's all-reduce."""
+        """AdamW on flat slice [b, e) — runs on the reducer's side stream right after that bucket's all-reduce.  The part of the
+        slice inside the tied embedding skips the rows flagged for this step (`_adamw_shared_late` takes those)."""
         st = self.model.store
-        ops.adamw(st.master[b:e], st.m[b:e], st.v[b:e], st.grad[b:e], None if st.lp is st.master else st.lp[b:e], self.hyper,
-                  self.b1, self.b2, self.eps, self.wd, grad_scale=1.0 / self.world, n=e - b)
+        sb, se, width = self._sh
+        lo, hi = max(b, sb), min(e, se)
+        if not self._split_shared or lo >= hi:
+            ops.adamw(st.master[b:e], st.m[b:e], st.v[b:e], st.grad[b:e], None if st.lp is st.master else st.lp[b:e], self.hyper,
+                      self.b1, self.b2, self.eps, self.wd, grad_scale=1.0 / self.world, n=e - b)
+            return
+        assert lo == sb and hi == se, "bucket cuts sit on segment boundaries: the tied embedding lies inside one bucket"
+        for (x, y) in ((b, lo), (hi, e)):
+            if y > x:
+                ops.adamw(st.master[x:y], st.m[x:y], st.v[x:y], st.grad[x:y], None if st.lp is st.master else st.lp[x:y], self.hyper,
+                          self.b1, self.b2, self.eps, self.wd, grad_scale=1.0 / self.world, n=y - x)
+        self._adamw_shared(0)
+
+    def _adamw_shared(self, want: int):
+        st = self.model.store
+        sb, se, width = self._sh
+        ops.adamw_rows((se - sb) // width, width, self._row_flag, want, st.master[sb:se], st.m[sb:se], st.v[sb:se], st.grad[sb:se],
+                       None if st.lp is st.master else st.lp[sb:se], self.hyper, self.b1, self.b2, self.eps, self.wd,
+                       grad_scale=1.0 / self.world)
+
+    def _adamw_shared_late(self):
+        """end of backward (after the sparse embedding rows have been added): the flagged rows of the tied embedding"""
+        self._adamw_shared(1)
+
+    def _flag_embedding_rows(self, ids: torch.Tensor):
+        """flags the rows of `shared` that this step's decoder input ids (of every rank) will add a sparse gradient to"""
+        if self.world > 1:
+            import torch.distributed as dist
+
+            all_ids = torch.empty((self.world * ids.numel(),), dtype=ids.dtype, device=ids.device)
+            dist.all_gather_into_tensor(all_ids, ids.contiguous(), group=self.group)
+            ids = all_ids
+        ops.row_flags(ids, ids.numel(), self._row_flag)
 
     def _scatter_embedding_rows(self):
         """Data parallel: the sparse half of the tied-embedding gradient.  Every rank all-gathers (ids, dh0) — <= B*T rows
@@ -462,6 +535,18 @@ class Trainer:
 
     def train_step(self, batch: Dict) -> Dict[str, float]:
         """main.py:684-707."""
+        ms = self.reducer.step_stream
+        if ms is None:
+            return self._train_step(batch)
+        # the optimizer's stream carries a CU mask, which makes it a blocking stream: the step keeps off the null stream
+        cur = torch.cuda.current_stream()
+        ms.wait_stream(cur)
+        with torch.cuda.stream(ms):
+            out = self._train_step(batch)
+        cur.wait_stream(ms)
+        return out
+
+    def _train_step(self, batch: Dict) -> Dict[str, float]:
         m, st, eng = self.model, self.model.store, self.model.engine
         px, labels, mask, dec_in, pos, B, T = self._prep(batch)
         seed = (self.dropout_seed + self.step * 0x9E3779B1) & 0xFFFFFFFF  # split(dropout_rng) per step (main.py:686)
@@ -471,6 +556,8 @@ class Trainer:
         eng.grad_progress = self.reducer.progress if self.reducer.active else None
         eng.defer_embed = self.world > 1
         with ops.pinned_stream():
+            if self._split_shared:
+                self._flag_embedding_rows(self._pack[1] if self._pack is not None else dec_in.reshape(-1))
             if self._pack is not None:  # the decoder sees the valid positions only
                 pack, ids_p, pos_p = self._pack
                 loss = eng.loss_and_grads(px, ids_p, pos_p, None, labels.reshape(-1), B, T, label_smoothing=self.ls, seed=seed,

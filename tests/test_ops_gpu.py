@@ -422,6 +422,42 @@ def test_adamw_matches_oracle(dev):
     assert torch.equal(plp.cpu(), pd.cpu().to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("rows,width", [(37, 256), (5, 1024), (1003, 64), (64, 12)])
+def test_adamw_rows_split_is_exact(dev, rows, width):
+    """mic_adamw over a [rows][width] slice == mic_adamw_rows on the unflagged rows followed by mic_adamw_rows on the flagged ones,
+    bit for bit (AdamW is elementwise), with the flags built by mic_row_flags from ids that repeat and that fall outside the range."""
+    from mic_amd import ops
+
+    n = rows * width
+    g = torch.Generator().manual_seed(61)
+    p, m, v, gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 0.1, torch.rand(n, generator=g) * 0.01, torch.randn(n, generator=g)
+    hyper = torch.tensor([3e-4, 7.0], device=dev)
+    ids = torch.randint(0, rows, (max(rows // 3, 2),), generator=g, dtype=torch.int32)
+    ids = torch.cat([ids, ids[:2], torch.tensor([-1, rows, rows + 5], dtype=torch.int32)])  # repeats; out-of-range ids are ignored
+    flags = torch.full((rows,), 7, dtype=torch.uint8, device=dev)
+    ops.row_flags(ids.to(dev), ids.numel(), flags)
+    want = torch.zeros(rows, dtype=torch.uint8)
+    want[ids[(ids >= 0) & (ids < rows)].long()] = 1
+    assert torch.equal(flags.cpu(), want) and 0 < int(want.sum()) < rows
+
+    def state():
+        return [t.clone().to(dev) for t in (p, m, v)] + [torch.zeros(n, dtype=torch.bfloat16, device=dev)]
+
+    a, b = state(), state()
+    grd = gr.to(dev)
+    ops.adamw(a[0], a[1], a[2], grd, a[3], hyper, 0.9, 0.999, 1e-8, 0.01, grad_scale=0.5)
+    ops.adamw_rows(rows, width, flags, 0, b[0], b[1], b[2], grd, b[3], hyper, 0.9, 0.999, 1e-8, 0.01, grad_scale=0.5)
+    mid = [t.clone() for t in b]
+    ops.adamw_rows(rows, width, flags, 1, b[0], b[1], b[2], grd, b[3], hyper, 0.9, 0.999, 1e-8, 0.01, grad_scale=0.5)
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    # the first pass left the flagged rows alone
+    fl = want.bool().to(dev)
+    assert torch.equal(mid[0].reshape(rows, width)[fl], p.to(dev).reshape(rows, width)[fl])
+    assert torch.equal(mid[0].reshape(rows, width)[~fl], a[0].reshape(rows, width)[~fl])
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("V,Vpad", [(5003, 5008), (1003, 1024), (250054, 250112)])
 def test_row_lse_topk(dev, dtype, V, Vpad):
