@@ -27,7 +27,8 @@ w = load(sys.argv[2], "WRITE_SIZE")
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 N = 547_223_040
 KB = 1024.0
-ad_f, ad_w = f["adamw_kernel"][1] / steps * KB, w["adamw_kernel"][1] / steps * KB
+ad_f = sum(v[1] for k, v in f.items() if k.startswith("adamw_kernel")) / steps * KB  # adamw_kernel<false> (+ <true>: the row passes)
+ad_w = sum(v[1] for k, v in w.items() if k.startswith("adamw_kernel")) / steps * KB
 print(f"# adamw_kernel per step: FETCH_SIZE {ad_f / 1e9:.3f} GB raw (expected 16 B x {N} = {16 * N / 1e9:.3f} GB -> factor {16 * N / ad_f:.3f}); "
       f"WRITE_SIZE {ad_w / 1e9:.3f} GB raw (expected 14 B x n = {14 * N / 1e9:.3f} GB -> factor {14 * N / ad_w:.3f})")
 cf, cw = 16 * N / ad_f, 14 * N / ad_w
