@@ -422,6 +422,35 @@ def test_adamw_matches_oracle(dev):
     assert torch.equal(plp.cpu(), pd.cpu().to(torch.bfloat16))
 
 
+def test_cu_masked_stream_runs_kernels_and_rejects_bad_ranges(dev):
+    """mic_stream_create_cu_masked: a stream over a proper subset of the CUs runs this library's launches (same results as the
+    default stream); empty, oversized and whole-device ranges are refused with an error, not a crash."""
+    from mic_amd import ops
+    from mic_amd._lib import MicError
+
+    total = torch.cuda.get_device_properties(dev).multi_processor_count
+    n = 1 << 16
+    g = torch.Generator().manual_seed(3)
+    p, m, v, gr = (torch.randn(n, generator=g).to(dev) for _ in range(4))
+    v = v.abs()
+    hyper = torch.tensor([1e-3, 2.0], device=dev)
+    ref = [t.clone() for t in (p, m, v)]
+    ops.adamw(ref[0], ref[1], ref[2], gr, None, hyper, 0.9, 0.999, 1e-8, 0.0)
+    torch.cuda.synchronize()
+    for first, cnt in ((0, 8), (total - 32, 32), (8, total - 8)):
+        st = ops.cu_masked_stream(first, cnt, dev)
+        got = [t.clone() for t in (p, m, v)]
+        torch.cuda.synchronize()
+        with torch.cuda.stream(st):
+            ops.adamw(got[0], got[1], got[2], gr, None, hyper, 0.9, 0.999, 1e-8, 0.0)
+        st.synchronize()
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+    for first, cnt in ((0, 0), (0, total), (total - 8, 16), (-1, 8)):
+        with pytest.raises(MicError):
+            ops.cu_masked_stream(first, cnt, dev)
+
+
 @pytest.mark.parametrize("rows,width", [(37, 256), (5, 1024), (1003, 64), (64, 12)])
 def test_adamw_rows_split_is_exact(dev, rows, width):
     """mic_adamw over a [rows][width] slice == mic_adamw_rows on the unflagged rows followed by mic_adamw_rows on the flagged ones,
