@@ -185,6 +185,12 @@ int mic_attn_bwd(int dtype, int B, int H, int Tq, int Tk, const void* q, int ldq
                  const int32_t* key_mask, int causal, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv,
                  void* stream);
 
+/* The attention weights themselves, for `output_attentions=True` (modeling:499-510 forwards the flag to the Flax modules, which
+ * return every layer's softmax weights): out[B][H][Tq][Tk] (fp32) = softmax over the keys of q.k / sqrt(64) with the masks of
+ * mic_attn_fwd.  A diagnostic kernel (one wave per query row), never launched by the train / generate paths.  Tk <= 1024. */
+int mic_attn_probs(int dtype, int B, int H, int Tq, int Tk, const void* q, int ldq, const void* k, int ldk,
+                   const int32_t* key_mask, int causal, float* out, void* stream);
+
 /* The same cores on variable-length ("packed") rows: sequence b owns the q rows [q_off[b], q_off[b] + q_len[b]) of a packed
  * [sum q_len][ld] matrix — padded positions have no rows at all (their loss weight is 0 and no valid position attends to them,
  * main.py:678, 692: every gradient they would contribute is exactly 0).  kv_packed = 1: keys / values are the same packed rows

@@ -566,6 +566,69 @@ static int set_lds(K kernel, size_t bytes) {
   return MIC_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The attention WEIGHTS themselves (`output_attentions=True`, modeling:499-510): the fused cores above never write them, this
+// diagnostic kernel does — one wave per (sequence, head, query): softmax over the keys of q.k / sqrt(64) with the same masks,
+// fp32 arithmetic on the stored q / k.  Not on any hot path.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_probs_kernel(int n_rows, int H, int Tq, int Tk, const T* __restrict__ q, int ldq,
+                                                         const T* __restrict__ k, int ldk, const int32_t* __restrict__ key_mask,
+                                                         int causal, float* __restrict__ out) {
+  __shared__ float qs[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + w;
+  if (r >= n_rows) return;  // (no block-wide barrier below: the waves are independent)
+  const int t = r % Tq, h = (r / Tq) % H, b = r / (Tq * H);
+  qs[w][lane] = ElemT<T>::ld(q + (size_t)(b * Tq + t) * ldq + h * 64 + lane) * 0.125f;
+  __builtin_amdgcn_wave_barrier();
+  float sc[16];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int sidx = i * 64 + lane;
+    sc[i] = -INFINITY;
+    if (sidx < Tk) {
+      const bool ok = !(causal && sidx > t) && !(key_mask && key_mask[b * Tk + sidx] == 0);
+      if (ok) {
+        const T* kr = k + (size_t)(b * Tk + sidx) * ldk + h * 64;
+        float a = 0.0f;
+        for (int d = 0; d < 64; ++d) a = fmaf(qs[w][d], ElemT<T>::ld(kr + d), a);
+        sc[i] = a;
+      }
+    }
+    mx = fmaxf(mx, sc[i]);
+  }
+  mx = wave_max(mx);
+  float sum = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    sc[i] = sc[i] > -INFINITY ? __expf(sc[i] - mx) : 0.0f;
+    sum += sc[i];
+  }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int sidx = i * 64 + lane;
+    if (sidx < Tk) out[(size_t)r * Tk + sidx] = sc[i] * inv;
+  }
+}
+
+extern "C" int mic_attn_probs(int dtype, int B, int H, int Tq, int Tk, const void* q, int ldq, const void* k, int ldk,
+                              const int32_t* key_mask, int causal, float* out, void* stream) {
+  MIC_CHECK(B > 0 && H > 0 && Tq > 0 && Tk > 0 && Tk <= 1024, "mic_attn_probs: bad shape B=%d H=%d Tq=%d Tk=%d (Tk <= 1024)", B, H, Tq, Tk);
+  MIC_CHECK(q && k && out, "mic_attn_probs: null pointer");
+  const int n_rows = B * H * Tq;
+  dim3 grid((n_rows + 3) / 4), block(256);
+  if (dtype == MIC_BF16)
+    hipLaunchKernelGGL(attn_probs_kernel<uint16_t>, grid, block, 0, (hipStream_t)stream, n_rows, H, Tq, Tk, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk, key_mask, causal, out);
+  else if (dtype == MIC_F32)
+    hipLaunchKernelGGL(attn_probs_kernel<float>, grid, block, 0, (hipStream_t)stream, n_rows, H, Tq, Tk, (const float*)q, ldq, (const float*)k, ldk, key_mask, causal, out);
+  else MIC_CHECK(false, "mic_attn_probs: bad dtype");
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}
+
 extern "C" int mic_attn_fwd(int dtype, int B, int H, int Tq, int Tk, const void* q, int ldq, const void* k, int ldk,
                             const void* v, int ldv, void* out, int ldo, const int32_t* key_mask, int causal, float* lse,
                             void* stream) {

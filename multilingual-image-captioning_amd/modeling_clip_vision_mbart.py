@@ -206,17 +206,17 @@ class FlaxCLIPVisionMBartForConditionalGeneration(FlaxCLIPVisionMBartPreTrainedM
         seed = _seed_from(dropout_rng) if train else None  # deterministic = not train (508)
         output_hidden_states = output_hidden_states if output_hidden_states is not None else getattr(self.config, "output_hidden_states", False)
         output_attentions = output_attentions if output_attentions is not None else getattr(self.config, "output_attentions", False)
-        if output_attentions:
-            # modeling:499-510 forwards the flag to the Flax modules, which return the softmax weights of every layer; the fused
-            # attention kernels here never materialise them
-            raise NotImplementedError("output_attentions=True: the attention kernels do not materialise the attention weights")
-        logits, ehs = self.engine.forward_logits(px, ids.reshape(-1), pos.reshape(-1), mask, B, T, save=bool(output_hidden_states), seed=seed)
+        if output_attentions and (self.store.d // self.store.H != 64 or self.store.vd // self.store.vH != 64):
+            raise NotImplementedError("output_attentions=True: the weights kernel is built for 64-wide heads")
+        logits, ehs = self.engine.forward_logits(px, ids.reshape(-1), pos.reshape(-1), mask, B, T,
+                                                 save=bool(output_hidden_states or output_attentions), seed=seed)
         V = self.store.V
         out = logits[: B * T, :V].reshape(B, T, V)
+        att = self._attention_weights(B, T, mask) if output_attentions else {}
         if not output_hidden_states:
             if return_dict is False:
-                return (out,)
-            return ModelOutput(logits=out)
+                return (out,) + tuple(att[k] for k in ("decoder_attentions", "cross_attentions", "encoder_attentions") if k in att)
+            return ModelOutput(logits=out, **att)
         # FlaxSeq2SeqLMOutput fields of the reference's module output (modeling:176-192): the per-layer activations the forward
         # pass kept (`save=True`), copied out of the engine's buffers.  Decoder: the embedding output (after layernorm_embedding)
         # and every layer's output — the last one before the final layer_norm, as the Flax decoder collects them; encoder: the
@@ -225,11 +225,43 @@ class FlaxCLIPVisionMBartForConditionalGeneration(FlaxCLIPVisionMBartPreTrainedM
         S, d, vd = st.S, st.d, st.vd
         dec = [eng.buf("d.x0", B * T, d)] + [eng.buf(f"d{l}.x3", B * T, d) for l in range(st.L)]
         enc = [eng.buf("v.x0", B * S, vd)] + [eng.buf(f"v{l}.xo", B * S, vd) for l in range(st.vL)]
-        res = ModelOutput(logits=out,
-                          decoder_hidden_states=tuple(t[: B * T].reshape(B, T, d).clone() for t in dec),
-                          encoder_last_hidden_state=ehs[: B * S].reshape(B, S, d).clone(),
-                          encoder_hidden_states=tuple(t[: B * S].reshape(B, S, vd).clone() for t in enc))
+        res = ModelOutput(logits=out, decoder_hidden_states=tuple(t[: B * T].reshape(B, T, d).clone() for t in dec))  # field order of
+        for k in ("decoder_attentions", "cross_attentions"):                                                       # FlaxSeq2SeqLMOutput
+            if k in att:
+                res[k] = att[k]
+        res["encoder_last_hidden_state"] = ehs[: B * S].reshape(B, S, d).clone()
+        res["encoder_hidden_states"] = tuple(t[: B * S].reshape(B, S, vd).clone() for t in enc)
+        if "encoder_attentions" in att:
+            res["encoder_attentions"] = att["encoder_attentions"]
         return res if return_dict is not False else res.to_tuple()
+
+    def _attention_weights(self, B: int, T: int, mask: torch.Tensor) -> dict:
+        """`output_attentions=True` (modeling:499-510): the softmax weights of every attention of the pass that has just run with
+        `save=True`, recomputed from the kept q / k projections by the diagnostic kernel `mic_attn_probs` (the fused attention cores
+        never write them).  [B, H, Tq, Tk] per layer, in the compute dtype like the Flax modules return them; they are the
+        weights BEFORE attention dropout (the reference's attention_dropout is 0: config defaults)."""
+        eng, st = self.engine, self.store
+        S, d, vd, H, vH = st.S, st.d, st.vd, st.H, st.vH
+        dt = eng.dt
+
+        def probs(q, k, Hh, Tq, Tk, ldq, ldk, key_mask=None, causal=False):
+            o = torch.empty((B, Hh, Tq, Tk), dtype=torch.float32, device=self.device)
+            ops.attn_probs(q, k, o, B, Hh, Tq, Tk, ldq=ldq, ldk=ldk, key_mask=key_mask, causal=causal)
+            return o.to(dt)
+
+        enc, dec, cross = [], [], []
+        for l in range(st.vL):
+            qkv = eng.buf(f"v{l}.qkv", B * S, 3 * vd)
+            enc.append(probs(qkv, qkv[:, vd:], vH, S, S, 3 * vd, 3 * vd))
+        hoist = eng.ckv_hoisted()
+        kvcat = eng.buf("d.ckvcat", B * S, st.L * 2 * d) if hoist else None
+        for l in range(st.L):
+            qkv = eng.buf(f"d{l}.qkv", B * T, 3 * d)
+            dec.append(probs(qkv, qkv[:, d:], H, T, T, 3 * d, 3 * d, key_mask=mask, causal=True))
+            cq = eng.buf(f"d{l}.cq", B * T, d)
+            ck, ldk = (kvcat[:, l * 2 * d:], kvcat.stride(0)) if hoist else (eng.buf(f"d{l}.ckv", B * S, 2 * d), 2 * d)
+            cross.append(probs(cq, ck, H, T, S, d, ldk))
+        return {"decoder_attentions": tuple(dec), "cross_attentions": tuple(cross), "encoder_attentions": tuple(enc)}
 
     # ------------------------------------------------------------------ encode (modeling:284-337)
     def encode(self, pixel_values, output_attentions=None, output_hidden_states=None, return_dict=None, train: bool = False,

@@ -165,6 +165,12 @@ def attn_fwd(q, k, v, out, B, H, Tq, Tk, *, ldq, ldk, ldv, ldo, key_mask=None, c
     return out
 
 
+def attn_probs(q, k, out, B, H, Tq, Tk, *, ldq, ldk, key_mask=None, causal=False):
+    """out [B,H,Tq,Tk] fp32 = the attention weights of q / k (views into the saved projection buffers); diagnostic only"""
+    L.check(L.lib().mic_attn_probs(_dt(q), B, H, Tq, Tk, _p(q), ldq, _p(k), ldk, _p(key_mask), int(causal), _p(out), _stream()), "mic_attn_probs")
+    return out
+
+
 def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, Tq, Tk, *, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, key_mask=None,
              causal=False):
     L.check(L.lib().mic_attn_bwd(_dt(q), B, H, Tq, Tk, _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), ldo, _p(dout), lddo, _p(lse),

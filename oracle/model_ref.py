@@ -99,6 +99,9 @@ def gelu(x: torch.Tensor, kind: str) -> torch.Tensor:
     raise ValueError(kind)
 
 
+ATTN_TAP: Optional[list] = None  # set to a list to collect the attention weights [B,H,T,S] of every attention_core call
+
+
 def attention_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     """flax `dot_product_attention_weights`: q scaled by 1/sqrt(D) BEFORE q.k^T,
     softmax over keys of (scores + bias), weights @ v.  q,k,v: [B,T,H,D] / [B,S,H,D]; bias [B,1|H,T,S]."""
@@ -108,6 +111,8 @@ def attention_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, bias: Opti
     if bias is not None:
         w = w + bias
     w = torch.softmax(w, dim=-1)
+    if ATTN_TAP is not None:  # tests of `output_attentions`: the weights of every attention, in call order
+        ATTN_TAP.append(w)
     return torch.einsum("bhts,bshd->bthd", w, v)
 
 

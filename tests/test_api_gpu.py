@@ -242,7 +242,7 @@ def test_evaluate_loop(dev):
 
 def test_output_hidden_states_match_oracle(dev):
     """`output_hidden_states=True` (modeling:499-510 forwards it to the modules): decoder and encoder per-layer states of the
-    forward pass against the oracle's; `output_attentions=True` is refused (the fused kernels keep no attention weights)."""
+    forward pass against the oracle's."""
     import numpy as np
 
     from oracle import model_ref as M
@@ -272,7 +272,52 @@ def test_output_hidden_states_match_oracle(dev):
         assert (got.cpu() - ref)[valid].abs().max().item() < 2e-4 * ref[valid].abs().max().item()
     assert (out.encoder_last_hidden_state.cpu() - ehs).abs().max().item() < 2e-4 * ehs.abs().max().item()
     assert len(model(px.numpy(), dec_in.numpy(), mask.numpy(), output_hidden_states=True, return_dict=False)) == 4
-    import pytest
 
-    with pytest.raises(NotImplementedError, match="attention weights"):
-        model(px.numpy(), dec_in.numpy(), mask.numpy(), output_attentions=True)
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_output_attentions_match_oracle(dev, dtype):
+    """`output_attentions=True` (modeling:499-510): decoder self-, cross- and encoder attention weights of every layer against the
+    oracle's softmax weights (flax `dot_product_attention_weights`), with and without the hidden states, dict and tuple returns."""
+    from oracle import model_ref as M
+    from util_small import batch, make_pair
+
+    rc, p, model = make_pair(dtype, dev, gelu="tanh", decoder_ln_eps=1e-6)
+    px, labels, mask, dec_in = batch(rc, 3, 12, seed=19)
+    out = model(px.numpy(), dec_in.numpy(), mask.numpy(), output_attentions=True)
+    plain = model(px.numpy(), dec_in.numpy(), mask.numpy())
+    assert torch.equal(out.logits, plain.logits)
+    assert list(out.keys()) == ["logits", "decoder_attentions", "cross_attentions", "encoder_attentions"]
+    M.ATTN_TAP = []
+    try:
+        with torch.no_grad():
+            B, T = dec_in.shape
+            M.forward_logits(rc, p, px, dec_in, mask, torch.arange(T)[None].expand(B, T))
+        tap = M.ATTN_TAP
+    finally:
+        M.ATTN_TAP = None
+    assert len(tap) == rc.v_layers + 2 * rc.d_layers
+    enc, rest = tap[: rc.v_layers], tap[rc.v_layers:]
+    dec, cross = rest[0::2], rest[1::2]
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    valid = mask.bool()[:, None, :, None]  # query rows of padded positions attend over garbage states: not compared
+    for name, got_l, ref_l, qmask in (("encoder", out.encoder_attentions, enc, None), ("decoder", out.decoder_attentions, dec, valid),
+                                      ("cross", out.cross_attentions, cross, valid)):
+        assert len(got_l) == len(ref_l)
+        for got, ref in zip(got_l, ref_l):
+            assert got.dtype == dtype and tuple(got.shape) == tuple(ref.shape), (name, got.shape, ref.shape)
+            diff = (got.float().cpu() - ref).abs()
+            if qmask is not None:
+                diff = diff * qmask
+            assert diff.max().item() < tol, (name, diff.max().item())
+            rows = got.float().sum(-1).cpu()
+            assert (rows - 1).abs().max().item() < (1e-5 if dtype == torch.float32 else 2e-2)
+    # causal + key padding: no weight above the diagonal or on padded keys
+    for got in out.decoder_attentions:
+        g = got.float().cpu()
+        assert torch.triu(g, diagonal=1).abs().max().item() == 0.0
+        assert (g * (~mask.bool())[:, None, None, :]).abs().max().item() == 0.0
+    both = model(px.numpy(), dec_in.numpy(), mask.numpy(), output_attentions=True, output_hidden_states=True)
+    assert list(both.keys()) == ["logits", "decoder_hidden_states", "decoder_attentions", "cross_attentions", "encoder_last_hidden_state",
+                                 "encoder_hidden_states", "encoder_attentions"]  # FlaxSeq2SeqLMOutput order (past_key_values is None)
+    assert len(model(px.numpy(), dec_in.numpy(), mask.numpy(), output_attentions=True, return_dict=False)) == 4
+    assert len(both.to_tuple()) == 7
