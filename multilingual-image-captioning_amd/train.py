@@ -290,10 +290,11 @@ class GradReducer:
                     self._ready(b, e)
                     self._gather(b, e)
                 self.held = []
-            if self.late is not None:
+            if self.late is not None and self.on_ready is not None:
                 self.late()
             return
-        if not self.held and before is None and self.late is None:
+        late = self.late if self.on_ready is not None else None  # the late pass belongs to the per-bucket optimizer
+        if not self.held and before is None and late is None:
             return
         ev = torch.cuda.Event()
         ev.record(self.stream if self.world > 1 else torch.cuda.current_stream())
@@ -310,8 +311,8 @@ class GradReducer:
                     before()
                 for (b, e) in self.held:
                     self._ready(b, e)
-                if self.late is not None:
-                    self.late()
+                if late is not None:
+                    late()
         if tail is not self.opt_stream:
             self.opt_stream.wait_stream(tail)  # finish() and the sharded gather order themselves behind opt_stream
         self._after_ready_gather(self.held)

@@ -544,3 +544,32 @@ def test_split_embedding_adamw_and_masked_optimizer_stream_change_nothing(dev, d
     # the flags really split the segment: some rows early, some late
     flagged = int(tr._row_flag.sum().item())
     assert 0 < flagged < tr._row_flag.numel()
+
+
+@pytest.mark.gpu
+def test_serial_optimizer_toggle_skips_the_row_passes(dev, monkeypatch):
+    """bench.py's instrumented step switches the per-bucket optimizer off on a live Trainer (`overlap_optimizer = False`,
+    `reducer.on_ready = None`): the whole flat buffer is then updated by ONE mic_adamw launch and neither row pass of the tied
+    embedding may run (a late pass on top of the full update would apply AdamW twice to the step's id rows)."""
+    from mic_amd import Trainer, create_learning_rate_fn, ops
+
+    rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.0)
+    tr = Trainer(model, create_learning_rate_fn(64, 2, 4, 0, 1e-3))
+    assert tr._split_shared
+    calls = {"rows": 0, "full": 0}
+    real_rows, real_full = ops.adamw_rows, ops.adamw
+    monkeypatch.setattr(ops, "adamw_rows", lambda *a, **k: (calls.__setitem__("rows", calls["rows"] + 1), real_rows(*a, **k))[1])
+    monkeypatch.setattr(ops, "adamw", lambda *a, **k: (calls.__setitem__("full", calls["full"] + 1), real_full(*a, **k))[1])
+    px, labels, mask, dec_in = batch(rc, 4, 12, seed=33)
+    b = {"pixel_values": px.numpy(), "input_ids": labels.numpy(), "attention_mask": mask.numpy(), "decoder_input_ids": dec_in.numpy()}
+    tr.train_step(b)
+    assert calls["rows"] == 2 and calls["full"] >= 1  # early + late pass, the other buckets as plain slices
+    saved = tr.overlap_optimizer, tr.reducer.on_ready
+    tr.overlap_optimizer, tr.reducer.on_ready = False, None
+    calls.update(rows=0, full=0)
+    tr.train_step(b)
+    assert calls == {"rows": 0, "full": 1}
+    tr.overlap_optimizer, tr.reducer.on_ready = saved
+    calls.update(rows=0, full=0)
+    out = tr.train_step(b)
+    assert calls["rows"] == 2 and np.isfinite(float(out["loss"]))
