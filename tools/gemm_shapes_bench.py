@@ -16,7 +16,8 @@ pkg = importlib.import_module("multilingual-image-captioning_amd")
 ops = importlib.import_module("multilingual-image-captioning_amd.ops")
 
 dev = torch.device("cuda:0")
-MV, MD = 64 * 50, 64 * 64  # encoder rows (B * 50 patches+cls), decoder rows (B * T)
+MV, MD = 64 * 50, int(os.environ.get("MD", 64 * 64))  # encoder rows (B * 50 patches+cls), decoder rows (B * T; MD=2176: packed rows)
+NO_LIB = "--no-lib" in sys.argv  # only this repo's kernels (e.g. under MIC_GEMM_TILE=256|128|64)
 SHAPES = [
     # name, M, N, K
     ("vit qkv", MV, 3 * 768, 768),
@@ -30,6 +31,8 @@ SHAPES = [
     ("dec fc2", MD, 1024, 4096),
     ("head", 2048, 250112, 1024),
 ]
+if "--no-head" in sys.argv:
+    SHAPES = SHAPES[:-1]
 # one beam-4 decoder step (configs[3]: 256 images x 4 beams = 1024 rows), forward only
 DECODE = [
     ("gen d x d", 1024, 1024, 1024),
@@ -74,7 +77,8 @@ def main():
         if name.startswith("gen"):
             cases = cases[:1]
         for lay, mine, lib in cases:
-            tm, tl = timeit(mine), timeit(lib)
+            tm = timeit(mine)
+            tl = tm if NO_LIB else timeit(lib)
             print(f"{name:12s} {lay:4s} {M:6d} {N:7d} {K:6d} {tm:9.1f} {tl:9.1f} {fl / tm * 1e-6:9.1f} {fl / tl * 1e-6:9.1f} {tm / tl:8.2f}", flush=True)
 
 
