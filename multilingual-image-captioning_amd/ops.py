@@ -279,13 +279,21 @@ def zero(t: torch.Tensor):
 
 def cu_masked_stream(first_cu: int, n_cus: int, device) -> "torch.cuda.Stream":
     """A torch stream over a HIP stream that may use only bits [first_cu, first_cu + n_cus) of the CU mask (mic_stream_create_cu_masked).  The HIP
-    stream lives as long as the process (a handful per Trainer)."""
+    stream lives as long as the process and is shared by every caller that asks for the same range."""
     import ctypes
 
-    h = ctypes.c_void_p()
-    with torch.cuda.device(device):
-        L.check(L.lib().mic_stream_create_cu_masked(int(first_cu), int(n_cus), ctypes.byref(h)), "mic_stream_create_cu_masked")
-    return torch.cuda.ExternalStream(h.value, device=device)
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(first_cu), int(n_cus))
+    st = _masked_streams.get(key)
+    if st is None:  # one HIP stream per (device, CU range) and process: every masked stream is a hardware queue of its own, and a
+        h = ctypes.c_void_p()  # process that keeps creating them (a Trainer per test, say) ends up time-slicing queues
+        with torch.cuda.device(dev):
+            L.check(L.lib().mic_stream_create_cu_masked(int(first_cu), int(n_cus), ctypes.byref(h)), "mic_stream_create_cu_masked")
+        st = _masked_streams[key] = torch.cuda.ExternalStream(h.value, device=dev)
+    return st
+
+
+_masked_streams = {}
 
 
 def sum_slabs(src, n_slabs, slab_stride, dst, rows, cols, ld_src, ld_dst):
