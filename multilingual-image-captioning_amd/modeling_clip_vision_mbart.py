@@ -90,7 +90,12 @@ class FlaxCLIPVisionMBartPreTrainedModel(FlaxCLIPVisionMBartGenerationMixin):
         self.device = torch.device(device)
         self.store = ParamStore(config, self.dtype, self.device)
         self.engine = Engine(self.store)
-        self.engine.on_free.append(self.release_decode_plans)  # captured decoder steps point into the engine's buffers
+        # captured decoder steps point into the engine's buffers.  A weak reference: engine -> bound method -> model -> engine would keep
+        # the ~16 GB of a dropped model alive until the cycle collector gets round to it
+        import weakref
+
+        me = weakref.ref(self)
+        self.engine.on_free.append(lambda: me() is not None and me().release_decode_plans())
         self._required_params = set(tuple(k.split("/")) for k in self.store.flax_shapes())  # utils:78
         self._params_cache = None
         self._state_sync = None  # set by a Trainer with a sharded optimizer: all-gathers the master weights before an export

@@ -393,9 +393,13 @@ class Trainer:
         self._sh = (sh.offset, sh.offset + sh.numel, st.d)
         self._row_flag = torch.zeros(sh.numel // st.d, dtype=torch.uint8, device=model.device) if self._split_shared else None
         opt_cus = int(_os.environ.get("MIC_OPT_CUS", str(OPT_CUS_DEFAULT))) if (model.device.type == "cuda" and self._split_shared) else 0
-        self.reducer = GradReducer(st.grad, self.buckets, group, on_ready=self._adamw_slice if self.overlap_optimizer else None,
+        import weakref
+
+        me = weakref.ref(self)  # the reducer's callbacks must not own the Trainer (Trainer -> reducer -> bound method -> Trainer is a cycle
+        #                         that keeps ~16 GB of device state alive after `del trainer, model` until the cycle collector runs)
+        self.reducer = GradReducer(st.grad, self.buckets, group, on_ready=(lambda b, e: me()._adamw_slice(b, e)) if self.overlap_optimizer else None,
                                    hold=None if self._split_shared else (sh.offset, sh.offset + sh.numel), comm_dtype=grad_comm_dtype,
-                                   sharded=self.sharded, gather=[st.lp], late=self._adamw_shared_late if self._split_shared else None,
+                                   sharded=self.sharded, gather=[st.lp], late=(lambda: me()._adamw_shared_late()) if self._split_shared else None,
                                    opt_cus=opt_cus)
         self.metrics_buf = torch.zeros(2, dtype=torch.float32, device=model.device)
         self._state_dirty = False
@@ -403,7 +407,10 @@ class Trainer:
             # params export / checkpoints need every rank's master weights + moments.  The all-gather is a COLLECTIVE: it is only
             # ever started explicitly (`sync_full_state()` / `save_checkpoint()` on every rank); `model.params` on stale state
             # raises instead of starting one on whichever rank happened to ask (a rank-0-only access would deadlock RCCL)
-            model._state_sync = self._require_synced_state
+            import weakref
+
+            me = weakref.ref(self)  # (model -> bound method -> Trainer -> model would be a reference cycle)
+            model._state_sync = lambda: me() is not None and me()._require_synced_state()
 
     def _require_synced_state(self):
         if self.sharded and self._state_dirty:

@@ -321,3 +321,31 @@ def test_output_attentions_match_oracle(dev, dtype):
                                  "encoder_hidden_states", "encoder_attentions"]  # FlaxSeq2SeqLMOutput order (past_key_values is None)
     assert len(model(px.numpy(), dec_in.numpy(), mask.numpy(), output_attentions=True, return_dict=False)) == 4
     assert len(both.to_tuple()) == 7
+
+
+def test_dropping_a_model_frees_its_device_memory(dev):
+    """`del model` (and its Trainer) must give the parameter / optimizer / activation buffers back without waiting for the cycle
+    collector: the full-size state is ~16 GB, a sweep that builds models in a loop would otherwise hold several at once."""
+    import gc
+
+    from mic_amd import Trainer, create_learning_rate_fn
+    from util_small import batch, make_pair
+
+    gc.collect()
+    torch.cuda.synchronize()
+    gc.disable()
+    try:
+        base = torch.cuda.memory_allocated()
+        rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6)
+        tr = Trainer(model, create_learning_rate_fn(64, 2, 4, 0, 1e-3))
+        px, labels, mask, dec_in = batch(rc, 2, 8, seed=3)
+        tr.train_step({"pixel_values": px.numpy(), "input_ids": labels.numpy(), "attention_mask": mask.numpy(), "decoder_input_ids": dec_in.numpy()})
+        model.generate(px.numpy(), max_length=6, num_beams=2)
+        torch.cuda.synchronize()
+        assert torch.cuda.memory_allocated() > base + (1 << 20)
+        del tr, model, p
+        torch.cuda.synchronize()
+        left = torch.cuda.memory_allocated() - base
+    finally:
+        gc.enable()
+    assert left < (1 << 20), f"{left / 1e6:.1f} MB still allocated after the model and its Trainer were dropped (a reference cycle?)"
