@@ -40,6 +40,14 @@ _MAX_PLANS = 2     # decode plans kept per model (each owns a KV cache: 24 x row
 _AUTO_SLICES = 1   # MIC_DECODE_SLICES=auto
 
 
+# Captured graphs of dropped plans are never destroyed while the process lives.  On this stack (ROCm 7.2) destroying an instantiated
+# graph with parallel branches — the sliced beam search — breaks the NEXT multi-branch graph: its replay dies inside
+# hip::Graph::UpdateStreams (hipGraphLaunch -> GraphExec::Run; rocgdb backtrace in profiles/README.md).  As long as models lingered in
+# reference cycles the graphs happened to outlive every later replay; now that a dropped model frees its device state at once, the
+# graph objects (host-side nodes, no device memory of their own: nothing is allocated inside a capture) are parked here instead.
+_RETIRED_GRAPHS = []
+
+
 class _DecodePlan:
     """Fixed-address device state of one generate configuration + its captured decoder steps."""
 
@@ -50,18 +58,38 @@ class _DecodePlan:
         self.stream = None   # capture stream
         self.subs = []       # beam search: one sub-plan (state tensors + KV cache) per image slice
         self.streams = []    # ... and the streams their chains run on
+        self.graph_events = {}  # cur_len -> the fork / join events recorded while that step was captured (kept as long as the graph)
+        self._events_now = []
+
+    def __del__(self):
+        # see _RETIRED_GRAPHS: the graphs (and the events recorded into them) outlive the plan
+        try:
+            _RETIRED_GRAPHS.extend((g, self.graph_events.get(k)) for k, g in self.graphs.items())
+            self.graphs.clear()
+        except Exception:  # interpreter shutdown
+            pass
+
+    def new_event(self) -> "torch.cuda.Event":
+        """an event for the fork / join of the slices' chains; the ones recorded inside a capture are kept as long as the graph (a
+        precaution: the capture turns their records into dependencies of the graph's nodes)"""
+        ev = torch.cuda.Event()
+        self._events_now.append(ev)
+        return ev
 
     def run_step(self, cur_len: int, fn, use_graphs: bool):
         """fn() issues the launches of decoder step `cur_len` on the current stream.  First call of a plan: eager.  Later calls:
         replay the step's graph, capturing it the first time (capture executes nothing; the replay does)."""
         if not use_graphs or self.calls == 0:
+            self._events_now = []
             fn()
+            self._events_now = []
             return
         g = self.graphs.get(cur_len)
         if g is None:
             if self.stream is None:
                 self.stream = torch.cuda.Stream()
             g = torch.cuda.CUDAGraph()
+            self._events_now = []
             with torch.cuda.stream(self.stream):
                 g.capture_begin(capture_error_mode="thread_local")
                 try:
@@ -69,6 +97,7 @@ class _DecodePlan:
                 finally:
                     g.capture_end()
             self.graphs[cur_len] = g
+            self.graph_events[cur_len], self._events_now = self._events_now, []
         g.replay()
 
 
@@ -359,13 +388,13 @@ class FlaxCLIPVisionMBartGenerationMixin:
                 # fork: every slice's chain on its own stream behind what the current stream has enqueued; join: the current
                 # stream waits for all of them (inside a capture these are the graph's parallel branches)
                 cur = torch.cuda.current_stream()
-                fork = torch.cuda.Event()
+                fork = plan.new_event()
                 fork.record(cur)
                 for i, s_ in enumerate(plan.streams):
                     s_.wait_event(fork)
                     with torch.cuda.stream(s_):
                         steps_fn[i](cur_len)
-                        done = torch.cuda.Event()
+                        done = plan.new_event()
                         done.record(s_)
                     cur.wait_event(done)
             return fn
