@@ -231,7 +231,7 @@ class FlaxCLIPVisionMBartGenerationMixin:
         sequences, finished, next_token, top_val, top_idx, pos_all = (t[k] for k in ("sequences", "finished", "next_token", "top_val",
                                                                                      "top_idx", "pos_all"))
         sequences.fill_(pad_token_id)  # gen:457
-        sequences[:, 0] = start_token
+        sequences[:, 0].fill_(start_token)  # (a fill kernel: assigning a Python scalar into a device tensor is a synchronous copy)
         finished.zero_()
         next_token.fill_(start_token)
         cache = self._plan_cache(plan, B, max_length)
@@ -272,7 +272,7 @@ class FlaxCLIPVisionMBartGenerationMixin:
         lim = torch.empty(B, dtype=torch.int32, device=dev) if (use_k or use_p) else None
         key = prng.prng_key(0 if prng_key is None else prng_key)  # gen:561
         sequences = torch.full((B, max_length), pad_token_id, dtype=torch.int32, device=dev)
-        sequences[:, 0] = start_token
+        sequences[:, 0].fill_(start_token)  # (a fill kernel: assigning a Python scalar into a device tensor is a synchronous copy)
         finished = torch.zeros(B, dtype=torch.int32, device=dev)
         next_token = torch.full((B,), start_token, dtype=torch.int32, device=dev)
         cache = self.init_cache(B, max_length)
@@ -359,7 +359,7 @@ class FlaxCLIPVisionMBartGenerationMixin:
         for i, sub in enumerate(plan.subs):
             t = sub.t
             t["running_seq"].fill_(pad_token_id)  # gen:751-757
-            t["running_seq"][:, :, 0] = start_token
+            t["running_seq"][:, :, 0].fill_(start_token)
             t["seq"].fill_(pad_token_id)
             t["finished"].zero_()  # gen:760
             t["running_scores"].copy_(t["score0"])  # gen:763-765
