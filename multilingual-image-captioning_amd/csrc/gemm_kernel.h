@@ -179,10 +179,10 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
         // small wave tiles (32 x 32: one MFMA per k-step on one accumulator; 64 x 32: two): the K-tile's fragment reads all go
         // out together, then the MFMAs (the compiler otherwise issues k-step kk+1's reads behind the MFMAs of kk and waits a full
         // LDS latency in every k-step; these launches are latency chains, not throughput)
-        if (t + 1 < nk) {
-          write_lds(gsm + ((t + 1) & 1) * STAGE, t + 1);
-          if (t + 2 < nk) load_regs(t + 2);
-        }
+        // Order inside the iteration: this tile's fragment reads FIRST, then the next tile's LDS writes (its buffer was last read
+        // in iteration t-1; the data was requested a whole iteration ago) and the global loads of the tile after it, then the
+        // MFMAs.  The LDS port serves the reads first, so the MFMAs start as soon as the first fragments arrive and run beside the
+        // remaining reads AND the writes; with the writes in front (as before) every wave's MFMAs waited for the write pass.
         bf16x8 af[KSTEPS][AI], bfr[KSTEPS][NJ];
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
@@ -190,6 +190,10 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
           for (int i = 0; i < AI; ++i) af[kk][i] = read_frag<AK, BKT, UA>(At, a_off + i * 32, kk, lane);
 #pragma unroll
           for (int j = 0; j < NJ; ++j) bfr[kk][j] = read_frag<BKM, BKT, UB>(Bt, b_off + j * 32, kk, lane);
+        }
+        if (t + 1 < nk) {
+          write_lds(gsm + ((t + 1) & 1) * STAGE, t + 1);
+          if (t + 2 < nk) load_regs(t + 2);
         }
         if constexpr (RS) {
           if (rs_tile) {
@@ -218,8 +222,9 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
           for (int i = 0; i < AI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
-        // pin the order (the scheduler otherwise sinks every read next to its MFMA): all DS reads, then the MFMAs
+        // pin the order (the scheduler otherwise sinks every read next to its MFMA): all DS reads, the DS writes, then the MFMAs
         __builtin_amdgcn_sched_group_barrier(0x100, ((AK ? 2 : 1) * AI + (BKM ? 2 : 1) * NJ) * KSTEPS, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, NHA * SA::PER + NHB * SB::PER, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, KSTEPS * AI * NJ, 0);
       } else {
 #pragma unroll
