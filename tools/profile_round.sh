@@ -1,5 +1,5 @@
 R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp
-O=$R/gpurun_out/r3prof2; mkdir -p $O
+O=$R/gpurun_out/r3prof3; mkdir -p $O
 TR="--steps 1 --warmup 1 --no-generate --no-cpu-baseline --no-dense-leg --no-roofline"
 # train: kernel trace with the default overlap (dW / optimizer streams) and serial
 rocprofv3 --kernel-trace --output-format csv -d $O/train_kt -- python3 $R/bench.py --steps 3 --warmup 1 --no-generate --no-cpu-baseline --no-dense-leg --no-roofline > $O/train_kt.log 2>&1
