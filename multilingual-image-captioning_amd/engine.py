@@ -597,6 +597,16 @@ class Engine:
             hf = self.buf("d.hf" if pack is not None else "d.hfc", Mcap, d)  # compacted final hidden states (pad rows zero)
             Mh = rows[1]
         Mhp = _rup(Mh, 64)
+        if self.dt == torch.bfloat16:  # final_logits_bias gradient = row sums of dlogits^T, fused into the dE GEMM
+            ops.zero(P.g("flb"))        # (atomics; this segment sits in front of the pre-zeroed atomic region)
+            ops.gemm(dlogits, hf, P.g("shared"), P.Vpad, d, Mhp, a_kmajor=True, b_kmajor=True, a_rowsum=P.g("flb"), rowsum_k=Mh)
+        else:
+            ops.colsum(dlogits, P.g("flb"), Mh, P.Vpad, dlogits.stride(0))
+            ops.gemm(dlogits, hf, P.g("shared"), P.Vpad, d, Mhp, a_kmajor=True, b_kmajor=True)
+        # dense (LM head) part of the tied embedding gradient: the first thing backward completes — its exchange starts here.  The
+        # dX GEMM below still READS the embedding: the Trainer's reducer issues this bucket's optimizer pass at the next progress
+        # report, behind it (GradReducer `defer`)
+        self._done("shared")
         dhc = dhf if (rows is None or pack is not None) else self.buf("db.dhfc", Mcap, d)
         if self.dt == torch.bfloat16 and P.Vpad >= 16384:
             # [Mh, d] output, reduction over the whole vocabulary: far too few tiles to fill 256 CUs.  Split-K 32 with K-range
@@ -608,15 +618,6 @@ class Engine:
             ops.sum_slabs(d32, nsp, slab, dhc, Mh, d, d32.stride(0), dhc.stride(0))
         else:
             ops.gemm(dlogits, P.w("shared"), dhc, Mh, d, P.Vpad, b_kmajor=True)
-        if self.dt == torch.bfloat16:  # final_logits_bias gradient = row sums of dlogits^T, fused into the dE GEMM
-            ops.zero(P.g("flb"))        # (atomics; this segment sits in front of the pre-zeroed atomic region)
-            ops.gemm(dlogits, hf, P.g("shared"), P.Vpad, d, Mhp, a_kmajor=True, b_kmajor=True, a_rowsum=P.g("flb"), rowsum_k=Mh)
-        else:
-            ops.colsum(dlogits, P.g("flb"), Mh, P.Vpad, dlogits.stride(0))
-            ops.gemm(dlogits, hf, P.g("shared"), P.Vpad, d, Mhp, a_kmajor=True, b_kmajor=True)
-        # dense (LM head) part of the tied embedding gradient: the first thing backward completes.  Reported only now, BEHIND the dX
-        # GEMM above that reads the embedding: the optimizer may rewrite the rows of `shared` this step's ids do not touch from here on
-        self._done("shared")
         if rows is not None and pack is None:
             ops.zero(dhf[:M])  # masked-out positions receive exactly zero gradient from the loss
             ops.copy_rows(dhc, dhf, Mh, d, dst_idx=rows[0])

@@ -124,9 +124,13 @@ class GradReducer:
 
     def __init__(self, flat_grad: torch.Tensor, buckets: List[Tuple[int, int]], group=None, on_ready=None, hold=None,
                  comm_dtype: Optional[torch.dtype] = None, sharded: bool = False, gather: Optional[List[torch.Tensor]] = None,
-                 late=None, opt_cus: int = 0):
+                 late=None, opt_cus: int = 0, defer=None):
         """late: called once per step in `release_held`, after `before()` and the postponed slices (the part of the optimizer
-        that needs the end of backward).  opt_cus: CUs of the optimizer stream's mask (0: no mask)."""
+        that needs the end of backward).  opt_cus: CUs of the optimizer stream's mask (0: no mask).  defer: (begin, end) — a bucket
+        touching this range is EXCHANGED as soon as backward reports it, but its on_ready is issued at the next progress() call,
+        behind everything the step's stream has enqueued by then: "gradient final" (the exchange may start) and "weights free" (the
+        optimizer may rewrite them) are different moments for the tied embedding, whose weights the LM head's dX GEMM still reads
+        after its weight-gradient GEMM has finished."""
         import torch.distributed as dist
 
         self.dist, self.group = dist, group
@@ -158,6 +162,8 @@ class GradReducer:
         self.handles = []
         self.hold = hold  # (begin, end): buckets touching this range are reduced as usual but their on_ready is postponed
         self.held: List[Tuple[int, int]] = []
+        self.defer = defer
+        self.deferred: List[Tuple[int, int, object]] = []
         self.last_comm_event = None
         # opt-in reduced-precision exchange (e.g. torch.bfloat16): every rank rounds its bucket, the collective sums in that
         # dtype, the result is widened back into the fp32 buffer.  Halves the xGMI bytes; NOT the reference's fp32 pmean.
@@ -228,7 +234,23 @@ class GradReducer:
         self.next = 0
         self.handles = []
         self.held = []
+        self.deferred = []
         self.last_comm_event = None
+
+    def _flush_deferred(self):
+        """issue the on_ready of the buckets whose exchange was started at the previous progress() call"""
+        if not self.deferred:
+            return
+        here = torch.cuda.Event()
+        here.record(torch.cuda.current_stream())
+        for (b, e, ev) in self.deferred:
+            with torch.cuda.stream(self.opt_stream):
+                self.opt_stream.wait_event(ev)    # the bucket's exchange (world 1: its last gradient kernel)
+                self.opt_stream.wait_event(here)  # ... and every reader of its weights that backward has issued since
+                with ops.pinned_stream():
+                    self._ready(b, e)
+            self._after_ready_gather([(b, e)])
+        self.deferred = []
 
     def _after_ready_gather(self, items: List[Tuple[int, int]]):
         """sharded: all-gather the refreshed weights of `items` on the collective stream, behind the optimizer stream"""
@@ -245,6 +267,8 @@ class GradReducer:
         """Backward reports that every gradient with flat offset < offset_done is final."""
         if not self.active:
             return
+        if self.cuda:
+            self._flush_deferred()
         while self.next < len(self.buckets) and self.buckets[self.next][1] <= offset_done:
             b, e = self.buckets[self.next]
             if self.cuda:
@@ -259,6 +283,8 @@ class GradReducer:
                 self.last_comm_event = ev
                 if self.hold is not None and b < self.hold[1] and e > self.hold[0]:
                     self.held.append((b, e))
+                elif self.on_ready is not None and self.defer is not None and b < self.defer[1] and e > self.defer[0]:
+                    self.deferred.append((b, e, ev))
                 elif self.on_ready is not None:
                     # the optimizer slice runs on its own stream: it must not sit between two collectives
                     with torch.cuda.stream(self.opt_stream):
@@ -293,6 +319,7 @@ class GradReducer:
             if self.late is not None and self.on_ready is not None:
                 self.late()
             return
+        self._flush_deferred()
         late = self.late if self.on_ready is not None else None  # the late pass belongs to the per-bucket optimizer
         if not self.held and before is None and late is None:
             return
@@ -400,7 +427,7 @@ class Trainer:
         self.reducer = GradReducer(st.grad, self.buckets, group, on_ready=(lambda b, e: me()._adamw_slice(b, e)) if self.overlap_optimizer else None,
                                    hold=None if self._split_shared else (sh.offset, sh.offset + sh.numel), comm_dtype=grad_comm_dtype,
                                    sharded=self.sharded, gather=[st.lp], late=(lambda: me()._adamw_shared_late()) if self._split_shared else None,
-                                   opt_cus=opt_cus)
+                                   opt_cus=opt_cus, defer=(sh.offset, sh.offset + sh.numel) if self._split_shared else None)
         self.metrics_buf = torch.zeros(2, dtype=torch.float32, device=model.device)
         self._state_dirty = False
         if self.sharded:
