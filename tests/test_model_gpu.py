@@ -573,3 +573,35 @@ def test_serial_optimizer_toggle_skips_the_row_passes(dev, monkeypatch):
     calls.update(rows=0, full=0)
     out = tr.train_step(b)
     assert calls["rows"] == 2 and np.isfinite(float(out["loss"]))
+
+
+@pytest.mark.gpu
+def test_reducer_defers_the_optimizer_pass_of_a_bucket_to_the_next_progress_report(dev):
+    """`GradReducer(defer=(b, e))`: a bucket touching that range is handed to the exchange when backward reports it, its on_ready
+    only at the NEXT report (or at release_held) — "gradient final" is not "weights free" for the tied embedding, whose weights
+    the LM head's dX GEMM reads after the weight-gradient GEMM."""
+    from mic_amd.train import GradReducer
+
+    grad = torch.zeros(4096, device=dev)
+    buckets = [(0, 1024), (1024, 2048), (2048, 4096)]
+    calls = []
+    red = GradReducer(grad, buckets, on_ready=lambda b, e: calls.append((b, e)), defer=(0, 1024))
+    red.start_step()
+    red.progress(1024)
+    assert calls == []                        # exchanged (world 1: nothing to do), not optimised yet
+    red.progress(2048)
+    assert calls == [(0, 1024), (1024, 2048)]  # the deferred bucket first, then the one just reported
+    red.progress(4096)
+    red.release_held()
+    red.finish()
+    assert calls == [(0, 1024), (1024, 2048), (2048, 4096)]
+    # a deferred bucket that is the LAST report is flushed by release_held
+    calls.clear()
+    red2 = GradReducer(grad, buckets, on_ready=lambda b, e: calls.append((b, e)), defer=(2048, 4096))
+    red2.start_step()
+    red2.progress(4096)
+    assert calls == [(0, 1024), (1024, 2048)]
+    red2.release_held()
+    red2.finish()
+    assert calls == [(0, 1024), (1024, 2048), (2048, 4096)]
+    torch.cuda.synchronize()
