@@ -91,25 +91,37 @@ def synth_batch(B, T, V, img, seed, lang_ids=(250004, 250008, 250003, 250005), d
 
 
 # ---------------------------------------------------------------------------------------------- CPU baselines (oracle)
-def cpu_baseline_train(budget_s=25.0):
+_CPU_PARAMS = {}
+
+
+def _cpu_oracle_params():
+    """full-size oracle parameters, initialised once for both CPU legs (the init is ~10 s of the baselines' budget)"""
+    from oracle import model_ref as M
+
+    if "p" not in _CPU_PARAMS:
+        rc = M.RefConfig()
+        _CPU_PARAMS["rc"], _CPU_PARAMS["p"] = rc, M.init_params(rc, seed=0)
+    return _CPU_PARAMS["rc"], _CPU_PARAMS["p"]
+
+
+def cpu_baseline_train(budget_s=10.0):
     """The oracle (torch-CPU fp32 restatement of the reference path; NOT Flax) on this box's host cores: train step
-    (fwd + bwd + AdamW) images/s at B=8 on the full-size model.  BASELINE.md §3 protocol: 3 warm-up + 10 timed iterations,
-    cut short when the timed part exceeds `budget_s` (the sample actually taken is stated)."""
+    (fwd + bwd + AdamW) images/s at B=8 on the full-size model.  Bounded sample: one warm-up iteration, then timed iterations
+    until `budget_s` of timed work (both CPU legs together stay near 30 s; the sample actually taken is stated)."""
     import torch
 
-    from oracle import model_ref as M
     from oracle import train_ref
 
     cores = host_threads()
     torch.set_num_threads(cores)
-    rc = M.RefConfig()
-    p = M.init_params(rc, seed=0)
+    rc, p0 = _cpu_oracle_params()
+    p = dict(p0)
     m = {k: torch.zeros_like(v) for k, v in p.items()}
     v2 = {k: torch.zeros_like(v) for k, v in p.items()}
     b = synth_batch(8, 64, rc.vocab_size, rc.image_size, 7)
     t = {k: torch.from_numpy(v) for k, v in b.items()}
-    n, t_used, warm, n_warm = 0, 0.0, 0, 3
-    for it in range(13):
+    n, t_used, warm, n_warm = 0, 0.0, 0, 1
+    for it in range(11):
         t0 = time.time()
         _, g = train_ref.loss_and_grads(rc, p, t["pixel_values"], t["input_ids"], t["attention_mask"], t["decoder_input_ids"])
         with torch.no_grad():
@@ -119,21 +131,19 @@ def cpu_baseline_train(budget_s=25.0):
         note(f"cpu baseline (train) iteration {it}: {dt:.1f} s")
         if it < n_warm:
             warm += 1
-            if it == 0 and dt > budget_s / 4:  # a slow host: one warm-up iteration only
-                n_warm = 1
             continue
         n += 8
         t_used += dt
-        if t_used > budget_s:
+        if t_used + dt > budget_s:
             break
     return {"value": round(n / t_used, 3), "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": f"oracle (torch-CPU fp32 restatement, not Flax) train step fwd+bwd+AdamW, full-size model, B=8, "
-                      f"{warm} warm-up + {n // 8} timed iterations (protocol 3 + 10, cut at {budget_s:.0f} s of timed work), {cores} threads of {os.cpu_count()} logical CPUs"}
+                      f"{warm} warm-up + {n // 8} timed iterations (cut at {budget_s:.0f} s of timed work), {cores} threads of {os.cpu_count()} logical CPUs"}
 
 
-def cpu_baseline_beam(budget_s=30.0):
+def cpu_baseline_beam(budget_s=10.0):
     """Beam-4 captions/s of the oracle at B=8 (evaluation.py:80-94 shape: num_beams 4, max_length 64, forced BOS), one call.
-    Bounded: when the first 4 decoder steps predict more than `budget_s` for 63 steps, max_length is shortened and said so."""
+    Bounded: when the first 3 decoder steps predict more than `budget_s` for 63 steps, max_length is shortened and said so."""
     import numpy as np
     import torch
 
@@ -142,8 +152,8 @@ def cpu_baseline_beam(budget_s=30.0):
 
     cores = host_threads()
     torch.set_num_threads(cores)
-    rc = M.RefConfig()
-    p = M.init_params(rc, seed=0)
+    rc, p0 = _cpu_oracle_params()
+    p = dict(p0)
     p["final_logits_bias"] = p["final_logits_bias"].clone()
     p["final_logits_bias"][0, rc.eos_token_id] = -1e9  # as in the GPU leg: always the full number of steps
     B, K = 8, 4
@@ -157,15 +167,15 @@ def cpu_baseline_beam(budget_s=30.0):
                        max_length=L, forced_bos_token_id=250004)
         return time.time() - t0, r.steps
 
-    t5, _ = run(5)  # warm-up and probe: encoder + 4 steps
-    note(f"cpu baseline (beam-4) probe of 4 steps: {t5:.1f} s")
-    per_step = t5 / 5.0
-    L = 64 if per_step * 63 <= budget_s else max(8, int(budget_s / per_step))
+    t4, _ = run(4)  # warm-up and probe: encoder + 3 steps
+    note(f"cpu baseline (beam-4) probe of 3 steps: {t4:.1f} s")
+    per_step = t4 / 4.0
+    L = 64 if per_step * 63 <= budget_s else max(6, int(budget_s / per_step))
     dt, steps = run(L)
     scale = 63.0 / steps  # captions/s for the full 63-step caption, extrapolated linearly when shortened
     return {"value": round(B / (dt * scale), 4), "unit": "captions/sec", "cores": cores, "kind": "port",
             "sample": f"oracle (torch-CPU fp32 restatement, not Flax) beam-4 generate, full-size model, B=8, max_length {L} "
-                      f"({steps} decoder steps in {dt:.1f} s" + ("" if L == 64 else ", scaled to 63 steps") + f"), 1 call after a 4-step warm-up, {cores} threads of {os.cpu_count()} logical CPUs"}
+                      f"({steps} decoder steps in {dt:.1f} s" + ("" if L == 64 else ", scaled to 63 steps") + f"), 1 call after a 3-step warm-up, {cores} threads of {os.cpu_count()} logical CPUs"}
 
 
 # ---------------------------------------------------------------------------------------------- beam-4 leg
@@ -344,11 +354,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"])
-    ap.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"],
-                    help="gradient exchange precision for --gpus > 1 (fp32 = the reference's pmean; bf16 = opt-in, halves xGMI bytes)")
+    ap.add_argument("--grad-comm", default="auto", choices=["auto", "fp32", "bf16"],
+                    help="gradient exchange precision for --gpus > 1: auto = fp32 (the reference's pmean) where the projected all-reduce hides "
+                         "under backward, bf16 where it would not (N = 2, 4: mic_amd.train.choose_comm_dtype); fp32 / bf16 force either")
+    ap.add_argument("--emulate-comm", default=None, help="(default 2,4,8; off for --small) ""world sizes whose gradient exchange is EMULATED on this one GPU after the timed region "
+                    "(a kernel holding --comm-cus CUs for the projected all-reduce time of every bucket): reported as `comm_emulated`, a "
+                    "scheduling probe, not a scaling result; '' or 0 = off; only with --gpus 1")
+    ap.add_argument("--comm-cus", type=int, default=None, help="CUs the collectives are assumed to hold (default mic_amd.train.COMM_CUS_DEFAULT)")
     ap.add_argument("--fp8-scaling", default="delayed", choices=["delayed", "current"],
                     help="--dtype fp8: scale from the previous step's amax (one pass per tensor) or from the current amax (two)")
-    ap.add_argument("--sharded-optimizer", action="store_true", help="reduce-scatter gradients, AdamW on 1/N of the flat buffer, all-gather weights")
     ap.add_argument("--dense-captions", action="store_true", help="every caption has T-2 tokens (no padded label positions): dense upper bound")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -418,9 +432,10 @@ def main():
     if args.dtype == "fp8":
         tkw["gemm_dtype"] = "fp8"
         tkw["fp8_scaling"] = args.fp8_scaling
-    if args.sharded_optimizer:
-        tkw["sharded_optimizer"] = True
-    tr = Trainer(model, lr_fn, seed=42, grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else None, **tkw)
+    if args.comm_cus is not None:
+        tkw["comm_cus"] = args.comm_cus
+    comm_arg = {"auto": "auto", "fp32": None, "bf16": torch.bfloat16}[args.grad_comm]
+    tr = Trainer(model, lr_fn, seed=42, grad_comm_dtype=comm_arg, **tkw)
     V, img = cfg.mbart_config.vocab_size, cfg.clip_vision_config.image_size
     batches = [synth_batch(B, T, V, img, 1234 + rank * 100 + i, dense=args.dense_captions) for i in range(2)]
     # inputs resident in HBM before the timed region
@@ -497,6 +512,40 @@ def main():
                          "201.3 GFLOP per sample are executed in full; roofline_frac = the GEMM fraction of peak of THIS step "
                          "(instrumented like `roofline`), i.e. the kernels' efficiency when no row can be packed away"}
 
+    # the same step with an EMULATED gradient exchange among N ranks on this one GPU: every bucket's all-reduce is replaced by a
+    # kernel that holds `comm_cus` CUs (a CU-masked collective stream) for the time a ring all-reduce of that bucket is projected to
+    # take over xGMI (mic_amd.train.allreduce_ms), the bucket's optimizer pass waits for it as it would for RCCL, and the GEMM tile
+    # planner is sized for the remaining CUs.  What it shows: whether the step's scheduling (bucket order, optimizer stream, CU
+    # budget) holds up when a collective stream is busy beside backward.  NOT a scaling result: no byte crosses a link.
+    emulated = None
+    emu_arg = args.emulate_comm if args.emulate_comm is not None else ("" if args.small else "2,4,8")
+    emu_worlds = [int(x) for x in str(emu_arg).split(",") if x.strip() not in ("", "0", "1")]
+    if world == 1 and emu_worlds and args.dtype != "f32":
+        from mic_amd.train import allreduce_ms
+
+        emulated = {"note": "1-GPU step with every bucket's all-reduce replaced by a kernel holding comm_cus CUs on a CU-masked stream for the "
+                            "projected ring all-reduce time of that bucket (2 (N-1)/N x bytes over N-1 xGMI links at 64 GB/s each); optimizer "
+                            "passes wait for it as for RCCL; GEMM tile planner sized for 256 - comm_cus CUs.  A scheduling probe, NOT a scaling result",
+                    "baseline_ms_per_step": round(dt / args.steps * 1e3, 3), "worlds": {}}
+        for ew in emu_worlds:
+            etr = Trainer(model, lr_fn, seed=42, grad_comm_dtype=comm_arg, emulate_comm=ew, **tkw)
+            esteps = max(2, min(args.steps, 6))
+            for i in range(2):
+                etr.train_step(dbatches[i % 2])
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(esteps):
+                etr.train_step(dbatches[i % 2])
+            barrier()
+            edt = (time.perf_counter() - t0) / esteps
+            cb = 2 if etr.grad_comm_dtype is not None else 4
+            emulated["worlds"][str(ew)] = {"ms_per_step": round(edt * 1e3, 3), "images_per_sec_per_gpu": round(B / edt, 1),
+                                           "comm_dtype": "bf16" if cb == 2 else "fp32", "comm_cus": etr.comm_cus,
+                                           "projected_allreduce_ms_per_step": round(etr.reducer.emulated_ms, 2),
+                                           "projected_allreduce_ms_fp32": round(allreduce_ms(4.0 * model.store.numel, ew), 2)}
+            del etr
+        ops.set_cu_budget(0)
+
     if rank == 0:
         note(f"{images_per_sec:.1f} images/s; roofline step")
     roofline = None
@@ -535,7 +584,7 @@ def main():
         eng = model.engine
         overlap, eng.dw_overlap = eng.dw_overlap, False
         opt_overlap, on_ready = tr.overlap_optimizer, tr.reducer.on_ready
-        if world == 1 and not tr.sharded:
+        if world == 1:
             tr.overlap_optimizer, tr.reducer.on_ready = False, None
         # an un-instrumented step goes first WITHOUT a sync in between: the host then issues the instrumented step while the GPU
         # is still busy, so no event pair contains the host's issue time of its kernel (two event records + a ctypes launch cost
@@ -648,8 +697,9 @@ def main():
             "config": {"workload": ("configs[4]" if args.dtype == "fp8" else "configs[1]") + ": ViT-B/32 + mBART-large-50 train step (fwd+loss+bwd+all-reduce+AdamW), "
                                    f"per-GPU batch {B}, 224x224 NHWC fp32 pixels, seq_len {T}, dropout 0.1" + (" [SMALL DEBUG MODEL]" if args.small else "")
                                    + (" [ALL RANKS SHARE cuda:0 OVER gloo: functional check, not a benchmark]" if share and world > 1 else ""),
-                       "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}" + ("+sharded-optimizer" if args.sharded_optimizer else ""),
-                       "grad_allreduce": f"{args.grad_comm} flat buckets, RCCL, side stream",
+                       "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}",
+                       "grad_allreduce": (f"{'bf16' if tr.grad_comm_dtype is not None else 'fp32'} flat buckets (--grad-comm {args.grad_comm}), RCCL, side stream, "
+                                          f"{len(tr.buckets)} buckets <= 128 MB" + (f", GEMM tile planner sized for {256 - tr.comm_cus} CUs" if world > 1 and tr.comm_cus else "")),
                        "optimizer": ("AdamW per gradient bucket behind backward" + (f", on a stream masked to {os.environ.get('MIC_OPT_CUS', '96')} CUs" if tr.reducer.step_stream is not None else "")
                                      + ("; tied embedding updated in two row passes (rows without / with sparse gradient)" if tr._split_shared else "")) if tr.overlap_optimizer else "AdamW, one launch after backward",
                        "decoder_rows": ("valid caption positions only (packed rows: padded positions neither carry loss nor are attended to — exact; "
@@ -663,6 +713,7 @@ def main():
                                  "by the same time (NOT executed work); dense_captions is the measured step when every position carries loss",
             "dense_equivalent_tflops_per_gpu": round(dense_flops * args.steps / dt / 1e12, 1),
             "dense_captions": dense,
+            "comm_emulated": emulated,
             "final_loss": round(loss, 4),
             "roofline": roofline, "cpu_baseline": cpu, "beam4_generate": gen,
         }

@@ -122,6 +122,18 @@ int mic_sum_slabs(int dst_dtype, int n_slabs, long long slab_stride, int rows, i
 /* `count` GEMMs that share dtype and operand layouts in as few launches as possible (one launch per 8 problems):
  * the weight-gradient GEMMs of a layer have 36..256 output tiles each — grouped they fill the 256 CUs. */
 int mic_gemm_grouped(const mic_gemm_args* args, int count, void* stream);
+/* The CU budget of the GEMM tile planner: how many of the device's CUs a launch may count on (0 = default: the device's 256, or
+ * MIC_FREE_CUS from the environment).  The planner sizes "one round" launches (one 16-wave block with two / four K-groups per CU)
+ * and persistent grids for this number; a data-parallel job lowers it by the CUs its collectives occupy — the reference's
+ * `lax.pmean` (main.py:698) is scheduled by XLA inside the step, here RCCL's channel blocks sit on CUs of their own beside backward —
+ * so that a launch sized for 256 free CUs re-plans instead of spilling a few blocks into a second round.  Process-wide. */
+int mic_set_cu_budget(int cus);
+int mic_get_cu_budget(void);
+/* What mic_gemm_grouped would launch for these problems under the current CU budget (host arithmetic only, nothing is launched;
+ * pointers in `args` are not dereferenced): tile edge (256 / 128 / 64), K-groups per block, logical blocks, launched grid
+ * (persistent launches: the budget), blocks of this configuration that fit one CU, and whether the LDS-DMA phased kernel is taken. */
+typedef struct { int tile, kgroups, blocks, grid, blocks_per_cu, phased, cu_budget; } mic_gemm_plan_info;
+int mic_gemm_plan(const mic_gemm_args* args, int count, mic_gemm_plan_info* out);
 /* Operands of a LayerNorm-folded Linear (see mic_gemm_args.a_ln_stats): for w [N][K] (the compute-dtype weight), gamma / beta
  * fp32 [K], bias fp32 [N] or NULL:  w_fold[n][k] = round(w[n][k] * gamma[k]),  colsum[n] = sum_k w_fold[n][k] (of the ROUNDED
  * values: the epilogue subtracts exactly what the MFMAs added),  bias_fold[n] = bias[n] + sum_k w[n][k] beta[k]. */
@@ -279,6 +291,12 @@ int mic_zero(void* p, int64_t bytes, void* stream);
  * CUs beside backward. */
 int mic_stream_create_cu_masked(int first_cu, int n_cus, void** stream);
 int mic_stream_destroy(void* stream);
+/* Stand-in for a collective on ONE GPU (bench.py --emulate-comm; never part of a real data-parallel step): a kernel of `blocks`
+ * workgroups that copies `bytes` from src to dst twice (the HBM traffic of a ring all-reduce's local reads and writes) and then
+ * holds its CUs until `micros` microseconds have passed since it started (bounded: <= 200 000).  Launched on a CU-masked stream it
+ * occupies the CUs and the time an RCCL all-reduce of that bucket is projected to take (main.py:698 `lax.pmean`), so the step's
+ * scheduling against a busy collective stream can be measured without a second GPU. */
+int mic_comm_emulate(const void* src, void* dst, int64_t bytes, float micros, int blocks, void* stream);
 /* row gather/scatter: dst[dst_idx ? dst_idx[i] : i] = src[src_idx ? src_idx[i] : i], i < n.  Used to run the LM head and
  * the cross-entropy only on the label positions whose loss mask is 1 (main.py:678: masked positions contribute exactly 0). */
 int mic_copy_rows(int dtype, int n, int width, const void* src, int ld_src, const int32_t* src_idx, void* dst, int ld_dst,

@@ -56,6 +56,11 @@ class BeamStepArgs(C.Structure):
     ]
 
 
+class GemmPlanInfo(C.Structure):
+    _fields_ = [("tile", C.c_int), ("kgroups", C.c_int), ("blocks", C.c_int), ("grid", C.c_int), ("blocks_per_cu", C.c_int),
+                ("phased", C.c_int), ("cu_budget", C.c_int)]
+
+
 class ImageItem(C.Structure):
     _fields_ = [("src", C.c_void_p), ("H", C.c_int), ("W", C.c_int), ("hwc", C.c_int)]
 
@@ -66,6 +71,10 @@ _SIGS = {
     "mic_last_error": ([], C.c_char_p),
     "mic_gemm": ([C.POINTER(GemmArgs), _p], C.c_int),
     "mic_gemm_grouped": ([C.POINTER(GemmArgs), _i, _p], C.c_int),
+    "mic_set_cu_budget": ([_i], C.c_int),
+    "mic_get_cu_budget": ([], C.c_int),
+    "mic_gemm_plan": ([C.POINTER(GemmArgs), _i, C.POINTER(GemmPlanInfo)], C.c_int),
+    "mic_comm_emulate": ([_p, _p, _i64, _f, _i, _p], C.c_int),
     "mic_ln_fold_weight": ([_i, _i, _i, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p], C.c_int),
     "mic_fp8_amax": ([C.POINTER(Fp8Item), _i, _p], C.c_int),
     "mic_fp8_quantize": ([C.POINTER(Fp8Item), _i, _p], C.c_int),

@@ -498,6 +498,28 @@ extern "C" int mic_stream_destroy(void* stream) {
   return MIC_OK;
 }
 
+// ------------------------------------------------------------------ emulated collective (bench.py --emulate-comm)
+__global__ __launch_bounds__(256) void comm_emulate_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long n16, unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  for (int pass = 0; pass < 2; ++pass)
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);  // bounded by `ticks` (checked on the host side)
+}
+
+extern "C" int mic_comm_emulate(const void* src, void* dst, int64_t bytes, float micros, int blocks, void* stream) {
+  MIC_CHECK(src && dst && bytes >= 0 && blocks > 0 && blocks <= 4096, "mic_comm_emulate: bad args");
+  MIC_CHECK(micros >= 0.f && micros <= 200000.f, "mic_comm_emulate: micros=%g (0..200000)", (double)micros);
+  MIC_CHECK((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "mic_comm_emulate: 16-B aligned buffers");
+  int dev = 0, khz = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e == hipSuccess) e = hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev);
+  if (e != hipSuccess || khz <= 0) khz = 100000;  // 100 MHz constant clock on MI300-class parts
+  const unsigned long long ticks = (unsigned long long)((double)micros * 1e-3 * (double)khz);
+  hipLaunchKernelGGL(comm_emulate_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst, (long)(bytes / 16), ticks);
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}
+
 extern "C" int mic_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream) {
   MIC_CHECK(n > 0 && n < (1LL << 40), "mic_cast: bad n");
   // split into rows of <= 2^20 so the 2-D kernel's int shape holds

@@ -155,10 +155,31 @@ static bool any_rowsum_early(const mic_gemm_args* args, int count) {
     if (args[i].a_rowsum) return true;
   return false;
 }
-static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
-  LaunchTable tab;
-  tab.count = count;
-  const int f8 = args[0].dtype == MIC_FP8 ? (args[0].a_fmt == MIC_E5M2 ? 2 : 1) : 0;
+// ---- the CU budget of the tile planner.  Every threshold below that used to say "256" means "the CUs this process's GEMM blocks
+// can expect to get": a launch is "one round" when its blocks fit the budget at the configuration's residency.  Default = the
+// device (256 on MI355X); a data-parallel job whose collectives occupy CUs (RCCL's channels are persistent blocks, one CU each)
+// lowers it — `mic_set_cu_budget`, or MIC_FREE_CUS in the environment — so that a launch sized for 256 free CUs re-plans
+// (fewer K-groups, i.e. more blocks per CU) instead of spilling a few blocks into a second round.
+static int g_cu_budget = 0;
+int mic_cu_budget_now() {
+  static const int env = [] { const char* e = getenv("MIC_FREE_CUS"); return e ? atoi(e) : 0; }();
+  int c = g_cu_budget > 0 ? g_cu_budget : (env > 0 ? env : 256);
+  c = c < 8 ? 8 : (c > 256 ? 256 : c);
+  return c & ~7;  // whole CUs per XCD: persistent grids are multiples of 8
+}
+extern "C" int mic_set_cu_budget(int cus) {
+  MIC_CHECK(cus == 0 || (cus >= 8 && cus <= 1024), "mic_set_cu_budget: %d (0 = default, else 8..1024)", cus);
+  g_cu_budget = cus;
+  return MIC_OK;
+}
+extern "C" int mic_get_cu_budget(void) { return mic_cu_budget_now(); }
+
+struct GemmPlan { int bm, kgroups, blocks, grid, per_cu, phased; };
+
+// tile configuration of one (grouped) bf16 / fp8 launch: pure host arithmetic on the shapes and the CU budget
+static GemmPlan plan_bf16(const mic_gemm_args* args, int count) {
+  const int cus = mic_cu_budget_now();
+  GemmPlan pl{};
   long tiles_big = 0, tiles_small = 0;
   for (int i = 0; i < count; ++i) {
     const int sp = args[i].split_k > 1 ? args[i].split_k : 1;
@@ -170,10 +191,71 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
   // several blocks per CU.  MIC_GEMM_TILE=256|128|64 forces a configuration (benchmarking).
   static const int force = [] { const char* e = getenv("MIC_GEMM_TILE"); return e ? atoi(e) : 0; }();
   static const int tiny_below = [] { const char* e = getenv("MIC_TINY_BELOW"); return e ? atoi(e) : MIC_TINY_BELOW; }();
-  int bm = tiles_big >= 200 ? 256 : (tiles_small < tiny_below ? 64 : 128);
+  int bm = tiles_big >= (200L * cus) / 256 ? 256 : (tiles_small < ((long)tiny_below * cus) / 256 ? 64 : 128);
+  // ... and a 256x256 launch that fills the CUs 1.1 times costs two rounds.  Under a reduced CU budget (the defaults for all 256
+  // CUs were tuned by measurement and stay as they are; MIC_GEMM_QUANT=1 applies the rule there too) compare the longest per-CU
+  // tile queue of both configurations: a 128x128 tile costs ~0.31 of a 256x256 one in CU time (a quarter of the work at ~0.8 of
+  // the efficiency).
+  static const int quant_env = [] { const char* e = getenv("MIC_GEMM_QUANT"); return e ? atoi(e) : 0; }();
+  if (bm == 256 && (cus < 256 || quant_env)) {
+    const double c256 = (double)((tiles_big + cus - 1) / cus), c128 = 0.3125 * (double)((tiles_small + cus - 1) / cus);
+    if (c128 < c256) bm = 128;
+  }
   if (force == 256 || force == 128 || force == 64) bm = force;
   for (int i = 0; i < count; ++i)
     if (args[i].rowstat) bm = 256;  // softmax partials per 64-column granule = the wave tile width of this configuration
+  int blocks = 0, kmin = 1 << 30;
+  for (int i = 0; i < count; ++i) {
+    int nsplit = args[i].split_k > 1 ? args[i].split_k : 1;
+    const int kt = (args[i].dtype == MIC_FP8 ? args[i].K / 2 : args[i].K) / 64;
+    if (nsplit > kt) nsplit = kt;
+    if (nsplit < 1) nsplit = 1;
+    blocks += ((args[i].M + bm - 1) / bm) * ((args[i].N + bm - 1) / bm) * nsplit;
+    kmin = kt / nsplit < kmin ? kt / nsplit : kmin;
+  }
+  pl.bm = bm; pl.blocks = pl.grid = blocks; pl.kgroups = 1; pl.per_cu = 1;
+  // LDS-DMA four-phase 256x256 kernel for the single-problem NT launches (both operands k-contiguous: LM-head forward, FFN-in
+  // forward), where its deeper operand prefetch wins; MIC_GEMM_PHASED=0 switches it off (A/B).  On every 256x256 launch it
+  // measured +1.6 ms per train step (DESIGN.md): that mode is gone.
+  static const int phased_env = [] { const char* e = getenv("MIC_GEMM_PHASED"); return e ? atoi(e) : 2; }();
+  const bool f8 = args[0].dtype == MIC_FP8;
+  pl.phased = bm == 256 && !f8 && phased_env != 0 && !args[0].a_kmajor && !args[0].b_kmajor && count == 1 && !any_rowsum_early(args, count);
+  if (bm == 256) {
+    pl.per_cu = 1;  // 128 KiB of LDS: a block holds its CU alone; PLAIN launches with more tiles than CUs run as `cus` persistent blocks
+  } else if (bm == 128) {
+    // 8 waves (measured better than the 4-wave 64x64 wave tile at every tile count), two blocks per CU; two K-groups (16 waves, one
+    // block per CU) when the launch is a single round of at most one block per CU
+    static const int kg128 = [] { const char* e = getenv("MIC_GEMM_KG128"); return e ? atoi(e) : -1; }();
+    const bool two = kg128 >= 0 ? kg128 == 2 : (blocks <= cus && kmin >= 8);
+    pl.kgroups = two ? 2 : 1;
+    pl.per_cu = two ? 1 : 2;
+  } else {  // 64x64x64 tiles, 4 waves per K-group (32 KiB of LDS each); K-groups while the grid leaves CUs under-occupied
+    static const int kg_force = [] { const char* e = getenv("MIC_GEMM_KG"); return e ? atoi(e) : 0; }();
+    int kgs = blocks <= cus && kmin >= 16 ? 4 : (blocks <= 2 * cus && kmin >= 8 ? 2 : 1);
+    if (kg_force == 1 || kg_force == 2 || kg_force == 4) kgs = kg_force;
+    pl.kgroups = kgs;
+    pl.per_cu = 4 / kgs;
+  }
+  return pl;
+}
+
+extern "C" int mic_gemm_plan(const mic_gemm_args* args, int count, mic_gemm_plan_info* out) {
+  MIC_CHECK(args && out && count >= 1 && count <= MAX_PROBLEMS, "mic_gemm_plan: bad args (1..%d problems)", MAX_PROBLEMS);
+  MIC_CHECK(args[0].dtype == MIC_BF16 || args[0].dtype == MIC_FP8, "mic_gemm_plan: the planner belongs to the bf16 / fp8 kernels");
+  const GemmPlan pl = plan_bf16(args, count);
+  out->tile = pl.bm; out->kgroups = pl.kgroups; out->blocks = pl.blocks; out->blocks_per_cu = pl.per_cu; out->phased = pl.phased;
+  out->cu_budget = mic_cu_budget_now();
+  const bool persist = pl.bm == 256 && !pl.phased && pl.blocks > out->cu_budget;  // (the PLAIN instantiations only: an upper bound on the grid otherwise)
+  out->grid = persist ? out->cu_budget : pl.blocks;
+  return MIC_OK;
+}
+
+static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
+  LaunchTable tab;
+  tab.count = count;
+  const int f8 = args[0].dtype == MIC_FP8 ? (args[0].a_fmt == MIC_E5M2 ? 2 : 1) : 0;
+  const GemmPlan pl = plan_bf16(args, count);
+  const int bm = pl.bm;
   int blocks = 0;
   for (int i = 0; i < count; ++i) {
     Problem& p = tab.p[i];
@@ -207,29 +289,10 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
   tab.total_blocks = blocks;
   for (int i = 0; i < count; ++i)
     MIC_CHECK(!args[i].rowsum2 || table_is_plain(tab), "mic_gemm_grouped: rowsum2 needs every problem of the launch on the bare / residual epilogue");
-  // LDS-DMA four-phase 256x256 kernel for the single-problem NT launches (both operands k-contiguous: LM-head forward, FFN-in
-  // forward), where its deeper operand prefetch wins; MIC_GEMM_PHASED=0 switches it off (A/B).  On every 256x256 launch it
-  // measured +1.6 ms per train step (DESIGN.md): that mode is gone.
-  static const int phased_env = [] { const char* e = getenv("MIC_GEMM_PHASED"); return e ? atoi(e) : 2; }();
-  const bool phased = phased_env != 0 && !args[0].a_kmajor && !args[0].b_kmajor && count == 1 && !any_rowsum_early(args, count);
-  if (bm == 256 && f8 == 0 && phased) launch_gemm_phased(tab, args[0].a_kmajor, args[0].b_kmajor, table_is_plain(tab), s);  // LDS-DMA, phased
+  if (bm == 256 && pl.phased) launch_gemm_phased(tab, args[0].a_kmajor, args[0].b_kmajor, table_is_plain(tab), s);  // LDS-DMA, phased
   else if (bm == 256) launch_gemm_t256(tab, args[0].a_kmajor, args[0].b_kmajor, s, f8);     // 256x256x64, 8 waves
-  else if (bm == 128) {  // 128x128x64, 8 waves (measured better than the 4-wave 64x64 wave tile at every tile count);
-                         // two K-groups (16 waves) when the launch is a single round of at most one block per CU
-    static const int kg128 = [] { const char* e = getenv("MIC_GEMM_KG128"); return e ? atoi(e) : -1; }();
-    int kmin = 1 << 30;
-    for (int i = 0; i < count; ++i) kmin = tab.p[i].K / 64 / tab.p[i].nsplit < kmin ? tab.p[i].K / 64 / tab.p[i].nsplit : kmin;
-    const bool two = kg128 >= 0 ? kg128 == 2 : (blocks <= 256 && kmin >= 8);
-    launch_gemm_t128(tab, args[0].a_kmajor, args[0].b_kmajor, s, f8, two ? 2 : 1);
-  }
-  else {  // 64x64x64 tiles, 4 waves per K-group; K-groups while the grid leaves CUs under-occupied
-    static const int kg_force = [] { const char* e = getenv("MIC_GEMM_KG"); return e ? atoi(e) : 0; }();
-    int kmin = 1 << 30;
-    for (int i = 0; i < count; ++i) kmin = tab.p[i].K / 64 / tab.p[i].nsplit < kmin ? tab.p[i].K / 64 / tab.p[i].nsplit : kmin;
-    int kgs = blocks <= 256 && kmin >= 16 ? 4 : (blocks <= 512 && kmin >= 8 ? 2 : 1);
-    if (kg_force == 1 || kg_force == 2 || kg_force == 4) kgs = kg_force;
-    launch_gemm_t64(tab, args[0].a_kmajor, args[0].b_kmajor, s, f8, kgs);
-  }
+  else if (bm == 128) launch_gemm_t128(tab, args[0].a_kmajor, args[0].b_kmajor, s, f8, pl.kgroups);  // 128x128x64, 8 waves per K-group
+  else launch_gemm_t64(tab, args[0].a_kmajor, args[0].b_kmajor, s, f8, pl.kgroups);                  // 64x64x64, 4 waves per K-group
   MIC_LAUNCH_CHECK();
   return MIC_OK;
 }

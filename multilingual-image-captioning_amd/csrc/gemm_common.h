@@ -20,6 +20,8 @@ struct Problem {
   EpiArgs epi;
 };
 struct LaunchTable { int count; int total_blocks; Problem p[MAX_PROBLEMS]; };
+// CUs the planner sizes one-round launches and persistent grids for (gemm.hip: mic_set_cu_budget / MIC_FREE_CUS; multiple of 8)
+int mic_cu_budget_now();
 // gemm_phased.hip: 256x256 tiles, LDS-DMA operands, four-phase K-tile schedule (bf16 operands, no K-groups)
 void launch_gemm_phased(const LaunchTable& tab, int akm, int bkm, bool plain, hipStream_t s);
 // one translation unit per tile configuration of the main kernel (gemm_kernel.h): 256x256 / 128x128 (K-groups 1, 2) / 64x64 (1, 2, 4)

@@ -318,10 +318,11 @@ static inline void launch_cfg_p(const LaunchTable& tab, int akm, int bkm, hipStr
   const size_t red = (size_t)(KG - 1) * 2 * WNW * (WM / 32) * (WN / 32) * 16 * 64 * 4;  // K-group partial sums
   if (epi > lds) lds = epi;
   if (red > lds) lds = red;
-  // 256x256 tiles hold a CU alone (128 KiB LDS): launches with more tiles than CUs run as 256 persistent blocks
+  // 256x256 tiles hold a CU alone (128 KiB LDS): launches with more tiles than (free) CUs run as that many persistent blocks
   static const int persist = [] { const char* e = getenv("MIC_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
   int nblk = tab.total_blocks;
-  if (persist && BM == 256 && PLAIN && KG == 1 && nblk > 256) nblk = 256;
+  const int cus = mic_cu_budget_now();  // a multiple of 8 (the XCD remap of a persistent grid needs that)
+  if (persist && BM == 256 && PLAIN && KG == 1 && nblk > cus) nblk = cus;
   dim3 grid(nblk), block(128 * WNW * KG);
 #define LAUNCH(AKM, BKMM)                                                                                                  \
   do {                                                                                                                     \

@@ -61,6 +61,7 @@ class Engine:
         self._dw_stream = None
         self._dw_events = []
         self._dw_side = False  # True while launching on the dW stream
+        self._ckv_block_name = None  # set while the all-layer cross k/v weight gradient (one launch) sits in the dW queue
 
     # ------------------------------------------------------------------ fp8 GEMM operands (BASELINE configs[4])
     FP8_KINDS = ("qkv", "cq", "ckv", "fc1", "fc2")  # the QKV and FFN projections of both towers; out-projections and the head stay bf16
@@ -175,8 +176,12 @@ class Engine:
         if hit is not None and (hit[1] is not None or not want_qT):
             return hit
         rp = _rup(rows, ROWPAD)
-        q = self.buf(buf_tag + ".q8", rows, cols, fmt)
-        qT = self.buf(buf_tag + ".q8T", cols, rp, fmt) if want_qT else None
+        # sized by the CAPACITY of x (its row count is the step-independent [B*T] / [B*S] capacity), not by this step's valid rows:
+        # with packed decoder rows `rows` changes from step to step and a buffer per distinct count would never be freed.  The
+        # quantiser rewrites q[:rows] and qT[:, :rp] (zero beyond `rows`) on every call; nothing reads past them.
+        cap = max(int(x.shape[0]), rp)
+        q = self.buf(buf_tag + ".q8", cap, cols, fmt)
+        qT = self.buf(buf_tag + ".q8T", cols, cap, fmt) if want_qT else None
         slot = self._a8_slot(tag)
         st = self._a8_state[slot]
         delayed = self.fp8_scaling == "delayed"
@@ -375,8 +380,14 @@ class Engine:
             ops.gemm_grouped([q[0] for q in self._dw_queue])
             names += [q[1] for q in self._dw_queue]
             self._dw_queue = []
+        # every queued gradient of the layer is in flight on this stream: report the one that sits last in the flat layout.  The
+        # cross-attention k/v weights of ALL layers form one block behind decoder layer 0 (ParamStore.ckv_cat): a per-layer k/v
+        # gradient (fp8 GEMMs / MIC_CKV_HOIST=0) must not count here — its offset lies behind every decoder layer, reporting it at
+        # layer L-1 would declare the gradients of layers L-2 .. 0 final before their GEMMs have run.  The hoisted launch queues the
+        # whole block under the name of its LAST member at the end of decoder backward; the per-layer path reports the block once,
+        # after layer 0 (decoder_backward).
+        names = [n for n in names if not n.endswith(".ckv") or n == self._ckv_block_name]
         if names:
-            # every queued gradient of the layer is in flight on this stream: report the one that sits last in the flat layout
             self._done(max(names, key=lambda n: self.P.segs[n + ".w"].offset) + ".w")
 
     # ------------------------------------------------------------------ ViT
@@ -710,7 +721,14 @@ class Engine:
             self._dw_queue.append((ops.gemm_args(dkvcat, ehs, gw, N, d, Mvp, a_kmajor=True, b_kmajor=True, **rs), f"dec{P.L - 1}.ckv", True))
             if not fuse:
                 self._cs_queue.append((dkvcat, gb, Mv, N, dkvcat.stride(0)))
-            self.flush_dw()
+            self._ckv_block_name = f"dec{P.L - 1}.ckv"
+            try:
+                self.flush_dw()
+            finally:
+                self._ckv_block_name = None
+        else:
+            # per-layer k/v projections: every layer's dW GEMM (and the dX GEMMs that read these weights) has been issued by now
+            self._done(f"dec{P.L - 1}.ckv.w")
         # embedding LayerNorm (+ its dropout) and the token/position embedding scatter
         h0 = self.buf("d.h0", Mcap, d)
         ste = self.buf("d.emb.stats", 2, _rup(Mcap, ROWPAD), torch.float32)
@@ -799,12 +817,13 @@ class Engine:
         return pack
 
     def ones_i32(self, n: int):
-        key = f"ones_i32:{n}"
-        t = self._bufs.get(key)
-        if t is None:
-            t = torch.ones(max(n, 1), dtype=torch.int32, device=self.dev)
-            self._bufs[key] = t
-        return t
+        """int32 ones [n] (the loss mask of the compacted rows): one buffer that only ever grows — the row count changes from step to
+        step, a buffer per distinct count would accumulate"""
+        t = self._bufs.get("ones_i32")
+        if t is None or t.numel() < n:
+            t = torch.ones(max(_rup(max(n, 1), 4096), 2 * (t.numel() if t is not None else 0)), dtype=torch.int32, device=self.dev)
+            self._bufs["ones_i32"] = t
+        return t[:n]
 
     def loss_and_grads(self, pixels, ids, pos_ids, key_mask, labels, B, T, *, label_smoothing=0.0, seed=None, rows=None,
                        row_labels=None, pack=None):

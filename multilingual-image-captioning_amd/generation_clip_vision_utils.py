@@ -62,9 +62,15 @@ class _DecodePlan:
         self._events_now = []
 
     def __del__(self):
-        # see _RETIRED_GRAPHS: the graphs (and the events recorded into them) outlive the plan
+        # see _RETIRED_GRAPHS: multi-branch graphs (a sliced beam search: `streams` is non-empty) and the events recorded into them
+        # outlive the plan; single-chain graphs are destroyed with it (a server cycling through plans must not accumulate them)
         try:
-            _RETIRED_GRAPHS.extend((g, self.graph_events.get(k)) for k, g in self.graphs.items())
+            if self.streams:
+                _RETIRED_GRAPHS.extend((g, self.graph_events.get(k)) for k, g in self.graphs.items())
+                if len(_RETIRED_GRAPHS) % 256 == 0:
+                    import sys
+
+                    print(f"[mic_amd.generate] {len(_RETIRED_GRAPHS)} retired multi-branch decode graphs are parked (ROCm 7.2 workaround)", file=sys.stderr)
             self.graphs.clear()
         except Exception:  # interpreter shutdown
             pass
@@ -303,8 +309,12 @@ class FlaxCLIPVisionMBartGenerationMixin:
 
     # ------------------------------------------------------------------ gen:665-990
     def _decode_slices(self, B: int, K: int) -> int:
-        """Number of independent image slices a beam search is cut into.  Images never interact in beam search (gen:665-990 is
-        vmapped over the batch), and a decoder step is a chain of ~110 dependent launches most of which leave the chip idle
+        """Number of independent image slices a beam search is cut into (opt-in experiment, default 1 = off).  Images do not interact
+        inside a beam-search step, but the reference's STOP test is global over the batch (`beam_search_cond_fn`, gen:798-820:
+        `jnp.all(...)` over every image) — one image that can still improve keeps all of them stepping.  Each slice evaluates that
+        test over its own images only, so with n > 1 a slice may stop earlier than the reference would have stopped it and its
+        sequences / scores can differ from the unsliced search; the default therefore stays at 1.  A decoder step is a chain of ~110
+        dependent launches most of which leave the chip idle
         (one 64x64 tile per CU, latency-bound) or use one resource only (decode attention: HBM; GEMMs: MFMA + LDS).  Slices run
         the same chain on their own streams — as parallel branches of the step's hipGraph — so one slice's latency chain and
         HBM-bound kernels overlap another's.  MIC_DECODE_SLICES=n forces n (1 = off)."""

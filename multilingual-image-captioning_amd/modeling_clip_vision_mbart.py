@@ -98,7 +98,6 @@ class FlaxCLIPVisionMBartPreTrainedModel(FlaxCLIPVisionMBartGenerationMixin):
         self.engine.on_free.append(lambda: me() is not None and me().release_decode_plans())
         self._required_params = set(tuple(k.split("/")) for k in self.store.flax_shapes())  # utils:78
         self._params_cache = None
-        self._state_sync = None  # set by a Trainer with a sharded optimizer: all-gathers the master weights before an export
         if _do_init:
             self.store.init_random(seed, float(config.mbart_config.init_std))
 
@@ -115,8 +114,6 @@ class FlaxCLIPVisionMBartPreTrainedModel(FlaxCLIPVisionMBartGenerationMixin):
     def params(self) -> Dict[str, Any]:
         """The reference's nested parameter pytree (numpy leaves, Flax layouts), exported from the device buffers."""
         if self._params_cache is None:
-            if self._state_sync is not None:
-                self._state_sync()
             self._params_cache = unflatten_tree(self.store.export_flat("master"))
         return self._params_cache
 
@@ -155,8 +152,6 @@ class FlaxCLIPVisionMBartPreTrainedModel(FlaxCLIPVisionMBartGenerationMixin):
         self.config.save_pretrained(save_directory)
         from .checkpoint import save_flax_msgpack
 
-        if params is None and self._state_sync is not None:
-            self._state_sync()
         flat = flatten_tree(params) if params is not None else self.store.export_flat("master")
         save_flax_msgpack(os.path.join(save_directory, "flax_model.msgpack"), unflatten_tree(flat))
 

@@ -104,6 +104,32 @@ def gemm_grouped(arg_list):
     L.check(L.lib().mic_gemm_grouped(arr, len(arg_list), _stream()), "mic_gemm_grouped")
 
 
+def set_cu_budget(cus: int) -> None:
+    """CUs the GEMM tile planner may count on (0 = default: all 256, or MIC_FREE_CUS); see mic_set_cu_budget"""
+    L.check(L.lib().mic_set_cu_budget(int(cus)), "mic_set_cu_budget")
+
+
+def get_cu_budget() -> int:
+    return int(L.lib().mic_get_cu_budget())
+
+
+def gemm_plan(shapes, *, a_kmajor=False, b_kmajor=False, split_k=0, dtype=None) -> dict:
+    """What the planner would launch for the problems [(M, N, K), ...] of one grouped bf16 launch under the current CU budget
+    (host arithmetic; nothing runs and no device memory is needed)."""
+    arr = (L.GemmArgs * len(shapes))()
+    for g, (M, N, K) in zip(arr, shapes):
+        g.dtype = g.c_dtype = L.MIC_BF16 if dtype is None else dtype
+        g.M, g.N, g.K, g.a_kmajor, g.b_kmajor, g.split_k = M, N, K, int(a_kmajor), int(b_kmajor), int(split_k)
+    out = L.GemmPlanInfo()
+    L.check(L.lib().mic_gemm_plan(arr, len(shapes), C.byref(out)), "mic_gemm_plan")
+    return {k: getattr(out, k) for k, _ in L.GemmPlanInfo._fields_}
+
+
+def comm_emulate(src: torch.Tensor, dst: torch.Tensor, nbytes: int, micros: float, blocks: int):
+    """bench.py --emulate-comm: occupy the current (CU-masked) stream like an all-reduce of `nbytes` projected to take `micros`"""
+    L.check(L.lib().mic_comm_emulate(_p(src), _p(dst), int(nbytes), float(micros), int(blocks), _stream()), "mic_comm_emulate")
+
+
 def ln_fold_weight(w, gamma, beta, bias, w_fold, colsum, bias_fold):
     """w [N][K] -> w_fold = round(w * gamma), colsum[n] = sum_k w_fold[n][k], bias_fold = bias + w . beta (see gemm_args ln_*)"""
     N, K = w.shape

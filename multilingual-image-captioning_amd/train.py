@@ -77,25 +77,48 @@ def packed_rows(attention_mask, decoder_input_ids):
     return off, ln, ids, pos
 
 
-def plan_buckets(numel: int, bucket_elems: int, boundaries: List[int], granule: int = 1) -> List[Tuple[int, int]]:
+def plan_buckets(numel: int, bucket_elems: int, boundaries: List[int], max_elems: int = 0,
+                 splittable: Tuple[Tuple[int, int, int], ...] = ()) -> List[Tuple[int, int]]:
     """Contiguous [begin, end) slices of the flat gradient buffer, cut at segment boundaries, each >= bucket_elems
-    (except the last).  `granule` > 1 (sharded optimizer: world * 64) rounds every interior cut DOWN to a multiple of it,
-    so each bucket splits evenly over the ranks; a bucket is still complete once backward has passed the segment boundary
-    the cut was derived from.  Pure host logic (tested on CPU)."""
+    (except the last).  `max_elems` > 0: a slice larger than that is cut further, but only INSIDE the segments listed in
+    `splittable` ((begin, end, align): cuts at begin + k * step, step = the largest multiple of `align` <= max_elems) — the tied
+    embedding is ONE segment of 256 M elements (1 GB in fp32): whole, its optimizer pass could not start before the last byte of
+    its all-reduce had arrived.  Pure host logic (tested on CPU)."""
     cuts, start = [], 0
     for b in sorted(set(boundaries)):
-        c = (b // granule) * granule
-        if c - start >= bucket_elems and c < numel:
-            cuts.append((start, c))
-            start = c
+        if b - start >= bucket_elems and b < numel:
+            cuts.append((start, b))
+            start = b
     cuts.append((start, numel))
-    return cuts
+    if max_elems <= 0:
+        return cuts
+    out = []
+    for (b, e) in cuts:
+        pts = set()
+        if e - b > max_elems:
+            for (sb, se, align) in splittable:
+                step = max(align, (max_elems // align) * align)
+                x = sb + step
+                while x < min(e, se):
+                    if x > b:
+                        pts.add(x)
+                    x += step
+        edges = [b] + sorted(pts) + [e]
+        out += [(edges[i], edges[i + 1]) for i in range(len(edges) - 1)]
+    return out
 
 
-def bucket_plan(store, bucket_mb: float = 64.0, world: int = 1, sharded: bool = False) -> List[Tuple[int, int]]:
-    """the gradient-exchange buckets of a ParamStore layout (a store built with allocate=False is enough)"""
+MAX_BUCKET_MB = 128.0  # largest piece of the tied embedding that goes on the wire as one collective
+
+
+def bucket_plan(store, bucket_mb: float = 64.0, max_mb: float = MAX_BUCKET_MB) -> List[Tuple[int, int]]:
+    """the gradient-exchange buckets of a ParamStore layout (a store built with allocate=False is enough): >= bucket_mb each, cut
+    at segment boundaries in the order backward completes them; the tied embedding in pieces of <= max_mb (whole rows)"""
     bounds = [s.offset for s in store.segs.values()]
-    return plan_buckets(store.numel, int(bucket_mb * 1024 * 1024 / 4), bounds, granule=world * 64 if sharded else 1)
+    sh = store.segs["shared"]
+    split = ((sh.offset, sh.offset + sh.numel, store.d),) if sh.numel % store.d == 0 else ()
+    return plan_buckets(store.numel, int(bucket_mb * 1024 * 1024 / 4), bounds, max_elems=int(max(max_mb, bucket_mb) * 1024 * 1024 / 4),
+                        splittable=split)
 
 
 def describe_buckets(store, buckets: List[Tuple[int, int]], comm_bytes: int = 4) -> List[Dict]:
@@ -110,32 +133,54 @@ def describe_buckets(store, buckets: List[Tuple[int, int]], comm_bytes: int = 4)
     return out
 
 
+# ---- what the gradient exchange costs, from byte counts (no N > 1 hardware has been available to measure it)
+XGMI_LINK_GBPS = 64.0      # per direction and peer link, what a ring gets out of one xGMI link (7 links x ~153 GB/s bidirectional per GPU)
+BACKWARD_WINDOW_MS = 13.0  # backward of the batch-64 step: the time the exchange can hide under (profiles/README.md)
+COMM_CUS_DEFAULT = 32      # CUs the collectives are assumed to occupy while backward runs (RCCL: one persistent block per channel)
+
+
+def allreduce_ms(nbytes: float, world: int, link_gbps: float = XGMI_LINK_GBPS) -> float:
+    """ring all-reduce of `nbytes` per rank over the world-1 xGMI links of a GPU: every rank sends and receives 2 (world-1)/world
+    of its bytes, spread over world-1 links"""
+    if world <= 1:
+        return 0.0
+    return 2.0 * (world - 1) / world * nbytes / ((world - 1) * link_gbps * 1e9) * 1e3
+
+
+def choose_comm_dtype(world: int, numel: int, window_ms: float = BACKWARD_WINDOW_MS) -> Optional[torch.dtype]:
+    """`grad_comm_dtype="auto"`: fp32 — the reference's `lax.pmean` of fp32 gradients (main.py:698) — wherever the projected fp32
+    exchange fits under backward, bf16 where it would not (the step would be communication-bound; a bf16 sum changes pmean's
+    arithmetic by one rounding per rank and element, tests/test_ddp_gpu.py).  By the byte counts of the 547 M-parameter model:
+    N = 2: 34 ms, N = 4: 17 ms -> bf16 (17 / 8.5 ms); N = 8: 8.5 ms -> fp32."""
+    if world <= 1 or allreduce_ms(4.0 * numel, world) <= window_ms:
+        return None
+    return torch.bfloat16
+
+
 class GradReducer:
-    """Bucketed all-reduce(mean) of the flat gradient buffer on a side stream (C1 of SURVEY §2.3), optionally followed —
-    still on the side stream — by a per-bucket callback (the fused AdamW of that slice): HBM-bound optimizer traffic then
-    overlaps the MFMA-bound remainder of backward instead of trailing it.
+    """Bucketed all-reduce(mean) of the flat gradient buffer on a side stream (C1 of SURVEY §2.3), followed — on a third stream —
+    by a per-bucket callback (the fused AdamW of that slice): HBM-bound optimizer traffic then overlaps the MFMA-bound remainder
+    of backward instead of trailing it.
 
-    sharded=True (ZeRO-1 style, same arithmetic): every bucket is REDUCE-SCATTERED instead of all-reduced — rank r receives
-    the summed gradients of the r-th 1/world of the bucket in place — `on_ready` then runs on that shard only, and the
-    tensors in `gather` (the compute-dtype weights) are ALL-GATHERED back over the bucket.  Per step and rank that is
-    (world-1)/world x (4 B + 2 B) per parameter on the wire instead of 2 x 4 B, and 1/world of the optimizer traffic.  A
-    bucket tail that does not divide by world x 64 elements (only the last bucket can have one) is all-reduced and updated on
-    every rank."""
+    ONE ordering rule per bucket, `ready_when[i]`: when may the bucket's optimizer pass be issued, beyond "its exchange is done"?
+      "exchanged"  right behind the exchange (the default);
+      "next"       at the next progress report, behind everything backward has enqueued by then — a kernel issued right after
+                   the gradient became final still READS the weights (the LM head's dX GEMM reads the tied embedding);
+      "end"        in finish(), after `before()` — the gradient receives a late part (the sparse input-embedding rows).
+    """
 
-    def __init__(self, flat_grad: torch.Tensor, buckets: List[Tuple[int, int]], group=None, on_ready=None, hold=None,
-                 comm_dtype: Optional[torch.dtype] = None, sharded: bool = False, gather: Optional[List[torch.Tensor]] = None,
-                 late=None, opt_cus: int = 0, defer=None):
-        """late: called once per step in `release_held`, after `before()` and the postponed slices (the part of the optimizer
-        that needs the end of backward).  opt_cus: CUs of the optimizer stream's mask (0: no mask).  defer: (begin, end) — a bucket
-        touching this range is EXCHANGED as soon as backward reports it, but its on_ready is issued at the next progress() call,
-        behind everything the step's stream has enqueued by then: "gradient final" (the exchange may start) and "weights free" (the
-        optimizer may rewrite them) are different moments for the tied embedding, whose weights the LM head's dX GEMM still reads
-        after its weight-gradient GEMM has finished."""
+    def __init__(self, flat_grad: torch.Tensor, buckets: List[Tuple[int, int]], group=None, on_ready=None,
+                 ready_when: Optional[List[str]] = None, comm_dtype: Optional[torch.dtype] = None, opt_cus: int = 0,
+                 emulate: Optional[Dict] = None):
+        """opt_cus: CUs of the optimizer stream's mask (0: no mask).  emulate (one GPU only, bench.py --emulate-comm):
+        {"world": N, "cus": CUs of the collective stream, "comm_bytes": bytes per element on the wire} — every bucket's exchange
+        is replaced by a kernel that occupies `cus` CUs for the projected duration of that bucket's all-reduce."""
         import torch.distributed as dist
 
         self.dist, self.group = dist, group
-        self.late = late
         self.grad, self.buckets = flat_grad, buckets
+        self.ready_when = list(ready_when) if ready_when is not None else ["exchanged"] * len(buckets)
+        assert len(self.ready_when) == len(buckets) and all(w in ("exchanged", "next", "end") for w in self.ready_when)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.cuda = flat_grad.is_cuda
@@ -144,8 +189,9 @@ class GradReducer:
         # ... on CUs of its own (`opt_cus` of them; 0 = no mask): the optimizer is HBM-bound and needs few CUs, while the backward
         # GEMM blocks own a CU's whole register file and never share one — with a mask the two run side by side instead of taking
         # turns.  A CU-masked HIP stream is a BLOCKING stream (it synchronises with the null stream, torch's default): the step then
-        # runs on `step_stream`, and the slices postponed to the end of backward on the unmasked `tail_stream`.
+        # runs on `step_stream`, and the passes postponed to the end of backward on the unmasked `tail_stream`.
         self.step_stream = self.tail_stream = None
+        self.emulate = dict(emulate) if (emulate and self.cuda and self.world == 1) else None
         if self.cuda and on_ready is not None and opt_cus > 0:
             try:
                 self.opt_stream = ops.cu_masked_stream(0, opt_cus, flat_grad.device)
@@ -155,44 +201,26 @@ class GradReducer:
                 import sys
 
                 print(f"[mic_amd.GradReducer] no CU-masked optimizer stream ({ex}); using a plain stream", file=sys.stderr)
-        self.sharded = bool(sharded) and self.world > 1
-        self.on_ready = on_ready if (self.cuda or self.sharded) else None
-        self.gather = list(gather or []) if self.sharded else []
+        if self.emulate is not None:
+            # the stand-in collectives sit on the LAST `cus` bits of the CU mask (the optimizer's mask starts at bit 0)
+            cus = int(self.emulate.get("cus", COMM_CUS_DEFAULT))
+            self.stream = ops.cu_masked_stream(256 - cus, cus, flat_grad.device)
+            if self.step_stream is None:  # a masked stream is a blocking stream: keep the step off the null stream
+                self.step_stream = torch.cuda.Stream(device=flat_grad.device)
+            self._emu_scratch = torch.empty(max(e - b for b, e in buckets), dtype=flat_grad.dtype, device=flat_grad.device)
+            self.emulated_ms = 0.0
+        self.on_ready = on_ready if self.cuda else None
         self.next = 0
         self.handles = []
-        self.hold = hold  # (begin, end): buckets touching this range are reduced as usual but their on_ready is postponed
-        self.held: List[Tuple[int, int]] = []
-        self.defer = defer
-        self.deferred: List[Tuple[int, int, object]] = []
-        self.last_comm_event = None
+        self._pending: List[Tuple[int, int, object]] = []  # "next": exchange started, optimizer pass due at the next report
+        self._at_end: List[Tuple[int, int]] = []           # "end"
         # opt-in reduced-precision exchange (e.g. torch.bfloat16): every rank rounds its bucket, the collective sums in that
         # dtype, the result is widened back into the fp32 buffer.  Halves the xGMI bytes; NOT the reference's fp32 pmean.
         self.comm_dtype = comm_dtype if (comm_dtype is not None and comm_dtype != flat_grad.dtype) else None
-        if self.sharded and self.comm_dtype is not None:
-            raise ValueError("sharded optimizer: the reduce-scatter runs in the gradient dtype (grad_comm_dtype is an all-reduce option)")
         # two staging buffers used alternately: the narrowing copy of bucket k+1 does not wait for the widening copy of bucket k
         self.stage = ([torch.empty(max(e - b for b, e in buckets), dtype=self.comm_dtype, device=flat_grad.device) for _ in range(2)]
                       if self.comm_dtype is not None and self.world > 1 else None)
         self._stage_i = 0
-
-    # ---- shard geometry
-    def split(self, b: int, e: int) -> Tuple[int, int, int]:
-        """(shard_begin, shard_end, main_end): [b, main_end) divides evenly over the ranks in 64-element units, this rank owns
-        [shard_begin, shard_end); [main_end, e) is the replicated tail."""
-        if not self.sharded:
-            return b, e, e
-        unit = self.world * 64
-        main = ((e - b) // unit) * unit
-        sh = main // self.world
-        return b + self.rank * sh, b + (self.rank + 1) * sh, b + main
-
-    def owned_ranges(self, b: int, e: int) -> List[Tuple[int, int]]:
-        """slices of bucket [b, e) this rank runs the optimizer on"""
-        sb, se, me = self.split(b, e)
-        out = [(sb, se)] if se > sb else []
-        if e > me and self.sharded:
-            out.append((me, e))
-        return out if self.sharded else [(b, e)]
 
     def _all_reduce(self, b: int, e: int, async_op: bool = False):
         if self.stage is None:
@@ -204,157 +232,120 @@ class GradReducer:
         self.grad[b:e].copy_(st)
         return None
 
-    def _reduce(self, b: int, e: int):
-        """the bucket's gradient exchange on the current stream / synchronously on CPU"""
-        if not self.sharded:
-            return self._all_reduce(b, e)
-        sb, se, me = self.split(b, e)
-        if me > b:  # in place: the output is this rank's slice of the input
-            self.dist.reduce_scatter_tensor(self.grad[sb:se], self.grad[b:me], op=self.dist.ReduceOp.SUM, group=self.group)
-        if e > me:
-            self.dist.all_reduce(self.grad[me:e], op=self.dist.ReduceOp.SUM, group=self.group)
-        return None
-
-    def _gather(self, b: int, e: int):
-        sb, se, me = self.split(b, e)
-        if me > b:
-            for t in self.gather:
-                self.dist.all_gather_into_tensor(t[b:me], t[sb:se], group=self.group)
-
-    def _ready(self, b: int, e: int):
-        if self.on_ready is not None:
-            for (x, y) in self.owned_ranges(b, e):
-                self.on_ready(x, y)
+    def _emulated_exchange(self, b: int, e: int):
+        """one GPU: hold the collective stream's CUs for as long as the all-reduce of this bucket is projected to take"""
+        em = self.emulate
+        nbytes = (e - b) * int(em.get("comm_bytes", 4))
+        ms = allreduce_ms(nbytes, int(em["world"]), float(em.get("link_gbps", XGMI_LINK_GBPS)))
+        self.emulated_ms += ms
+        with ops.pinned_stream():
+            ops.comm_emulate(self.grad[b:e], self._emu_scratch[: e - b], (e - b) * self.grad.element_size(), ms * 1e3,
+                             2 * int(em.get("cus", COMM_CUS_DEFAULT)))
 
     @property
     def active(self) -> bool:
-        return self.world > 1 or self.on_ready is not None
+        return self.world > 1 or self.on_ready is not None or self.emulate is not None
 
     def start_step(self):
         self.next = 0
         self.handles = []
-        self.held = []
-        self.deferred = []
-        self.last_comm_event = None
+        self._pending = []
+        self._at_end = []
+        if self.emulate is not None:
+            self.emulated_ms = 0.0
 
-    def _flush_deferred(self):
-        """issue the on_ready of the buckets whose exchange was started at the previous progress() call"""
-        if not self.deferred:
+    def _issue(self, b: int, e: int, ev, here=None):
+        """the bucket's optimizer pass on the optimizer stream, behind its exchange (`ev`) and, for "next" buckets, behind
+        everything the step's stream had enqueued at the report that released them (`here`)"""
+        with torch.cuda.stream(self.opt_stream):
+            self.opt_stream.wait_event(ev)
+            if here is not None:
+                self.opt_stream.wait_event(here)
+            with ops.pinned_stream():  # launch on that stream, not on the step's pinned main stream
+                self.on_ready(b, e)
+
+    def _issue_pending(self):
+        if not self._pending:
             return
         here = torch.cuda.Event()
         here.record(torch.cuda.current_stream())
-        for (b, e, ev) in self.deferred:
-            with torch.cuda.stream(self.opt_stream):
-                self.opt_stream.wait_event(ev)    # the bucket's exchange (world 1: its last gradient kernel)
-                self.opt_stream.wait_event(here)  # ... and every reader of its weights that backward has issued since
-                with ops.pinned_stream():
-                    self._ready(b, e)
-            self._after_ready_gather([(b, e)])
-        self.deferred = []
-
-    def _after_ready_gather(self, items: List[Tuple[int, int]]):
-        """sharded: all-gather the refreshed weights of `items` on the collective stream, behind the optimizer stream"""
-        if not (self.sharded and self.gather and items):
-            return
-        ev = torch.cuda.Event()
-        ev.record(self.opt_stream)
-        with torch.cuda.stream(self.stream):
-            self.stream.wait_event(ev)
-            for (b, e) in items:
-                self._gather(b, e)
+        for (b, e, ev) in self._pending:
+            self._issue(b, e, ev, here)
+        self._pending = []
 
     def progress(self, offset_done: int):
         """Backward reports that every gradient with flat offset < offset_done is final."""
         if not self.active:
             return
         if self.cuda:
-            self._flush_deferred()
+            self._issue_pending()
         while self.next < len(self.buckets) and self.buckets[self.next][1] <= offset_done:
             b, e = self.buckets[self.next]
+            when = self.ready_when[self.next]
             if self.cuda:
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream())
-                if self.world > 1:
+                if self.world > 1 or self.emulate is not None:
                     with torch.cuda.stream(self.stream):
                         self.stream.wait_event(ev)
-                        self._reduce(b, e)
+                        if self.world > 1:
+                            self._all_reduce(b, e)
+                        else:
+                            self._emulated_exchange(b, e)
                         ev = torch.cuda.Event()
                         ev.record(self.stream)
-                self.last_comm_event = ev
-                if self.hold is not None and b < self.hold[1] and e > self.hold[0]:
-                    self.held.append((b, e))
-                elif self.on_ready is not None and self.defer is not None and b < self.defer[1] and e > self.defer[0]:
-                    self.deferred.append((b, e, ev))
-                elif self.on_ready is not None:
-                    # the optimizer slice runs on its own stream: it must not sit between two collectives
-                    with torch.cuda.stream(self.opt_stream):
-                        self.opt_stream.wait_event(ev)
-                        with ops.pinned_stream():  # launch on that stream, not on the step's pinned main stream
-                            self._ready(b, e)
-                    self._after_ready_gather([(b, e)])
-            elif self.sharded:  # CPU tensors (host-logic tests over gloo): synchronous
-                self._reduce(b, e)
-                if self.hold is not None and b < self.hold[1] and e > self.hold[0]:
-                    self.held.append((b, e))
+                if self.on_ready is None:
+                    pass
+                elif when == "end":
+                    self._at_end.append((b, e))
+                elif when == "next":
+                    self._pending.append((b, e, ev))
                 else:
-                    self._ready(b, e)
-                    self._gather(b, e)
-            else:
+                    self._issue(b, e, ev)
+            else:  # CPU tensors (host-logic tests over gloo)
                 h = self._all_reduce(b, e, async_op=True)
                 if h is not None:
                     self.handles.append(h)
             self.next += 1
 
-    def release_held(self, before=None):
-        """Run `before()` (e.g. the sparse embedding scatter) and then the postponed on_ready calls, on the optimizer stream,
-        after every collective issued so far."""
-        if not self.cuda:
-            if self.sharded:
-                if before is not None:
-                    before()
-                for (b, e) in self.held:
-                    self._ready(b, e)
-                    self._gather(b, e)
-                self.held = []
-            if self.late is not None and self.on_ready is not None:
-                self.late()
-            return
-        self._flush_deferred()
-        late = self.late if self.on_ready is not None else None  # the late pass belongs to the per-bucket optimizer
-        if not self.held and before is None and late is None:
-            return
-        ev = torch.cuda.Event()
-        ev.record(self.stream if self.world > 1 else torch.cuda.current_stream())
-        # the postponed slices run after backward, with nothing beside them: on the unmasked tail stream when the optimizer
-        # stream is restricted to a few CUs
-        tail = self.tail_stream if self.tail_stream is not None else self.opt_stream
-        with torch.cuda.stream(tail):
-            tail.wait_event(ev)
-            if tail is not self.opt_stream:
-                tail.wait_stream(self.opt_stream)
-            tail.wait_stream(torch.cuda.current_stream())  # the end of backward (the sparse embedding rows come from there)
-            with ops.pinned_stream():
-                if before is not None:
-                    before()
-                for (b, e) in self.held:
-                    self._ready(b, e)
-                if late is not None:
-                    late()
-        if tail is not self.opt_stream:
-            self.opt_stream.wait_stream(tail)  # finish() and the sharded gather order themselves behind opt_stream
-        self._after_ready_gather(self.held)
-        self.held = []
-
-    def finish(self):
+    def finish(self, before=None, after=None):
+        """End of backward: the remaining buckets go out; then, behind every collective and everything backward has enqueued,
+        `before()` (the sparse embedding-row exchange), the optimizer passes of the "end" buckets and `after()` (the part of the
+        optimizer that needed `before`); finally the step's stream waits for the side streams."""
         self.progress(self.grad.numel())
         if not self.active:
             return
-        if self.cuda:
-            torch.cuda.current_stream().wait_stream(self.stream)
-            torch.cuda.current_stream().wait_stream(self.opt_stream)
-        else:
+        if not self.cuda:
             for h in self.handles:
                 h.wait()
+            return
+        self._issue_pending()
+        if self.on_ready is None:
+            after = None  # the late pass belongs to the per-bucket optimizer
+            self._at_end = []
+        cur = torch.cuda.current_stream()
+        if self._at_end or before is not None or after is not None:
+            # these run after backward, with nothing beside them: on the unmasked tail stream when the optimizer stream is
+            # restricted to a few CUs
+            tail = self.tail_stream if self.tail_stream is not None else self.opt_stream
+            with torch.cuda.stream(tail):
+                if self.world > 1 or self.emulate is not None:
+                    tail.wait_stream(self.stream)
+                if tail is not self.opt_stream:
+                    tail.wait_stream(self.opt_stream)
+                tail.wait_stream(cur)  # the end of backward (the sparse embedding rows come from there)
+                with ops.pinned_stream():
+                    if before is not None:
+                        before()
+                    for (b, e) in self._at_end:
+                        self.on_ready(b, e)
+                    if after is not None:
+                        after()
+            if tail is not self.opt_stream:
+                self.opt_stream.wait_stream(tail)
+            self._at_end = []
+        cur.wait_stream(self.stream)
+        cur.wait_stream(self.opt_stream)
 
 
 OPT_CUS_DEFAULT = 96  # CUs of the optimizer stream (12 per XCD of an MI355X): profiles/README.md, round 3 A/B
@@ -365,12 +356,18 @@ class Trainer:
 
     def __init__(self, model, learning_rate_fn: Callable[[int], float], b1=0.9, b2=0.999, eps=1e-8, weight_decay=0.0,
                  label_smoothing_factor=0.0, seed: int = 42, bucket_mb: float = 64.0, group=None, compact_head: bool = True,
-                 overlap_optimizer: bool = True, grad_comm_dtype: Optional[torch.dtype] = None, sharded_optimizer: bool = False,
-                 gemm_dtype: Optional[str] = None, fp8_scaling: str = "delayed", pack_rows: bool = True):
+                 overlap_optimizer: bool = True, grad_comm_dtype="auto", gemm_dtype: Optional[str] = None,
+                 fp8_scaling: str = "delayed", pack_rows: bool = True, comm_cus: Optional[int] = None, emulate_comm: int = 0):
         """pack_rows (bfloat16 mode, with compact_head): the decoder runs on the valid caption positions only (`packed_rows`);
         exact — padded positions neither carry loss nor are attended to — and ~1/3 fewer decoder rows on ragged captions.  Needs
         prefix-shaped masks available on the host: a numpy / CPU `attention_mask`, or `batch["packed_rows"]` from the collate
-        function; otherwise the step runs padded.  MIC_PACK_ROWS=0 switches it off."""
+        function; otherwise the step runs padded.  MIC_PACK_ROWS=0 switches it off.
+        grad_comm_dtype: "auto" (default; `choose_comm_dtype`: fp32 where the projected exchange hides under backward, bf16 where
+        it would not), None / torch.float32 (always the reference's fp32 pmean) or torch.bfloat16.
+        comm_cus (data parallel): CUs the collectives are assumed to hold while backward runs — the GEMM tile planner sizes its
+        one-round launches for the rest (`mic_set_cu_budget`); default COMM_CUS_DEFAULT when world > 1, 0 otherwise.
+        emulate_comm = N (one GPU only; bench.py --emulate-comm): every bucket's exchange is replaced by a kernel holding
+        `comm_cus` CUs for the projected duration of its all-reduce among N ranks — a scheduling probe, not a scaling result."""
         import torch.distributed as dist
 
         self.model, self.lr_fn = model, learning_rate_fn
@@ -390,32 +387,42 @@ class Trainer:
             model.engine.set_gemm_dtype(gemm_dtype, scaling=fp8_scaling)
         self.hyper = torch.zeros(2, dtype=torch.float32, device=model.device)
         self._hyper_pin, self._hyper_ev = None, None
-        # sharded optimizer (data parallel only): reduce-scatter / AdamW on 1/world of every bucket / all-gather the weights
-        self.sharded = bool(sharded_optimizer) and self.world > 1
-        self.buckets = bucket_plan(st, bucket_mb, self.world, self.sharded)
-        if self.world > 1 and self.rank == 0:
+        emu_world = int(emulate_comm) if (self.world == 1 and model.device.type == "cuda") else 0
+        eff_world = emu_world if emu_world > 1 else self.world
+        if isinstance(grad_comm_dtype, str):
+            if grad_comm_dtype != "auto":
+                raise ValueError(f"grad_comm_dtype must be 'auto', None or a torch dtype, got {grad_comm_dtype!r}")
+            grad_comm_dtype = choose_comm_dtype(eff_world, st.numel)
+        self.grad_comm_dtype = grad_comm_dtype if grad_comm_dtype not in (None, torch.float32) else None
+        self.comm_cus = int(comm_cus) if comm_cus is not None else (COMM_CUS_DEFAULT if eff_world > 1 else 0)
+        # one-round GEMM launches are sized for the CUs the collectives leave (process-wide planner state: set for the duration of a
+        # train step, see train_step)
+        self._cu_budget = 256 - self.comm_cus if (model.device.type == "cuda" and eff_world > 1 and self.comm_cus > 0) else 0
+        self.buckets = bucket_plan(st, bucket_mb)
+        cb = 2 if self.grad_comm_dtype in (torch.bfloat16, torch.float16) else 4
+        if eff_world > 1 and self.rank == 0:
             import sys
 
-            cb = 2 if grad_comm_dtype in (torch.bfloat16, torch.float16) else 4
             desc = describe_buckets(st, self.buckets, cb)
-            print(f"[mic_amd.Trainer] data parallel over {self.world} ranks: {len(desc)} gradient buckets in backward-completion order, "
-                  f"{sum(d['MB'] for d in desc):.0f} MB per exchange in {'bf16' if cb == 2 else 'fp32'} "
-                  f"({'reduce-scatter + all-gather, sharded optimizer' if self.sharded else 'all-reduce'}); first: "
-                  f"{desc[0]['first']}..{desc[0]['last']} {desc[0]['MB']:.0f} MB, last: {desc[-1]['first']}..{desc[-1]['last']} {desc[-1]['MB']:.0f} MB; "
-                  f"sizes MB {[d['MB'] for d in desc]}", file=sys.stderr, flush=True)
+            total = sum(d["MB"] for d in desc)
+            print(f"[mic_amd.Trainer] data parallel over {eff_world} ranks{' (EMULATED on one GPU)' if emu_world > 1 else ''}: {len(desc)} gradient "
+                  f"buckets in backward-completion order, {total:.0f} MB per exchange in {'bf16' if cb == 2 else 'fp32'} (all-reduce, projected "
+                  f"{allreduce_ms(total * 1e6, eff_world):.1f} ms over xGMI against ~{BACKWARD_WINDOW_MS:.0f} ms of backward); GEMM tile planner sized for "
+                  f"{256 - self.comm_cus} CUs; first: {desc[0]['first']}..{desc[0]['last']} {desc[0]['MB']:.0f} MB, last: {desc[-1]['first']}..{desc[-1]['last']} "
+                  f"{desc[-1]['MB']:.0f} MB; sizes MB {[d['MB'] for d in desc]}", file=sys.stderr, flush=True)
         # MIC_OPT_OVERLAP=0: AdamW as one launch after backward (profiling aid: per-bucket AdamW on its own stream shares HBM with
         # the backward kernels it overlaps, so their individual durations read longer than the kernels are)
         import os
 
-        if os.environ.get("MIC_OPT_OVERLAP", "1") == "0" and not self.sharded:
+        if os.environ.get("MIC_OPT_OVERLAP", "1") == "0":
             overlap_optimizer = False
-        self.overlap_optimizer = overlap_optimizer or self.sharded
+        self.overlap_optimizer = overlap_optimizer
         sh = st.segs["shared"]
-        # The tied embedding's gradient is complete only at the end of backward (its sparse input-embedding rows).  Replicated
-        # optimizer: AdamW runs early on every row this step's decoder ids do not touch and late on the <= world*B*T rows they do
-        # (`_adamw_slice` / `_adamw_shared_late`; MIC_OPT_SPLIT_SHARED=0: the whole segment waits for the end, as the sharded
-        # optimizer does).  MIC_OPT_CUS: CUs of the optimizer stream's mask.
-        self._split_shared = (self.overlap_optimizer and not self.sharded and model.device.type == "cuda"
+        # The tied embedding's gradient is complete only at the end of backward (its sparse input-embedding rows): AdamW runs
+        # early on every row this step's decoder ids do not touch and late on the <= world*B*T rows they do (`_adamw_slice` /
+        # `_adamw_shared_late`; MIC_OPT_SPLIT_SHARED=0: the whole segment waits for the end).  MIC_OPT_CUS: CUs of the optimizer
+        # stream's mask.
+        self._split_shared = (self.overlap_optimizer and model.device.type == "cuda"
                               and _os.environ.get("MIC_OPT_SPLIT_SHARED", "1") != "0" and sh.numel % st.d == 0)
         self._sh = (sh.offset, sh.offset + sh.numel, st.d)
         self._row_flag = torch.zeros(sh.numel // st.d, dtype=torch.uint8, device=model.device) if self._split_shared else None
@@ -424,46 +431,19 @@ class Trainer:
 
         me = weakref.ref(self)  # the reducer's callbacks must not own the Trainer (Trainer -> reducer -> bound method -> Trainer is a cycle
         #                         that keeps ~16 GB of device state alive after `del trainer, model` until the cycle collector runs)
+        # the pieces of the tied embedding: "next" (the head's dX GEMM, issued right behind the dE GEMM that completes the dense
+        # half of the gradient, still reads the weights) when the row split is on, "end" otherwise
+        gate = "next" if self._split_shared else "end"
+        when = [gate if (b < sh.offset + sh.numel and e > sh.offset) else "exchanged" for (b, e) in self.buckets]
         self.reducer = GradReducer(st.grad, self.buckets, group, on_ready=(lambda b, e: me()._adamw_slice(b, e)) if self.overlap_optimizer else None,
-                                   hold=None if self._split_shared else (sh.offset, sh.offset + sh.numel), comm_dtype=grad_comm_dtype,
-                                   sharded=self.sharded, gather=[st.lp], late=(lambda: me()._adamw_shared_late()) if self._split_shared else None,
-                                   opt_cus=opt_cus, defer=(sh.offset, sh.offset + sh.numel) if self._split_shared else None)
+                                   ready_when=when, comm_dtype=self.grad_comm_dtype, opt_cus=opt_cus,
+                                   emulate=dict(world=emu_world, cus=self.comm_cus or COMM_CUS_DEFAULT, comm_bytes=cb) if emu_world > 1 else None)
         self.metrics_buf = torch.zeros(2, dtype=torch.float32, device=model.device)
-        self._state_dirty = False
-        if self.sharded:
-            # params export / checkpoints need every rank's master weights + moments.  The all-gather is a COLLECTIVE: it is only
-            # ever started explicitly (`sync_full_state()` / `save_checkpoint()` on every rank); `model.params` on stale state
-            # raises instead of starting one on whichever rank happened to ask (a rank-0-only access would deadlock RCCL)
-            import weakref
-
-            me = weakref.ref(self)  # (model -> bound method -> Trainer -> model would be a reference cycle)
-            model._state_sync = lambda: me() is not None and me()._require_synced_state()
-
-    def _require_synced_state(self):
-        if self.sharded and self._state_dirty:
-            raise RuntimeError("sharded optimizer: the fp32 master weights of this rank are current only on its own shard; call "
-                               "Trainer.sync_full_state() on EVERY rank (a collective) before reading model.params / save_pretrained")
-
-    def sync_full_state(self):
-        """Sharded optimizer: the fp32 master weights and AdamW moments of a bucket are current only on the rank that owns the
-        shard.  All-gather them (a checkpoint / `model.params` export needs the full state on the exporting rank).  Collective:
-        every rank must call it (save_checkpoint and the `params` getter do)."""
-        if not (self.sharded and self._state_dirty):
-            return
-        import torch.distributed as dist
-
-        st = self.model.store
-        torch.cuda.synchronize(self.model.device) if self.model.device.type == "cuda" else None
-        for (b, e) in self.buckets:
-            sb, se, me = self.reducer.split(b, e)
-            if me > b:
-                for t in ([st.m, st.v] + ([st.master] if st.lp is not st.master else [])):
-                    dist.all_gather_into_tensor(t[b:me], t[sb:se], group=self.group)
-        self._state_dirty = False
 
     def _adamw_slice(self, b: int, e: int):
         """AdamW on flat slice [b, e) — runs on the reducer's side stream right after that bucket's all-reduce.  The part of the
-        slice inside the tied embedding skips the rows flagged for this step (`_adamw_shared_late` takes those)."""
+        slice inside the tied embedding (whole rows: the bucket cuts inside that segment are row-aligned) skips the rows flagged
+        for this step when the row split is on (`_adamw_shared_late` takes those)."""
         st = self.model.store
         sb, se, width = self._sh
         lo, hi = max(b, sb), min(e, se)
@@ -471,18 +451,21 @@ class Trainer:
             ops.adamw(st.master[b:e], st.m[b:e], st.v[b:e], st.grad[b:e], None if st.lp is st.master else st.lp[b:e], self.hyper,
                       self.b1, self.b2, self.eps, self.wd, grad_scale=1.0 / self.world, n=e - b)
             return
-        assert lo == sb and hi == se, "bucket cuts sit on segment boundaries: the tied embedding lies inside one bucket"
+        assert (lo - sb) % width == 0 and (hi - sb) % width == 0, "bucket cuts inside the tied embedding are row-aligned"
         for (x, y) in ((b, lo), (hi, e)):
             if y > x:
                 ops.adamw(st.master[x:y], st.m[x:y], st.v[x:y], st.grad[x:y], None if st.lp is st.master else st.lp[x:y], self.hyper,
                           self.b1, self.b2, self.eps, self.wd, grad_scale=1.0 / self.world, n=y - x)
-        self._adamw_shared(0)
+        self._adamw_shared(0, (lo - sb) // width, (hi - sb) // width)
 
-    def _adamw_shared(self, want: int):
+    def _adamw_shared(self, want: int, r0: int = 0, r1: Optional[int] = None):
+        """AdamW on rows [r0, r1) of the tied embedding whose flag equals `want`"""
         st = self.model.store
         sb, se, width = self._sh
-        ops.adamw_rows((se - sb) // width, width, self._row_flag, want, st.master[sb:se], st.m[sb:se], st.v[sb:se], st.grad[sb:se],
-                       None if st.lp is st.master else st.lp[sb:se], self.hyper, self.b1, self.b2, self.eps, self.wd,
+        r1 = (se - sb) // width if r1 is None else r1
+        x, y = sb + r0 * width, sb + r1 * width
+        ops.adamw_rows(r1 - r0, width, self._row_flag[r0:r1], want, st.master[x:y], st.m[x:y], st.v[x:y], st.grad[x:y],
+                       None if st.lp is st.master else st.lp[x:y], self.hyper, self.b1, self.b2, self.eps, self.wd,
                        grad_scale=1.0 / self.world)
 
     def _adamw_shared_late(self):
@@ -543,6 +526,14 @@ class Trainer:
         self._pack = None
         eng = m.engine
         if pk is not None and rows is not None and eng.dt == torch.bfloat16 and T <= 64 and m.store.S <= 64:
+            ql = pk[1]
+            if not (isinstance(ql, torch.Tensor) and ql.is_cuda):
+                # host-side description: it must describe the same positions as `loss_rows` (a collate function that built the two
+                # from different masks would make the attention kernels index rows the LM head does not own).  Device-resident
+                # descriptions are trusted: checking them would put a device-to-host sync into every step.
+                n_pk = int(np.asarray(ql).sum()) if not isinstance(ql, torch.Tensor) else int(ql.sum())
+                if n_pk != rows[1]:
+                    raise ValueError(f"batch['packed_rows'] describes {n_pk} decoder rows but batch['loss_rows'] has {rows[1]}: both must come from the same attention_mask")
             q_off, q_len, ids_p, pos_p = (m._dev(t, torch.int32) for t in pk)
             self._pack = ((q_off, q_len, rows[1]), ids_p, pos_p)
         self._rows, self._row_labels = rows, row_labels
@@ -570,16 +561,22 @@ class Trainer:
 
     def train_step(self, batch: Dict) -> Dict[str, float]:
         """main.py:684-707."""
-        ms = self.reducer.step_stream
-        if ms is None:
-            return self._train_step(batch)
-        # the optimizer's stream carries a CU mask, which makes it a blocking stream: the step keeps off the null stream
-        cur = torch.cuda.current_stream()
-        ms.wait_stream(cur)
-        with torch.cuda.stream(ms):
-            out = self._train_step(batch)
-        cur.wait_stream(ms)
-        return out
+        if self._cu_budget:
+            ops.set_cu_budget(self._cu_budget)
+        try:
+            ms = self.reducer.step_stream
+            if ms is None:
+                return self._train_step(batch)
+            # the optimizer's stream carries a CU mask, which makes it a blocking stream: the step keeps off the null stream
+            cur = torch.cuda.current_stream()
+            ms.wait_stream(cur)
+            with torch.cuda.stream(ms):
+                out = self._train_step(batch)
+            cur.wait_stream(ms)
+            return out
+        finally:
+            if self._cu_budget:
+                ops.set_cu_budget(0)  # generation / evaluation have no collective beside them
 
     def _train_step(self, batch: Dict) -> Dict[str, float]:
         m, st, eng = self.model, self.model.store, self.model.engine
@@ -600,14 +597,14 @@ class Trainer:
             else:
                 loss = eng.loss_and_grads(px, dec_in.reshape(-1), pos.reshape(-1), mask, labels.reshape(-1), B, T,
                                           label_smoothing=self.ls, seed=seed, rows=self._rows, row_labels=self._row_labels)
-        self.reducer.progress(st.numel)  # everything is final now: remaining buckets go out
-        self.reducer.release_held(self._scatter_embedding_rows if self.world > 1 else None)
-        self.reducer.finish()  # pmean(grad) (main.py:698): SUM here, 1/world folded into AdamW's grad_scale
+        # pmean(grad) (main.py:698): SUM here, 1/world folded into AdamW's grad_scale.  The remaining buckets go out; behind them the
+        # sparse embedding-row exchange, the optimizer passes that had to wait for it, and the flagged rows of the tied embedding
+        self.reducer.finish(before=self._scatter_embedding_rows if self.world > 1 else None,
+                            after=self._adamw_shared_late if self._split_shared else None)
         if not self.overlap_optimizer:
             ops.adamw(st.master, st.m, st.v, st.grad, None if st.lp is st.master else st.lp, self.hyper, self.b1, self.b2, self.eps,
                       self.wd, grad_scale=1.0 / self.world)
         m.invalidate_params_cache(by_optimizer=True)
-        self._state_dirty = True
         self.step += 1
         self.metrics_buf[0:1].copy_(loss)
         self.metrics_buf[1:2].copy_(self.hyper[0:1])  # lr, device to device (a Python scalar assigned into a device tensor syncs)
@@ -639,7 +636,6 @@ class Trainer:
         from .checkpoint import save_train_state
 
         ckpt = os.path.join(save_dir, f"ckpt-{self.step - 1}")
-        self.sync_full_state()  # collective in sharded mode: before the rank-0-only part
         if self.rank != 0 or (os.path.exists(ckpt) and not overwrite):  # main.py:304-305
             return ckpt
         torch.cuda.synchronize(self.model.device) if self.model.device.type == "cuda" else None

@@ -33,11 +33,17 @@ def test_bench_self_launches_two_ranks(dev):
     assert abs(d["final_loss"]) < 100
 
 
-def test_bench_sharded_optimizer_two_ranks(dev):
-    r = _run(["--gpus", "2", "--sharded-optimizer", "--no-generate"], {"MIC_BENCH_SHARE_GPU0": "1"})
+def test_bench_emulated_comm_leg(dev):
+    """`--emulate-comm N`: the 1-GPU step with every bucket's exchange replaced by a kernel holding the collective stream's CUs for
+    the projected all-reduce time; reported beside the headline, labelled as what it is"""
+    r = _run(["--emulate-comm", "2,8", "--no-generate", "--no-roofline"])
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
-    assert d["config"]["parallelism"] == "dp2+sharded-optimizer" and d["value"] > 0
+    e = d["comm_emulated"]
+    assert "NOT a scaling result" in e["note"] and set(e["worlds"]) == {"2", "8"}
+    for w in e["worlds"].values():
+        assert w["ms_per_step"] > 0 and w["comm_cus"] == 32 and w["comm_dtype"] == "fp32"  # (a reduced model's exchange hides at any N)
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak"
 
 
 def test_bench_refuses_more_ranks_than_gpus(dev):

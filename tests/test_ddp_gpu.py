@@ -101,106 +101,7 @@ def test_two_rank_bf16_gradient_exchange(dev):
     assert all(r[1] for r in res), res
 
 
-def _sharded_worker(rank, world, port, q):
-    """Two optimizer steps with the sharded optimizer vs the same two steps with the replicated one (same process, same data):
-    the same parameters afterwards on every rank, full master/moment state after sync_full_state, and the oracle's AdamW."""
-    import torch.distributed as dist
-
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        from util_small import batch, make_pair
-
-        import mic_amd  # noqa: F401
-        from mic_amd import Trainer, create_learning_rate_fn
-        from mic_amd.params import flatten_tree
-        from oracle import train_ref
-
-        dev = torch.device("cuda:0")
-        B, T = 2, 12
-        ok, msg = True, ""
-        results = {}
-        for mode in ("replicated", "sharded"):
-            for dtype in (torch.float32, torch.bfloat16):
-                rc, p, model = make_pair(dtype, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.0)
-                data = [[batch(rc, B, T, seed=600 + 10 * s + r) for r in range(world)] for s in range(2)]
-                tr = Trainer(model, create_learning_rate_fn(40, 4, 1, 0, 1e-3), weight_decay=0.01, seed=42, bucket_mb=0.25,
-                             sharded_optimizer=(mode == "sharded"))
-                assert tr.sharded == (mode == "sharded") and len(tr.buckets) > 3
-                for s in range(2):
-                    px, labels, mask, dec_in = data[s][rank]
-                    out = tr.train_step({"pixel_values": px.numpy(), "input_ids": labels.numpy(), "attention_mask": mask.numpy(),
-                                         "decoder_input_ids": dec_in.numpy()})
-                torch.cuda.synchronize()
-                lp = model.store.lp.float().clone()            # the weights the next forward would use
-                if mode == "sharded":
-                    # the all-gather of the master shards is an explicit collective; reading params on stale state raises
-                    # (it used to start the collective implicitly: a rank-0-only access would have deadlocked)
-                    try:
-                        model.params
-                        raise AssertionError("model.params on unsynced sharded state must raise")
-                    except RuntimeError as e:
-                        assert "sync_full_state" in str(e)
-                tr.sync_full_state()
-                full = flatten_tree(model.params)
-                results[(mode, dtype)] = (float(out["loss"]), lp, full, model.store.m.clone(), model.store.v.clone())
-        # float32: the two optimizers must agree to rounding (the embedding scatter accumulates duplicate rows with fp32 atomics
-        # whose order varies, hence not bit-for-bit).  bfloat16: two separate runs already differ in the last gradient bits, and
-        # Adam's first steps (update ~ lr * sign(g)) turn noise-level gradients into +-lr differences, so a leaf-by-leaf
-        # comparison says nothing there; the bf16 leg checks what sharding can break: every rank ends with the same weights,
-        # master copy and moments (the reduce-scatter / all-gather plumbing), and the loss matches.
-        a, b = results[("replicated", torch.float32)], results[("sharded", torch.float32)]
-        if abs(a[0] - b[0]) > 1e-5 * max(1.0, abs(a[0])):
-            ok, msg = False, f"f32 loss {a[0]} vs {b[0]}"
-        if (a[1] - b[1]).abs().max().item() > 2e-5:
-            ok, msg = False, f"f32 compute weights differ: {(a[1] - b[1]).abs().max().item()}"
-        for k in a[2]:
-            d = np.abs(a[2][k] - b[2][k]).max()
-            if d > 2e-5:
-                ok, msg = False, f"f32 master {k} differs by {d}"
-                break
-        em = ((a[3] - b[3]).abs().max() / a[3].abs().max()).item()
-        ev = ((a[4] - b[4]).abs().max() / a[4].abs().max()).item()
-        if em > 1e-4 or ev > 1e-4:
-            ok, msg = False, f"f32 AdamW moments differ after sync_full_state: m {em} v {ev}"
-        a, b = results[("replicated", torch.bfloat16)], results[("sharded", torch.bfloat16)]
-        if abs(a[0] - b[0]) > 2e-3 * max(1.0, abs(a[0])):
-            ok, msg = False, f"bf16 loss {a[0]} vs {b[0]}"
-        # rank consistency (both dtypes): identical weights, master copy and moments on every rank after the sharded step
-        for dtype in (torch.float32, torch.bfloat16):
-            r = results[("sharded", dtype)]
-            flat_master = np.concatenate([v.reshape(-1) for v in r[2].values()]).astype(np.float64)
-            chk = torch.tensor([r[1].double().sum().item(), r[1].double().abs().sum().item(), flat_master.sum(), np.abs(flat_master).sum(),
-                                r[3].double().sum().item(), r[4].double().sum().item()], dtype=torch.float64)
-            both = [torch.zeros_like(chk) for _ in range(world)]
-            dist.all_gather(both, chk)
-            if not all(torch.equal(both[0], x) for x in both):
-                ok, msg = False, f"{dtype}: ranks disagree after the sharded step: {both}"
-        q.put((rank, ok, msg))
-    finally:
-        dist.destroy_process_group()
-
-
-def test_two_rank_sharded_optimizer_equals_replicated(dev):
-    """Trainer(sharded_optimizer=True): reduce-scatter + AdamW on 1/world + all-gather gives the same parameters,
-    compute weights and (after the state all-gather) moments to the all-reduce + replicated AdamW path (main.py:698-701)."""
-    import torch.multiprocessing as mp
-
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29800 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
-    for pr in procs:
-        pr.start()
-    res = sorted(q.get(timeout=600) for _ in range(2))
-    for pr in procs:
-        pr.join(timeout=60)
-    assert all(r[1] for r in res), res
-
-
-def _packed_worker(rank, world, port, q):
+def _packed_worker(rank, world, port, q, full=False):
     """bf16, two ranks with different numbers of valid caption positions: the data-parallel step with packed decoder rows against
     the same step on padded rows (same process, same data, fresh model each): same loss, same summed gradients to the summation-order
     tolerance, on both ranks; the sparse embedding-row exchange carries a FIXED number of rows per rank whatever the rank's valid
@@ -218,17 +119,30 @@ def _packed_worker(rank, world, port, q):
         from mic_amd import Trainer, create_learning_rate_fn
 
         dev = torch.device("cuda:0")
-        B, T = 3, 16
-        px, labels, mask, dec_in = batch(make_pair(torch.bfloat16, dev, dropout=0.0)[0], B, T, seed=900 + rank)
-        b = {"pixel_values": px.numpy(), "input_ids": labels.numpy(), "attention_mask": mask.numpy(), "decoder_input_ids": dec_in.numpy()}
+        if full:  # ViT-B/32 + mBART-large-50 size, 16 of the bench's ragged captions per rank (different valid-row counts per rank)
+            import bench
+            from mic_amd import CLIPVisionMBartConfig, FlaxCLIPVisionMBartForConditionalGeneration
+
+            b = bench.synth_batch(16, 64, 250054, 224, 900 + rank)
+        else:
+            B, T = 3, 16
+            px, labels, mask, dec_in = batch(make_pair(torch.bfloat16, dev, dropout=0.0)[0], B, T, seed=900 + rank)
+            b = {"pixel_values": px.numpy(), "input_ids": labels.numpy(), "attention_mask": mask.numpy(), "decoder_input_ids": dec_in.numpy()}
         res = {}
         for pack in (True, False):
-            rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.0)
-            tr = Trainer(model, create_learning_rate_fn(40, 4, 1, 0, 1e-3), seed=42, bucket_mb=0.25, pack_rows=pack)
+            if full:
+                cfg = CLIPVisionMBartConfig(mbart_config=dict(dropout=0.0), clip_vision_config={})
+                model = FlaxCLIPVisionMBartForConditionalGeneration(cfg, seed=0, dtype=torch.bfloat16, device=dev)  # same seed: same weights on both ranks
+                tr = Trainer(model, create_learning_rate_fn(10_000_000, 32, 7, 0, 1e-4), seed=42, pack_rows=pack, grad_comm_dtype=None)
+                assert len(tr.buckets) > 20
+            else:
+                rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.0)
+                tr = Trainer(model, create_learning_rate_fn(40, 4, 1, 0, 1e-3), seed=42, bucket_mb=0.25, pack_rows=pack)
             out = tr.train_step(b)
             torch.cuda.synchronize()
             assert (tr._pack is not None) == pack
             res[pack] = (float(out["loss"]), model.store.grad.clone(), model.store.lp.float().clone())
+            del tr, model
         ok, msg = True, ""
         if res[True][0] != res[False][0]:
             ok, msg = False, f"loss {res[True][0]} vs {res[False][0]}"
@@ -259,4 +173,21 @@ def test_two_rank_packed_rows_equal_padded_rows(dev):
     res = sorted(q.get(timeout=300) for _ in range(2))
     for pr in procs:
         pr.join(timeout=60)
+    assert all(r[1] for r in res), res
+
+
+def test_two_rank_packed_rows_equal_padded_rows_full_size(dev):
+    """the same at ViT-B/32 + mBART-large-50 size: two ranks with different valid-row counts (16 ragged captions each), the bucket plan
+    of the real layout (the tied embedding in eight pieces), the sparse embedding-row exchange at 1024 fixed rows per rank"""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30300 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_packed_worker, args=(r, 2, port, q, True)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = sorted(q.get(timeout=900) for _ in range(2))
+    for pr in procs:
+        pr.join(timeout=120)
     assert all(r[1] for r in res), res

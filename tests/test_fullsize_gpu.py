@@ -546,3 +546,110 @@ def test_fullsize_bf16_decisions_after_training_follow_fp32_wherever_the_margin_
         m16.params = tree
         m32.params = tree
         m16.engine.free_buffers()
+
+
+
+# ---------------------------------------------------------------- the BENCHMARKED path pinned at the benchmarked size (round 4)
+def _bench_like_batch(seed, B=64, T=64):
+    """bench.synth_batch: N(0,1) pixels clipped to [-1.8, 2.2], ragged captions n ~ U{8..62}"""
+    import bench
+
+    return bench.synth_batch(B, T, 250054, 224, seed)
+
+
+def _fresh_bf16_model(dev, p, dropout=0.0):
+    from mic_amd import CLIPVisionMBartConfig, FlaxCLIPVisionMBartForConditionalGeneration
+    from mic_amd.params import unflatten_tree
+
+    cfg = CLIPVisionMBartConfig(mbart_config=dict(dropout=dropout), clip_vision_config={})
+    m = FlaxCLIPVisionMBartForConditionalGeneration(cfg, dtype=torch.bfloat16, device=dev)
+    m.params = unflatten_tree({k: v.numpy() for k, v in p.items()})
+    return m
+
+
+def test_benchmarked_trainer_path_equals_the_padded_serial_path_at_batch64(full, dev, monkeypatch):
+    """What bench.py times — `Trainer` defaults: packed decoder rows, per-bucket AdamW on a 96-CU stream beside backward, the tied
+    embedding updated in two row passes (in <= 128 MB pieces), weight-gradient GEMMs on their own stream — against the plain path:
+    padded [B*T] rows, dW on the main stream, ONE AdamW launch after backward.  configs[1] size (batch 64, seq 64, full model), the
+    bench's own ragged batches, dropout off (the fused dropout masks are keyed by row index, which packing changes).  First-step loss
+    the same number, every gradient segment within 2e-4 of its scale, 3 optimizer steps: same losses and the same weights up to what
+    Adam's normalised update makes of last-bit gradient differences."""
+    from mic_amd import Trainer, create_learning_rate_fn
+
+    rc, p, *_ = full
+    lr, steps = 1e-4, 3
+    lr_fn = create_learning_rate_fn(10_000_000, 64, 7, 0, lr)
+    batches = [_bench_like_batch(1234 + i) for i in range(steps)]
+    res = {}
+    for name in ("bench", "plain"):
+        if name == "plain":
+            monkeypatch.setenv("MIC_DW_OVERLAP", "0")
+        model = _fresh_bf16_model(dev, p)
+        tr = Trainer(model, lr_fn, seed=42) if name == "bench" else Trainer(model, lr_fn, seed=42, pack_rows=False, overlap_optimizer=False)
+        if name == "bench":
+            assert tr.pack_rows and tr.overlap_optimizer and tr._split_shared and tr.reducer.step_stream is not None and model.engine.dw_overlap
+            assert len([b for b in tr.buckets if b[1] <= tr._sh[1]]) == 8  # the tied embedding in 8 pieces of <= 128 MB
+        else:
+            assert not tr.pack_rows and not tr.overlap_optimizer and not model.engine.dw_overlap
+        losses, g1 = [], None
+        for i, b in enumerate(batches):
+            losses.append(float(tr.train_step(b)["loss"]))
+            assert (tr._pack is not None) == (name == "bench")
+            if i == 0:
+                torch.cuda.synchronize()
+                g1 = model.store.grad.clone()
+        torch.cuda.synchronize()
+        res[name] = (losses, g1, model.store.master.clone(), {k: (s_.offset, s_.numel) for k, s_ in model.store.segs.items()})
+        n_valid = int(batches[0]["attention_mask"].sum())
+        del tr, model
+    monkeypatch.delenv("MIC_DW_OVERLAP", raising=False)
+    (la, ga, pa, segs), (lb, gb, pb, _) = res["bench"], res["plain"]
+    assert 2000 < n_valid < 3000
+    assert la[0] == lb[0], (la[0], lb[0])                      # same weights, same per-row arithmetic: the same number
+    worst = {}
+    for k, (off, n) in segs.items():
+        a, b = ga[off: off + n], gb[off: off + n]
+        sc = b.abs().max().item()
+        if sc > 0:
+            worst[k] = ((a - b).abs().max() / sc).item()
+    bad = {k: v for k, v in worst.items() if v > 2e-4}
+    print(f"[bench path vs plain path] losses {la} vs {lb}; worst gradient segment {max(worst.values()):.2e} of its scale over {len(worst)} segments")
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+    assert np.allclose(la, lb, rtol=2e-3), (la, lb)
+    diff = (pa - pb).abs()
+    frac = (diff > 1e-6).float().mean().item()
+    print(f"[bench path vs plain path] master weights after {steps} steps: max |diff| {diff.max().item():.2e} (lr {lr}), differing by > 1e-6: {frac:.4f}")
+    assert diff.max().item() <= 2.5 * lr * steps and frac < 0.2, (diff.max().item(), frac)
+
+
+def test_fullsize_packed_rows_against_the_fp32_oracle_batch8(full, dev):
+    """The packed decoder path (what the benchmark runs) next to the fp32 ORACLE at full size, batch 8 of the bench's ragged
+    captions: loss within 2e-2, gradient direction of every large leaf and of all leaves together (the tolerances of
+    tests/test_model_gpu.py::test_loss_and_grads_match_oracle at the reduced size)."""
+    from mic_amd import loss_rows, packed_rows
+    from oracle import train_ref
+
+    rc, p, models, _, _ = full
+    model = models[torch.bfloat16]
+    b = _bench_like_batch(77, B=8)
+    px, labels, mask, dec_in = (torch.from_numpy(b[k]) for k in ("pixel_values", "input_ids", "attention_mask", "decoder_input_ids"))
+    ref_loss, ref_g = train_ref.loss_and_grads(rc, p, px, labels, mask, dec_in)
+    d = model._dev
+    B, T = labels.shape
+    idx, rl = loss_rows(b["attention_mask"], b["input_ids"])
+    q_off, q_len, ids_p, pos_p = (d(t, torch.int32) for t in packed_rows(b["attention_mask"], b["decoder_input_ids"]))
+    assert len(idx) < B * T
+    loss = model.engine.loss_and_grads(d(px, torch.float32), ids_p, pos_p, None, d(labels, torch.int32).reshape(-1), B, T,
+                                       rows=(d(idx, torch.int32), len(idx)), row_labels=d(rl, torch.int32), pack=(q_off, q_len, len(idx)))
+    torch.cuda.synchronize()
+    assert abs(loss.item() - ref_loss.item()) < 2e-2 * abs(ref_loss.item()), (loss.item(), ref_loss.item())
+    got = model.store.export_flat("grad")
+    cos = lambda a, b_: torch.nn.functional.cosine_similarity(a.reshape(-1).double(), b_.reshape(-1).double(), dim=0).item()
+    leaf = {k: cos(torch.from_numpy(got[k]).reshape(rg.shape), rg) for k, rg in ref_g.items() if rg.abs().max().item() > 1e-5 and rg.numel() >= 4096}
+    allc = cos(torch.cat([torch.from_numpy(got[k]).reshape(-1) for k in ref_g]), torch.cat([v.reshape(-1) for v in ref_g.values()]))
+    print(f"[fullsize packed bf16 vs fp32 oracle, B=8] loss {loss.item():.4f} vs {ref_loss.item():.4f}; worst leaf cosine {min(leaf.values()):.4f} "
+          f"over {len(leaf)} leaves; all leaves {allc:.5f}")
+    bad = {k: v for k, v in leaf.items() if v < 0.99}
+    assert not bad, sorted(bad.items(), key=lambda kv: kv[1])[:6]
+    assert allc > 0.995, allc
+    model.engine.free_buffers()

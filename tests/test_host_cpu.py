@@ -131,11 +131,10 @@ def test_plan_buckets():
     assert b[0][0] == 0 and b[-1][1] == 1000 and all(x[1] == y[0] for x, y in zip(b, b[1:]))
     assert all(e - s >= 300 for s, e in b[:-1])
     assert plan_buckets(10, 100, [0, 5]) == [(0, 10)]
-    # sharded optimizer: interior cuts are rounded down to world*64 so that every bucket but the last splits evenly
-    g = plan_buckets(100_000, 20_000, [0, 7_001, 21_013, 45_777, 70_001, 99_990], granule=2 * 64)
-    assert g[0][0] == 0 and g[-1][1] == 100_000 and all(x[1] == y[0] for x, y in zip(g, g[1:]))
-    assert all(e % 128 == 0 for _, e in g[:-1]) and all(e - s >= 20_000 for s, e in g[:-1])
-    assert [e for _, e in g[:-1]] == [(x // 128) * 128 for x in (21_013, 45_777, 70_001, 99_990)]
+    # a slice above max_elems is cut further, inside the segments declared splittable only, at multiples of their row width
+    g = plan_buckets(100_000, 20_000, [0, 500, 60_500, 80_000], max_elems=16_000, splittable=((500, 60_500, 1000),))
+    assert g == [(0, 16_500), (16_500, 32_500), (32_500, 48_500), (48_500, 60_500), (60_500, 100_000)]
+    assert plan_buckets(100_000, 20_000, [0, 500, 60_500, 80_000], max_elems=16_000) == plan_buckets(100_000, 20_000, [0, 500, 60_500, 80_000])
 
 
 def test_packed_rows_helper():
@@ -163,33 +162,84 @@ def test_bucket_plan_full_size_world8():
 
     st = ParamStore(CLIPVisionMBartConfig(mbart_config={}, clip_vision_config={}), torch.bfloat16, "cpu", allocate=False)
     assert st.numel == 547_223_040 and st.master is None
-    for world, sharded in ((8, False), (8, True), (2, False)):
-        b = bucket_plan(st, 64.0, world, sharded)
-        d = describe_buckets(st, b)
-        assert b[0][0] == 0 and b[-1][1] == st.numel and all(x[1] == y[0] for x, y in zip(b, b[1:]))
-        assert all(x["elements"] * 4 >= 64 * 1024 * 1024 for x in d[:-1])
-        # bucket 0 = flb + shared: the first gradients backward completes
-        sh = st.segs["shared"]
-        assert d[0]["first"] == "flb" and d[0]["last"] == "shared" and abs(b[0][1] - (sh.offset + sh.numel)) < 8 * 64
-        assert 1.0e3 < d[0]["MB"] < 1.1e3
-        # then decoder layers 11 -> 0 (14.7 M elements each without the cross k/v projections: a bucket spans a little more than
-        # one layer), the cross k/v projections of all layers (complete at the end of decoder backward), projection + ViT; the
-        # region accumulated by atomics last
-        firsts = [x["first"] for x in d]
-        dec = [f for f in firsts if f.startswith("dec") and f.endswith(".w") and ".ckv." not in f]
-        layer = lambda n: int(n[3:].split(".")[0])
-        ls = [layer(f) for f in dec]
-        assert ls == sorted(ls, reverse=True) and ls[0] >= 10 and ls[-1] <= 1 and 8 <= len(dec) <= 12, ls
-        segs = sorted(st.segs.values(), key=lambda s: s.offset)
-        names = [s.name for s in segs]
-        assert names.index("dec0.qkv.w") < names.index("dec0.ckv.w") < names.index("dec11.ckv.w") < names.index("vp.w")
-        assert st.segs["dec11.ckv.w"].offset - st.segs["dec0.ckv.w"].offset == 11 * 2 * 1024 * 1024  # contiguous: one [L*2d][d] matrix
-        assert d[-1]["last"] == "vit.cls"
-        vit_first = next(i for i, f in enumerate(firsts) if f.startswith("vit") or f == "vp.w")
-        assert all(not f.startswith("dec") or not f.endswith(".w") for f in firsts[vit_first:])
-        if sharded:
-            assert all(e % (world * 64) == 0 for _, e in b[:-1])
-        assert 14 <= len(b) <= 24, len(b)
+    b = bucket_plan(st, 64.0)
+    d = describe_buckets(st, b)
+    assert b[0][0] == 0 and b[-1][1] == st.numel and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+    assert all(x["elements"] * 4 >= 64 * 1024 * 1024 for x in d[:-1])
+    # the first buckets = flb + the tied embedding in pieces of <= 128 MB (whole rows): the first gradients backward completes —
+    # all pieces at once (one weight-gradient GEMM), but piece k's optimizer pass can start behind piece k's all-reduce
+    sh = st.segs["shared"]
+    pieces = [x for x in d if x["last"] == "shared"]
+    assert d[0]["first"] == "flb" and len(pieces) == 8 and pieces == d[: len(pieces)]
+    assert all(x["MB"] <= 128 * 1.048576 + 1.1 for x in pieces) and b[len(pieces) - 1][1] == sh.offset + sh.numel
+    assert all((e - sh.offset) % st.d == 0 for (_, e) in b[: len(pieces)])
+    assert 1.0e3 < sum(x["MB"] for x in pieces) < 1.1e3
+    whole = bucket_plan(st, 64.0, max_mb=1e9)  # without the cap: one 1 GB bucket, as in rounds 1-3
+    assert len(whole) == len(b) - 7 and whole[1:] == b[8:]
+    # then decoder layers 11 -> 0 (14.7 M elements each without the cross k/v projections: a bucket spans a little more than
+    # one layer), the cross k/v projections of all layers (complete at the end of decoder backward), projection + ViT; the
+    # region accumulated by atomics last
+    firsts = [x["first"] for x in d]
+    dec = [f for f in firsts if f.startswith("dec") and f.endswith(".w") and ".ckv." not in f]
+    layer = lambda n: int(n[3:].split(".")[0])
+    ls = [layer(f) for f in dec]
+    assert ls == sorted(ls, reverse=True) and ls[0] >= 10 and ls[-1] <= 1 and 8 <= len(dec) <= 12, ls
+    segs = sorted(st.segs.values(), key=lambda s: s.offset)
+    names = [s.name for s in segs]
+    assert names.index("dec0.qkv.w") < names.index("dec0.ckv.w") < names.index("dec11.ckv.w") < names.index("vp.w")
+    assert st.segs["dec11.ckv.w"].offset - st.segs["dec0.ckv.w"].offset == 11 * 2 * 1024 * 1024  # contiguous: one [L*2d][d] matrix
+    assert d[-1]["last"] == "vit.cls"
+    vit_first = next(i for i, f in enumerate(firsts) if f.startswith("vit") or f == "vp.w")
+    assert all(not f.startswith("dec") or not f.endswith(".w") for f in firsts[vit_first:])
+    assert 21 <= len(b) <= 31, len(b)
+
+
+def test_comm_dtype_follows_the_byte_counts():
+    """`grad_comm_dtype="auto"`: fp32 (the reference's pmean, main.py:698) where the projected ring all-reduce of the 2.19 GB of
+    fp32 gradients hides under ~13 ms of backward, bf16 where it would not"""
+    from mic_amd.train import allreduce_ms, choose_comm_dtype
+
+    n = 547_223_040
+    assert [round(allreduce_ms(4.0 * n, w), 1) for w in (1, 2, 4, 8)] == [0.0, 34.2, 17.1, 8.6]
+    assert choose_comm_dtype(1, n) is None and choose_comm_dtype(8, n) is None
+    assert choose_comm_dtype(2, n) is torch.bfloat16 and choose_comm_dtype(4, n) is torch.bfloat16
+    assert choose_comm_dtype(2, 1_000_000) is None  # a small model's exchange hides at any world size
+
+
+def test_gemm_planner_follows_the_cu_budget():
+    """The tile planner under a reduced CU budget (collectives hold CUs beside backward): a launch that was ONE round of blocks on
+    256 CUs stays one round on 224 / 192 — it re-plans (fewer K-groups = more blocks per CU, or smaller tiles) instead of spilling
+    a few blocks into a second round.  Host arithmetic of libmic_hip.so (mic_gemm_plan): no GPU needed."""
+    from mic_amd import ops
+
+    step = {  # the one-round launches of the batch-64 train step and of the decoder step (M, N, K)
+        "dec so/cq/co dense": [(4096, 1024, 1024)], "dec so/cq/co packed": [(2404, 1024, 1024)], "dec fc2 packed": [(2404, 1024, 4096)],
+        "vit out": [(3200, 768, 768)], "vit fc2": [(3200, 768, 3072)], "gen d x d": [(1024, 1024, 1024)], "gen fc2": [(1024, 1024, 4096)],
+        "gen qkv": [(1024, 1024, 1024)] * 3, "gen fc1": [(1024, 4096, 1024)],
+    }
+    try:
+        ops.set_cu_budget(0)
+        assert ops.get_cu_budget() == 256
+        base = {k: ops.gemm_plan(v) for k, v in step.items()}
+        assert all(p["blocks"] <= 256 * p["blocks_per_cu"] for p in base.values()), base  # one round today
+        assert base["dec so/cq/co dense"]["kgroups"] == 2 and base["gen d x d"] == dict(tile=64, kgroups=4, blocks=256, grid=256, blocks_per_cu=1, phased=0, cu_budget=256)
+        for cus in (224, 192):
+            ops.set_cu_budget(cus)
+            for k, v in step.items():
+                p = ops.gemm_plan(v)
+                assert p["cu_budget"] == cus and p["blocks"] <= cus * p["blocks_per_cu"], (cus, k, p)
+            # the dense 256-tile projection gives up its second K-group (two 8-wave blocks per CU instead of one 16-wave block)
+            assert ops.gemm_plan(step["dec so/cq/co dense"])["kgroups"] == 1 and ops.gemm_plan(step["gen d x d"])["kgroups"] == 2
+            # 256 tiles of 256 x 256 would be two rounds on fewer than 256 CUs: quarter tiles instead
+            assert ops.gemm_plan([(4096, 4096, 1024)])["tile"] == 128
+            # persistent grids shrink with the budget
+            head = ops.gemm_plan([(3072, 1024, 4096), (1024, 1024, 4096), (1024, 1024, 4096), (1024, 1024, 4096), (4096, 1024, 4096), (1024, 4096, 4096)],
+                                 a_kmajor=True, b_kmajor=True)
+            assert head["grid"] <= max(cus, head["blocks"] if head["tile"] != 256 else 0) or head["tile"] != 256
+        ops.set_cu_budget(0)
+        assert {k: ops.gemm_plan(v) for k, v in step.items()} == base  # the default plan is what it was
+    finally:
+        ops.set_cu_budget(0)
 
 
 def _ddp_worker(rank, world, port, q):
@@ -244,61 +294,6 @@ def test_grad_reducer_gloo_world2():
         p.join(timeout=60)
     assert [r[1] for r in res] == [True, True]
     assert all(abs(r[2] - 1.5) < 1e-9 for r in res)
-
-
-def _sharded_worker(rank, world, port, q):
-    """Sharded optimizer host logic on CPU tensors over gloo: reduce-scatter in place, the update callback on the owned
-    slices only (incl. the replicated tail and a held bucket), all-gather of the updated weights."""
-    import torch.distributed as dist
-
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    sys.path.insert(0, ROOT)
-    import mic_amd  # noqa: F401
-    from mic_amd.train import GradReducer, plan_buckets
-
-    n = 5000 + 37  # not a multiple of world*64: the last bucket has a replicated tail
-    g = torch.arange(n, dtype=torch.float32) * (rank + 1)
-    w = torch.ones(n)
-    touched = torch.zeros(n)
-    buckets = plan_buckets(n, 1200, list(range(0, n, 500)), granule=world * 64)
-
-    def upd(b, e):  # "optimizer": w -= mean gradient, on the slices this rank owns
-        w[b:e] -= g[b:e] / world
-        touched[b:e] += 1
-
-    red = GradReducer(g, buckets, on_ready=upd, sharded=True, gather=[w], hold=(buckets[1][0], buckets[1][0] + 10))
-    red.start_step()
-    for off in list(range(500, n, 500)) + [n]:
-        red.progress(off)
-    red.release_held()
-    red.finish()
-    expect = 1.0 - torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world)) / world
-    own = sum(e - b for (x, y) in buckets for (b, e) in red.owned_ranges(x, y))
-    tail = n - (n // (world * 64)) * (world * 64) if buckets[-1][1] - buckets[-1][0] >= world * 64 else 0
-    ok = torch.allclose(w, expect) and int(touched.sum()) == own and touched.max() == 1
-    # every element is updated by exactly one rank, except the replicated tail (every rank)
-    tot = touched.clone()
-    dist.all_reduce(tot)
-    sb, se, me = red.split(*buckets[-1])
-    ok = ok and bool((tot[: me] == 1).all()) and bool((tot[me:] == world).all()) and me < n
-    q.put((rank, bool(ok)))
-    dist.destroy_process_group()
-
-
-def test_sharded_reducer_gloo_world2():
-    import torch.multiprocessing as mp
-
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=120) for _ in range(2))
-    for p in procs:
-        p.join(timeout=60)
-    assert [r[1] for r in res] == [True, True]
 
 
 def test_optimizer_state_files_roundtrip(tmp_path):
