@@ -360,6 +360,8 @@ def main():
     ap.add_argument("--emulate-comm", default=None, help="(default 2,4,8; off for --small) ""world sizes whose gradient exchange is EMULATED on this one GPU after the timed region "
                     "(a kernel holding --comm-cus CUs for the projected all-reduce time of every bucket): reported as `comm_emulated`, a "
                     "scheduling probe, not a scaling result; '' or 0 = off; only with --gpus 1")
+    ap.add_argument("--emulate-main", type=int, default=0, help="profiling aid: the TIMED trainer itself runs with the emulated exchange among N ranks "
+                    "(the line is labelled; not a benchmark)")
     ap.add_argument("--comm-cus", type=int, default=None, help="CUs the collectives are assumed to hold (default mic_amd.train.COMM_CUS_DEFAULT)")
     ap.add_argument("--fp8-scaling", default="delayed", choices=["delayed", "current"],
                     help="--dtype fp8: scale from the previous step's amax (one pass per tensor) or from the current amax (two)")
@@ -435,7 +437,7 @@ def main():
     if args.comm_cus is not None:
         tkw["comm_cus"] = args.comm_cus
     comm_arg = {"auto": "auto", "fp32": None, "bf16": torch.bfloat16}[args.grad_comm]
-    tr = Trainer(model, lr_fn, seed=42, grad_comm_dtype=comm_arg, **tkw)
+    tr = Trainer(model, lr_fn, seed=42, grad_comm_dtype=comm_arg, emulate_comm=args.emulate_main, **tkw)
     V, img = cfg.mbart_config.vocab_size, cfg.clip_vision_config.image_size
     batches = [synth_batch(B, T, V, img, 1234 + rank * 100 + i, dense=args.dense_captions) for i in range(2)]
     # inputs resident in HBM before the timed region
@@ -538,10 +540,15 @@ def main():
                 etr.train_step(dbatches[i % 2])
             barrier()
             edt = (time.perf_counter() - t0) / esteps
+            etr.reducer.emulate["timing"] = True  # one more step with the stand-in kernels bracketed by events
+            etr.train_step(dbatches[0])
+            barrier()
+            busy = sum(a.elapsed_time(b_) for a, b_ in etr.reducer.emulated_events)
             cb = 2 if etr.grad_comm_dtype is not None else 4
             emulated["worlds"][str(ew)] = {"ms_per_step": round(edt * 1e3, 3), "images_per_sec_per_gpu": round(B / edt, 1),
                                            "comm_dtype": "bf16" if cb == 2 else "fp32", "comm_cus": etr.comm_cus,
                                            "projected_allreduce_ms_per_step": round(etr.reducer.emulated_ms, 2),
+                                           "collective_stream_busy_ms_per_step": round(busy, 2),
                                            "projected_allreduce_ms_fp32": round(allreduce_ms(4.0 * model.store.numel, ew), 2)}
             del etr
         ops.set_cu_budget(0)
@@ -695,7 +702,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic (random-init weights, N(0,1) pixels, " + ("dense 62-token" if args.dense_captions else "ragged") + " random captions)",
             "config": {"workload": ("configs[4]" if args.dtype == "fp8" else "configs[1]") + ": ViT-B/32 + mBART-large-50 train step (fwd+loss+bwd+all-reduce+AdamW), "
-                                   f"per-GPU batch {B}, 224x224 NHWC fp32 pixels, seq_len {T}, dropout 0.1" + (" [SMALL DEBUG MODEL]" if args.small else "")
+                                   f"per-GPU batch {B}, 224x224 NHWC fp32 pixels, seq_len {T}, dropout 0.1" + (" [SMALL DEBUG MODEL]" if args.small else "") + (f" [EMULATED {args.emulate_main}-rank exchange on one GPU: profiling aid, not a benchmark]" if args.emulate_main else "")
                                    + (" [ALL RANKS SHARE cuda:0 OVER gloo: functional check, not a benchmark]" if share and world > 1 else ""),
                        "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}",
                        "grad_allreduce": (f"{'bf16' if tr.grad_comm_dtype is not None else 'fp32'} flat buckets (--grad-comm {args.grad_comm}), RCCL, side stream, "

@@ -500,9 +500,19 @@ extern "C" int mic_stream_destroy(void* stream) {
 
 // ------------------------------------------------------------------ emulated collective (bench.py --emulate-comm)
 __global__ __launch_bounds__(256) void comm_emulate_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long n16, unsigned long long ticks) {
+  // copy src -> dst (local HBM reads and writes, as the reduce / gather steps of a ring all-reduce make them) for AS LONG AS the
+  // projected duration allows — the copy is cut when the time is up, the kernel never runs longer than asked — then hold the CUs
   const unsigned long long t0 = wall_clock64();
-  for (int pass = 0; pass < 2; ++pass)
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (; i + 3 * stride < n16; i += 4 * stride) {  // four 16-B loads in flight per lane
+      if (wall_clock64() - t0 >= ticks) return;
+      const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+      dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  }
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);  // bounded by `ticks` (checked on the host side)
 }
 

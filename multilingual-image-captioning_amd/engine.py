@@ -339,7 +339,7 @@ class Engine:
         side = None
         if self._dw_on():
             if self._dw_stream is None:
-                self._dw_stream = torch.cuda.Stream(device=self.dev)
+                self._dw_stream = ops.role_stream(self.dev, "dw")
             side = self._dw_stream
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())

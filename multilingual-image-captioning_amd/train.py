@@ -184,8 +184,8 @@ class GradReducer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.cuda = flat_grad.is_cuda
-        self.stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None       # collectives
-        self.opt_stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None   # per-bucket optimizer work
+        self.stream = ops.role_stream(flat_grad.device, "collective") if self.cuda else None    # collectives
+        self.opt_stream = ops.role_stream(flat_grad.device, "optimizer") if self.cuda else None  # per-bucket optimizer work
         # ... on CUs of its own (`opt_cus` of them; 0 = no mask): the optimizer is HBM-bound and needs few CUs, while the backward
         # GEMM blocks own a CU's whole register file and never share one — with a mask the two run side by side instead of taking
         # turns.  A CU-masked HIP stream is a BLOCKING stream (it synchronises with the null stream, torch's default): the step then
@@ -195,8 +195,8 @@ class GradReducer:
         if self.cuda and on_ready is not None and opt_cus > 0:
             try:
                 self.opt_stream = ops.cu_masked_stream(0, opt_cus, flat_grad.device)
-                self.step_stream = torch.cuda.Stream(device=flat_grad.device)
-                self.tail_stream = torch.cuda.Stream(device=flat_grad.device)
+                self.step_stream = ops.role_stream(flat_grad.device, "step")
+                self.tail_stream = ops.role_stream(flat_grad.device, "tail")
             except Exception as ex:  # the stack refuses CU masks: plain streams, as before
                 import sys
 
@@ -206,9 +206,10 @@ class GradReducer:
             cus = int(self.emulate.get("cus", COMM_CUS_DEFAULT))
             self.stream = ops.cu_masked_stream(256 - cus, cus, flat_grad.device)
             if self.step_stream is None:  # a masked stream is a blocking stream: keep the step off the null stream
-                self.step_stream = torch.cuda.Stream(device=flat_grad.device)
+                self.step_stream = ops.role_stream(flat_grad.device, "step")
             self._emu_scratch = torch.empty(max(e - b for b, e in buckets), dtype=flat_grad.dtype, device=flat_grad.device)
             self.emulated_ms = 0.0
+            self.emulated_events = []
         self.on_ready = on_ready if self.cuda else None
         self.next = 0
         self.handles = []
@@ -238,9 +239,16 @@ class GradReducer:
         nbytes = (e - b) * int(em.get("comm_bytes", 4))
         ms = allreduce_ms(nbytes, int(em["world"]), float(em.get("link_gbps", XGMI_LINK_GBPS)))
         self.emulated_ms += ms
+        ev = None
+        if em.get("timing"):  # bench.py: how long the stand-in kernels really held the stream
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         with ops.pinned_stream():
             ops.comm_emulate(self.grad[b:e], self._emu_scratch[: e - b], (e - b) * self.grad.element_size(), ms * 1e3,
                              2 * int(em.get("cus", COMM_CUS_DEFAULT)))
+        if ev is not None:
+            ev[1].record()
+            self.emulated_events.append(ev)
 
     @property
     def active(self) -> bool:
@@ -253,6 +261,7 @@ class GradReducer:
         self._at_end = []
         if self.emulate is not None:
             self.emulated_ms = 0.0
+            self.emulated_events = []
 
     def _issue(self, b: int, e: int, ev, here=None):
         """the bucket's optimizer pass on the optimizer stream, behind its exchange (`ev`) and, for "next" buckets, behind

@@ -144,12 +144,23 @@ def _packed_worker(rank, world, port, q, full=False):
             res[pack] = (float(out["loss"]), model.store.grad.clone(), model.store.lp.float().clone())
             del tr, model
         ok, msg = True, ""
-        if res[True][0] != res[False][0]:
+        # reduced model: the same number (every valid row goes through the same per-row arithmetic).  Full size at 16 captions per
+        # rank: the packed (~560 rows) and the padded (1024 rows) step get different K-group counts from the tile planner in FORWARD
+        # GEMMs too, i.e. different fp32 summation orders: equal to bf16 rounding, not bit for bit
+        if (abs(res[True][0] - res[False][0]) > 1e-4 * abs(res[False][0])) if full else (res[True][0] != res[False][0]):
             ok, msg = False, f"loss {res[True][0]} vs {res[False][0]}"
         g1, g0 = res[True][1], res[False][1]
         e = ((g1 - g0).abs().max() / g0.abs().max()).item()
-        if e > 2e-3:
+        # reduced model (2 + 2 layers): summation order only.  Full size: the packed and the padded step pick different tile
+        # configurations for their different row counts, whose last-bit differences in the bf16 activation gradients cascade through
+        # 12 + 12 layers exactly like the forward cascade of tests/test_oracle_cpu.py — the direction must agree, not the last bits
+        if e > (2e-2 if full else 2e-3):
             ok, msg = False, f"summed gradients differ: {e}"
+        c = torch.nn.functional.cosine_similarity(g1.double(), g0.double(), dim=0).item()
+        if c < 0.9995:
+            ok, msg = False, f"summed gradients: cosine {c}"
+        if rank == 0:
+            print(f"[two ranks, {'full size' if full else 'reduced'}] packed vs padded: loss {res[True][0]} / {res[False][0]}, summed gradients max diff {e:.2e} of the largest entry, cosine {c:.6f}", flush=True)
         # every rank ends with the same weights (the all-reduce and the embedding-row exchange are rank-symmetric)
         lp = res[True][2]
         gathered = [torch.zeros_like(lp.cpu()) for _ in range(world)]
