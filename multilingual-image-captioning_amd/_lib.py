@@ -58,7 +58,7 @@ class BeamStepArgs(C.Structure):
 
 class GemmPlanInfo(C.Structure):
     _fields_ = [("tile", C.c_int), ("kgroups", C.c_int), ("blocks", C.c_int), ("grid", C.c_int), ("blocks_per_cu", C.c_int),
-                ("phased", C.c_int), ("cu_budget", C.c_int)]
+                ("phased", C.c_int), ("cu_budget", C.c_int), ("tile_m", C.c_int)]
 
 
 class ImageItem(C.Structure):

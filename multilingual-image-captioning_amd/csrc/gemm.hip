@@ -174,7 +174,7 @@ extern "C" int mic_set_cu_budget(int cus) {
 }
 extern "C" int mic_get_cu_budget(void) { return mic_cu_budget_now(); }
 
-struct GemmPlan { int bm, kgroups, blocks, grid, per_cu, phased; };
+struct GemmPlan { int bm, bm_m, kgroups, blocks, grid, per_cu, phased; };  // bm_m: tile rows (bm, or 192 with bm = 128)
 
 // tile configuration of one (grouped) bf16 / fp8 launch: pure host arithmetic on the shapes and the CU budget
 static GemmPlan plan_bf16(const mic_gemm_args* args, int count) {
@@ -204,16 +204,25 @@ static GemmPlan plan_bf16(const mic_gemm_args* args, int count) {
   if (force == 256 || force == 128 || force == 64) bm = force;
   for (int i = 0; i < count; ++i)
     if (args[i].rowstat) bm = 256;  // softmax partials per 64-column granule = the wave tile width of this configuration
+  // 192 x 128 tiles for the single-problem NT / NN launches whose 128 x 128 tiles would need a second round of the 2-per-CU slots
+  // while 192-row tiles fit one (packed decoder rows 2049..3072 and the ViT's 3200 rows against N = 3072 / 4096);
+  // MIC_GEMM_T192=0 switches the configuration off (A/B)
+  static const int t192 = [] { const char* e = getenv("MIC_GEMM_T192"); return e ? atoi(e) : 1; }();
+  int bm_m = bm;
+  if (bm == 128 && t192 && force == 0 && count == 1 && args[0].dtype == MIC_BF16 && !args[0].a_kmajor && args[0].split_k <= 1) {
+    const long t128 = (long)((args[0].M + 127) / 128) * ((args[0].N + 127) / 128), t192n = (long)((args[0].M + 191) / 192) * ((args[0].N + 127) / 128);
+    if (t128 > 2L * cus && t192n <= 2L * cus) bm_m = 192;
+  }
   int blocks = 0, kmin = 1 << 30;
   for (int i = 0; i < count; ++i) {
     int nsplit = args[i].split_k > 1 ? args[i].split_k : 1;
     const int kt = (args[i].dtype == MIC_FP8 ? args[i].K / 2 : args[i].K) / 64;
     if (nsplit > kt) nsplit = kt;
     if (nsplit < 1) nsplit = 1;
-    blocks += ((args[i].M + bm - 1) / bm) * ((args[i].N + bm - 1) / bm) * nsplit;
+    blocks += ((args[i].M + bm_m - 1) / bm_m) * ((args[i].N + bm - 1) / bm) * nsplit;
     kmin = kt / nsplit < kmin ? kt / nsplit : kmin;
   }
-  pl.bm = bm; pl.blocks = pl.grid = blocks; pl.kgroups = 1; pl.per_cu = 1;
+  pl.bm = bm; pl.bm_m = bm_m; pl.blocks = pl.grid = blocks; pl.kgroups = 1; pl.per_cu = 1;
   // LDS-DMA four-phase 256x256 kernel for the single-problem NT launches (both operands k-contiguous: LM-head forward, FFN-in
   // forward), where its deeper operand prefetch wins; MIC_GEMM_PHASED=0 switches it off (A/B).  On every 256x256 launch it
   // measured +1.6 ms per train step: that mode is gone.
@@ -226,7 +235,7 @@ static GemmPlan plan_bf16(const mic_gemm_args* args, int count) {
     // 8 waves (measured better than the 4-wave 64x64 wave tile at every tile count), two blocks per CU; two K-groups (16 waves, one
     // block per CU) when the launch is a single round of at most one block per CU
     static const int kg128 = [] { const char* e = getenv("MIC_GEMM_KG128"); return e ? atoi(e) : -1; }();
-    const bool two = kg128 >= 0 ? kg128 == 2 : (blocks <= cus && kmin >= 8);
+    const bool two = bm_m == 128 && (kg128 >= 0 ? kg128 == 2 : (blocks <= cus && kmin >= 8));
     pl.kgroups = two ? 2 : 1;
     pl.per_cu = two ? 1 : 2;
   } else {  // 64x64x64 tiles, 4 waves per K-group (32 KiB of LDS each); K-groups while the grid leaves CUs under-occupied
@@ -243,7 +252,7 @@ extern "C" int mic_gemm_plan(const mic_gemm_args* args, int count, mic_gemm_plan
   MIC_CHECK(args && out && count >= 1 && count <= MAX_PROBLEMS, "mic_gemm_plan: bad args (1..%d problems)", MAX_PROBLEMS);
   MIC_CHECK(args[0].dtype == MIC_BF16 || args[0].dtype == MIC_FP8, "mic_gemm_plan: the planner belongs to the bf16 / fp8 kernels");
   const GemmPlan pl = plan_bf16(args, count);
-  out->tile = pl.bm; out->kgroups = pl.kgroups; out->blocks = pl.blocks; out->blocks_per_cu = pl.per_cu; out->phased = pl.phased;
+  out->tile = pl.bm; out->tile_m = pl.bm_m; out->kgroups = pl.kgroups; out->blocks = pl.blocks; out->blocks_per_cu = pl.per_cu; out->phased = pl.phased;
   out->cu_budget = mic_cu_budget_now();
   const bool persist = pl.bm == 256 && !pl.phased && pl.blocks > out->cu_budget;  // (the PLAIN instantiations only: an upper bound on the grid otherwise)
   out->grid = persist ? out->cu_budget : pl.blocks;
@@ -255,7 +264,7 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
   tab.count = count;
   const int f8 = args[0].dtype == MIC_FP8 ? (args[0].a_fmt == MIC_E5M2 ? 2 : 1) : 0;
   const GemmPlan pl = plan_bf16(args, count);
-  const int bm = pl.bm;
+  const int bm = pl.bm, bm_m = pl.bm_m;
   int blocks = 0;
   for (int i = 0; i < count; ++i) {
     Problem& p = tab.p[i];
@@ -270,7 +279,7 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
       p.lda /= 2; p.ldb /= 2; p.K /= 2;
       p.sa = args[i].a_scale_inv; p.sb = args[i].b_scale_inv;
     }
-    p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bm - 1) / bm;
+    p.tiles_m = (p.M + bm_m - 1) / bm_m; p.tiles_n = (p.N + bm - 1) / bm;
     p.nsplit = args[i].split_k > 1 ? args[i].split_k : 1;
     if (p.nsplit > p.K / 64) p.nsplit = p.K / 64;
     p.split_stride = p.nsplit > 1 ? args[i].split_stride : 0;
@@ -291,6 +300,7 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
     MIC_CHECK(!args[i].rowsum2 || table_is_plain(tab), "mic_gemm_grouped: rowsum2 needs every problem of the launch on the bare / residual epilogue");
   if (bm == 256 && pl.phased) launch_gemm_phased(tab, args[0].a_kmajor, args[0].b_kmajor, table_is_plain(tab), s);  // LDS-DMA, phased
   else if (bm == 256) launch_gemm_t256(tab, args[0].a_kmajor, args[0].b_kmajor, s, f8);     // 256x256x64, 8 waves
+  else if (bm == 128 && bm_m == 192) launch_gemm_t192(tab, args[0].b_kmajor, s);                     // 192x128x64, 8 waves, two blocks per CU
   else if (bm == 128) launch_gemm_t128(tab, args[0].a_kmajor, args[0].b_kmajor, s, f8, pl.kgroups);  // 128x128x64, 8 waves per K-group
   else launch_gemm_t64(tab, args[0].a_kmajor, args[0].b_kmajor, s, f8, pl.kgroups);                  // 64x64x64, 4 waves per K-group
   MIC_LAUNCH_CHECK();

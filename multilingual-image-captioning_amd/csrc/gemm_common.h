@@ -3,6 +3,7 @@
 // registers, MFMA fragment reads from the swizzled LDS images, the XCD-aware tile order and the fused epilogue.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 #define MAX_PROBLEMS 8
 #ifndef MIC_TINY_BELOW
@@ -28,6 +29,7 @@ void launch_gemm_phased(const LaunchTable& tab, int akm, int bkm, bool plain, hi
 bool table_is_plain(const LaunchTable& t);
 void launch_gemm_t256(const LaunchTable& tab, int akm, int bkm, hipStream_t s, int f8);
 void launch_gemm_t128(const LaunchTable& tab, int akm, int bkm, hipStream_t s, int f8, int kgroups);
+void launch_gemm_t192(const LaunchTable& tab, int bkm, hipStream_t s);  // 192 x 128 tiles, bf16, k-contiguous A (NT / NN)
 void launch_gemm_t64(const LaunchTable& tab, int akm, int bkm, hipStream_t s, int f8, int kgroups);
 
 // --- stage one operand image (ROWS x BKT k, or BKT k x ROWS x; ROWS = 128 or 64) HBM/L2 -> registers -> LDS.
@@ -178,15 +180,18 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], c
   const bool ln_fold = E.ln_stats != nullptr;
   // each wave restages an RP x WN fp32 block of its accumulators through its own LDS region, then the whole block streams
   // them out: every thread owns 8 consecutive columns of a row (16-B vectors).
-  constexpr int RP = WM < 64 ? WM : 64;  // rows per pass
+  constexpr int RP = WM % 64 == 0 ? 64 : 32;  // rows per pass (WM = 32, 96: 32-row passes)
   constexpr int REGION = RP * WN;        // floats per wave region
   constexpr int CPR = WN / 8;            // 8-column chunks per region row
   constexpr int NGRP = NWAVES * RP * CPR;                 // 8-column groups per pass (whole tile)
   constexpr int NIT = (NGRP + NTHREADS - 1) / NTHREADS;   // ... per thread
   float* Cw = reinterpret_cast<float*>(smem) + wave * REGION;
   const bool pre = !is_split && epilogue_pre_ok(E) && epilogue_vec_ok(E, 8);
-#pragma unroll
-  for (int p = 0; p < WM / RP; ++p) {
+  // one pass per RP rows of the wave tile.  The pass index must be a compile-time constant (it selects accumulator registers): a
+  // generic lambda called once per pass — `#pragma unroll` gave up on the three passes of the 96-row wave tile and the accumulators
+  // went to scratch, stored in every K-loop iteration
+  auto pass = [&](auto pc) __attribute__((always_inline)) {
+    constexpr int p = decltype(pc)::value;
     if (p > 0) __syncthreads();
     if (kg == 0) {
 #pragma unroll
@@ -327,5 +332,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], c
       }
     }
     }
-  }
+  };
+  pass(std::integral_constant<int, 0>{});
+  if constexpr (WM / RP > 1) pass(std::integral_constant<int, 1>{});
+  if constexpr (WM / RP > 2) pass(std::integral_constant<int, 2>{});
+  static_assert(WM / RP <= 3, "at most three epilogue passes");
 }

@@ -25,7 +25,11 @@ template <int WM, int WN, int WNW, int BKT, bool AK, bool BKM, int KG = 1, bool 
 __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kernel(LaunchTable tab) {
   static_assert(F8 == 0 || (!AK && !BKM && BKT == 64), "fp8: k-contiguous operands, 128-byte stages");
   constexpr int BM = 2 * WM, BN = WN * WNW, NWAVES = 2 * WNW, NTHREADS = 64 * NWAVES * KG;
-  constexpr int UA = BM < 128 ? BM : 128, UB = BN < 128 ? BN : 128;  // rows per staged image (128, or 64 for the 64-wide tiles)
+  // rows per staged image: 128, or 64 for the 64-wide tiles and for BM = 192 (three 64-row images side by side: a wave's 96 rows
+  // start at row 0 or 96 and run across image boundaries — images of a k-contiguous operand are contiguous 128-B rows whose
+  // swizzle depends on (row >> 1) & 7 only, so the fragment reads need no image arithmetic)
+  constexpr int UA = (BM % 128 == 0) ? 128 : 64, UB = BN < 128 ? BN : 128;
+  static_assert(BM % 128 == 0 || BM == 64 || !AK, "BM = 192: k-contiguous A only (NT / NN launches)");
   constexpr int HALF_A = UA * BKT * 2, HALF_B = UB * BKT * 2;
   constexpr int NHA = BM / UA, NHB = BN / UB, STAGE = NHA * HALF_A + NHB * HALF_B, AI = WM / 32, NJ = WN / 32, KSTEPS = BKT / 16;
   constexpr int STAGE_AT = 0;  // k-step in front of which the next tile's LDS writes / global loads are issued (1..3 measured equal)
@@ -314,7 +318,7 @@ template <int WM, int WN, int WNW, int BKT, int KG, bool PLAIN, int F8 = 0>
 static inline void launch_cfg_p(const LaunchTable& tab, int akm, int bkm, hipStream_t s) {
   constexpr int BM = 2 * WM, BN = WN * WNW;
   size_t lds = (size_t)KG * 2 * (BM + BN) * BKT * 2;
-  const size_t epi = (size_t)2 * WNW * (WM < 64 ? WM : 64) * WN * 4;  // the epilogue restages min(WM,64) x WN floats per wave
+  const size_t epi = (size_t)2 * WNW * (WM % 64 == 0 ? 64 : 32) * WN * 4;  // the epilogue restages 64 (or 32) x WN floats per wave
   const size_t red = (size_t)(KG - 1) * 2 * WNW * (WM / 32) * (WN / 32) * 16 * 64 * 4;  // K-group partial sums
   if (epi > lds) lds = epi;
   if (red > lds) lds = red;
@@ -339,6 +343,9 @@ static inline void launch_cfg_p(const LaunchTable& tab, int akm, int bkm, hipStr
   } while (0)
   if constexpr (F8 != 0) {
     LAUNCH(false, false);
+  } else if constexpr (WM == 96) {  // BM = 192: k-contiguous A only
+    if (!bkm) LAUNCH(false, false);
+    else LAUNCH(false, true);
   } else {
     if (!akm && !bkm) LAUNCH(false, false);
     else if (!akm && bkm) LAUNCH(false, true);

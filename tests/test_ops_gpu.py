@@ -746,3 +746,43 @@ def test_gemm_layernorm_fold_and_rowsum2(dev, M, N, K, act):
         ops.gemm(a0.to(dev), b0.to(dev), x, M, K, 64, act=2, rowsum2=st)
     with pytest.raises(L.MicError, match="folded LayerNorm"):
         ops.gemm(x, wf, out, M, N, K, ln_stats=st, ln_colsum=cs, ln_width=K, ln_eps=eps)   # bias' missing
+
+
+
+@pytest.mark.parametrize("M,N,K", [(2404, 4096, 1024), (3200, 3072, 768), (2049, 4096, 128), (3072, 4096, 64)])
+def test_gemm_192_row_tiles(dev, M, N, K):
+    """192 x 128 tiles (wave tile 96 x 32, three 64-row A images, three 32-row epilogue passes): taken for the single-problem NT / NN
+    launches whose 128-row tiles would spill into a second round.  NT with bias + GELU + saved pre-activation (FFN-in forward), NN
+    with act'(z) (the dGELU dX), NN bare with a residual; a last row tile that is partial (2404 = 12 x 192 + 100) or absent."""
+    from mic_amd import _lib as L
+    from mic_amd import ops
+
+    for bkm in (False, True):
+        assert ops.gemm_plan([(M, N, K)], b_kmajor=bkm)["tile_m"] == 192
+    assert ops.gemm_plan([(M, N, K)], a_kmajor=True, b_kmajor=True)["tile_m"] != 192  # k-major A: not built
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(M + N + K)
+    A, B = rnd((M, K), g, dt), rnd((N, K), g, dt, 0.1)
+    bias = torch.randn(N, generator=g)
+    out = torch.full((M + 64, N), float("nan"), dtype=dt, device=dev)  # rows behind M must stay untouched
+    z = torch.full((M + 64, N), float("nan"), dtype=dt, device=dev)
+    ops.gemm(A.to(dev), B.to(dev), out, M, N, K, bias=bias.to(dev), act=L.ACT_GELU_TANH, zout=z)
+    zr = A.float() @ B.float().T + bias
+    ref = torch.nn.functional.gelu(zr.to(dt).float(), approximate="tanh")
+    torch.cuda.synchronize()
+    assert relerr(z[:M], zr) < tol(dt) and relerr(out[:M], ref) < tol(dt)
+    assert torch.isnan(out[M:].float()).all() and torch.isnan(z[M:].float()).all()
+    # NN: dz = (dy @ W) * act'(z);  W stored [K][N] (k-major B)
+    dY, W = rnd((M, K), g, dt), rnd((K, N), g, dt, 0.1)
+    dz = torch.full((M + 64, N), float("nan"), dtype=dt, device=dev)
+    ops.gemm(dY.to(dev), W.to(dev), dz, M, N, K, b_kmajor=True, zin=z, dact=L.ACT_GELU_TANH)
+    zz = z[:M].float().cpu().requires_grad_(True)
+    torch.nn.functional.gelu(zz, approximate="tanh").backward(torch.ones_like(zz))
+    torch.cuda.synchronize()
+    assert relerr(dz[:M], (dY.float() @ W.float()) * zz.grad) < tol(dt) and torch.isnan(dz[M:].float()).all()
+    # NN, PLAIN epilogue with a residual
+    R = rnd((M, N), g, dt)
+    o2 = torch.full((M + 64, N), float("nan"), dtype=dt, device=dev)
+    ops.gemm(dY.to(dev), W.to(dev), o2, M, N, K, b_kmajor=True, residual=R.to(dev))
+    torch.cuda.synchronize()
+    assert relerr(o2[:M], dY.float() @ W.float() + R.float()) < tol(dt) and torch.isnan(o2[M:].float()).all()
