@@ -7,7 +7,7 @@
 
 #define MAX_PROBLEMS 8
 #ifndef MIC_TINY_BELOW
-#define MIC_TINY_BELOW 128  // 128x128-tile count under which a launch uses 64x64 tiles (tools/bench_tile_cfg.py)
+#define MIC_TINY_BELOW 128  // 128x128-tile count under which a launch uses 64x64 tiles (round-1 tile-configuration sweep)
 #endif
 
 struct Problem {

@@ -137,6 +137,71 @@ def test_plan_buckets():
     assert plan_buckets(100_000, 20_000, [0, 500, 60_500, 80_000], max_elems=16_000) == plan_buckets(100_000, 20_000, [0, 500, 60_500, 80_000])
 
 
+def test_plan_buckets_invariants_random():
+    """whatever the layout: the buckets tile [0, numel) in order, every cut sits on a segment boundary or (inside a splittable segment)
+    on one of its row boundaries, no bucket but the last is below the minimum, and no piece of a splittable segment exceeds the cap by
+    more than the segment's head that rides with its first piece"""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    from mic_amd.train import plan_buckets
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.lists(st.integers(1, 5000), min_size=1, max_size=40), st.integers(1, 4000), st.integers(1, 6000), st.integers(0, 39), st.integers(1, 64))
+    def check(sizes, min_elems, max_elems, big, align):
+        sizes = list(sizes)
+        big %= len(sizes)
+        sizes[big] = sizes[big] * align  # the splittable segment is a whole number of rows
+        bounds = [0]
+        for x in sizes:
+            bounds.append(bounds[-1] + x)
+        numel = bounds[-1]
+        seg = (bounds[big], bounds[big + 1], align)
+        b = plan_buckets(numel, min_elems, bounds[:-1], max_elems=max_elems, splittable=(seg,))
+        assert b[0][0] == 0 and b[-1][1] == numel and all(x[1] == y[0] and x[1] > x[0] for x, y in zip(b, b[1:]))
+        base = plan_buckets(numel, min_elems, bounds[:-1])
+        assert all(e - s >= min_elems for s, e in base[:-1])
+        cuts, base_cuts = {e for _, e in b[:-1]}, {e for _, e in base[:-1]}
+        assert base_cuts <= cuts and base_cuts <= set(bounds)
+        step = max(align, (max_elems // align) * align)
+        for c in cuts - base_cuts:   # the extra cuts: inside the splittable segment, on its row grid, `step` apart
+            assert seg[0] < c < seg[1] and (c - seg[0]) % step == 0
+        for s_, e in b:
+            if s_ >= seg[0] and e <= seg[1] and e - s_ > step:
+                raise AssertionError((s_, e, step))
+
+    check()
+
+
+def test_gemm_planner_invariants_random():
+    """for any single bf16 NT / NN problem and any CU budget: the plan's blocks are the tile count of its tile shape, two / four
+    K-groups are only chosen for launches that fit one round, a persistent grid never exceeds the budget"""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    from mic_amd import ops
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.integers(1, 6000), st.integers(1, 40), st.integers(1, 64), st.sampled_from([0, 256, 224, 192, 160, 96]), st.booleans())
+    def check(M, n8, k64, cus, bkm):
+        N, K = n8 * 128, k64 * 64
+        ops.set_cu_budget(cus)
+        p = ops.gemm_plan([(M, N, K)], b_kmajor=bkm)
+        c = p["cu_budget"]
+        assert c == (cus or 256) and p["tile"] in (64, 128, 256) and p["tile_m"] in (p["tile"], 192)
+        assert p["blocks"] == -(-M // p["tile_m"]) * -(-N // p["tile"])
+        if p["kgroups"] > 1:
+            assert p["blocks"] <= c * p["blocks_per_cu"] and p["tile"] != 256
+        assert p["grid"] <= max(p["blocks"], 1) and (p["grid"] == p["blocks"] or p["grid"] == c)
+        if p["tile_m"] == 192:
+            assert p["blocks"] <= 2 * c < -(-M // 128) * -(-N // 128)
+
+    try:
+        check()
+    finally:
+        ops.set_cu_budget(0)
+
+
 def test_packed_rows_helper():
     from mic_amd import loss_rows, packed_rows
 
