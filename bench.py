@@ -514,44 +514,19 @@ def main():
                          "201.3 GFLOP per sample are executed in full; roofline_frac = the GEMM fraction of peak of THIS step "
                          "(instrumented like `roofline`), i.e. the kernels' efficiency when no row can be packed away"}
 
-    # the same step with an EMULATED gradient exchange among N ranks on this one GPU: every bucket's all-reduce is replaced by a
-    # kernel that holds `comm_cus` CUs (a CU-masked collective stream) for the time a ring all-reduce of that bucket is projected to
-    # take over xGMI (mic_amd.train.allreduce_ms), the bucket's optimizer pass waits for it as it would for RCCL, and the GEMM tile
-    # planner is sized for the remaining CUs.  What it shows: whether the step's scheduling (bucket order, optimizer stream, CU
-    # budget) holds up when a collective stream is busy beside backward.  NOT a scaling result: no byte crosses a link.
-    emulated = None
-    emu_arg = args.emulate_comm if args.emulate_comm is not None else ("" if args.small else "2,4,8")
-    emu_worlds = [int(x) for x in str(emu_arg).split(",") if x.strip() not in ("", "0", "1")]
-    if world == 1 and emu_worlds and args.dtype != "f32":
+    # this trainer's own emulation figures (bench.py --emulate-main N: the child processes of the `comm_emulated` legs, and the profiling aid)
+    emulation = None
+    if args.emulate_main and world == 1 and tr.reducer.emulate is not None:
         from mic_amd.train import allreduce_ms
 
-        emulated = {"note": "1-GPU step with every bucket's all-reduce replaced by a kernel holding comm_cus CUs on a CU-masked stream for the "
-                            "projected ring all-reduce time of that bucket (2 (N-1)/N x bytes over N-1 xGMI links at 64 GB/s each); optimizer "
-                            "passes wait for it as for RCCL; GEMM tile planner sized for 256 - comm_cus CUs.  A scheduling probe, NOT a scaling result",
-                    "baseline_ms_per_step": round(dt / args.steps * 1e3, 3), "worlds": {}}
-        for ew in emu_worlds:
-            etr = Trainer(model, lr_fn, seed=42, grad_comm_dtype=comm_arg, emulate_comm=ew, **tkw)
-            esteps = max(2, min(args.steps, 6))
-            for i in range(2):
-                etr.train_step(dbatches[i % 2])
-            barrier()
-            t0 = time.perf_counter()
-            for i in range(esteps):
-                etr.train_step(dbatches[i % 2])
-            barrier()
-            edt = (time.perf_counter() - t0) / esteps
-            etr.reducer.emulate["timing"] = True  # one more step with the stand-in kernels bracketed by events
-            etr.train_step(dbatches[0])
-            barrier()
-            busy = sum(a.elapsed_time(b_) for a, b_ in etr.reducer.emulated_events)
-            cb = 2 if etr.grad_comm_dtype is not None else 4
-            emulated["worlds"][str(ew)] = {"ms_per_step": round(edt * 1e3, 3), "images_per_sec_per_gpu": round(B / edt, 1),
-                                           "comm_dtype": "bf16" if cb == 2 else "fp32", "comm_cus": etr.comm_cus,
-                                           "projected_allreduce_ms_per_step": round(etr.reducer.emulated_ms, 2),
-                                           "collective_stream_busy_ms_per_step": round(busy, 2),
-                                           "projected_allreduce_ms_fp32": round(allreduce_ms(4.0 * model.store.numel, ew), 2)}
-            del etr
-        ops.set_cu_budget(0)
+        tr.reducer.emulate["timing"] = True  # one more step with the stand-in kernels bracketed by events
+        tr.train_step(dbatches[0])
+        barrier()
+        busy = sum(a.elapsed_time(b_) for a, b_ in tr.reducer.emulated_events)
+        tr.reducer.emulate["timing"] = False
+        emulation = {"world": args.emulate_main, "comm_dtype": "bf16" if tr.grad_comm_dtype is not None else "fp32", "comm_cus": tr.comm_cus,
+                     "projected_allreduce_ms_per_step": round(tr.reducer.emulated_ms, 2), "collective_stream_busy_ms_per_step": round(busy, 2),
+                     "projected_allreduce_ms_fp32": round(allreduce_ms(4.0 * model.store.numel, args.emulate_main), 2)}
 
     if rank == 0:
         note(f"{images_per_sec:.1f} images/s; roofline step")
@@ -685,6 +660,37 @@ def main():
             except Exception as e:
                 gen["cpu_baseline"] = {"value": None, "unit": "captions/sec", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
 
+    # The same step with an EMULATED gradient exchange among N ranks on this one GPU, one fresh child process per N (`--emulate-main N`:
+    # exactly one Trainer per process, as a data-parallel rank has): every bucket's all-reduce is replaced by a kernel that holds
+    # `comm_cus` CUs (a CU-masked collective stream) for the time a ring all-reduce of that bucket is projected to take over xGMI
+    # (mic_amd.train.allreduce_ms), the bucket's optimizer pass waits for it as it would for RCCL, and the GEMM tile planner is sized
+    # for the remaining CUs.  What it shows: whether the step's scheduling (bucket order, optimizer stream, CU budget) holds up when
+    # a collective stream is busy beside backward.  NOT a scaling result: no byte crosses a link.
+    emulated = None
+    emu_arg = args.emulate_comm if args.emulate_comm is not None else ("" if args.small else "2,4,8")
+    emu_worlds = [int(x) for x in str(emu_arg).split(",") if x.strip() not in ("", "0", "1")]
+    if rank == 0 and world == 1 and emu_worlds and args.dtype != "f32" and not args.emulate_main:
+        note(f"emulated-exchange legs for N = {emu_worlds} (one child process each)")
+        torch.cuda.synchronize()
+        emulated = {"note": "1-GPU step (a fresh process per N, 6 timed steps) with every bucket's all-reduce replaced by a kernel holding comm_cus CUs on a "
+                            "CU-masked stream for the projected ring all-reduce time of that bucket (2 (N-1)/N x bytes over N-1 xGMI links at 64 GB/s "
+                            "each); optimizer passes wait for it as for RCCL; GEMM tile planner sized for 256 - comm_cus CUs.  A scheduling probe, NOT a "
+                            "scaling result", "baseline_ms_per_step": round(dt / args.steps * 1e3, 3), "worlds": {}}
+        drop = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE")
+        env = {k: v for k, v in os.environ.items() if k not in drop and not k.startswith(("MASTER_", "TORCHELASTIC_"))}
+        for ew in emu_worlds:
+            cmd = [sys.executable, os.path.abspath(__file__), "--emulate-main", str(ew), "--emulate-comm", "0", "--steps", "6", "--warmup", "3",
+                   "--no-generate", "--no-cpu-baseline", "--no-roofline", "--no-dense-leg", "--dtype", args.dtype, "--grad-comm", args.grad_comm,
+                   "--batch", str(args.batch)] + (["--small"] if args.small else []) + (["--comm-cus", str(args.comm_cus)] if args.comm_cus is not None else [])
+            try:
+                r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+                cd = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                e = dict(cd["emulation"])
+                e.pop("world", None)
+                emulated["worlds"][str(ew)] = {"ms_per_step": cd["ms_per_step"], "images_per_sec_per_gpu": cd["value"], **e}
+            except Exception as ex:  # a reported figure, never a dependency of the headline number
+                emulated["worlds"][str(ew)] = {"ms_per_step": None, "error": f"{type(ex).__name__}: {ex}"[:300]}
+
     if rank == 0:
         # executed work: the LM head (forward, dE, dX: 3 x 2 x rows x V x d) runs only on the label positions that carry loss
         n_loss = sum(int(b["attention_mask"].sum()) for b in batches) / len(batches)
@@ -720,7 +726,7 @@ def main():
                                  "by the same time (NOT executed work); dense_captions is the measured step when every position carries loss",
             "dense_equivalent_tflops_per_gpu": round(dense_flops * args.steps / dt / 1e12, 1),
             "dense_captions": dense,
-            "comm_emulated": emulated,
+            "comm_emulated": emulated, "emulation": emulation,
             "final_loss": round(loss, 4),
             "roofline": roofline, "cpu_baseline": cpu, "beam4_generate": gen,
         }

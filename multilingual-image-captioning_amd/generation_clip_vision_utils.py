@@ -67,7 +67,7 @@ class _DecodePlan:
         try:
             if self.streams:
                 _RETIRED_GRAPHS.extend((g, self.graph_events.get(k)) for k, g in self.graphs.items())
-                if len(_RETIRED_GRAPHS) % 256 == 0:
+                if _RETIRED_GRAPHS and len(_RETIRED_GRAPHS) % 256 == 0:
                     import sys
 
                     print(f"[mic_amd.generate] {len(_RETIRED_GRAPHS)} retired multi-branch decode graphs are parked (ROCm 7.2 workaround)", file=sys.stderr)

@@ -325,10 +325,11 @@ _role_streams = {}
 
 def role_stream(device, role: str) -> "torch.cuda.Stream":
     """One side stream per (device, role) and process ("collective", "optimizer", "step", "tail", "dw"), shared by every reducer /
-    engine: HIP multiplexes streams onto a handful of hardware queues, and two streams that share a queue serialise.  A second
-    Trainer in the same process (bench.py's emulated-comm legs, the tests) with streams of its own measured 25 / 33 ms per step where
-    the same schedule on the first Trainer's streams measured 22 / 27 ms — its collective stream had landed on the step stream's
-    queue."""
+    engine: HIP multiplexes streams onto a handful of hardware queues and streams that share a queue serialise, so a process should
+    not keep minting side streams (a Trainer per test, bench.py's legs).  How streams map onto queues depends on the process's whole
+    stream history: even with shared role streams a SECOND Trainer in one process measured 2.5-6 ms more per emulated-exchange step
+    than the same schedule run by the process's only Trainer (and +10 ms under GPU_MAX_HW_QUEUES=8) — bench.py runs those legs in fresh
+    child processes, one Trainer each, like a data-parallel rank."""
     dev = torch.device(device)
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), role)
     st = _role_streams.get(key)

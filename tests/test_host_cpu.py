@@ -287,7 +287,7 @@ def test_gemm_planner_follows_the_cu_budget():
         assert ops.get_cu_budget() == 256
         base = {k: ops.gemm_plan(v) for k, v in step.items()}
         assert all(p["blocks"] <= 256 * p["blocks_per_cu"] for p in base.values()), base  # one round today
-        assert base["dec so/cq/co dense"]["kgroups"] == 2 and base["gen d x d"] == dict(tile=64, kgroups=4, blocks=256, grid=256, blocks_per_cu=1, phased=0, cu_budget=256)
+        assert base["dec so/cq/co dense"]["kgroups"] == 2 and base["gen d x d"] == dict(tile=64, tile_m=64, kgroups=4, blocks=256, grid=256, blocks_per_cu=1, phased=0, cu_budget=256)
         for cus in (224, 192):
             ops.set_cu_budget(cus)
             for k, v in step.items():
