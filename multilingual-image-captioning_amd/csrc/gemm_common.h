@@ -3,7 +3,6 @@
 // registers, MFMA fragment reads from the swizzled LDS images, the XCD-aware tile order and the fused epilogue.
 #pragma once
 #include "common.h"
-#include <type_traits>
 
 #define MAX_PROBLEMS 8
 #ifndef MIC_TINY_BELOW
@@ -181,160 +180,38 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], c
   // each wave restages an RP x WN fp32 block of its accumulators through its own LDS region, then the whole block streams
   // them out: every thread owns 8 consecutive columns of a row (16-B vectors).
   constexpr int RP = WM % 64 == 0 ? 64 : 32;  // rows per pass (WM = 32, 96: 32-row passes)
+  static_assert(RP % 32 == 0 && WM % RP == 0, "restage passes are whole 32-row accumulator blocks");
   constexpr int REGION = RP * WN;        // floats per wave region
   constexpr int CPR = WN / 8;            // 8-column chunks per region row
   constexpr int NGRP = NWAVES * RP * CPR;                 // 8-column groups per pass (whole tile)
   constexpr int NIT = (NGRP + NTHREADS - 1) / NTHREADS;   // ... per thread
   float* Cw = reinterpret_cast<float*>(smem) + wave * REGION;
   const bool pre = !is_split && epilogue_pre_ok(E) && epilogue_vec_ok(E, 8);
-  // one pass per RP rows of the wave tile.  The pass index must be a compile-time constant (it selects accumulator registers): a
-  // generic lambda called once per pass — `#pragma unroll` gave up on the three passes of the 96-row wave tile and the accumulators
-  // went to scratch, stored in every K-loop iteration
-  auto pass = [&](auto pc) __attribute__((always_inline)) {
-    constexpr int p = decltype(pc)::value;
-    if (p > 0) __syncthreads();
-    if (kg == 0) {
+  // one pass per RP rows of the wave tile (body: gemm_epilogue_pass.inc).  The pass index selects accumulator registers, so it must
+  // end up a constant: up to two passes the loop is unrolled by the compiler (the code every kernel had before the 96-row wave
+  // tile, same register allocation); with three or four passes `#pragma unroll` gave up, the index stayed a run-time value and the
+  // accumulators went to scratch — stored in every K-loop iteration — and a lambda called per pass made the compiler keep the
+  // side-load arrays in scratch instead: those configurations get the body textually once per pass with `p` a constant
+#define MIC_EPILOGUE_PASS_K(K_) { constexpr int p = K_;
+  if constexpr (WM / RP <= 2) {
 #pragma unroll
-      for (int i2 = 0; i2 < RP / 32; ++i2)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            Cw[(i2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * WN + j * 32 + (lane & 31)] = acc[(RP / 32) * p + i2][j][r];
+    for (int p = 0; p < WM / RP; ++p) {
+#include "gemm_epilogue_pass.inc"
     }
-    if constexpr (PLAIN) {
-      // C = acc (+ dropout) (+ residual): the residual rows are fetched before the barrier like every side operand
-      u32x4 rq[NIT];
-      const bool has_r = E.R != nullptr;
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int id = it * NTHREADS + tid;
-        const int w = id / (RP * CPR), rem = id % (RP * CPR);
-        const int m = m0 + (w / WNW) * WM + p * RP + rem / CPR, n = n0 + (w % WNW) * WN + (rem % CPR) * 8;
-        rq[it] = u32x4{0u, 0u, 0u, 0u};
-        if (has_r && id < NGRP && m < M && n + 8 <= N) rq[it] = *reinterpret_cast<const u32x4*>((const uint16_t*)E.R + (size_t)m * E.ldr + n);
-      }
-      __syncthreads();
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int id = it * NTHREADS + tid;
-        const int w = id / (RP * CPR), rem = id % (RP * CPR);
-        const int row = rem / CPR, c8 = (rem % CPR) * 8;
-        const int m = m0 + (w / WNW) * WM + p * RP + row, n = n0 + (w % WNW) * WN + c8;
-        if (id >= NGRP || m >= M || n >= N) continue;
-        const float* src = reinterpret_cast<const float*>(smem) + w * REGION + row * WN + c8;
-        float v[8];
-        const float4 lo = *reinterpret_cast<const float4*>(src);
-        const float4 hi = *reinterpret_cast<const float4*>(src + 4);
-        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-        if (ln_fold) ln_fold_apply8(E, m, n, v);
-        if (E.drop_thr) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i)
-            v[i] = dropout_keep(E.drop_seed, (uint32_t)m * (uint32_t)E.N + (uint32_t)(n + i), E.drop_thr) ? v[i] * E.drop_scale : 0.0f;
-        }
-        if (n + 8 <= N) {  // host side guarantees 16-B alignment of the C (and R) rows for PLAIN launches
-          if (has_r) {
-            float r[8];
-            unpack8(rq[it], r);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] += r[i];
-          }
-          if (E.c_f32) st8((float*)E.C + (size_t)m * E.ldc + n, v);
-          else st8((uint16_t*)E.C + (size_t)m * E.ldc + n, v);
-          if (E.rowsum2 != nullptr) {
-            // by-product for the next LayerNorm (folded into ITS consumer GEMM): sum and sum of squares of this output row as
-            // stored; the CPR lanes that hold one region row's chunks are consecutive, one pair of int64 atomics per (row, WN columns)
-            float s1 = 0.0f, s2 = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              const float x = E.c_f32 ? v[i] : bf2f(f2bf(v[i]));
-              s1 += x;
-              s2 = fmaf(x, x, s2);
-            }
-            s1 = group_sum<CPR>(s1);
-            s2 = group_sum<CPR>(s2);
-            if ((tid & (CPR - 1)) == 0) {  // fixed point: integer atomics commute, the sums are the same bits in any order
-              const float lim = 4.0e18f;
-              const long long i1 = __float2ll_rn(fminf(fmaxf(s1 * MIC_ROWSUM_SCALE, -lim), lim));
-              const long long i2 = __float2ll_rn(fminf(s2 * MIC_ROWSUM_SCALE, lim));
-              atomicAdd(reinterpret_cast<unsigned long long*>(E.rowsum2 + 2 * (size_t)m), (unsigned long long)i1);
-              atomicAdd(reinterpret_cast<unsigned long long*>(E.rowsum2 + 2 * (size_t)m + 1), (unsigned long long)i2);
-            }
-          }
-          if (E.rowstat != nullptr) {
-            // by-product for the LM head: (max, sum exp(x - max)) of the values AS STORED over this row's 64-column granule.
-            // The 8 threads that hold the granule's 8-column chunks are 8 consecutive lanes: thread-local over 8 values, then
-            // three DPP steps.  Consumers (mic_ce_rows_tiles / mic_row_topk_tiles) merge the granules of a row instead of
-            // streaming the 250 054-wide row again.
-            float mx = -INFINITY;
-            float x[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              x[i] = n + i < E.stat_nvalid ? (E.c_f32 ? v[i] : bf2f(f2bf(v[i]))) : -INFINITY;
-              mx = fmaxf(mx, x[i]);
-            }
-            const float gm = group8_max(mx);
-            float sm = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) sm += x[i] > -INFINITY ? __expf(x[i] - gm) : 0.0f;
-            sm = group8_sum(sm);
-            if ((tid & 7) == 0) reinterpret_cast<float2*>(E.rowstat)[(size_t)m * E.stat_ld + n / 64] = make_float2(gm, sm);
-          }
-        } else {
-          for (int i = 0; i < N - n; ++i) {
-            float x = v[i];
-            if (has_r) x += bf2f(((const uint16_t*)E.R)[(size_t)m * E.ldr + n + i]);
-            if (E.c_f32) ((float*)E.C)[(size_t)m * E.ldc + n + i] = x;
-            else ((uint16_t*)E.C)[(size_t)m * E.ldc + n + i] = f2bf(x);
-          }
-        }
-      }
-    } else {
-    // side loads of all this thread's groups go out before the barrier (their latency hides behind it and each other)
-    u32x4 zq[NIT], rq[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int id = it * NTHREADS + tid;
-      const int w = id / (RP * CPR), rem = id % (RP * CPR);
-      const int m = m0 + (w / WNW) * WM + p * RP + rem / CPR, n = n0 + (w % WNW) * WN + (rem % CPR) * 8;
-      zq[it] = rq[it] = u32x4{0u, 0u, 0u, 0u};
-      if (pre && id < NGRP && m < M && n + 8 <= N) epilogue_prefetch8(E, m, n, zq[it], rq[it]);
+  } else {
+    static_assert(WM / RP <= 4, "at most four epilogue passes");
+    MIC_EPILOGUE_PASS_K(0)
+#include "gemm_epilogue_pass.inc"
     }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int id = it * NTHREADS + tid;
-      const int w = id / (RP * CPR), rem = id % (RP * CPR);
-      const int row = rem / CPR, c8 = (rem % CPR) * 8;
-      const int m = m0 + (w / WNW) * WM + p * RP + row, n = n0 + (w % WNW) * WN + c8;
-      if (id >= NGRP || m >= M || n >= N) continue;
-      const float* src = reinterpret_cast<const float*>(smem) + w * REGION + row * WN + c8;
-      float v[8];
-      const float4 lo = *reinterpret_cast<const float4*>(src);
-      const float4 hi = *reinterpret_cast<const float4*>(src + 4);
-      v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-      const int cnt = min(8, N - n);
-      if (is_split) {  // split-K: fp32 atomic accumulation into a zero-initialised C, or a plain store into this split's slab
-        float* c = (float*)E.C + (size_t)m * E.ldc + n;
-        if (split_stride > 0) {
-          c += (size_t)split * (size_t)split_stride;
-          if (cnt == 8 && (E.ldc & 3) == 0) st8(c, v);
-          else for (int i = 0; i < cnt; ++i) c[i] = v[i];
-        } else {
-          for (int i = 0; i < cnt; ++i) atomicAdd(c + i, v[i]);
-        }
-      } else if (pre && cnt == 8) {
-        if (ln_fold) ln_fold_apply8(E, m, n, v);
-        epilogue_store8_pre(E, m, n, v, zq[it], rq[it]);
-      } else {
-        epilogue_store8<uint16_t>(E, m, n, v, cnt);
-      }
+    MIC_EPILOGUE_PASS_K(1)
+#include "gemm_epilogue_pass.inc"
     }
+    MIC_EPILOGUE_PASS_K(2)
+#include "gemm_epilogue_pass.inc"
     }
-  };
-  pass(std::integral_constant<int, 0>{});
-  if constexpr (WM / RP > 1) pass(std::integral_constant<int, 1>{});
-  if constexpr (WM / RP > 2) pass(std::integral_constant<int, 2>{});
-  static_assert(WM / RP <= 3, "at most three epilogue passes");
+    if constexpr (WM / RP > 3) MIC_EPILOGUE_PASS_K(3)
+#include "gemm_epilogue_pass.inc"
+    }
+  }
+#undef MIC_EPILOGUE_PASS_K
 }

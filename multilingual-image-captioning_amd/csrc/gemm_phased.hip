@@ -101,7 +101,10 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(LaunchTable tab) {
   float bsum[AI];
 #pragma unroll
   for (int i = 0; i < AI; ++i) bsum[i] = 0.0f;
-  const bool do_rowsum = P.a_rowsum != nullptr;
+  // row sums of A ride on k-major A operands only (the bias gradient of dW = dy^T x): this kernel is built for NT launches, where
+  // the code would sit in the K loop as never-taken branches that cost registers (255 -> 234 VGPRs without it)
+  constexpr bool RS = AK;
+  const bool do_rowsum = RS && P.a_rowsum != nullptr;
   const int rs_tiles_n = P.tiles_n, rs_k = P.rowsum_k;
 
   const int nk_total = P.K / BKT;
@@ -140,6 +143,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(LaunchTable tab) {
     const bool rs_tile = do_rowsum && ((kt0 + t) % rs_tiles_n) == tn;
     bf16x8 a0[2][4], a1[2][4], b0[4], b1[4];
     auto rowsum = [&](const bf16x8 (&af)[2][4], int qi) __attribute__((always_inline)) {
+      if constexpr (!RS) return;
       if (!rs_tile) return;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {

@@ -786,3 +786,48 @@ def test_gemm_192_row_tiles(dev, M, N, K):
     ops.gemm(dY.to(dev), W.to(dev), o2, M, N, K, b_kmajor=True, residual=R.to(dev))
     torch.cuda.synchronize()
     assert relerr(o2[:M], dY.float() @ W.float() + R.float()) < tol(dt) and torch.isnan(o2[M:].float()).all()
+
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 16384, 192), (1000, 66048, 64), (1024, 131072, 1024), (3200, 24576, 1024), (600, 98304, 128)])
+def test_gemm_phased_many_tiles(dev, M, N, K):
+    """the LDS-DMA 256 x 256 kernel on single NT problems with several tiles per CU: odd and even K-tile counts, a single K-tile,
+    partial row tiles, the bias / activation epilogues and the LM head's softmax partials; run-to-run identical bits.  (Written for
+    the persistent variant with next-tile prefetch that round 4 measured slower and took out again; kept as coverage of the kernel.)"""
+    from mic_amd import _lib as L
+    from mic_amd import ops
+
+    plan = ops.gemm_plan([(M, N, K)])
+    assert plan["tile"] == 256 and plan["phased"] == 1 and plan["blocks"] > 256
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(M + N + K)
+    A, B = rnd((M, K), g, dt), rnd((N, K), g, dt, 0.1)
+    bias = torch.randn(N, generator=g)
+    ref = A.float() @ B.float().T + bias
+    out = torch.full((M + 8, N), float("nan"), dtype=dt, device=dev)
+    ops.gemm(A.to(dev), B.to(dev), out, M, N, K, bias=bias.to(dev))
+    torch.cuda.synchronize()
+    assert relerr(out[:M], ref) < tol(dt) and torch.isnan(out[M:].float()).all()
+    base = out[:M].clone()
+    for _ in range(3):  # run to run: the same bits (no dependence on which tile a block reaches when)
+        ops.gemm(A.to(dev), B.to(dev), out, M, N, K, bias=bias.to(dev))
+        torch.cuda.synchronize()
+        assert torch.equal(out[:M], base)
+    # non-PLAIN epilogue: GELU + saved pre-activation
+    z = torch.empty((M, N), dtype=dt, device=dev)
+    o2 = torch.empty((M, N), dtype=dt, device=dev)
+    ops.gemm(A.to(dev), B.to(dev), o2, M, N, K, bias=bias.to(dev), act=L.ACT_GELU_TANH, zout=z)
+    torch.cuda.synchronize()
+    assert relerr(z, ref) < tol(dt) and relerr(o2, torch.nn.functional.gelu(ref.to(dt).float(), approximate="tanh")) < tol(dt)
+    # the LM head's by-product: (max, sum exp) per 64-column granule of the values as stored
+    stat = torch.zeros((M, 2 * (N // 64)), dtype=torch.float32, device=dev)
+    o3 = torch.empty((M, N), dtype=dt, device=dev)
+    ops.gemm(A.to(dev), B.to(dev), o3, M, N, K, bias=bias.to(dev), rowstat=stat, rowstat_nvalid=N - 37)
+    torch.cuda.synchronize()
+    assert torch.equal(o3, base)
+    x = o3.float().cpu().reshape(M, N // 64, 64).clone()
+    x.reshape(M, N)[:, N - 37:] = float("-inf")
+    mx = x.max(dim=2).values
+    sm = torch.exp(x - mx[..., None]).sum(dim=2)
+    st = stat.cpu().reshape(M, N // 64, 2)
+    assert torch.equal(st[..., 0], mx) and torch.allclose(st[..., 1], sm, rtol=2e-5, atol=1e-6)
