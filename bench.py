@@ -326,16 +326,16 @@ def pmc_traffic(argv, kernel_prefix="gemm_"):
     for a in argv:
         if skip:
             skip = False
-        elif a in ("--gpus", "--steps", "--warmup"):
+        elif a in ("--gpus", "--steps", "--warmup", "--emulate-comm"):
             skip = True
-        elif a != "--pmc-traffic" and not a.startswith(("--gpus=", "--steps=", "--warmup=")):
+        elif a != "--pmc-traffic" and not a.startswith(("--gpus=", "--steps=", "--warmup=", "--emulate-comm=")):
             child_argv.append(a)
     for ctr, factor in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
         d = tempfile.mkdtemp(prefix="mic_pmc_", dir="/tmp")
         env = {k: v for k, v in os.environ.items() if k not in drop and not k.startswith(("MASTER_", "TORCHELASTIC_"))}
         env["TMPDIR"] = "/tmp"
         cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__)] + \
-              child_argv + ["--steps", "1", "--warmup", "1", "--no-roofline", "--no-generate", "--no-cpu-baseline", "--no-dense-leg"]
+              child_argv + ["--steps", "1", "--warmup", "1", "--no-roofline", "--no-generate", "--no-cpu-baseline", "--no-dense-leg", "--emulate-comm", "0"]
         subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
         n = 0
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
