@@ -10,7 +10,10 @@ A step = forward + loss + backward + gradient all-reduce (RCCL, N > 1) + AdamW o
 the full architecture; fused dropout active as in training).  Prints ONE JSON line on rank 0.
 Variants: --dtype fp8 (configs[4]: e4m3/e5m2 QKV/FFN GEMMs), --dense-captions (n = 62 tokens in every caption: no padded
 label positions, the dense upper bound of SURVEY §8d), --pmc-traffic (re-measure roofline.traffic with two rocprofv3
-counter passes of this same command as child processes).
+counter passes of this same command as child processes).  With --gpus 1 the line also carries `comm_emulated`: the same step
+with the gradient exchange among 2 / 4 / 8 ranks EMULATED on this one GPU (a kernel holding 32 CUs of a CU-masked collective
+stream for the projected all-reduce time of every bucket; one fresh child process per N) — a scheduling probe, not a scaling
+result; --emulate-comm '' switches it off, --emulate-main N makes the timed trainer itself emulate (profiling aid).
 """
 import argparse
 import json
