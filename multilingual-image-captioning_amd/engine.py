@@ -207,16 +207,15 @@ class Engine:
     # ------------------------------------------------------------------ buffers
     def buf(self, name: str, rows: int, cols: int, dtype=None) -> torch.Tensor:
         dtype = dtype or self.dt
-        rp = _rup(max(rows, 1), ROWPAD)
-        key = f"{name}:{rows}:{cols}:{dtype}"
+        key = (name, rows, cols, dtype)  # (a tuple: this lookup runs ~1500 times per train step on the host)
         t = self._bufs.get(key)
         if t is None:
-            t = torch.zeros((rp, cols), dtype=dtype, device=self.dev)
+            t = torch.zeros((_rup(max(rows, 1), ROWPAD), cols), dtype=dtype, device=self.dev)
             self._bufs[key] = t
         return t
 
     def vec(self, name: str, n: int, dtype=torch.float32) -> torch.Tensor:
-        key = f"{name}:{n}:{dtype}"
+        key = (name, n, dtype)
         t = self._bufs.get(key)
         if t is None:
             t = torch.zeros(n, dtype=dtype, device=self.dev)

@@ -40,7 +40,7 @@ for n in ("vit_forward", "decoder_forward", "head_logits", "loss_and_dlogits", "
     if hasattr(eng, n):
         wrap(eng, n)
 wrap(eng, "loss_and_grads")
-for n in ("start_step", "progress", "release_held", "finish"):
+for n in ("start_step", "progress", "finish"):
     wrap(tr.reducer, n, "reducer." + n)
 wrap(model, "invalidate_params_cache")
 wrap(ops, "adamw", "ops.adamw")
