@@ -229,6 +229,10 @@ static GemmPlan plan_bf16(const mic_gemm_args* args, int count) {
   static const int phased_env = [] { const char* e = getenv("MIC_GEMM_PHASED"); return e ? atoi(e) : 2; }();
   const bool f8 = args[0].dtype == MIC_FP8;
   pl.phased = bm == 256 && !f8 && phased_env != 0 && !args[0].a_kmajor && !args[0].b_kmajor && count == 1 && !any_rowsum_early(args, count);
+  // MIC_GEMM_W4=1 (opt-in, A/B): the four-wave 128x128-wave-tile kernel (gemm_w4.hip) instead, where the shape allows it and — decided
+  // at launch, gemm_w4_takes — the epilogue is a bare one; plan.phased reads 2 for such a launch
+  static const int w4_env = [] { const char* e = getenv("MIC_GEMM_W4"); return e ? atoi(e) : 0; }();
+  if (pl.phased && w4_env && args[0].split_k <= 1 && args[0].K >= 256 && args[0].K % 128 == 0) pl.phased = 2;
   if (bm == 256) {
     pl.per_cu = 1;  // 128 KiB of LDS: a block holds its CU alone; PLAIN launches with more tiles than CUs run as `cus` persistent blocks
   } else if (bm == 128) {
@@ -298,7 +302,8 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
   tab.total_blocks = blocks;
   for (int i = 0; i < count; ++i)
     MIC_CHECK(!args[i].rowsum2 || table_is_plain(tab), "mic_gemm_grouped: rowsum2 needs every problem of the launch on the bare / residual epilogue");
-  if (bm == 256 && pl.phased) launch_gemm_phased(tab, args[0].a_kmajor, args[0].b_kmajor, table_is_plain(tab), s);  // LDS-DMA, phased
+  if (bm == 256 && pl.phased == 2 && gemm_w4_takes(tab)) launch_gemm_w4(tab, s);  // opt-in: 4 waves x 128x128, bare epilogue
+  else if (bm == 256 && pl.phased) launch_gemm_phased(tab, args[0].a_kmajor, args[0].b_kmajor, table_is_plain(tab), s);  // LDS-DMA, phased
   else if (bm == 256) launch_gemm_t256(tab, args[0].a_kmajor, args[0].b_kmajor, s, f8);     // 256x256x64, 8 waves
   else if (bm == 128 && bm_m == 192) launch_gemm_t192(tab, args[0].b_kmajor, s);                     // 192x128x64, 8 waves, two blocks per CU
   else if (bm == 128) launch_gemm_t128(tab, args[0].a_kmajor, args[0].b_kmajor, s, f8, pl.kgroups);  // 128x128x64, 8 waves per K-group

@@ -24,6 +24,9 @@ struct LaunchTable { int count; int total_blocks; Problem p[MAX_PROBLEMS]; };
 int mic_cu_budget_now();
 // gemm_phased.hip: 256x256 tiles, LDS-DMA operands, four-phase K-tile schedule (bf16 operands, no K-groups)
 void launch_gemm_phased(const LaunchTable& tab, int akm, int bkm, bool plain, hipStream_t s);
+// gemm_w4.hip: 256x256 tiles on four waves (128x128 wave tiles, one wave per SIMD), LDS-DMA ring of 32-k steps; NT, single problem
+bool gemm_w4_takes(const LaunchTable& tab);
+void launch_gemm_w4(const LaunchTable& tab, hipStream_t s);
 // one translation unit per tile configuration of the main kernel (gemm_kernel.h): 256x256 / 128x128 (K-groups 1, 2) / 64x64 (1, 2, 4)
 bool table_is_plain(const LaunchTable& t);
 void launch_gemm_t256(const LaunchTable& tab, int akm, int bkm, hipStream_t s, int f8);
@@ -193,20 +196,20 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], c
   // accumulators went to scratch — stored in every K-loop iteration — and a lambda called per pass made the compiler keep the
   // side-load arrays in scratch instead: those configurations get the body textually once per pass with `p` a constant
 #define MIC_EPILOGUE_PASS_K(K_) { constexpr int p = K_;
-  if constexpr (WM / RP <= 2) {
+  if constexpr (WM / RP <= 2 && WN <= 64) {
 #pragma unroll
     for (int p = 0; p < WM / RP; ++p) {
 #include "gemm_epilogue_pass.inc"
     }
-  } else {
+  } else {  // (also the 128-column wave tile of gemm_w4.hip: 16 groups per thread and pass, the loop form is not unrolled either)
     static_assert(WM / RP <= 4, "at most four epilogue passes");
     MIC_EPILOGUE_PASS_K(0)
 #include "gemm_epilogue_pass.inc"
     }
-    MIC_EPILOGUE_PASS_K(1)
+    if constexpr (WM / RP > 1) MIC_EPILOGUE_PASS_K(1)
 #include "gemm_epilogue_pass.inc"
     }
-    MIC_EPILOGUE_PASS_K(2)
+    if constexpr (WM / RP > 2) MIC_EPILOGUE_PASS_K(2)
 #include "gemm_epilogue_pass.inc"
     }
     if constexpr (WM / RP > 3) MIC_EPILOGUE_PASS_K(3)

@@ -3,6 +3,7 @@ the same op on the same seeded inputs.  Tolerances: f32 path 2e-5 relative-to-sc
 summation order); bf16 path = inputs rounded to bf16 on both sides, fp32 accumulate, output rounded to bf16:
 <= 1 bf16 ulp of the output scale (2^-8 relative) + accumulation-order noise."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -798,7 +799,8 @@ def test_gemm_phased_many_tiles(dev, M, N, K):
     from mic_amd import ops
 
     plan = ops.gemm_plan([(M, N, K)])
-    assert plan["tile"] == 256 and plan["phased"] == 1 and plan["blocks"] > 256
+    w4 = os.environ.get("MIC_GEMM_W4") == "1" and K >= 256 and K % 128 == 0  # (the opt-in four-wave kernel, see the test below)
+    assert plan["tile"] == 256 and plan["phased"] == (2 if w4 else 1) and plan["blocks"] > 256
     dt = torch.bfloat16
     g = torch.Generator().manual_seed(M + N + K)
     A, B = rnd((M, K), g, dt), rnd((N, K), g, dt, 0.1)
@@ -831,3 +833,51 @@ def test_gemm_phased_many_tiles(dev, M, N, K):
     sm = torch.exp(x - mx[..., None]).sum(dim=2)
     st = stat.cpu().reshape(M, N // 64, 2)
     assert torch.equal(st[..., 0], mx) and torch.allclose(st[..., 1], sm, rtol=2e-5, atol=1e-6)
+
+
+def test_gemm_layernorm_fold_with_softmax_partials(dev):
+    """the decode-time LM head in one launch: LayerNorm folded around the GEMM AND the (max, sum exp) partials per 64-column granule
+    — the logits equal the same launch without the partials bit for bit, the partials describe the values as stored"""
+    from mic_amd import ops
+
+    M, N, K = 600, 66048, 256
+    assert ops.gemm_plan([(M, N, K)])["tile"] == 256
+    g = torch.Generator().manual_seed(7)
+    dt = torch.bfloat16
+    x = (rnd((M, K), g, dt, 1.0) + 0.5).to(dev)
+    xs = x.float().cpu().double()
+    st = torch.stack([(xs.sum(1) * 2 ** 20).round(), ((xs ** 2).sum(1) * 2 ** 20).round()], 1).to(torch.int64).to(dev)
+    gamma, beta = 1 + 0.2 * torch.randn(K, generator=g), 0.2 * torch.randn(K, generator=g)
+    w, bias = rnd((N, K), g, dt, 0.05), 0.1 * torch.randn(N, generator=g)
+    wf = torch.empty((N, K), dtype=dt, device=dev)
+    cs, bf = torch.empty(N, device=dev), torch.empty(N, device=dev)
+    ops.ln_fold_weight(w.to(dev), gamma.to(dev), beta.to(dev), bias.to(dev), wf, cs, bf)
+    lk = dict(bias=bf, ln_stats=st, ln_colsum=cs, ln_width=K, ln_eps=1e-5)
+    o1, o2 = torch.empty((M, N), dtype=dt, device=dev), torch.empty((M, N), dtype=dt, device=dev)
+    stat = torch.zeros((M, 2 * (N // 64)), dtype=torch.float32, device=dev)
+    ops.gemm(x, wf, o1, M, N, K, **lk)
+    ops.gemm(x, wf, o2, M, N, K, rowstat=stat, rowstat_nvalid=N - 5, **lk)
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.layer_norm(x.float().cpu(), (K,), gamma, beta, 1e-5).to(dt).float() @ w.float().T + bias
+    assert relerr(o1, ref) < 1.2e-2 and torch.equal(o1, o2)
+    v = o2.float().cpu().reshape(M, N // 64, 64).clone()
+    v.reshape(M, N)[:, N - 5:] = float("-inf")
+    mx = v.max(dim=2).values
+    sm = torch.exp(v - mx[..., None]).sum(dim=2)
+    got = stat.cpu().reshape(M, N // 64, 2)
+    assert torch.equal(got[..., 0], mx) and torch.allclose(got[..., 1], sm, rtol=2e-5, atol=1e-6)
+
+
+def test_gemm_four_wave_kernel_opt_in(dev):
+    """MIC_GEMM_W4=1 routes the single-problem NT 256 x 256 launches with a bare epilogue (bias, the folded LayerNorm, the LM head's
+    softmax partials) to gemm_w4.hip.  The library reads the switch once, so the launches run in a child process: the many-tiles
+    cases with K = 1024 (bias, bit-identical reruns, partial row tiles, the softmax partials; the GELU case falls back to the
+    four-phase kernel) and the folded-LayerNorm / softmax-partial tests of this file (each of the kernel's four epilogue builds)."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, MIC_GEMM_W4="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "-k",
+                        "(phased_many_tiles and 1024) or head_rowstat or layernorm_fold"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
