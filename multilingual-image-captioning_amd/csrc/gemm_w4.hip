@@ -2,8 +2,8 @@
 // (16 accumulator blocks of 32x32 = 256 AGPRs), ONE barrier per 32-k step.  Where gemm_phased.hip lets the two waves of a SIMD take
 // turns at the matrix pipe (eight barrier hand-offs per 64-k tile), here every wave feeds its own pipe from one instruction stream
 // with the side work pinned into the gaps between its 32 MFMAs per step.  OPT-IN (MIC_GEMM_W4=1): it needs 12 % fewer cycles than
-// the four-phase kernel at 4096^3 (222 k against 251 k, rocprofv3 GRBM_GUI_ACTIVE) and takes the same wall time, because the chip
-// clocks these kernels by power (1.80 GHz against 1.99; DESIGN.md section 3, "Round 4"); on the LM-head shapes it is 2-3 % slower.
+// the four-phase kernel at 4096^3 (222 k against 251 k, rocprofv3 GRBM_GUI_ACTIVE) and takes about the same wall time, because the chip
+// clocks these kernels by power (1.80 GHz against 1.99; DESIGN.md section 3, "Round 4"): 0-3 % ahead in isolation, level in situ.
 //
 //   * LDS: four slots of 32 KiB, step X in slot X%4 = [A rows 0-127 | A rows 128-255 | B cols 0-127 | B cols 128-255], each a
 //     k-contiguous image of 128 rows x 32 k (64-B rows, 16-B chunk position p of row R holds source chunk p ^ ((R>>2)&3):
@@ -11,12 +11,14 @@
 //     the chunk that belongs at its lane-linear LDS position, so the swizzle sits on the SOURCE address.
 //   * Operands travel global -> registers -> LDS: an LDS-DMA piece costs 60-100 cycles of ISSUE time and with one wave per SIMD
 //     nobody else feeds the matrix pipe meanwhile (first build of this file: 930-1020 TF/s at 4096^3 / 8192^3);
-//     global_load_dwordx4 (scalar base + 32-bit offset) + ds_write_b128 are ~20.  Four register sets of eight 16-B pieces: step
-//     X's pieces are requested in step X-6, written to LDS in step X-2, read into fragments in steps X-1 (k 0-15) and X (k 16-31).
-//   * step S: s_barrier {gaps 0-7: read this step's k 16-31 fragments} {gaps 8-15: write step S+2 from its register set, request
-//     step S+6 into the same registers} {gaps 16-23: read step S+1's k 0-15 fragments} {gaps 24-31 bare} s_waitcnt lgkmcnt(0).
-//     RAW: a wave's own lgkmcnt(0), then the barrier, order its LDS writes before the other waves' reads one step later.  WAR: a
-//     slot is rewritten two steps after its last read.  vmcnt is left to the compiler (it emits the counted vmcnt(31)...(24)).
+//     global_load_dwordx4 (scalar base + 32-bit offset) + ds_write_b128 are ~20.  Two register sets of sixteen 16-B pieces per
+//     64-k tile (8 rows x 128 B each: whole lines); tile U is requested in step 2U-6, written to the LDS slots of its two steps in
+//     step 2U-2, read into fragments one half step ahead of the MFMAs that use them.
+//   * step S: s_barrier {gaps 0-7: read this step's k 16-31 fragments} {gaps 16-23: read step S+1's k 0-15 fragments}; even steps
+//     also {gaps 8-15 and 24-31: write the tile of steps S+2, S+3 from its register set, request the tile of steps S+6, S+7 into
+//     the same registers}; s_waitcnt lgkmcnt(0).  RAW: a wave's own lgkmcnt(0), then the barrier, order its LDS writes before the
+//     other waves' reads one step later.  WAR: a slot is rewritten at least one barrier after its last read.  vmcnt is left to the
+//     compiler (counted waits).
 //   * Same launch table, tile order and k ranges as the other kernels; its own bare epilogue (below).  Single-problem NT launches
 //     without split, K a multiple of 128.
 #include "gemm_common.h"
@@ -25,15 +27,14 @@ namespace {
 
 constexpr int W4_BK = 32, W4_HIMG = 128 * W4_BK * 2, W4_SLOT = 4 * W4_HIMG;
 
-// byte offset of this lane's source (k = 0) for 1-KiB piece `piece` (16 rows x 64 B) of a half image whose row 0 is x0; the
-// operand base stays a scalar (global_load saddr + 32-bit voffset: 8 registers for the eight pieces instead of 16)
+// byte offset of this lane's source (k = 0) for 1-KiB piece `piece` of a 256-row operand tile whose row 0 is x0: 8 rows x 128 B (a
+// whole line per row and 64-k tile: half the L2 requests of 64-B segments per 32-k step — the 16-rows-x-64-B form of the first build
+// measured 5-7 % slower on the LM-head shapes); the operand base stays a scalar (global_load saddr + 32-bit voffset)
 __device__ __forceinline__ uint32_t w4_source(int ld, int x0, int lim, int piece, int lane) {
-  const int R = piece * 16 + (lane >> 2), c = (lane & 3) ^ ((R >> 2) & 3);
-  int gx = x0 + R;
+  int gx = x0 + piece * 8 + (lane >> 3);
   gx = gx < lim ? gx : lim - 1;
-  return ((uint32_t)gx * (uint32_t)ld + (uint32_t)(c * 8)) * 2u;
+  return ((uint32_t)gx * (uint32_t)ld + (uint32_t)((lane & 7) * 8)) * 2u;
 }
-
 
 // The bare epilogue of a four-wave block: C = alpha acc + bias as bf16, optionally the folded LayerNorm and the LM head's softmax
 // partials.  The shared epilogue (gemm_common.h) is unrolled over every feature of mic_gemm_args; with one wave per SIMD nothing
@@ -143,55 +144,65 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(LaunchTable tab) {
   const int kt0 = split * nk_per, kt1 = min(nk_total, kt0 + nk_per);
   const int nsteps = 2 * max(kt1 - kt0, 0);  // even, 32 k each
 
-  // the eight 1-KiB pieces this wave brings per step: pieces 2w, 2w+1 of each of the four half images
-  uint32_t go[8];
+  // the sixteen 1-KiB pieces this wave brings per 64-k TILE (= two steps): pieces 8w .. 8w+7 of the A tile and of the B tile.  Lane
+  // (row r = lane>>3, chunk c = lane&7) of piece q holds k 8c..8c+7 of tile row 64w + 8q + r: chunks 0-3 belong to the tile's even
+  // step, 4-7 to its odd step, so one ds_write_b128 scatters a piece over the two steps' LDS slots
+  uint32_t go[16];
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      go[h * 2 + i] = w4_source(P.lda, m0 + h * 128, P.M, wave * 2 + i, lane);
-      go[4 + h * 2 + i] = w4_source(P.ldb, n0 + h * 128, P.N, wave * 2 + i, lane);
-    }
+  for (int q = 0; q < 8; ++q) {
+    go[q] = w4_source(P.lda, m0, P.M, wave * 8 + q, lane);
+    go[8 + q] = w4_source(P.ldb, n0, P.N, wave * 8 + q, lane);
+  }
   const char* gA = reinterpret_cast<const char*>(P.A) + (size_t)kt0 * 128;  // scalar bases, advanced by the loop
   const char* gB = reinterpret_cast<const char*>(P.B) + (size_t)kt0 * 128;
+  // this lane's LDS write offset inside a pair of slots, for even / odd pieces: row 8q + r of the wave's 64 rows sits in half image
+  // w>>1 at row 64(w&1) + 8q + r, chunk position (c&3) ^ ((row>>2)&3) with (row>>2)&3 = (2(q&1) + (lane>>5)) & 3
+  uint32_t wl[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+    wl[e] = (uint32_t)(((lane >> 2) & 1) * W4_SLOT + (wave >> 1) * W4_HIMG + ((wave & 1) * 64 + (lane >> 3)) * 64 +
+                       ((((lane & 3) ^ ((2 * e + (lane >> 5)) & 3))) << 4));
   // operands travel global -> registers -> LDS (an LDS-DMA piece costs 60-100 cycles of ISSUE time, and with one wave per SIMD nobody
-  // else feeds the matrix pipe meanwhile; global_load_dwordx4 + ds_write_b128 are ~20).  Four register sets of eight 16-B pieces:
-  // step X's pieces are requested in step X-6, written to LDS slot X%4 in step X-2 (four steps of latency budget), read into
-  // fragments in steps X-1 (k 0-15) and X (k 16-31).
-  u32x4 l0[8], l1[8], l2[8], l3[8];
-  auto ld = [&](u32x4 (&l)[8], int x) __attribute__((always_inline)) {
+  // else feeds the matrix pipe meanwhile; global_load_dwordx4 + ds_write_b128 are ~20).  Two register sets of sixteen pieces: tile
+  // U (steps 2U, 2U+1) is requested in step 2U-6, written to LDS slots 2U%4 and (2U+1)%4 in step 2U-2 (four steps of latency
+  // budget), its fragments are read in steps 2U-1 .. 2U+1.
+  u32x4 lA[16], lB[16];
+  auto ld = [&](u32x4 (&l)[16], int tile, bool on) __attribute__((always_inline)) {
+    const uint32_t m = on ? 0xffffffffu : 0u;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) l[q] = *reinterpret_cast<const u32x4*>((q < 4 ? gA : gB) + x * (W4_BK * 2) + go[q]);
+    for (int q = 0; q < 16; ++q) l[q] = *reinterpret_cast<const u32x4*>((q < 8 ? gA : gB) + tile * 128 + (go[q] & m));
   };
-  auto st = [&](const u32x4 (&l)[8], int x) __attribute__((always_inline)) {
-    char* slot = smem + (x & 3) * W4_SLOT + wave * 2048 + lane * 16;
+  auto st = [&](const u32x4 (&l)[16], int pair) __attribute__((always_inline)) {
+    char* base = smem + pair * 2 * W4_SLOT;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) *reinterpret_cast<u32x4*>(slot + (q >> 1) * W4_HIMG + (q & 1) * 1024) = l[q];
+    for (int q = 0; q < 16; ++q) *reinterpret_cast<u32x4*>(base + (q >> 3) * 2 * W4_HIMG + (q & 7) * 512 + wl[q & 1]) = l[q];
   };
   bf16x8 a0[AI], b0[NJ], a1[AI], b1[NJ];  // fragments of k 0-15 / k 16-31 of a step
   const char* fa_ = smem + wr * W4_HIMG;        // + slot: this wave's A half image
   const char* fb_ = smem + (2 + wc) * W4_HIMG;  // ... B half image
 // step S = s + C (s a multiple of 4, C a constant: LDS slots and register sets are compile-time).  The order is pinned gap by gap
 // (the scheduler's group pipelines came apart on three instruction classes).  MFMA gaps 0-7: read this step's k 16-31 fragments;
-// 8-15: write step S+2 from register set L and request step S+6 into it; 16-23: read step S+1's k 0-15 fragments;
-// 24-31 bare, so that the lgkmcnt(0) in front of the next barrier finds the LDS queue empty.
-#define W4_STEP(C, L)                                                                                                          \
+// 16-23: read step S+1's k 0-15 fragments.  EVEN steps also write the tile of steps S+2, S+3 from register set L and request the
+// tile of steps S+6, S+7 into it: A pieces in gaps 8-15, B pieces in gaps 24-31.  s_waitcnt lgkmcnt(0) closes the step.
+#define W4_STEP(C, L, EVEN)                                                                                                    \
   do {                                                                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                                         \
-    __builtin_amdgcn_s_barrier();                                                                                                            \
+    __builtin_amdgcn_s_barrier();                                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                                         \
-    char* ws_ = smem + (((C) + 2) & 3) * W4_SLOT + wave * 2048 + lane * 16;                                                    \
+    char* ws_ = smem + (((C) + 2) & 2) * W4_SLOT;                                                                              \
     const uint32_t lm_ = s + (C) + 6 < nsteps ? 0xffffffffu : 0u;                                                              \
     _Pragma("unroll") for (int g_ = 0; g_ < 32; ++g_) {                                                                        \
       if (g_ < 16) acc[g_ >> 2][g_ & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[g_ >> 2], b0[g_ & 3], acc[g_ >> 2][g_ & 3], 0, 0, 0); \
       else acc[(g_ - 16) >> 2][g_ & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[(g_ - 16) >> 2], b1[g_ & 3], acc[(g_ - 16) >> 2][g_ & 3], 0, 0, 0); \
       if (g_ < 4) a1[g_] = read_frag<false, W4_BK, 128>(fa_ + ((C) & 3) * W4_SLOT, g_ * 32, 1, lane);                          \
       else if (g_ < 8) b1[g_ - 4] = read_frag<false, W4_BK, 128>(fb_ + ((C) & 3) * W4_SLOT, (g_ - 4) * 32, 1, lane);           \
-      else if (g_ < 16) {                                                                                                      \
-        *reinterpret_cast<u32x4*>(ws_ + ((g_ - 8) >> 1) * W4_HIMG + (g_ & 1) * 1024) = L[g_ - 8];                              \
-        L[g_ - 8] = *reinterpret_cast<const u32x4*>((g_ < 12 ? gA : gB) + ((C) + 6) * (W4_BK * 2) + (go[g_ - 8] & lm_));       \
-      } else if (g_ < 20) a0[g_ - 16] = read_frag<false, W4_BK, 128>(fa_ + (((C) + 1) & 3) * W4_SLOT, (g_ - 16) * 32, 0, lane); \
-      else if (g_ < 24) b0[g_ - 20] = read_frag<false, W4_BK, 128>(fb_ + (((C) + 1) & 3) * W4_SLOT, (g_ - 20) * 32, 0, lane);  \
+      else if (g_ >= 16 && g_ < 20) a0[g_ - 16] = read_frag<false, W4_BK, 128>(fa_ + (((C) + 1) & 3) * W4_SLOT, (g_ - 16) * 32, 0, lane); \
+      else if (g_ >= 20 && g_ < 24) b0[g_ - 20] = read_frag<false, W4_BK, 128>(fb_ + (((C) + 1) & 3) * W4_SLOT, (g_ - 20) * 32, 0, lane); \
+      else if (EVEN) {                                                                                                         \
+        const int q_ = g_ < 16 ? g_ - 8 : g_ - 16;  /* 0-7: A pieces, 8-15: B pieces */                                        \
+        *reinterpret_cast<u32x4*>(ws_ + (q_ >> 3) * 2 * W4_HIMG + (q_ & 7) * 512 + wl[q_ & 1]) = L[q_];                        \
+        L[q_] = *reinterpret_cast<const u32x4*>((q_ < 8 ? gA : gB) + ((C) + 6) * (W4_BK * 2) + (go[q_] & lm_));                \
+      }                                                                                                                        \
       __builtin_amdgcn_sched_barrier(0);                                                                                       \
     }                                                                                                                          \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                         \
@@ -199,14 +210,10 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(LaunchTable tab) {
   } while (0)
 
   if (nsteps >= 8) {
-    ld(l0, 0);
-    ld(l1, 1);
-    ld(l2, 2);
-    ld(l3, 3);
-    st(l0, 0);
-    st(l1, 1);
-    ld(l0, 4);
-    ld(l1, 5);
+    ld(lA, 0, true);
+    st(lA, 0);
+    ld(lA, 1, true);
+    ld(lB, 2, true);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -218,14 +225,14 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(LaunchTable tab) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    // one uniform loop, no peeled tail (the copies of the step for the last iterations made the register allocator spill the
-    // in-flight register sets around the loop, and spill traffic counts on vmcnt): past the end of K the requests collapse onto one
-    // 16-B address (offset mask 0), the LDS writes land in slots nobody reads again, the fragment reads fetch values nobody uses
+    // one uniform loop, no peeled tail (copies of the step for the last iterations made the register allocator spill the in-flight
+    // register sets around the loop, and spill traffic counts on vmcnt): past the end of K the requests collapse onto one 128-B
+    // line (offset mask 0), the LDS writes land in slots nobody reads again, the fragment reads fetch values nobody uses
     for (int s = 0; s < nsteps; s += 4) {
-      W4_STEP(0, l2);
-      W4_STEP(1, l3);
-      W4_STEP(2, l0);
-      W4_STEP(3, l1);
+      W4_STEP(0, lA, true);
+      W4_STEP(1, lA, false);
+      W4_STEP(2, lB, true);
+      W4_STEP(3, lB, false);
       gA += 4 * W4_BK * 2;
       gB += 4 * W4_BK * 2;
     }
