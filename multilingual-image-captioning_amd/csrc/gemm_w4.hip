@@ -7,8 +7,8 @@
 //
 //   * LDS: four slots of 32 KiB, step X in slot X%4 = [A rows 0-127 | A rows 128-255 | B cols 0-127 | B cols 128-255], each a
 //     k-contiguous image of 128 rows x 32 k (64-B rows, 16-B chunk position p of row R holds source chunk p ^ ((R>>2)&3):
-//     conflict-free for the 16-lane groups of ds_read_b128, see read_frag; SQ_LDS_BANK_CONFLICT reads 0).  Every lane fetches
-//     the chunk that belongs at its lane-linear LDS position, so the swizzle sits on the SOURCE address.
+//     conflict-free for the 16-lane groups of ds_read_b128, see read_frag).  The swizzle sits on the LDS destination of the
+//     register-staged pieces (per-lane write offsets `wl`).
 //   * Operands travel global -> registers -> LDS: an LDS-DMA piece costs 60-100 cycles of ISSUE time and with one wave per SIMD
 //     nobody else feeds the matrix pipe meanwhile (first build of this file: 930-1020 TF/s at 4096^3 / 8192^3);
 //     global_load_dwordx4 (scalar base + 32-bit offset) + ds_write_b128 are ~20.  Two register sets of sixteen 16-B pieces per
