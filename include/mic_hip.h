@@ -131,7 +131,8 @@ int mic_set_cu_budget(int cus);
 int mic_get_cu_budget(void);
 /* What mic_gemm_grouped would launch for these problems under the current CU budget (host arithmetic only, nothing is launched;
  * pointers in `args` are not dereferenced): tile edge (256 / 128 / 64; `tile_m` x `tile` when the rows differ), K-groups per block, logical blocks, launched grid
- * (persistent launches: the budget), blocks of this configuration that fit one CU, and whether the LDS-DMA phased kernel is taken. */
+ * (persistent launches: the budget), blocks of this configuration that fit one CU, and whether the LDS-DMA phased kernel is taken
+ * (phased = 1; 2 = MIC_GEMM_W4=1 is set and the shape fits the opt-in four-wave kernel, which takes the launch if its epilogue is a bare one). */
 typedef struct { int tile, kgroups, blocks, grid, blocks_per_cu, phased, cu_budget, tile_m; } mic_gemm_plan_info;  /* tile_m: tile rows (= tile, or 192 with tile 128) */
 int mic_gemm_plan(const mic_gemm_args* args, int count, mic_gemm_plan_info* out);
 /* Operands of a LayerNorm-folded Linear (see mic_gemm_args.a_ln_stats): for w [N][K] (the compute-dtype weight), gamma / beta
