@@ -327,7 +327,7 @@ int mic_row_flags(const int32_t* ids, int n_ids, uint8_t* flags, int n_rows, voi
 
 /* ---------------------------------------------------------------------------------------------
  * Generation epilogues
- *   mic_row_lse_topk: per row of logits [R][ld] (dtype): lse over V and the top-k (k <= 32) of
+ *   mic_row_lse_topk: per row of logits [R][ld] (dtype): lse over V and the top-k (k <= 64) of
  *       processed log-probs (forced_token >= 0: everything -inf except forced_token := 0; min-length: eos := -inf
  *       when suppress_eos), plus row_bias[row] (the beam's running score, gen:857) — candidates ordered
  *       (value desc, index asc), i.e. lax.top_k (gen:850-873).  raw_logits = 1: no log-softmax (greedy, gen:497-499).

@@ -4,7 +4,7 @@
 #include "common.h"
 
 #define TOPK_MAX 16   // widest top-k of the partials-based kernel (row_topk_tiles: k = 2 * num_beams <= 16, its candidate set lives in registers)
-#define TOPK_WIDE 32  // widest top-k of the streaming kernel and of the beam bookkeeping: num_beams <= 16
+#define TOPK_WIDE 64  // widest top-k of the streaming kernel and of the beam bookkeeping: num_beams <= 32
 #define NEG_BIG (-1.0e7f)
 
 __device__ __forceinline__ bool better(float av, int ai, float bv, int bi) { return av > bv || (av == bv && ai < bi); }
@@ -188,11 +188,11 @@ __global__ __launch_bounds__(256) void row_lse_topk_kernel(int V, const T* __res
 extern "C" int mic_row_lse_topk(int dtype, int R, int V, const void* logits, int ld, int k, int forced_token,
                                 int suppress_eos, int eos_token_id, int raw_logits, const float* row_bias, float* top_val,
                                 int32_t* top_idx, void* stream) {
-  MIC_CHECK(R > 0 && V > 0 && ld >= V && ld % 8 == 0 && k >= 1 && k <= TOPK_WIDE && logits && top_val && top_idx, "mic_row_lse_topk: bad args (k <= 32)");
+  MIC_CHECK(R > 0 && V > 0 && ld >= V && ld % 8 == 0 && k >= 1 && k <= TOPK_WIDE && logits && top_val && top_idx, "mic_row_lse_topk: bad args (k <= 64)");
   dim3 grid(R), block(256);
 #define TOPK_LAUNCH(TT, KM) hipLaunchKernelGGL((row_lse_topk_kernel<TT, KM>), grid, block, 0, (hipStream_t)stream, V, (const TT*)logits, ld, k, forced_token, suppress_eos, eos_token_id, raw_logits, row_bias, top_val, top_idx)
-  if (dtype == MIC_BF16) { if (k <= 8) TOPK_LAUNCH(uint16_t, 8); else if (k <= 16) TOPK_LAUNCH(uint16_t, 16); else TOPK_LAUNCH(uint16_t, 32); }
-  else if (dtype == MIC_F32) { if (k <= 8) TOPK_LAUNCH(float, 8); else if (k <= 16) TOPK_LAUNCH(float, 16); else TOPK_LAUNCH(float, 32); }
+  if (dtype == MIC_BF16) { if (k <= 8) TOPK_LAUNCH(uint16_t, 8); else if (k <= 16) TOPK_LAUNCH(uint16_t, 16); else if (k <= 32) TOPK_LAUNCH(uint16_t, 32); else TOPK_LAUNCH(uint16_t, 64); }
+  else if (dtype == MIC_F32) { if (k <= 8) TOPK_LAUNCH(float, 8); else if (k <= 16) TOPK_LAUNCH(float, 16); else if (k <= 32) TOPK_LAUNCH(float, 32); else TOPK_LAUNCH(float, 64); }
   else MIC_CHECK(false, "mic_row_lse_topk: bad dtype");
 #undef TOPK_LAUNCH
   MIC_LAUNCH_CHECK();
@@ -398,8 +398,8 @@ extern "C" int mic_row_topk_tiles(int dtype, int R, int V, const void* logits, i
 }
 
 // ------------------------------------------------------------------ one beam_search_body_fn iteration (gen:857-966)
-// One block per batch item, one thread per (beam, candidate) pair: 128 threads up to K = 8 beams (2K*K <= 128 candidates), 512 up
-// to K = 16.  All arithmetic is fp32 in the reference's operation order so scores are bit-identical to the oracle.
+// One block per batch item, the (beam, candidate) pairs over its threads: 128 threads up to K = 8 beams (2K*K <= 128 candidates), 512
+// beyond (one pair per thread up to K = 16, four at K = 32).  All arithmetic is fp32 in the reference's operation order so scores are bit-identical to the oracle.
 __global__ __launch_bounds__(512) void beam_step_kernel(mic_beam_step_args a) {
   extern __shared__ int32_t lds_i[];
   const int K = a.K, C = 2 * K, L = a.max_len, V = a.V;
@@ -430,29 +430,24 @@ __global__ __launch_bounds__(512) void beam_step_kernel(mic_beam_step_args a) {
   __syncthreads();
   // 1. top-2K of the K*2K per-row candidates, ordered (value desc, flat index asc)  (gen:872-874)
   const int N = K * C;
-  float myv = 0.f; int mybeam = 0, mytok = 0; long myflat = 0;
-  if (tid < N) {
-    mybeam = tid / C;
-    myv = a.cand_val[(size_t)(b * K + mybeam) * C + tid % C];
-    mytok = a.cand_idx[(size_t)(b * K + mybeam) * C + tid % C];
-    myflat = (long)mybeam * V + mytok;
-  }
-  {
+  for (int pr = tid; pr < N; pr += blockDim.x) {  // (512 threads: one pair per thread up to K = 16, four at K = 32)
+    const int mybeam = pr / C;
+    const float myv = a.cand_val[(size_t)(b * K + mybeam) * C + pr % C];
+    const int mytok = a.cand_idx[(size_t)(b * K + mybeam) * C + pr % C];
+    const long myflat = (long)mybeam * V + mytok;
     int rank = 0;
-    if (tid < N) {
-      for (int o = 0; o < N; ++o) {
-        const int ob = o / C;
-        const float ov = a.cand_val[(size_t)(b * K + ob) * C + o % C];
-        const long of = (long)ob * V + a.cand_idx[(size_t)(b * K + ob) * C + o % C];
-        if (ov > myv || (ov == myv && of < myflat)) ++rank;
-      }
-      if (rank < C) {
-        cand_seq_parent[rank] = mybeam;
-        cand_tok[rank] = mytok;
-        const int jf = (mytok == a.eos_token_id);
-        cand_fin[rank] = jf;                                   // gen:889
-        cand_lp[rank] = myv + (float)jf * NEG_BIG;             // gen:890
-      }
+    for (int o = 0; o < N; ++o) {
+      const int ob = o / C;
+      const float ov = a.cand_val[(size_t)(b * K + ob) * C + o % C];
+      const long of = (long)ob * V + a.cand_idx[(size_t)(b * K + ob) * C + o % C];
+      if (ov > myv || (ov == myv && of < myflat)) ++rank;
+    }
+    if (rank < C) {
+      cand_seq_parent[rank] = mybeam;
+      cand_tok[rank] = mytok;
+      const int jf = (mytok == a.eos_token_id);
+      cand_fin[rank] = jf;                                   // gen:889
+      cand_lp[rank] = myv + (float)jf * NEG_BIG;             // gen:890
     }
   }
   __syncthreads();
@@ -540,7 +535,7 @@ __global__ __launch_bounds__(512) void beam_step_kernel(mic_beam_step_args a) {
 }
 extern "C" int mic_beam_step(const mic_beam_step_args* a, void* stream) {
   MIC_CHECK(a && a->B > 0 && a->K >= 1 && 2 * a->K <= TOPK_WIDE && a->max_len > 1 && a->cur_len >= 1 && a->cur_len < a->max_len,
-            "mic_beam_step: bad shape (K <= 16 supported: per-row candidates come from mic_row_lse_topk with k = 2K <= 32)");
+            "mic_beam_step: bad shape (K <= 32 supported: per-row candidates come from mic_row_lse_topk with k = 2K <= 64)");
   MIC_CHECK(a->cand_val && a->cand_idx && a->running_seq && a->running_scores && a->seq && a->scores && a->finished && a->src_row && a->next_token && a->flags, "mic_beam_step: null pointer");
   const size_t lds = (size_t)(3 * a->K * a->max_len + 8 * 2 * a->K + 8 * a->K) * 4;
   MIC_CHECK(lds <= 65536, "mic_beam_step: max_len too large for the LDS staging");

@@ -332,8 +332,8 @@ class FlaxCLIPVisionMBartGenerationMixin:
     def _beam_search(self, ehs, B, K, start_token, max_length, pad_token_id, eos_token_id, length_penalty, early_stopping, procs):
         from .modeling_clip_vision_mbart import ModelOutput
 
-        if 2 * K > 32:
-            raise NotImplementedError("num_beams > 16 needs a wider per-row top-k than this build ships (k = 2*num_beams <= 32)")
+        if 2 * K > 64:
+            raise NotImplementedError("num_beams > 32 needs a wider per-row top-k than this build ships (k = 2*num_beams <= 64)")
         dev, st = self.device, self.store
         NS = self._decode_slices(B, K)
         Bs = B // NS          # images per slice

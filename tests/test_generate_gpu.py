@@ -72,7 +72,9 @@ def test_greedy_ids_exact(dev, kw):
                                 dict(max_length=9, num_beams=7, length_penalty=0.6),
                                 # wider than 8 beams: 2K > 16 candidates per row stream the logits (row_lse_topk's 32-wide build), the
                                 # bookkeeping kernel runs 512 threads per image
-                                dict(max_length=8, num_beams=12), dict(max_length=7, num_beams=16, forced_bos_token_id=994, length_penalty=0.8)])
+                                dict(max_length=8, num_beams=12), dict(max_length=7, num_beams=16, forced_bos_token_id=994, length_penalty=0.8),
+                                # wider than 16: the 64-wide build of the streaming top-k, four (beam, candidate) pairs per bookkeeping thread
+                                dict(max_length=7, num_beams=20), dict(max_length=6, num_beams=32, length_penalty=1.2)])
 def test_beam_ids_exact(dev, kw):
     rc, p, model = make_pair(torch.float32, dev, gelu="tanh", decoder_ln_eps=1e-6)
     B = 3
@@ -338,8 +340,8 @@ def test_generate_api_errors(dev):
     px, *_ = batch(rc, 1, 12, seed=1)
     with pytest.raises(NotImplementedError):
         model.generate(px.numpy(), do_sample=True, num_beams=4, max_length=5)
-    with pytest.raises(NotImplementedError, match="num_beams > 16"):
-        model.generate(px.numpy(), num_beams=17, max_length=5)
+    with pytest.raises(NotImplementedError, match="num_beams > 32"):
+        model.generate(px.numpy(), num_beams=33, max_length=5)
     model.config.mbart_config.decoder_start_token_id = None
     with pytest.raises(ValueError):
         model.generate(px.numpy(), max_length=5, num_beams=1)

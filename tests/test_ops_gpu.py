@@ -489,12 +489,13 @@ def test_adamw_rows_split_is_exact(dev, rows, width):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("V,Vpad", [(5003, 5008), (1003, 1024), (250054, 250112)])
-def test_row_lse_topk(dev, dtype, V, Vpad):
+@pytest.mark.parametrize("V,Vpad,k", [(5003, 5008, 8), (1003, 1024, 8), (250054, 250112, 8), (5003, 5008, 24), (250054, 250112, 40), (1003, 1024, 64)])
+def test_row_lse_topk(dev, dtype, V, Vpad, k):
+    """k = 2 * num_beams: the 8-, 16- (not here: beam tests), 32- and 64-wide builds of the streaming kernel"""
     from mic_amd import ops
     from oracle import generation_ref as G
 
-    R, k = 6, 8
+    R = 6
     g = torch.Generator().manual_seed(8)
     logits = torch.zeros((R, Vpad), dtype=dtype)
     logits[:, :V] = rnd((R, V), g, dtype, 2.0)
