@@ -25,15 +25,16 @@
 
 namespace {
 
-constexpr int W4_BK = 32, W4_HIMG = 128 * W4_BK * 2, W4_SLOT = 4 * W4_HIMG;
+constexpr int W4_BK = 64, W4_HIMG = 128 * W4_BK * 2, W4_SLOT = 4 * W4_HIMG;  // 64-k tiles: half image 16 KiB, slot 64 KiB
 
-// byte offset of this lane's source (k = 0) for 1-KiB piece `piece` of a 256-row operand tile whose row 0 is x0: 8 rows x 128 B (a
-// whole line per row and 64-k tile: half the L2 requests of 64-B segments per 32-k step — the 16-rows-x-64-B form of the first build
-// measured 5-7 % slower on the LM-head shapes); the operand base stays a scalar (global_load saddr + 32-bit voffset)
-__device__ __forceinline__ uint32_t w4_source(int ld, int x0, int lim, int piece, int lane) {
-  int gx = x0 + piece * 8 + (lane >> 3);
+// byte offset of this lane's source (k = 0 of the split) for 1-KiB piece q (8 rows x 128 B = whole lines) of a half image whose row 0
+// is x0.  LDS-DMA writes lane-linear, so the image's swizzle (chunk position p of row R holds source chunk p ^ ((R>>1)&7), see
+// read_frag) sits on the SOURCE address: every lane fetches the chunk that belongs at its LDS position.
+__device__ __forceinline__ uint32_t w4_source(int ld, int x0, int lim, int q, int lane) {
+  const int R = q * 8 + (lane >> 3), c = (lane & 7) ^ ((R >> 1) & 7);
+  int gx = x0 + R;
   gx = gx < lim ? gx : lim - 1;
-  return ((uint32_t)gx * (uint32_t)ld + (uint32_t)((lane & 7) * 8)) * 2u;
+  return ((uint32_t)gx * (uint32_t)ld + (uint32_t)(c * 8)) * 2u;
 }
 
 // The bare epilogue of a four-wave block: C = alpha acc + bias as bf16, optionally the folded LayerNorm and the LM head's softmax
@@ -144,98 +145,81 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(LaunchTable tab) {
   const int kt0 = split * nk_per, kt1 = min(nk_total, kt0 + nk_per);
   const int nsteps = 2 * max(kt1 - kt0, 0);  // even, 32 k each
 
-  // the sixteen 1-KiB pieces this wave brings per 64-k TILE (= two steps): pieces 8w .. 8w+7 of the A tile and of the B tile.  Lane
-  // (row r = lane>>3, chunk c = lane&7) of piece q holds k 8c..8c+7 of tile row 64w + 8q + r: chunks 0-3 belong to the tile's even
-  // step, 4-7 to its odd step, so one ds_write_b128 scatters a piece over the two steps' LDS slots
+  // the sixteen 1-KiB pieces this wave brings per 64-k tile: pieces 4w .. 4w+3 of each of the four half images, by LDS-DMA
+  // (buffer_load ... lds: scalar resource + 32-bit lane offset + scalar k offset — nothing to update per tile in vector registers;
+  // see W4_DMA for tiles past the end of K)
   uint32_t go[16];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    go[q] = w4_source(P.lda, m0, P.M, wave * 8 + q, lane);
-    go[8 + q] = w4_source(P.ldb, n0, P.N, wave * 8 + q, lane);
-  }
-  const char* gA = reinterpret_cast<const char*>(P.A) + (size_t)kt0 * 128;  // scalar bases, advanced by the loop
-  const char* gB = reinterpret_cast<const char*>(P.B) + (size_t)kt0 * 128;
-  // this lane's LDS write offset inside a pair of slots, for even / odd pieces: row 8q + r of the wave's 64 rows sits in half image
-  // w>>1 at row 64(w&1) + 8q + r, chunk position (c&3) ^ ((row>>2)&3) with (row>>2)&3 = (2(q&1) + (lane>>5)) & 3
-  uint32_t wl[2];
+  for (int h = 0; h < 4; ++h)
 #pragma unroll
-  for (int e = 0; e < 2; ++e)
-    wl[e] = (uint32_t)(((lane >> 2) & 1) * W4_SLOT + (wave >> 1) * W4_HIMG + ((wave & 1) * 64 + (lane >> 3)) * 64 +
-                       ((((lane & 3) ^ ((2 * e + (lane >> 5)) & 3))) << 4));
-  // operands travel global -> registers -> LDS (an LDS-DMA piece costs 60-100 cycles of ISSUE time, and with one wave per SIMD nobody
-  // else feeds the matrix pipe meanwhile; global_load_dwordx4 + ds_write_b128 are ~20).  Two register sets of sixteen pieces: tile
-  // U (steps 2U, 2U+1) is requested in step 2U-6, written to LDS slots 2U%4 and (2U+1)%4 in step 2U-2 (four steps of latency
-  // budget), its fragments are read in steps 2U-1 .. 2U+1.
-  u32x4 lA[16], lB[16];
-  auto ld = [&](u32x4 (&l)[16], int tile, bool on) __attribute__((always_inline)) {
-    const uint32_t m = on ? 0xffffffffu : 0u;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) l[q] = *reinterpret_cast<const u32x4*>((q < 8 ? gA : gB) + tile * 128 + (go[q] & m));
-  };
-  auto st = [&](const u32x4 (&l)[16], int pair) __attribute__((always_inline)) {
-    char* base = smem + pair * 2 * W4_SLOT;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) *reinterpret_cast<u32x4*>(base + (q >> 3) * 2 * W4_HIMG + (q & 7) * 512 + wl[q & 1]) = l[q];
-  };
-  bf16x8 a0[AI], b0[NJ], a1[AI], b1[NJ];  // fragments of k 0-15 / k 16-31 of a step
+    for (int i = 0; i < 4; ++i)
+      go[h * 4 + i] = h < 2 ? w4_source(P.lda, m0 + h * 128, P.M, wave * 4 + i, lane) : w4_source(P.ldb, n0 + (h - 2) * 128, P.N, wave * 4 + i, lane);
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(P.A) + (size_t)kt0 * 128), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(P.B) + (size_t)kt0 * 128), 0, 0x7fffffff, 0x00020000);
+  const int nk = nsteps / 2;  // 64-k tiles of this block
+  bf16x8 fa[AI][4], fb[NJ][4];  // one tile's fragments: [32-row block][k 16 kk .. 16 kk + 15]
   const char* fa_ = smem + wr * W4_HIMG;        // + slot: this wave's A half image
   const char* fb_ = smem + (2 + wc) * W4_HIMG;  // ... B half image
-// step S = s + C (s a multiple of 4, C a constant: LDS slots and register sets are compile-time).  The order is pinned gap by gap
-// (the scheduler's group pipelines came apart on three instruction classes).  MFMA gaps 0-7: read this step's k 16-31 fragments;
-// 16-23: read step S+1's k 0-15 fragments.  EVEN steps also write the tile of steps S+2, S+3 from register set L and request the
-// tile of steps S+6, S+7 into it: A pieces in gaps 8-15, B pieces in gaps 24-31.  s_waitcnt lgkmcnt(0) closes the step.
-#define W4_STEP(C, L, EVEN)                                                                                                    \
+  // (a tile past the end of K is requested through a resource of zero records: every lane is out of range, the hardware drops the
+  // request — the scalar k offset takes no part in the range check on this architecture, so it cannot do the masking)
+  const __amdgpu_buffer_rsrc_t rZ = __builtin_amdgcn_make_buffer_rsrc((void*)P.A, 0, 0, 0x00020000);
+#define W4_DMA(TILE, SLOT, Q)                                                                                                  \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds((TILE) < nk ? ((Q) < 8 ? rA : rB) : rZ,                                             \
+                                           LDS_PTR(void, smem + (SLOT) * W4_SLOT + ((Q) >> 2) * W4_HIMG + (wave * 4 + ((Q) & 3)) * 1024), \
+                                           16, go[Q], (TILE) * 128, 0, 0)
+#define W4_BARRIER()                       \
+  do {                                     \
+    __builtin_amdgcn_sched_barrier(0);     \
+    __builtin_amdgcn_s_barrier();          \
+    __builtin_amdgcn_sched_barrier(0);     \
+  } while (0)
+// tile T = t + C in LDS slot C (t even, C = 0 / 1): 64 MFMAs in four quarters of 16 (quarter = kk).  The order is pinned gap by gap.
+//   quarter 0: read this tile's kk = 3 fragments (gaps 0-7); then {lgkmcnt(0): every read of this slot is done; vmcnt(0): this
+//              wave's pieces of tile T+1 have landed} s_barrier — tile T+1 is readable, this tile's slot is dead
+//   quarters 1, 2: read tile T+1's kk = 0 / kk = 1 fragments (first 8 gaps of the quarter) into the registers the finished quarters
+//              freed; one LDS-DMA piece of tile T+2 into the dead slot in every other gap (an LDS-DMA piece costs 60-100 cycles of
+//              issue time: never two in a row)
+//   quarter 3: read tile T+1's kk = 2 fragments
+#define W4_TILE(C)                                                                                                             \
   do {                                                                                                                         \
-    __builtin_amdgcn_sched_barrier(0);                                                                                         \
-    __builtin_amdgcn_s_barrier();                                                                                              \
-    __builtin_amdgcn_sched_barrier(0);                                                                                         \
-    char* ws_ = smem + (((C) + 2) & 2) * W4_SLOT;                                                                              \
-    const uint32_t lm_ = s + (C) + 6 < nsteps ? 0xffffffffu : 0u;                                                              \
-    _Pragma("unroll") for (int g_ = 0; g_ < 32; ++g_) {                                                                        \
-      if (g_ < 16) acc[g_ >> 2][g_ & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[g_ >> 2], b0[g_ & 3], acc[g_ >> 2][g_ & 3], 0, 0, 0); \
-      else acc[(g_ - 16) >> 2][g_ & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[(g_ - 16) >> 2], b1[g_ & 3], acc[(g_ - 16) >> 2][g_ & 3], 0, 0, 0); \
-      if (g_ < 4) a1[g_] = read_frag<false, W4_BK, 128>(fa_ + ((C) & 3) * W4_SLOT, g_ * 32, 1, lane);                          \
-      else if (g_ < 8) b1[g_ - 4] = read_frag<false, W4_BK, 128>(fb_ + ((C) & 3) * W4_SLOT, (g_ - 4) * 32, 1, lane);           \
-      else if (g_ >= 16 && g_ < 20) a0[g_ - 16] = read_frag<false, W4_BK, 128>(fa_ + (((C) + 1) & 3) * W4_SLOT, (g_ - 16) * 32, 0, lane); \
-      else if (g_ >= 20 && g_ < 24) b0[g_ - 20] = read_frag<false, W4_BK, 128>(fb_ + (((C) + 1) & 3) * W4_SLOT, (g_ - 20) * 32, 0, lane); \
-      else if (EVEN) {                                                                                                         \
-        const int q_ = g_ < 16 ? g_ - 8 : g_ - 16;  /* 0-7: A pieces, 8-15: B pieces */                                        \
-        *reinterpret_cast<u32x4*>(ws_ + (q_ >> 3) * 2 * W4_HIMG + (q_ & 7) * 512 + wl[q_ & 1]) = L[q_];                        \
-        L[q_] = *reinterpret_cast<const u32x4*>((q_ < 8 ? gA : gB) + ((C) + 6) * (W4_BK * 2) + (go[q_] & lm_));                \
+    _Pragma("unroll") for (int g_ = 0; g_ < 64; ++g_) {                                                                        \
+      if (g_ == 16) {                                                                                                          \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                            \
+        W4_BARRIER();                                                                                                          \
       }                                                                                                                        \
+      acc[(g_ & 15) >> 2][g_ & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[(g_ & 15) >> 2][g_ >> 4], fb[g_ & 3][g_ >> 4],  \
+                                                                           acc[(g_ & 15) >> 2][g_ & 3], 0, 0, 0);             \
+      const int q_ = g_ >> 4, x_ = g_ & 15;                                                                                    \
+      const int rk_ = (q_ + 3) & 3, rs_ = q_ == 0 ? (C) : 1 - (C);  /* kk and slot of this quarter's fragment reads */          \
+      if (x_ < 4) fa[x_][rk_] = read_frag<false, W4_BK, 128>(fa_ + rs_ * W4_SLOT, x_ * 32, rk_, lane);                         \
+      else if (x_ < 8) fb[x_ - 4][rk_] = read_frag<false, W4_BK, 128>(fb_ + rs_ * W4_SLOT, (x_ - 4) * 32, rk_, lane);          \
+      if ((q_ == 1 || q_ == 2) && (x_ & 1) == 1) W4_DMA(t + (C) + 2, C, (q_ - 1) * 8 + (x_ >> 1));                             \
       __builtin_amdgcn_sched_barrier(0);                                                                                       \
     }                                                                                                                          \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                         \
-    __builtin_amdgcn_sched_barrier(0);                                                                                         \
   } while (0)
 
-  if (nsteps >= 8) {
-    ld(lA, 0, true);
-    st(lA, 0);
-    ld(lA, 1, true);
-    ld(lB, 2, true);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
+  if (nk >= 2) {
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      a0[x] = read_frag<false, W4_BK, 128>(fa_, x * 32, 0, lane);
-      b0[x] = read_frag<false, W4_BK, 128>(fb_, x * 32, 0, lane);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int q = 0; q < 16; ++q) W4_DMA(0, 0, q);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) W4_DMA(1, 1, q);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // tile 0 has landed (tile 1 may still fly)
+    W4_BARRIER();
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        fa[x][kk] = read_frag<false, W4_BK, 128>(fa_, x * 32, kk, lane);
+        fb[x][kk] = read_frag<false, W4_BK, 128>(fb_, x * 32, kk, lane);
+      }
     __builtin_amdgcn_sched_barrier(0);
-    // one uniform loop, no peeled tail (copies of the step for the last iterations made the register allocator spill the in-flight
-    // register sets around the loop, and spill traffic counts on vmcnt): past the end of K the requests collapse onto one 128-B
-    // line (offset mask 0), the LDS writes land in slots nobody reads again, the fragment reads fetch values nobody uses
-    for (int s = 0; s < nsteps; s += 4) {
-      W4_STEP(0, lA, true);
-      W4_STEP(1, lA, false);
-      W4_STEP(2, lB, true);
-      W4_STEP(3, lB, false);
-      gA += 4 * W4_BK * 2;
-      gB += 4 * W4_BK * 2;
+    // one uniform loop, no peeled tail: past the end of K the DMA requests are dropped (k offset out of the resource's range) and
+    // the fragment reads of the tile that does not exist fetch values nobody uses
+    for (int t = 0; t < nk; t += 2) {
+      W4_TILE(0);
+      W4_TILE(1);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (dropped requests still count)
   }
   __syncthreads();
   w4_epilogue_lean<(EPI & 1) != 0, (EPI & 4) != 0>(acc, P, smem, m0 + wr * WM, n0 + wc * WN, wave, lane);
@@ -243,7 +227,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(LaunchTable tab) {
 
 template <int EPI>
 void launch_w4(const LaunchTable& tab, hipStream_t s) {
-  constexpr int lds = 4 * W4_SLOT;  // the K loop uses two slots; the shared epilogue restages 4 x 32 KiB, the bare one 4 x 16.5
+  constexpr int lds = 2 * W4_SLOT;  // two 64-KiB tile slots (the bare epilogue restages 4 x 16.5 KiB through the same memory)
   static bool attr_set_dev[64] = {};  // per instantiation and device
   int dev_ = 0;
   (void)hipGetDevice(&dev_);
