@@ -229,9 +229,10 @@ static GemmPlan plan_bf16(const mic_gemm_args* args, int count) {
   static const int phased_env = [] { const char* e = getenv("MIC_GEMM_PHASED"); return e ? atoi(e) : 2; }();
   const bool f8 = args[0].dtype == MIC_FP8;
   pl.phased = bm == 256 && !f8 && phased_env != 0 && !args[0].a_kmajor && !args[0].b_kmajor && count == 1 && !any_rowsum_early(args, count);
-  // MIC_GEMM_W4=1 (opt-in, A/B): the four-wave 128x128-wave-tile kernel (gemm_w4.hip) instead, where the shape allows it and — decided
-  // at launch, gemm_w4_takes — the epilogue is a bare one; plan.phased reads 2 for such a launch
-  static const int w4_env = [] { const char* e = getenv("MIC_GEMM_W4"); return e ? atoi(e) : 0; }();
+  // ... and of those the four-wave 128x128-wave-tile kernel (gemm_w4.hip) takes the launches whose shape allows it and whose epilogue —
+  // decided at launch, gemm_w4_takes — is a bare one (LM head, all-layer cross k/v projection); plan.phased reads 2 for such a shape.
+  // MIC_GEMM_W4=0 keeps them on the four-phase kernel (A/B)
+  static const int w4_env = [] { const char* e = getenv("MIC_GEMM_W4"); return e ? atoi(e) : 1; }();
   if (pl.phased && w4_env && args[0].split_k <= 1 && args[0].K >= 256 && args[0].K % 128 == 0) pl.phased = 2;
   if (bm == 256) {
     pl.per_cu = 1;  // 128 KiB of LDS: a block holds its CU alone; PLAIN launches with more tiles than CUs run as `cus` persistent blocks

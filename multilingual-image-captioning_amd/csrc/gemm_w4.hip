@@ -66,6 +66,30 @@ __device__ __forceinline__ void w4_epilogue_lean(f32x16 (&acc)[4][4], const Prob
   uint16_t* C = (uint16_t*)E.C;
   const int ldc = E.ldc;
   const int urow = lane >> 4, c8 = (lane & 15) * 8;
+  const int n = nw + c8;
+  const bool nfull = n + 8 <= N;
+  // folded LayerNorm: (mean, rstd) of the wave's 128 rows once, through LDS (the shared helper's per-unit int64 loads and conversions
+  // would sit 32 times in every lane's path); the column terms of this lane's 8 columns once, in registers
+  float2* lnr = reinterpret_cast<float2*>(smem + 4 * 32 * W4_EP * 4) + wave * 128;
+  float g8[8], b8[8];
+  if constexpr (LNF) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int m = mw + lane + 64 * k;
+      float mu = 0.0f, rstd = 0.0f;
+      if (m < M) {
+        const longlong2 st = reinterpret_cast<const longlong2*>(E.ln_stats)[m];
+        mu = (float)st.x * (MIC_ROWSUM_INV_SCALE * E.ln_inv_d);
+        rstd = rsqrtf(fmaxf((float)st.y * (MIC_ROWSUM_INV_SCALE * E.ln_inv_d) - mu * mu, 0.0f) + E.ln_eps);
+      }
+      lnr[lane + 64 * k] = make_float2(mu, rstd);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g8[i] = b8[i] = 0.0f;
+    if (nfull) { ld8(E.ln_g + n, g8); ld8(E.ln_bias + n, b8); }
+  }
+  // softmax partials: only the column tile that holds the end of the vocabulary needs the per-column validity test
+  const bool stat_all = STATS && nw + 128 <= E.stat_nvalid;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
 #pragma unroll
@@ -76,32 +100,51 @@ __device__ __forceinline__ void w4_epilogue_lean(f32x16 (&acc)[4][4], const Prob
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int row = it * 4 + urow;
-      const int m = mw + p * 32 + row, n = nw + c8;
+      const int m = mw + p * 32 + row;
       const float* src = Cw + row * W4_EP + c8;
       const float4 lo = *reinterpret_cast<const float4*>(src);
       const float4 hi = *reinterpret_cast<const float4*>(src + 4);
       float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
       const bool ok = m < M && n < N;
       if constexpr (LNF) {
-        if (ok && n + 8 <= N) ln_fold_apply8(E, m, n, v);
+        const float2 mr = lnr[p * 32 + row];
+        if (nfull) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = fmaf(mr.y, v[i] - mr.x * g8[i], b8[i]);
+        }
       }
+      uint4 u;  // the values as stored
+      u.x = f2bf_pk(v[0], v[1]); u.y = f2bf_pk(v[2], v[3]);
+      u.z = f2bf_pk(v[4], v[5]); u.w = f2bf_pk(v[6], v[7]);
       if (ok) {
-        if (n + 8 <= N) st8(C + (size_t)m * ldc + n, v);
+        if (nfull) *reinterpret_cast<uint4*>(C + (size_t)m * ldc + n) = u;
         else
           for (int i = 0; i < N - n; ++i) C[(size_t)m * ldc + n + i] = f2bf(v[i]);
       }
       if constexpr (STATS) {
         // (max, sum exp(x - max)) of the values AS STORED over this row's 64-column granule = 8 consecutive lanes
-        float mx = -INFINITY, x[8];
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+        float x[8], mx = -INFINITY;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          x[i] = (ok && n + i < E.stat_nvalid) ? bf2f(f2bf(v[i])) : -INFINITY;
-          mx = fmaxf(mx, x[i]);
+        for (int i = 0; i < 4; ++i) {
+          x[2 * i] = __uint_as_float(w[i] << 16);
+          x[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
         }
+        if (!stat_all) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) x[i] = (ok && n + i < E.stat_nvalid) ? x[i] : -INFINITY;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mx = fmaxf(mx, x[i]);
         const float gm = group8_max(mx);
         float sm = 0.0f;
+        if (stat_all) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) sm += x[i] > -INFINITY ? __expf(x[i] - gm) : 0.0f;
+          for (int i = 0; i < 8; ++i) sm += __expf(x[i] - gm);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) sm += x[i] > -INFINITY ? __expf(x[i] - gm) : 0.0f;
+        }
         sm = group8_sum(sm);
         if ((lane & 7) == 0 && ok) reinterpret_cast<float2*>(E.rowstat)[(size_t)m * E.stat_ld + n / 64] = make_float2(gm, sm);
       }

@@ -800,7 +800,7 @@ def test_gemm_phased_many_tiles(dev, M, N, K):
     from mic_amd import ops
 
     plan = ops.gemm_plan([(M, N, K)])
-    w4 = os.environ.get("MIC_GEMM_W4") == "1" and K >= 256 and K % 128 == 0  # (the opt-in four-wave kernel, see the test below)
+    w4 = os.environ.get("MIC_GEMM_W4", "1") != "0" and K >= 256 and K % 128 == 0  # (the four-wave kernel takes these shapes by default)
     assert plan["tile"] == 256 and plan["phased"] == (2 if w4 else 1) and plan["blocks"] > 256
     dt = torch.bfloat16
     g = torch.Generator().manual_seed(M + N + K)
@@ -869,15 +869,18 @@ def test_gemm_layernorm_fold_with_softmax_partials(dev):
     assert torch.equal(got[..., 0], mx) and torch.allclose(got[..., 1], sm, rtol=2e-5, atol=1e-6)
 
 
-def test_gemm_four_wave_kernel_opt_in(dev):
-    """MIC_GEMM_W4=1 routes the single-problem NT 256 x 256 launches with a bare epilogue (bias, the folded LayerNorm, the LM head's
-    softmax partials) to gemm_w4.hip.  The library reads the switch once, so the launches run in a child process: the many-tiles
-    cases with K = 1024 (bias, bit-identical reruns, partial row tiles, the softmax partials; the GELU case falls back to the
-    four-phase kernel) and the folded-LayerNorm / softmax-partial tests of this file (each of the kernel's four epilogue builds)."""
+def test_gemm_four_phase_kernel_behind_its_switch(dev):
+    """The single-problem NT 256 x 256 launches with a bare epilogue (bias, the folded LayerNorm, the LM head's softmax partials) run on
+    gemm_w4.hip by default and on gemm_phased.hip under MIC_GEMM_W4=0.  The library reads the switch once, so the second configuration
+    runs in a child process: the many-tiles cases with K = 1024 (bias, bit-identical reruns, partial row tiles, the softmax partials)
+    and the folded-LayerNorm / softmax-partial tests of this file — the same tests this process runs on the four-wave kernel."""
     import subprocess
     import sys
 
-    env = dict(os.environ, MIC_GEMM_W4="1")
+    from mic_amd import ops
+
+    assert ops.gemm_plan([(1024, 131072, 1024)])["phased"] == (2 if os.environ.get("MIC_GEMM_W4", "1") != "0" else 1)
+    env = dict(os.environ, MIC_GEMM_W4="0")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "-k",
                         "(phased_many_tiles and 1024) or head_rowstat or layernorm_fold"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

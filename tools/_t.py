@@ -3,14 +3,22 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 importlib.import_module("multilingual-image-captioning_amd")
 ops = importlib.import_module("multilingual-image-captioning_amd.ops")
 dev = torch.device("cuda:0")
-for (M, N, K) in ((512, 66048, 256), (1024, 66048, 1024), (4096, 4096, 4096)):
-    a = (torch.rand(M, K, device=dev) * 2 - 1).to(torch.bfloat16); b = (torch.rand(N, K, device=dev) * 2 - 1).to(torch.bfloat16)
+def t(fn, n=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+for (M, N, K) in ((1024, 250112, 1024), (2432, 250112, 1024)):
+    a = (torch.rand(M, K, device=dev) * 2 - 1).to(torch.bfloat16); b = (torch.rand(N, K, device=dev) * 0.1).to(torch.bfloat16)
     c = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
-    print(ops.gemm_plan([(M, N, K)]), flush=True)
-    ops.gemm(a, b, c, M, N, K); torch.cuda.synchronize()
-    ref = a.float() @ b.float().T
-    err = (c.float() - ref).abs().max().item() / ref.abs().max().item()
-    print(M, N, K, "relerr", err, flush=True)
-    if err > 0.02:
-        bad = ((c.float() - ref).abs() > 0.05 * ref.abs().max()).nonzero()
-        print("bad count", bad.shape[0], bad[:10].tolist(), flush=True)
+    bias = torch.randn(N, device=dev)
+    stat = torch.zeros((M, 2 * (N // 64)), dtype=torch.float32, device=dev)
+    st = torch.zeros((M, 2), dtype=torch.int64, device=dev); st[:, 1] = 2 ** 20 * K
+    cs = torch.randn(N, device=dev)
+    print(M, N, K, "plain %.1f" % t(lambda: ops.gemm(a, b, c, M, N, K)),
+          "bias %.1f" % t(lambda: ops.gemm(a, b, c, M, N, K, bias=bias)),
+          "bias+stat %.1f" % t(lambda: ops.gemm(a, b, c, M, N, K, bias=bias, rowstat=stat, rowstat_nvalid=N - 58)),
+          "lnfold+stat %.1f" % t(lambda: ops.gemm(a, b, c, M, N, K, bias=bias, rowstat=stat, rowstat_nvalid=N - 58, ln_stats=st, ln_colsum=cs, ln_width=K, ln_eps=1e-5)), flush=True)
