@@ -1,26 +1,29 @@
 // gemm_w4.hip — the 256x256 bf16 tile on FOUR waves, one per SIMD, each with the whole 512-register file: wave tile 128 x 128
-// (16 accumulator blocks of 32x32 = 256 AGPRs), ONE barrier per 32-k step.  Where gemm_phased.hip lets the two waves of a SIMD take
+// (16 accumulator blocks of 32x32 = 256 AGPRs), ONE barrier per 64-k tile.  Where gemm_phased.hip lets the two waves of a SIMD take
 // turns at the matrix pipe (eight barrier hand-offs per 64-k tile), here every wave feeds its own pipe from one instruction stream
-// with the side work pinned into the gaps between its 32 MFMAs per step.  OPT-IN (MIC_GEMM_W4=1): it needs 12 % fewer cycles than
-// the four-phase kernel at 4096^3 (222 k against 251 k, rocprofv3 GRBM_GUI_ACTIVE) and takes about the same wall time, because the chip
-// clocks these kernels by power (1.80 GHz against 1.99; DESIGN.md section 3, "Round 4"): 0-3 % ahead in isolation, level in situ.
+// with the side work pinned into the gaps between its 64 MFMAs per tile (the structure hipBLASLt's MT256x256x64 kernels have, read
+// off their disassembly: four waves, 128 x 128 per wave, operands direct-to-LDS, one request every few MFMAs).  Takes the
+// single-problem NT launches with a bare epilogue by default (LM head, all-layer cross k/v projection; MIC_GEMM_W4=0: four-phase
+// kernel): 1305 TF/s at 4096^3 (1145 there), 202 k cycles against 252 k; 6-10 % faster on the LM-head shapes with their epilogues.
 //
-//   * LDS: four slots of 32 KiB, step X in slot X%4 = [A rows 0-127 | A rows 128-255 | B cols 0-127 | B cols 128-255], each a
-//     k-contiguous image of 128 rows x 32 k (64-B rows, 16-B chunk position p of row R holds source chunk p ^ ((R>>2)&3):
-//     conflict-free for the 16-lane groups of ds_read_b128, see read_frag).  The swizzle sits on the LDS destination of the
-//     register-staged pieces (per-lane write offsets `wl`).
-//   * Operands travel global -> registers -> LDS: an LDS-DMA piece costs 60-100 cycles of ISSUE time and with one wave per SIMD
-//     nobody else feeds the matrix pipe meanwhile (first build of this file: 930-1020 TF/s at 4096^3 / 8192^3);
-//     global_load_dwordx4 (scalar base + 32-bit offset) + ds_write_b128 are ~20.  Two register sets of sixteen 16-B pieces per
-//     64-k tile (8 rows x 128 B each: whole lines); tile U is requested in step 2U-6, written to the LDS slots of its two steps in
-//     step 2U-2, read into fragments one half step ahead of the MFMAs that use them.
-//   * step S: s_barrier {gaps 0-7: read this step's k 16-31 fragments} {gaps 16-23: read step S+1's k 0-15 fragments}; even steps
-//     also {gaps 8-15 and 24-31: write the tile of steps S+2, S+3 from its register set, request the tile of steps S+6, S+7 into
-//     the same registers}; s_waitcnt lgkmcnt(0).  RAW: a wave's own lgkmcnt(0), then the barrier, order its LDS writes before the
-//     other waves' reads one step later.  WAR: a slot is rewritten at least one barrier after its last read.  vmcnt is left to the
-//     compiler (counted waits).
-//   * Same launch table, tile order and k ranges as the other kernels; its own bare epilogue (below).  Single-problem NT launches
-//     without split, K a multiple of 128.
+//   * LDS: two slots of 64 KiB, tile T in slot T%2 = [A rows 0-127 | A rows 128-255 | B cols 0-127 | B cols 128-255], each a
+//     k-contiguous image of 128 rows x 64 k (128-B rows, 16-B chunk position p of row R holds source chunk p ^ ((R>>1)&7):
+//     conflict-free for the 16-lane groups of ds_read_b128, see read_frag; SQ_LDS_BANK_CONFLICT reads 0).
+//   * Operands by LDS-DMA: buffer_load_dwordx4 ... lds with a scalar resource, a 32-bit lane offset and a scalar k offset (nothing
+//     to update per tile in vector registers), 1-KiB pieces of 8 rows x 128 B = whole lines; LDS-DMA writes lane-linear, so the
+//     swizzle sits on the SOURCE address.  An LDS-DMA piece costs 60-100 cycles of ISSUE time and nobody else feeds this SIMD's
+//     matrix pipe meanwhile: ONE piece in every other MFMA gap, never two in a row (eight in a row per 32-k step was this file's
+//     first build: 930-1020 TF/s at deep K).  Register-staged operands (global_load + ds_write_b128, two builds of this file)
+//     ran the K loop in 12 % fewer cycles than the four-phase kernel and at a 10 % lower clock — equal wall time; the DMA path
+//     needs no vector registers for data in flight and is the one that is faster on the clock that power allows (DESIGN.md
+//     section 3, "Round 4").
+//   * A whole tile's fragments live in registers (128 VGPRs), re-read one quarter (16 k) behind their last use: quarter 0 of tile T
+//     reads T's last quarter, then {lgkmcnt(0), vmcnt(0)} s_barrier — tile T+1 has landed and T's slot is dead; quarters 1-3 read
+//     tile T+1's first three quarters; the 16 pieces of tile T+2 go out in quarters 1 and 2 into the dead slot.  RAW on DMA data:
+//     the issuing wave's vmcnt, then a barrier the reader has passed.  WAR: the slot is refilled behind the barrier that follows
+//     its last reads.  Past the end of K the requests go through a resource of zero records (dropped by the hardware).
+//   * Same launch table, tile order and k ranges as the other kernels; its own bare per-wave epilogue (below).  Single-problem NT
+//     launches without split, K a multiple of 128 and >= 256.
 #include "gemm_common.h"
 
 namespace {
