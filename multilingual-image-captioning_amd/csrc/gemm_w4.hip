@@ -244,6 +244,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(LaunchTable tab) {
     }                                                                                                                          \
   } while (0)
 
+  const bool live = m0 + wr * WM < P.M;  // (wave-uniform)
   if (nk >= 2) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) W4_DMA(0, 0, q);
@@ -261,14 +262,25 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(LaunchTable tab) {
     __builtin_amdgcn_sched_barrier(0);
     // one uniform loop, no peeled tail: past the end of K the DMA requests are dropped (k offset out of the resource's range) and
     // the fragment reads of the tile that does not exist fetch values nobody uses
-    for (int t = 0; t < nk; t += 2) {
-      W4_TILE(0);
-      W4_TILE(1);
+    if (live) {
+      for (int t = 0; t < nk; t += 2) {
+        W4_TILE(0);
+        W4_TILE(1);
+      }
+    } else {
+      // this wave's 128 rows lie past M (the last row tile of 2432 packed rows is half empty): it keeps bringing its DMA pieces and
+      // meeting the barriers, without MFMAs and fragment reads — on a power-clocked kernel idle matrix pipes are clock for the others
+      for (int t = 0; t < nk; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        W4_BARRIER();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) W4_DMA(t + 2, t & 1, q);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (dropped requests still count)
   }
   __syncthreads();
-  w4_epilogue_lean<(EPI & 1) != 0, (EPI & 4) != 0>(acc, P, smem, m0 + wr * WM, n0 + wc * WN, wave, lane);
+  if (live) w4_epilogue_lean<(EPI & 1) != 0, (EPI & 4) != 0>(acc, P, smem, m0 + wr * WM, n0 + wc * WN, wave, lane);
 }
 
 template <int EPI>
