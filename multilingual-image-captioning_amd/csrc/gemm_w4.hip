@@ -305,6 +305,10 @@ bool gemm_w4_takes(const LaunchTable& tab) {
   if (tab.count != 1 || !table_is_plain(tab)) return false;
   const Problem& p = tab.p[0];
   const EpiArgs& e = p.epi;
+  // the DMA addresses an operand through a buffer resource of 2^31 - 1 bytes with 32-bit lane offsets: larger operands stay on the
+  // four-phase kernel (64-bit addresses)
+  const long long lim = 0x7fffffffLL;
+  if ((long long)p.M * p.lda * 2 >= lim || (long long)p.N * p.ldb * 2 >= lim) return false;
   return p.nsplit == 1 && p.K >= 256 && p.K % 128 == 0 && !e.R && !e.drop_thr && !e.rowsum2 && !e.c_f32;
 }
 void launch_gemm_w4(const LaunchTable& tab, hipStream_t s) {
