@@ -880,8 +880,10 @@ def test_gemm_four_phase_kernel_behind_its_switch(dev):
     from mic_amd import ops
 
     assert ops.gemm_plan([(1024, 131072, 1024)])["phased"] == (2 if os.environ.get("MIC_GEMM_W4", "1") != "0" else 1)
-    env = dict(os.environ, MIC_GEMM_W4="0")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "-k",
-                        "(phased_many_tiles and 1024) or head_rowstat or layernorm_fold"], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
+    # ... and the four-wave kernel with one block per tile instead of persistent blocks drawing tiles from per-XCD counters
+    for extra in (dict(MIC_GEMM_W4="0"), dict(MIC_GEMM_W4_PERSIST="0")):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "-k",
+                            "(phased_many_tiles and 1024) or head_rowstat or layernorm_fold"], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, str(extra) + r.stdout[-3000:] + r.stderr[-2000:]
+        assert " passed" in r.stdout and "failed" not in r.stdout, str(extra) + r.stdout[-2000:]
