@@ -31,6 +31,7 @@
 //   * Same launch table, tile order and k ranges as the other kernels; its own bare per-wave epilogue (below).  Single-problem NT
 //     launches without split, K a multiple of 128 and >= 256.
 #include "gemm_common.h"
+#include <atomic>
 
 namespace {
 
@@ -308,15 +309,20 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(LaunchTable tab, int* __re
 
 // counters of the persistent form: a ring of 64 sets of 8 (one per XCD), zero at rest (the kernel resets what it used); a launch
 // takes the next set, so launches that overlap on different streams do not share one
-static int* w4_counter_set(int dev) {
+static int* w4_counter_set(int dev, hipStream_t s) {
   static int* base[64] = {};
-  static unsigned next[64] = {};
+  static std::atomic<unsigned> next[64];
   if (!base[dev & 63]) {
+    // first use on this device: allocate and clear (synchronous calls — not while the stream is being captured into a graph; such a
+    // launch runs with one block per tile and the next eager launch allocates)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
     int* p = nullptr;
-    if (hipMalloc(&p, 64 * 8 * sizeof(int)) != hipSuccess || hipMemset(p, 0, 64 * 8 * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMalloc(&p, 64 * 8 * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 64 * 8 * sizeof(int)) != hipSuccess) { (void)hipFree(p); return nullptr; }
     base[dev & 63] = p;
   }
-  return base[dev & 63] + 8 * (next[dev & 63]++ & 63);
+  return base[dev & 63] + 8 * (next[dev & 63].fetch_add(1) & 63);
 }
 
 template <int EPI>
@@ -332,7 +338,7 @@ void launch_w4(const LaunchTable& tab, hipStream_t s) {
   }
   static const int persist_env = [] { const char* e = getenv("MIC_GEMM_W4_PERSIST"); return e ? atoi(e) : 1; }();  // =0: one block per tile (A/B)
   const int cus = mic_cu_budget_now();
-  int* counters = (persist_env && tab.total_blocks > cus && (cus & 7) == 0) ? w4_counter_set(dev_) : nullptr;
+  int* counters = (persist_env && tab.total_blocks > cus && (cus & 7) == 0) ? w4_counter_set(dev_, s) : nullptr;
   const int grid = counters ? cus : tab.total_blocks;
   hipLaunchKernelGGL((gemm_w4_kernel<EPI>), dim3(grid), dim3(256), lds, s, tab, counters);
 }
