@@ -887,3 +887,40 @@ def test_gemm_four_phase_kernel_behind_its_switch(dev):
                             "(phased_many_tiles and 1024) or head_rowstat or layernorm_fold"], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, str(extra) + r.stdout[-3000:] + r.stderr[-2000:]
         assert " passed" in r.stdout and "failed" not in r.stdout, str(extra) + r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 131072, 256), (2300, 66048, 384)])
+def test_gemm_four_wave_persistent_blocks_repeat_bit_for_bit(dev, M, N, K):
+    """the four-wave kernel's persistent blocks draw their tiles from per-XCD counters: which block computes which tile changes from
+    run to run, the results must not — also when two launches overlap on two streams (each takes its own counter set) and when the
+    last row tile is partial (idle waves); the counters must be back at zero after every launch (the next one starts from tile 0)"""
+    from mic_amd import ops
+
+    assert ops.gemm_plan([(M, N, K)])["tile"] == 256 and ops.gemm_plan([(M, N, K)])["blocks"] > 256
+    g = torch.Generator().manual_seed(M + K)
+    a, b = rnd((M, K), g, torch.bfloat16).to(dev), rnd((N, K), g, torch.bfloat16, 0.1).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+
+    def run(stream=None):
+        c = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        st = torch.zeros((M, 2 * (N // 64)), dtype=torch.float32, device=dev)
+        if stream is not None:
+            stream.wait_stream(torch.cuda.current_stream())  # (the fills above run on the current stream)
+        with torch.cuda.stream(stream or torch.cuda.current_stream()):
+            ops.gemm(a, b, c, M, N, K, bias=bias, rowstat=st, rowstat_nvalid=N - 7)
+        return c, st
+
+    c0, s0 = run()
+    torch.cuda.synchronize()
+    assert relerr(c0, a.float().cpu() @ b.float().cpu().T + bias.cpu()) < tol(torch.bfloat16)
+    side = torch.cuda.Stream()
+    for it in range(12):
+        if it % 3 == 2:
+            cb, sb = run(side)
+            c, st = run()   # overlaps the launch on the side stream
+            torch.cuda.synchronize()
+            assert torch.equal(cb, c0) and torch.equal(sb, s0)
+        else:
+            c, st = run()
+            torch.cuda.synchronize()
+        assert torch.equal(c, c0) and torch.equal(st, s0)
