@@ -127,7 +127,7 @@ __device__ __forceinline__ void w4_epilogue_lean(f32x16 (&acc)[4][4], const Prob
       u.x = f2bf_pk(v[0], v[1]); u.y = f2bf_pk(v[2], v[3]);
       u.z = f2bf_pk(v[4], v[5]); u.w = f2bf_pk(v[6], v[7]);
       if (ok) {
-        if (nfull) *reinterpret_cast<uint4*>(C + (size_t)m * ldc + n) = u;
+        if (nfull) __builtin_nontemporal_store(u32x4{u.x, u.y, u.z, u.w}, reinterpret_cast<u32x4*>(C + (size_t)m * ldc + n));
         else
           for (int i = 0; i < N - n; ++i) C[(size_t)m * ldc + n + i] = f2bf(v[i]);
       }
