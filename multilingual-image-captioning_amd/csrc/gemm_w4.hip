@@ -22,16 +22,13 @@
 //     tile T+1's first three quarters; the 16 pieces of tile T+2 go out in quarters 1 and 2 into the dead slot.  RAW on DMA data:
 //     the issuing wave's vmcnt, then a barrier the reader has passed.  WAR: the slot is refilled behind the barrier that follows
 //     its last reads.  Past the end of K the requests go through a resource of zero records (dropped by the hardware).
-//   * Launches with more tiles than CUs run as one PERSISTENT block per CU: a block that has finished a tile draws its next one
-//     from its XCD's counter (every XCD keeps walking its own contiguous range of the tile order, the blocks of an XCD share it
-//     dynamically; the last draw of a launch resets the counter; a ring of counter sets keeps overlapping launches apart).  The
-//     stores of a finished tile drain under the next tile's first DMA round trip instead of holding the CU: -3.5 % on the LM head
-//     at 2432 rows, -0..1.5 % at 1024; train step -0.09 ms, decoder step -0.02 ms in same-box A/Bs (MIC_GEMM_W4_PERSIST=0: one
-//     block per tile).  Static round-robin persistence had measured slower on the four-phase kernel.
+//   * One block per tile, dispatched by the hardware.  Persistent blocks drawing tiles from per-XCD counters were built and measured
+//     level with this form (-2 % on the LM head at 2432 rows, +1.5 % at 1024 rows and on the cross-k/v launch) once one trap was out
+//     of the way: a tile index read back from LDS counts as DIVERGENT, and every buffer_load ... lds of the next tile then sits in a
+//     waterfall loop over its resource descriptor (+10 us per tile) — __builtin_amdgcn_readfirstlane on the index fixes it.
 //   * Same launch table, tile order and k ranges as the other kernels; its own bare per-wave epilogue (below).  Single-problem NT
 //     launches without split, K a multiple of 128 and >= 256.
 #include "gemm_common.h"
-#include <atomic>
 
 namespace {
 
@@ -127,7 +124,7 @@ __device__ __forceinline__ void w4_epilogue_lean(f32x16 (&acc)[4][4], const Prob
       u.x = f2bf_pk(v[0], v[1]); u.y = f2bf_pk(v[2], v[3]);
       u.z = f2bf_pk(v[4], v[5]); u.w = f2bf_pk(v[6], v[7]);
       if (ok) {
-        if (nfull) __builtin_nontemporal_store(u32x4{u.x, u.y, u.z, u.w}, reinterpret_cast<u32x4*>(C + (size_t)m * ldc + n));
+        if (nfull) *reinterpret_cast<uint4*>(C + (size_t)m * ldc + n) = u;
         else
           for (int i = 0; i < N - n; ++i) C[(size_t)m * ldc + n + i] = f2bf(v[i]);
       }
@@ -163,33 +160,21 @@ __device__ __forceinline__ void w4_epilogue_lean(f32x16 (&acc)[4][4], const Prob
 }
 
 template <int EPI>
-__global__ __launch_bounds__(256) void gemm_w4_kernel(LaunchTable tab, int* __restrict__ counters) {
+__global__ __launch_bounds__(256) void gemm_w4_kernel(LaunchTable tab) {
   constexpr int WM = 128, WN = 128, WNW = 2, AI = 4, NJ = 4, BM = 256, BN = 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const Problem& P = tab.p[0];
-  // persistent form (counters != nullptr): the grid is one block per CU; a block that has finished a tile draws its next one from
-  // its XCD's counter, so that every XCD keeps walking its own contiguous range of the tile order (L2 locality) while the blocks of
-  // an XCD share that range dynamically.  Virtual block index vb = 8 (g8 + draw) + xcd with g8 = gridDim.x / 8.
-  int vb = blockIdx.x;
-  int* next_word = reinterpret_cast<int*>(smem + 2 * W4_SLOT);  // two words, alternating per tile (a fast wave's next draw must not overwrite the word a slow wave still has to read)
- for (;; next_word = reinterpret_cast<int*>(reinterpret_cast<uintptr_t>(next_word) ^ 4)) {
-  if (counters != nullptr && wave == 0 && lane == 0) {
-    const int x = blockIdx.x & 7, nx = (tab.total_blocks - x + 7) >> 3;  // virtual blocks of this XCD
-    const int d = atomicAdd(counters + x, 1);
-    if (d == nx - 1) counters[x] = 0;  // the last draw of this launch on this XCD (every block ends on one draw past the range)
-    *next_word = 8 * ((int)(gridDim.x >> 3) + d) + x;
-  }
   int lid;
   {
-    const int bid = vb, nwg = tab.total_blocks;
+    const int bid = blockIdx.x, nwg = tab.total_blocks;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
+  const Problem& P = tab.p[0];
   int tile = lid / P.nsplit, split = lid - tile * P.nsplit;
   if (P.nsplit > 1 && (P.nsplit & 7) == 0) {  // split-K with K-range <-> XCD affinity (see gemm.hip)
-    const int T = P.tiles_m * P.tiles_n, S = P.nsplit >> 3, j = vb >> 3;
-    split = (vb & 7) * S + j / T;
+    const int T = P.tiles_m * P.tiles_n, S = P.nsplit >> 3, j = blockIdx.x >> 3;
+    split = (blockIdx.x & 7) * S + j / T;
     tile = j % T;
   }
   int tm, tn;
@@ -300,34 +285,11 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(LaunchTable tab, int* __re
   }
   __syncthreads();
   if (live) w4_epilogue_lean<(EPI & 1) != 0, (EPI & 4) != 0>(acc, P, smem, m0 + wr * WM, n0 + wc * WN, wave, lane);
-  if (counters == nullptr) break;
-  __syncthreads();  // every wave is done with its restage image: the next tile's DMA may land in the slots
-  vb = *next_word;
-  if (vb >= tab.total_blocks) break;
- }
-}
-
-// counters of the persistent form: a ring of 64 sets of 8 (one per XCD), zero at rest (the kernel resets what it used); a launch
-// takes the next set, so launches that overlap on different streams do not share one
-static int* w4_counter_set(int dev, hipStream_t s) {
-  static int* base[64] = {};
-  static std::atomic<unsigned> next[64];
-  if (!base[dev & 63]) {
-    // first use on this device: allocate and clear (synchronous calls — not while the stream is being captured into a graph; such a
-    // launch runs with one block per tile and the next eager launch allocates)
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
-    int* p = nullptr;
-    if (hipMalloc(&p, 64 * 8 * sizeof(int)) != hipSuccess) return nullptr;
-    if (hipMemset(p, 0, 64 * 8 * sizeof(int)) != hipSuccess) { (void)hipFree(p); return nullptr; }
-    base[dev & 63] = p;
-  }
-  return base[dev & 63] + 8 * (next[dev & 63].fetch_add(1) & 63);
 }
 
 template <int EPI>
 void launch_w4(const LaunchTable& tab, hipStream_t s) {
-  constexpr int lds = 2 * W4_SLOT + 16;  // two 64-KiB tile slots (the bare epilogue restages through the same memory) + the next-tile word
+  constexpr int lds = 2 * W4_SLOT;  // two 64-KiB tile slots (the bare epilogue restages 4 x 16.5 KiB through the same memory)
   static bool attr_set_dev[64] = {};  // per instantiation and device
   int dev_ = 0;
   (void)hipGetDevice(&dev_);
@@ -336,11 +298,7 @@ void launch_w4(const LaunchTable& tab, hipStream_t s) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  static const int persist_env = [] { const char* e = getenv("MIC_GEMM_W4_PERSIST"); return e ? atoi(e) : 1; }();  // =0: one block per tile (A/B)
-  const int cus = mic_cu_budget_now();
-  int* counters = (persist_env && tab.total_blocks > cus && (cus & 7) == 0) ? w4_counter_set(dev_, s) : nullptr;
-  const int grid = counters ? cus : tab.total_blocks;
-  hipLaunchKernelGGL((gemm_w4_kernel<EPI>), dim3(grid), dim3(256), lds, s, tab, counters);
+  hipLaunchKernelGGL((gemm_w4_kernel<EPI>), dim3(tab.total_blocks), dim3(256), lds, s, tab);
 }
 
 }  // namespace

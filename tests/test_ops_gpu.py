@@ -880,20 +880,17 @@ def test_gemm_four_phase_kernel_behind_its_switch(dev):
     from mic_amd import ops
 
     assert ops.gemm_plan([(1024, 131072, 1024)])["phased"] == (2 if os.environ.get("MIC_GEMM_W4", "1") != "0" else 1)
-    # ... and the four-wave kernel with one block per tile instead of persistent blocks drawing tiles from per-XCD counters
-    for extra in (dict(MIC_GEMM_W4="0"), dict(MIC_GEMM_W4_PERSIST="0")):
-        env = dict(os.environ, **extra)
-        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "-k",
-                            "(phased_many_tiles and 1024) or head_rowstat or layernorm_fold"], env=env, capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, str(extra) + r.stdout[-3000:] + r.stderr[-2000:]
-        assert " passed" in r.stdout and "failed" not in r.stdout, str(extra) + r.stdout[-2000:]
+    env = dict(os.environ, MIC_GEMM_W4="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "-k",
+                        "(phased_many_tiles and 1024) or head_rowstat or layernorm_fold"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
 
 
 @pytest.mark.parametrize("M,N,K", [(1024, 131072, 256), (2300, 66048, 384)])
-def test_gemm_four_wave_persistent_blocks_repeat_bit_for_bit(dev, M, N, K):
-    """the four-wave kernel's persistent blocks draw their tiles from per-XCD counters: which block computes which tile changes from
-    run to run, the results must not — also when two launches overlap on two streams (each takes its own counter set) and when the
-    last row tile is partial (idle waves); the counters must be back at zero after every launch (the next one starts from tile 0)"""
+def test_gemm_four_wave_kernel_repeats_bit_for_bit(dev, M, N, K):
+    """the four-wave kernel on many-tile launches with the LM head's epilogue: the same bits from run to run, also when two launches
+    overlap on two streams and when the last row tile is partial (waves whose rows lie past M idle through the K loop)"""
     from mic_amd import ops
 
     assert ops.gemm_plan([(M, N, K)])["tile"] == 256 and ops.gemm_plan([(M, N, K)])["blocks"] > 256
