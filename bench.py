@@ -57,6 +57,22 @@ def host_threads() -> int:
     return max(1, min(n, 64))
 
 
+def rccl_channels_from_log(path: str):
+    """the channel count RCCL itself reports in its INIT log (NCCL_DEBUG=INFO): "... N coll channels ..." or, failing that, the
+    largest "Channel xx/NN" denominator; None when the log has neither"""
+    import re
+
+    try:
+        txt = open(path, errors="replace").read()
+    except OSError:
+        return None
+    m = re.findall(r"(\d+) coll channels", txt)
+    if m:
+        return max(int(x) for x in m)
+    m = re.findall(r"Channel \d+/(\d+)", txt)
+    return max(int(x) for x in m) if m else None
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks as a child `torch.distributed.run` (never exec from
     a process that may touch the GPU; nothing here has imported torch yet) and pass its exit code on."""
@@ -359,15 +375,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"])
-    ap.add_argument("--grad-comm", default="auto", choices=["auto", "fp32", "bf16"],
-                    help="gradient exchange precision for --gpus > 1: auto = fp32 (the reference's pmean) where the projected all-reduce hides "
-                         "under backward, bf16 where it would not (N = 2, 4: mic_amd.train.choose_comm_dtype); fp32 / bf16 force either")
+    ap.add_argument("--grad-comm", default="fp32", choices=["auto", "fp32", "bf16"],
+                    help="gradient exchange precision for --gpus > 1: fp32 (default) = the reference's pmean (main.py:698); bf16 = half the xGMI "
+                         "bytes, opt-in; auto = bf16 where the PROJECTED fp32 all-reduce would not hide under backward (N = 2, 4: "
+                         "mic_amd.train.choose_comm_dtype), fp32 elsewhere")
     ap.add_argument("--emulate-comm", default=None, help="(default 2,4,8; off for --small) ""world sizes whose gradient exchange is EMULATED on this one GPU after the timed region "
                     "(a kernel holding --comm-cus CUs for the projected all-reduce time of every bucket): reported as `comm_emulated`, a "
                     "scheduling probe, not a scaling result; '' or 0 = off; only with --gpus 1")
     ap.add_argument("--emulate-main", type=int, default=0, help="profiling aid: the TIMED trainer itself runs with the emulated exchange among N ranks "
                     "(the line is labelled; not a benchmark)")
-    ap.add_argument("--comm-cus", type=int, default=None, help="CUs the collectives are assumed to hold (default mic_amd.train.COMM_CUS_DEFAULT)")
+    ap.add_argument("--comm-cus", type=int, default=None, help="RCCL channel cap = CUs the collectives may hold (NCCL_MAX_NCHANNELS, exported before "
+                    "init_process_group; default mic_amd.train.COMM_CUS_DEFAULT); the GEMM tile planner is sized for the rest")
     ap.add_argument("--fp8-scaling", default="delayed", choices=["delayed", "current"],
                     help="--dtype fp8: scale from the previous step's amax (one pass per tensor) or from the current amax (two)")
     ap.add_argument("--dense-captions", action="store_true", help="every caption has T-2 tokens (no padded label positions): dense upper bound")
@@ -401,12 +419,21 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rccl_cap, rccl_log, rccl_reported = 0, None, None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         try:
             if share:
                 dist.init_process_group("gloo", rank=rank, world_size=world)
             else:
+                # enforce what the tile planner assumes: RCCL held to --comm-cus channels (one persistent block = one CU each), and
+                # have rank 0 read back what RCCL reports (its INIT log) instead of trusting the cap
+                from importlib import import_module
+
+                rccl_cap = import_module("mic_amd.train").configure_rccl(args.comm_cus if args.comm_cus is not None else 32)
+                if rank == 0 and "NCCL_DEBUG" not in os.environ:
+                    rccl_log = f"/tmp/mic_rccl_init_{os.getpid()}.log"
+                    os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT", NCCL_DEBUG_FILE=rccl_log)
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
                 # the first collective creates the RCCL communicator (ring / tree set-up over xGMI): fail here, with the cause, not
                 # somewhere inside the first train step
@@ -414,6 +441,9 @@ def main():
                 dist.all_reduce(probe)
                 torch.cuda.synchronize()
                 assert int(probe.item()) == world, f"all-reduce probe returned {probe.item()} for world {world}"
+                if rank == 0:
+                    rccl_reported = rccl_channels_from_log(rccl_log) if rccl_log else None
+                    note(f"RCCL up over {world} ranks: channel cap NCCL_MAX_NCHANNELS={rccl_cap}, RCCL reports {rccl_reported} channels")
         except Exception as e:  # name the cause and leave with a non-zero code (the launcher then ends the other ranks)
             print(f"bench.py rank {rank}/{world} (device {local_rank}): torch.distributed / RCCL initialisation failed: {type(e).__name__}: {e}\n"
                   f"  MASTER_ADDR={os.environ.get('MASTER_ADDR')} MASTER_PORT={os.environ.get('MASTER_PORT')} "
@@ -717,7 +747,7 @@ def main():
                                    + (" [ALL RANKS SHARE cuda:0 OVER gloo: functional check, not a benchmark]" if share and world > 1 else ""),
                        "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}",
                        "grad_allreduce": (f"{'bf16' if tr.grad_comm_dtype is not None else 'fp32'} flat buckets (--grad-comm {args.grad_comm}), RCCL, side stream, "
-                                          f"{len(tr.buckets)} buckets <= 128 MB" + (f", GEMM tile planner sized for {256 - tr.comm_cus} CUs" if world > 1 and tr.comm_cus else "")),
+                                          f"{len(tr.buckets)} buckets <= 128 MB" + (f", RCCL capped at {rccl_cap} channels (reports {rccl_reported}), GEMM tile planner sized for {256 - tr.comm_cus} CUs" if world > 1 and tr.comm_cus else "")),
                        "optimizer": ("AdamW per gradient bucket behind backward" + (f", on a stream masked to {os.environ.get('MIC_OPT_CUS', '96')} CUs" if tr.reducer.step_stream is not None else "")
                                      + ("; tied embedding updated in two row passes (rows without / with sparse gradient)" if tr._split_shared else "")) if tr.overlap_optimizer else "AdamW, one launch after backward",
                        "decoder_rows": ("valid caption positions only (packed rows: padded positions neither carry loss nor are attended to — exact; "

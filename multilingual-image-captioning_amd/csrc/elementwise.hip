@@ -309,6 +309,127 @@ extern "C" int mic_ce_bwd(int dtype, int rows, int V, int Vpad, void* logits, in
   });
 }
 
+// ------------------------------------------------------------------ 64 x 512 tile transpose (bf16), optionally behind the CE backward
+// The LM head's two backward GEMMs reduce over the vocabulary (dX = dlogits E) and over the rows (dE = dlogits^T h): with the
+// tensors as forward leaves them, one operand of each is k-major.  The four-wave LDS-DMA kernel (gemm_w4.hip) is an NT kernel —
+// LDS-DMA cannot transpose and k-major fragments cost it two transposing reads each — so the head's backward gets k-contiguous
+// copies instead: dlogits^T [Vpad][Kp] written by THIS kernel beside the in-place dlogits (one more 1.2 GB write instead of a
+// second pass), h^T and E^T [d][Vpad] by the plain transpose below.
+// One block = 64 source rows (k) x 512 source columns (x): phase 1 streams the tile row by row (one wave = one row of 512
+// columns per trip, 16-B per lane, all 16 rows of a wave requested before the first is used), applies OP, writes the result back
+// in place (CE) and into a swizzled LDS image [64 k][64 chunks of 16 B] (chunk c of row k at (c & ~7) | ((c ^ (k >> 3)) & 7):
+// the row-wise ds_write_b128 and the column-wise 2-byte reads below are both conflict-free); phase 2 reads 8 consecutive k of one
+// x per lane and stores 16 B of dst[x][k0 ..]: one 128-B line per x and block.  Rows k >= rows (up to the grid's 64-row
+// multiple) are written as zeros — the padding of the GEMM's reduction dimension.
+struct TransposeArgs {
+  const uint16_t* src; uint16_t* src_rw; int ld_src;   // source [rows][ld_src]; src_rw != NULL: OP's result is written back in place
+  uint16_t* dst; int ld_dst;                            // dst [cols][ld_dst]
+  int rows, cols;
+  // CE backward (OP = 1): see ce_bwd_kernel
+  int V; const int32_t* labels; const int32_t* mask; float ls; const float* row_lse; const float* denom; float loss_scale;
+  float* colsum;  // += column sums of the stored dlogits (fp32 atomics; the final_logits_bias gradient), or NULL
+};
+template <int OP>
+__global__ __launch_bounds__(256) void tile_transpose_kernel(TransposeArgs a) {
+  __shared__ __attribute__((aligned(16))) char img[64 * 1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = blockIdx.x * 512, r0 = blockIdx.y * 64;
+  const int col = c0 + lane * 8;
+  const bool col_ok = col < a.cols;  // (cols % 8 == 0: a chunk is inside or outside as a whole)
+  uint4 q[16];
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    const int row = r0 + wave * 16 + rr;
+    q[rr] = make_uint4(0u, 0u, 0u, 0u);
+    if (row < a.rows && col_ok) q[rr] = *reinterpret_cast<const uint4*>(a.src + (size_t)row * a.ld_src + col);
+  }
+  float inv_denom = 0.f;
+  if constexpr (OP == 1) inv_denom = a.loss_scale / a.denom[0];
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    const int k = wave * 16 + rr, row = r0 + k;
+    uint4 u = q[rr];
+    if constexpr (OP == 1) {
+      if (row < a.rows && col_ok) {
+        const float w = a.mask[row] ? inv_denom : 0.f;
+        const float lse = a.row_lse[row];
+        const int label = a.labels[row];
+        const float conf = 1.0f - a.ls, low = a.ls > 0.f ? a.ls / (float)(a.V - 1) : 0.f;
+        const uint32_t wd[4] = {u.x, u.y, u.z, u.w};
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float x = __uint_as_float((i & 1) ? (wd[i >> 1] & 0xffff0000u) : (wd[i >> 1] << 16));
+          const int c = col + i;
+          o[i] = c < a.V ? w * (__expf(x - lse) - (c == label ? conf : low)) : 0.f;
+        }
+        u.x = f2bf_pk(o[0], o[1]); u.y = f2bf_pk(o[2], o[3]); u.z = f2bf_pk(o[4], o[5]); u.w = f2bf_pk(o[6], o[7]);
+        *reinterpret_cast<uint4*>(a.src_rw + (size_t)row * a.ld_src + col) = u;
+      }
+    }
+    const int pos = (lane & ~7) | ((lane ^ (k >> 3)) & 7);
+    *reinterpret_cast<uint4*>(img + k * 1024 + pos * 16) = u;
+  }
+  __syncthreads();
+  const int kc = lane & 7, xx = lane >> 3;
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int xl = wave * 128 + it * 8 + xx;  // column of the tile
+    const int c = xl >> 3;
+    const int pos = (c & ~7) | ((c ^ kc) & 7);
+    const char* base = img + (kc * 8) * 1024 + pos * 16 + (xl & 7) * 2;
+    uint16_t e[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = *reinterpret_cast<const uint16_t*>(base + i * 1024);
+    const int x = c0 + xl;
+    if (x < a.cols) {
+      uint4 u;
+      u.x = (uint32_t)e[0] | ((uint32_t)e[1] << 16); u.y = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
+      u.z = (uint32_t)e[4] | ((uint32_t)e[5] << 16); u.w = (uint32_t)e[6] | ((uint32_t)e[7] << 16);
+      *reinterpret_cast<uint4*>(a.dst + (size_t)x * a.ld_dst + r0 + kc * 8) = u;
+    }
+    if constexpr (OP == 1) {
+      if (a.colsum != nullptr) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sacc += bf2f(e[i]);
+        sacc = group8_sum(sacc);  // the 8 lanes kc = 0..7 of this x
+        if (kc == 0 && x < a.cols && sacc != 0.f) atomicAdd(a.colsum + x, sacc);
+      }
+    }
+  }
+}
+// dst[c][r] = src[r][c] for r < rows, 0 for rows <= r < rows_pad (rows_pad = rows rounded up to 64).  bf16 only.
+extern "C" int mic_transpose_bf16(int rows, int cols, const void* src, int ld_src, void* dst, int ld_dst, void* stream) {
+  const int rows_pad = (rows + 63) / 64 * 64;
+  MIC_CHECK(rows > 0 && cols > 0 && cols % 8 == 0 && src && dst && ld_src >= cols && ld_src % 8 == 0 && ld_dst >= rows_pad && ld_dst % 8 == 0,
+            "mic_transpose_bf16: bad args (cols %% 8 == 0, ld_src %% 8 == 0, ld_dst >= rows rounded up to 64 and %% 8 == 0)");
+  MIC_CHECK(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "mic_transpose_bf16: 16-B aligned operands");
+  TransposeArgs a{};
+  a.src = (const uint16_t*)src; a.ld_src = ld_src; a.dst = (uint16_t*)dst; a.ld_dst = ld_dst; a.rows = rows; a.cols = cols;
+  hipLaunchKernelGGL(tile_transpose_kernel<0>, dim3((cols + 511) / 512, rows_pad / 64), dim3(256), 0, (hipStream_t)stream, a);
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}
+// mic_ce_bwd (bf16) that ALSO writes dlogits^T [Vpad][ld_t] (columns rows .. rows rounded up to 64 zero) and, when `colsum` is
+// given, adds the column sums of the stored dlogits to it (the final_logits_bias gradient, main.py:178's parameter)
+extern "C" int mic_ce_bwd_t(int rows, int V, int Vpad, void* logits, int ld, const int32_t* labels, const int32_t* mask,
+                            float label_smoothing, const float* row_lse, const float* denom, float loss_scale, void* dlogits_t,
+                            int ld_t, float* colsum, void* stream) {
+  const int rows_pad = (rows + 63) / 64 * 64;
+  MIC_CHECK(rows > 0 && V > 1 && Vpad >= V && Vpad % 8 == 0 && ld >= Vpad && ld % 8 == 0 && logits && labels && mask && row_lse && denom && dlogits_t,
+            "mic_ce_bwd_t: bad args");
+  MIC_CHECK(ld_t >= rows_pad && ld_t % 8 == 0 && ((uintptr_t)logits & 15) == 0 && ((uintptr_t)dlogits_t & 15) == 0,
+            "mic_ce_bwd_t: ld_t >= rows rounded up to 64, ld_t %% 8 == 0, 16-B aligned operands");
+  TransposeArgs a{};
+  a.src = (const uint16_t*)logits; a.src_rw = (uint16_t*)logits; a.ld_src = ld; a.dst = (uint16_t*)dlogits_t; a.ld_dst = ld_t;
+  a.rows = rows; a.cols = Vpad; a.V = V; a.labels = labels; a.mask = mask; a.ls = label_smoothing; a.row_lse = row_lse; a.denom = denom;
+  a.loss_scale = loss_scale; a.colsum = colsum;
+  hipLaunchKernelGGL(tile_transpose_kernel<1>, dim3((Vpad + 511) / 512, rows_pad / 64), dim3(256), 0, (hipStream_t)stream, a);
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}
+
 // ------------------------------------------------------------------ column sums (bias gradients)
 // Table-driven so the 4..7 bias gradients of a layer go out as ONE launch (each alone is a ~9 us launch for ~2 us of
 // work).  Each thread owns 8 consecutive columns (one 16-B load per row); a block = 32 column-chunks x 8 row lanes

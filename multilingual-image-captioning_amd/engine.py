@@ -338,7 +338,10 @@ class Engine:
         side = None
         if self._dw_on():
             if self._dw_stream is None:
-                self._dw_stream = ops.role_stream(self.dev, "dw")
+                import os
+
+                n = int(os.environ.get("MIC_DW_CUS", "0"))  # A/B: the weight-gradient stream on the LAST n CUs of the mask only
+                self._dw_stream = ops.cu_masked_stream(256 - n, n, self.dev) if n > 0 else ops.role_stream(self.dev, "dw")
             side = self._dw_stream
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())

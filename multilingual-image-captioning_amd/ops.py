@@ -334,7 +334,11 @@ def role_stream(device, role: str) -> "torch.cuda.Stream":
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), role)
     st = _role_streams.get(key)
     if st is None:
-        st = _role_streams[key] = torch.cuda.Stream(device=dev)
+        # MIC_PRIO_<ROLE> (A/B only): HIP stream priority of that role's stream (-1 = high, 0 = default)
+        import os
+
+        prio = int(os.environ.get("MIC_PRIO_" + role.upper(), "0"))
+        st = _role_streams[key] = torch.cuda.Stream(device=dev, priority=prio) if prio else torch.cuda.Stream(device=dev)
     return st
 
 

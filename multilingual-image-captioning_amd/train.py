@@ -136,7 +136,31 @@ def describe_buckets(store, buckets: List[Tuple[int, int]], comm_bytes: int = 4)
 # ---- what the gradient exchange costs, from byte counts (no N > 1 hardware has been available to measure it)
 XGMI_LINK_GBPS = 64.0      # per direction and peer link, what a ring gets out of one xGMI link (7 links x ~153 GB/s bidirectional per GPU)
 BACKWARD_WINDOW_MS = 13.0  # backward of the batch-64 step: the time the exchange can hide under (profiles/README.md)
-COMM_CUS_DEFAULT = 32      # CUs the collectives are assumed to occupy while backward runs (RCCL: one persistent block per channel)
+COMM_CUS_DEFAULT = 32      # RCCL channels (= persistent blocks, one CU each) `configure_rccl` caps the collectives at
+
+
+def configure_rccl(max_channels: int = COMM_CUS_DEFAULT) -> int:
+    """Call BEFORE `torch.distributed.init_process_group("nccl")`: caps the CUs RCCL's collectives can occupy by bounding its channel
+    count (one persistent block per channel, one CU each): `NCCL_MAX_NCHANNELS` (and `NCCL_MIN_NCHANNELS` no larger than that).  A
+    value the user already exported wins.  Returns the cap now in force; `Trainer` reads it back (`rccl_channel_cap`) as its
+    `comm_cus` default, so the CU budget the GEMM tile planner works with is the number RCCL was actually held to — not an assumption."""
+    import os
+
+    cap = int(os.environ.setdefault("NCCL_MAX_NCHANNELS", str(int(max_channels))))
+    lo = os.environ.get("NCCL_MIN_NCHANNELS")
+    if lo is not None and int(lo) > cap:
+        os.environ["NCCL_MIN_NCHANNELS"] = str(cap)
+    return cap
+
+
+def rccl_channel_cap() -> int:
+    """the channel cap exported to RCCL (`configure_rccl` or the user's environment); 0 = none: RCCL picks its own count"""
+    import os
+
+    try:
+        return max(0, int(os.environ.get("NCCL_MAX_NCHANNELS", "0")))
+    except ValueError:
+        return 0
 
 
 def allreduce_ms(nbytes: float, world: int, link_gbps: float = XGMI_LINK_GBPS) -> float:
@@ -365,16 +389,20 @@ class Trainer:
 
     def __init__(self, model, learning_rate_fn: Callable[[int], float], b1=0.9, b2=0.999, eps=1e-8, weight_decay=0.0,
                  label_smoothing_factor=0.0, seed: int = 42, bucket_mb: float = 64.0, group=None, compact_head: bool = True,
-                 overlap_optimizer: bool = True, grad_comm_dtype="auto", gemm_dtype: Optional[str] = None,
+                 overlap_optimizer: bool = True, grad_comm_dtype=None, gemm_dtype: Optional[str] = None,
                  fp8_scaling: str = "delayed", pack_rows: bool = True, comm_cus: Optional[int] = None, emulate_comm: int = 0):
         """pack_rows (bfloat16 mode, with compact_head): the decoder runs on the valid caption positions only (`packed_rows`);
         exact — padded positions neither carry loss nor are attended to — and ~1/3 fewer decoder rows on ragged captions.  Needs
         prefix-shaped masks available on the host: a numpy / CPU `attention_mask`, or `batch["packed_rows"]` from the collate
         function; otherwise the step runs padded.  MIC_PACK_ROWS=0 switches it off.
-        grad_comm_dtype: "auto" (default; `choose_comm_dtype`: fp32 where the projected exchange hides under backward, bf16 where
-        it would not), None / torch.float32 (always the reference's fp32 pmean) or torch.bfloat16.
-        comm_cus (data parallel): CUs the collectives are assumed to hold while backward runs — the GEMM tile planner sizes its
-        one-round launches for the rest (`mic_set_cu_budget`); default COMM_CUS_DEFAULT when world > 1, 0 otherwise.
+        grad_comm_dtype: None / torch.float32 (default: the reference's fp32 `lax.pmean`, main.py:698), torch.bfloat16 (opt-in: half
+        the xGMI bytes, one more rounding per rank and element) or "auto" (opt-in; `choose_comm_dtype`: fp32 where the PROJECTED
+        exchange hides under backward, bf16 where it would not — a projection from byte counts, no N > 1 run backs it).  A
+        non-fp32 choice is printed by every rank.
+        comm_cus (data parallel): CUs the collectives hold while backward runs — the GEMM tile planner sizes its one-round
+        launches for the rest (`mic_set_cu_budget`).  Default: the channel cap exported to RCCL (`configure_rccl` before
+        `init_process_group`, or NCCL_MAX_NCHANNELS in the environment) when world > 1 — the budget then equals what RCCL was held to;
+        0 (planner untouched) when no cap is in force.  A user-set MIC_FREE_CUS wins over both.
         emulate_comm = N (one GPU only; bench.py --emulate-comm): every bucket's exchange is replaced by a kernel holding
         `comm_cus` CUs for the projected duration of its all-reduce among N ranks — a scheduling probe, not a scaling result."""
         import torch.distributed as dist
@@ -403,10 +431,21 @@ class Trainer:
                 raise ValueError(f"grad_comm_dtype must be 'auto', None or a torch dtype, got {grad_comm_dtype!r}")
             grad_comm_dtype = choose_comm_dtype(eff_world, st.numel)
         self.grad_comm_dtype = grad_comm_dtype if grad_comm_dtype not in (None, torch.float32) else None
-        self.comm_cus = int(comm_cus) if comm_cus is not None else (COMM_CUS_DEFAULT if eff_world > 1 else 0)
+        if self.grad_comm_dtype is not None and eff_world > 1:
+            import sys
+
+            print(f"[mic_amd.Trainer] rank {self.rank}: gradient exchange in {self.grad_comm_dtype} — NOT the reference's fp32 pmean "
+                  "(main.py:698); pass grad_comm_dtype=None for fp32", file=sys.stderr, flush=True)
+        if comm_cus is not None:
+            self.comm_cus = int(comm_cus)
+        elif emu_world > 1:
+            self.comm_cus = COMM_CUS_DEFAULT   # the stand-in collectives are held to exactly this many CUs by their stream's mask
+        else:
+            self.comm_cus = min(rccl_channel_cap(), 128) if self.world > 1 else 0
         # one-round GEMM launches are sized for the CUs the collectives leave (process-wide planner state: set for the duration of a
-        # train step, see train_step)
-        self._cu_budget = 256 - self.comm_cus if (model.device.type == "cuda" and eff_world > 1 and self.comm_cus > 0) else 0
+        # train step, see train_step); a MIC_FREE_CUS exported by the user is the user's budget and stays in force
+        self._cu_budget = 256 - self.comm_cus if (model.device.type == "cuda" and eff_world > 1 and self.comm_cus > 0
+                                                  and not _os.environ.get("MIC_FREE_CUS")) else 0
         self.buckets = bucket_plan(st, bucket_mb)
         cb = 2 if self.grad_comm_dtype in (torch.bfloat16, torch.float16) else 4
         if eff_world > 1 and self.rank == 0:
@@ -416,8 +455,10 @@ class Trainer:
             total = sum(d["MB"] for d in desc)
             print(f"[mic_amd.Trainer] data parallel over {eff_world} ranks{' (EMULATED on one GPU)' if emu_world > 1 else ''}: {len(desc)} gradient "
                   f"buckets in backward-completion order, {total:.0f} MB per exchange in {'bf16' if cb == 2 else 'fp32'} (all-reduce, projected "
-                  f"{allreduce_ms(total * 1e6, eff_world):.1f} ms over xGMI against ~{BACKWARD_WINDOW_MS:.0f} ms of backward); GEMM tile planner sized for "
-                  f"{256 - self.comm_cus} CUs; first: {desc[0]['first']}..{desc[0]['last']} {desc[0]['MB']:.0f} MB, last: {desc[-1]['first']}..{desc[-1]['last']} "
+                  f"{allreduce_ms(total * 1e6, eff_world):.1f} ms over xGMI against ~{BACKWARD_WINDOW_MS:.0f} ms of backward); "
+                  + (f"RCCL capped at {self.comm_cus} channels, GEMM tile planner sized for {256 - self.comm_cus} CUs" if self._cu_budget else
+                     "no RCCL channel cap in force (mic_amd.train.configure_rccl before init_process_group), GEMM tile planner sized for all CUs")
+                  + f"; first: {desc[0]['first']}..{desc[0]['last']} {desc[0]['MB']:.0f} MB, last: {desc[-1]['first']}..{desc[-1]['last']} "
                   f"{desc[-1]['MB']:.0f} MB; sizes MB {[d['MB'] for d in desc]}", file=sys.stderr, flush=True)
         # MIC_OPT_OVERLAP=0: AdamW as one launch after backward (profiling aid: per-bucket AdamW on its own stream shares HBM with
         # the backward kernels it overlaps, so their individual durations read longer than the kernels are)

@@ -271,6 +271,41 @@ def test_comm_dtype_follows_the_byte_counts():
     assert choose_comm_dtype(2, 1_000_000) is None  # a small model's exchange hides at any world size
 
 
+def test_exchange_defaults_are_the_references_and_the_cu_budget_is_enforced_not_assumed(monkeypatch):
+    """Trainer defaults: fp32 gradient exchange (`lax.pmean` of fp32 gradients, main.py:698; bf16 / "auto" are opt-in), and the CUs
+    the planner leaves to the collectives = the channel cap exported to RCCL (`configure_rccl` -> NCCL_MAX_NCHANNELS), 0 without one."""
+    import inspect
+
+    from mic_amd import Trainer
+    from mic_amd.train import COMM_CUS_DEFAULT, configure_rccl, rccl_channel_cap
+
+    sig = inspect.signature(Trainer.__init__).parameters
+    assert sig["grad_comm_dtype"].default is None and sig["comm_cus"].default is None
+    for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS"):
+        monkeypatch.delenv(k, raising=False)
+    assert rccl_channel_cap() == 0                      # nothing exported: no cap, the planner keeps all CUs
+    assert configure_rccl() == COMM_CUS_DEFAULT == 32 and os.environ["NCCL_MAX_NCHANNELS"] == "32" and rccl_channel_cap() == 32
+    assert configure_rccl(16) == 32                     # an exported value (here: ours, in general the user's) wins
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "24")
+    monkeypatch.setenv("NCCL_MIN_NCHANNELS", "40")
+    assert configure_rccl() == 24 and os.environ["NCCL_MIN_NCHANNELS"] == "24"  # min may not exceed the cap
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "junk")
+    assert rccl_channel_cap() == 0
+
+
+def test_bench_reads_rccl_channel_count_from_its_init_log(tmp_path):
+    import bench
+
+    p = tmp_path / "rccl.log"
+    p.write_text("host:1:1 [0] NCCL INFO Channel 00/32 :    0   1\nhost:1:1 [0] NCCL INFO Channel 31/32 :    0   1\n"
+                 "host:1:1 [0] NCCL INFO 32 coll channels, 32 collnet channels, 0 nvls channels, 32 p2p channels, 2 p2p channels per peer\n")
+    assert bench.rccl_channels_from_log(str(p)) == 32
+    p.write_text("host:1:1 [0] NCCL INFO Channel 00/16 :    0   1\n")
+    assert bench.rccl_channels_from_log(str(p)) == 16
+    p.write_text("nothing here\n")
+    assert bench.rccl_channels_from_log(str(p)) is None and bench.rccl_channels_from_log(str(tmp_path / "missing")) is None
+
+
 def test_gemm_planner_follows_the_cu_budget():
     """The tile planner under a reduced CU budget (collectives hold CUs beside backward): a launch that was ONE round of blocks on
     256 CUs stays one round on 224 / 192 — it re-plans (fewer K-groups = more blocks per CU, or smaller tiles) instead of spilling
