@@ -132,7 +132,8 @@ int mic_get_cu_budget(void);
 /* What mic_gemm_grouped would launch for these problems under the current CU budget (host arithmetic only, nothing is launched;
  * pointers in `args` are not dereferenced): tile edge (256 / 128 / 64; `tile_m` x `tile` when the rows differ), K-groups per block, logical blocks, launched grid
  * (persistent launches: the budget), blocks of this configuration that fit one CU, and whether the LDS-DMA phased kernel is taken
- * (phased = 1; 2 = MIC_GEMM_W4=1 is set and the shape fits the opt-in four-wave kernel, which takes the launch if its epilogue is a bare one). */
+ * (phased = 1; 2 = the shape fits the four-wave kernel gemm_w4.hip — on by default, MIC_GEMM_W4=0 switches it off — which takes the launch
+ * if its epilogue is a bare one: bf16 C with bias / folded LayerNorm / softmax partials, or fp32 C, also as split-K slabs). */
 typedef struct { int tile, kgroups, blocks, grid, blocks_per_cu, phased, cu_budget, tile_m; } mic_gemm_plan_info;  /* tile_m: tile rows (= tile, or 192 with tile 128) */
 int mic_gemm_plan(const mic_gemm_args* args, int count, mic_gemm_plan_info* out);
 /* Operands of a LayerNorm-folded Linear (see mic_gemm_args.a_ln_stats): for w [N][K] (the compute-dtype weight), gamma / beta
@@ -271,6 +272,17 @@ int mic_ce_reduce(int rows, const float* row_loss, const int32_t* mask, float* l
 int mic_ce_bwd(int dtype, int rows, int V, int Vpad, void* logits, int ld, const int32_t* labels,
                const int32_t* mask, float label_smoothing, const float* row_lse, const float* denom,
                float loss_scale, void* stream);
+/* mic_ce_bwd (bf16 logits) that ALSO writes the transposed gradient dlogits_t [Vpad][ld_t] (bf16; columns rows .. rows_pad — a
+ * multiple of 64, 0 = rows rounded up to 64 — are zeros) and, with `colsum` != NULL, ADDS the column sums of the dlogits as stored to colsum[0 .. Vpad) (fp32 atomics —
+ * the gradient of final_logits_bias, modeling:178).  The LM head's backward GEMMs (main.py:692-698 through the tied head,
+ * modeling:170-174) then run as NT launches: dE = dlogits_t . h_t^T reduces over the rows, dX = dlogits . E_t^T over the vocabulary. */
+int mic_ce_bwd_t(int rows, int V, int Vpad, void* logits, int ld, const int32_t* labels, const int32_t* mask, float label_smoothing,
+                 const float* row_lse, const float* denom, float loss_scale, void* dlogits_t, int ld_t, int rows_pad, float* colsum,
+                 void* stream);
+/* dst[c][r] = src[r][c] (bf16), r < rows, c < cols; dst columns rows .. rows_pad (a multiple of 64; 0 = rows rounded up to 64) are
+ * written as zeros (the padding of a GEMM's reduction dimension).  cols, ld_src, ld_dst multiples of 8; ld_dst >= rows_pad; 16-B
+ * aligned operands. */
+int mic_transpose_bf16(int rows, int rows_pad, int cols, const void* src, int ld_src, void* dst, int ld_dst, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Small reductions / elementwise

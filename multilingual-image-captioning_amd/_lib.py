@@ -100,6 +100,8 @@ _SIGS = {
     "mic_row_topk_tiles": ([_i, _i, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p], C.c_int),
     "mic_ce_reduce": ([_i, _p, _p, _p, _p, _p], C.c_int),
     "mic_ce_bwd": ([_i, _i, _i, _i, _p, _i, _p, _p, _f, _p, _p, _f, _p], C.c_int),
+    "mic_ce_bwd_t": ([_i, _i, _i, _p, _i, _p, _p, _f, _p, _p, _f, _p, _i, _i, _p, _p], C.c_int),
+    "mic_transpose_bf16": ([_i, _i, _i, _p, _i, _p, _i, _p], C.c_int),
     "mic_colsum": ([_i, _i, _i, _p, _i, _p, _i, _p], C.c_int),
     "mic_colsum_grouped": ([_i, C.POINTER(ColsumItem), _i, _p], C.c_int),
     "mic_dropout_mask": ([_p, _i64, _f, _u32, _p], C.c_int),

@@ -399,11 +399,12 @@ __global__ __launch_bounds__(256) void tile_transpose_kernel(TransposeArgs a) {
     }
   }
 }
-// dst[c][r] = src[r][c] for r < rows, 0 for rows <= r < rows_pad (rows_pad = rows rounded up to 64).  bf16 only.
-extern "C" int mic_transpose_bf16(int rows, int cols, const void* src, int ld_src, void* dst, int ld_dst, void* stream) {
-  const int rows_pad = (rows + 63) / 64 * 64;
-  MIC_CHECK(rows > 0 && cols > 0 && cols % 8 == 0 && src && dst && ld_src >= cols && ld_src % 8 == 0 && ld_dst >= rows_pad && ld_dst % 8 == 0,
-            "mic_transpose_bf16: bad args (cols %% 8 == 0, ld_src %% 8 == 0, ld_dst >= rows rounded up to 64 and %% 8 == 0)");
+// dst[c][r] = src[r][c] for r < rows, 0 for rows <= r < rows_pad (a multiple of 64; 0 = rows rounded up to 64).  bf16 only.
+extern "C" int mic_transpose_bf16(int rows, int rows_pad, int cols, const void* src, int ld_src, void* dst, int ld_dst, void* stream) {
+  if (rows_pad <= 0) rows_pad = (rows + 63) / 64 * 64;
+  MIC_CHECK(rows > 0 && cols > 0 && cols % 8 == 0 && src && dst && ld_src >= cols && ld_src % 8 == 0 && rows_pad >= rows && rows_pad % 64 == 0 &&
+                ld_dst >= rows_pad && ld_dst % 8 == 0,
+            "mic_transpose_bf16: bad args (cols %% 8 == 0, ld_src %% 8 == 0, rows_pad %% 64 == 0, ld_dst >= rows_pad and %% 8 == 0)");
   MIC_CHECK(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "mic_transpose_bf16: 16-B aligned operands");
   TransposeArgs a{};
   a.src = (const uint16_t*)src; a.ld_src = ld_src; a.dst = (uint16_t*)dst; a.ld_dst = ld_dst; a.rows = rows; a.cols = cols;
@@ -411,12 +412,13 @@ extern "C" int mic_transpose_bf16(int rows, int cols, const void* src, int ld_sr
   MIC_LAUNCH_CHECK();
   return MIC_OK;
 }
-// mic_ce_bwd (bf16) that ALSO writes dlogits^T [Vpad][ld_t] (columns rows .. rows rounded up to 64 zero) and, when `colsum` is
+// mic_ce_bwd (bf16) that ALSO writes dlogits^T [Vpad][ld_t] (columns rows .. rows_pad zero) and, when `colsum` is
 // given, adds the column sums of the stored dlogits to it (the final_logits_bias gradient, main.py:178's parameter)
 extern "C" int mic_ce_bwd_t(int rows, int V, int Vpad, void* logits, int ld, const int32_t* labels, const int32_t* mask,
                             float label_smoothing, const float* row_lse, const float* denom, float loss_scale, void* dlogits_t,
-                            int ld_t, float* colsum, void* stream) {
-  const int rows_pad = (rows + 63) / 64 * 64;
+                            int ld_t, int rows_pad, float* colsum, void* stream) {
+  if (rows_pad <= 0) rows_pad = (rows + 63) / 64 * 64;
+  MIC_CHECK(rows_pad >= rows && rows_pad % 64 == 0, "mic_ce_bwd_t: rows_pad >= rows, a multiple of 64");
   MIC_CHECK(rows > 0 && V > 1 && Vpad >= V && Vpad % 8 == 0 && ld >= Vpad && ld % 8 == 0 && logits && labels && mask && row_lse && denom && dlogits_t,
             "mic_ce_bwd_t: bad args");
   MIC_CHECK(ld_t >= rows_pad && ld_t % 8 == 0 && ((uintptr_t)logits & 15) == 0 && ((uintptr_t)dlogits_t & 15) == 0,

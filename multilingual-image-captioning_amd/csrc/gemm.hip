@@ -229,11 +229,12 @@ static GemmPlan plan_bf16(const mic_gemm_args* args, int count) {
   static const int phased_env = [] { const char* e = getenv("MIC_GEMM_PHASED"); return e ? atoi(e) : 2; }();
   const bool f8 = args[0].dtype == MIC_FP8;
   pl.phased = bm == 256 && !f8 && phased_env != 0 && !args[0].a_kmajor && !args[0].b_kmajor && count == 1 && !any_rowsum_early(args, count);
-  // ... and of those the four-wave 128x128-wave-tile kernel (gemm_w4.hip) takes the launches whose shape allows it and whose epilogue —
-  // decided at launch, gemm_w4_takes — is a bare one (LM head, all-layer cross k/v projection); plan.phased reads 2 for such a shape.
-  // MIC_GEMM_W4=0 keeps them on the four-phase kernel (A/B)
+  // ... and of those the four-wave 128x128-wave-tile kernel (gemm_w4.hip) takes, BY DEFAULT, the launches whose shape allows it and
+  // whose epilogue — decided at launch, gemm_w4_takes — is a bare one: bf16 C with bias / folded LayerNorm / softmax partials (LM
+  // head, all-layer cross k/v projection) or fp32 C, also as split-K slabs (the LM head's backward GEMMs on k-contiguous copies);
+  // plan.phased reads 2 for such a shape.  MIC_GEMM_W4=0 keeps them on the four-phase / register-staged kernels (A/B)
   static const int w4_env = [] { const char* e = getenv("MIC_GEMM_W4"); return e ? atoi(e) : 1; }();
-  if (pl.phased && w4_env && args[0].split_k <= 1 && args[0].K >= 256 && args[0].K % 128 == 0) pl.phased = 2;
+  if (pl.phased && w4_env && args[0].K >= 256 && args[0].K % 128 == 0) pl.phased = 2;  // (split-K: fp32 slabs, gemm_w4_takes)
   if (bm == 256) {
     pl.per_cu = 1;  // 128 KiB of LDS: a block holds its CU alone; PLAIN launches with more tiles than CUs run as `cus` persistent blocks
   } else if (bm == 128) {
@@ -259,7 +260,16 @@ extern "C" int mic_gemm_plan(const mic_gemm_args* args, int count, mic_gemm_plan
   const GemmPlan pl = plan_bf16(args, count);
   out->tile = pl.bm; out->tile_m = pl.bm_m; out->kgroups = pl.kgroups; out->blocks = pl.blocks; out->blocks_per_cu = pl.per_cu; out->phased = pl.phased;
   out->cu_budget = mic_cu_budget_now();
-  const bool persist = pl.bm == 256 && !pl.phased && pl.blocks > out->cu_budget;  // (the PLAIN instantiations only: an upper bound on the grid otherwise)
+  // persistent grid: the PLAIN 256x256 instantiations of the register-staged kernel only (launch_cfg_p) — decided from the
+  // epilogue these args describe, and MIC_GEMM_PERSIST
+  static const int persist_env = [] { const char* e = getenv("MIC_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
+  bool plain = true;
+  for (int i = 0; i < count; ++i) {
+    const mic_gemm_args& a = args[i];
+    if (a.split_k > 1 || a.act || a.Zout || a.dact || a.accumulate || (a.ldc & 7) || ((uintptr_t)a.C & 15)) plain = false;
+    if (a.R && ((a.ldr & 7) || ((uintptr_t)a.R & 15) || a.c_dtype == MIC_F32)) plain = false;
+  }
+  const bool persist = persist_env && plain && pl.bm == 256 && !pl.phased && pl.kgroups == 1 && pl.blocks > out->cu_budget;
   out->grid = persist ? out->cu_budget : pl.blocks;
   return MIC_OK;
 }
@@ -303,8 +313,8 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
   tab.total_blocks = blocks;
   for (int i = 0; i < count; ++i)
     MIC_CHECK(!args[i].rowsum2 || table_is_plain(tab), "mic_gemm_grouped: rowsum2 needs every problem of the launch on the bare / residual epilogue");
-  if (bm == 256 && pl.phased == 2 && gemm_w4_takes(tab)) launch_gemm_w4(tab, s);  // opt-in: 4 waves x 128x128, bare epilogue
-  else if (bm == 256 && pl.phased) launch_gemm_phased(tab, args[0].a_kmajor, args[0].b_kmajor, table_is_plain(tab), s);  // LDS-DMA, phased
+  if (bm == 256 && pl.phased == 2 && gemm_w4_takes(tab)) launch_gemm_w4(tab, s);  // 4 waves x 128x128, bare epilogues (default on)
+  else if (bm == 256 && pl.phased && tab.p[0].nsplit == 1) launch_gemm_phased(tab, args[0].a_kmajor, args[0].b_kmajor, table_is_plain(tab), s);  // LDS-DMA, phased
   else if (bm == 256) launch_gemm_t256(tab, args[0].a_kmajor, args[0].b_kmajor, s, f8);     // 256x256x64, 8 waves
   else if (bm == 128 && bm_m == 192) launch_gemm_t192(tab, args[0].b_kmajor, s);                     // 192x128x64, 8 waves, two blocks per CU
   else if (bm == 128) launch_gemm_t128(tab, args[0].a_kmajor, args[0].b_kmajor, s, f8, pl.kgroups);  // 128x128x64, 8 waves per K-group

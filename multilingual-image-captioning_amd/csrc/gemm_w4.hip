@@ -159,6 +159,57 @@ __device__ __forceinline__ void w4_epilogue_lean(f32x16 (&acc)[4][4], const Prob
   }
 }
 
+// The fp32 epilogue (weight-gradient-style launches: the LM head's dE, and the split-K slabs of its dX): C32[split][m][n] = alpha acc
+// (+ bias), four passes of 32 rows through the wave's private fp32 LDS image as above, read back as (row, 4 columns) units = 16-B
+// stores, 512 B contiguous per row and instruction (two rows per instruction).
+__device__ __forceinline__ void w4_epilogue_f32(f32x16 (&acc)[4][4], const Problem& P, char* smem, int mw, int nw, int split, int wave, int lane) {
+  const EpiArgs& E = P.epi;
+  const int M = P.M, N = P.N;
+  {
+    const float alpha = E.alpha;
+    float bj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = nw + j * 32 + (lane & 31);
+      bj[j] = (E.bias && n < N) ? E.bias[n] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * alpha + bj[j];
+  }
+  float* Cw = reinterpret_cast<float*>(smem) + wave * (32 * W4_EP);
+  float* C = (float*)E.C + (size_t)split * (size_t)P.split_stride;
+  const int ldc = E.ldc;
+  const int urow = lane >> 5, c4 = (lane & 31) * 4;
+  const int n = nw + c4;
+  const bool nfull = n + 4 <= N && (ldc & 3) == 0;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Cw[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * W4_EP + j * 32 + (lane & 31)] = acc[p][j][r];
+    // (one wave: its LDS operations complete in order, the reads below see the writes above)
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 2 + urow;
+      const int m = mw + p * 32 + row;
+      const float4 v = *reinterpret_cast<const float4*>(Cw + row * W4_EP + c4);
+      if (m < M && n < N) {
+        float* dst = C + (size_t)m * ldc + n;
+        if (nfull) *reinterpret_cast<float4*>(dst) = v;
+        else {
+          const float x[4] = {v.x, v.y, v.z, v.w};
+          for (int i = 0; i < N - n && i < 4; ++i) dst[i] = x[i];
+        }
+      }
+    }
+  }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(LaunchTable tab) {
   constexpr int WM = 128, WN = 128, WNW = 2, AI = 4, NJ = 4, BM = 256, BN = 256;
@@ -171,11 +222,21 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(LaunchTable tab) {
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
   const Problem& P = tab.p[0];
-  int tile = lid / P.nsplit, split = lid - tile * P.nsplit;
-  if (P.nsplit > 1 && (P.nsplit & 7) == 0) {  // split-K with K-range <-> XCD affinity (see gemm.hip)
-    const int T = P.tiles_m * P.tiles_n, S = P.nsplit >> 3, j = blockIdx.x >> 3;
-    split = (blockIdx.x & 7) * S + j / T;
-    tile = j % T;
+  // split-K (fp32 slabs): split-major — an XCD's contiguous run of logical blocks is a run of TILES of one K range (two at most), so
+  // the blocks that share its L2 read the same k-tiles of A and B at about the same time (tile-major order would give every block
+  // of an XCD a K range of its own: every operand byte from the fabric once per block); with a multiple of 8 splits, K-range <->
+  // XCD affinity as in gemm.hip
+  int tile = lid, split = 0;
+  if (P.nsplit > 1) {
+    const int T = P.tiles_m * P.tiles_n;
+    if ((P.nsplit & 7) == 0) {
+      const int S = P.nsplit >> 3, j = blockIdx.x >> 3;
+      split = (blockIdx.x & 7) * S + j / T;
+      tile = j % T;
+    } else {
+      split = lid / T;
+      tile = lid - split * T;
+    }
   }
   int tm, tn;
   tile_coords(tile, P.tiles_m, P.tiles_n, tm, tn);
@@ -190,9 +251,9 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(LaunchTable tab) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const int nk_total = P.K / 64;
-  const int nk_per = (nk_total + P.nsplit - 1) / P.nsplit;
-  const int kt0 = split * nk_per, kt1 = min(nk_total, kt0 + nk_per);
+  const int nk_total = P.K / 64;  // even (K % 128 == 0)
+  const int nk_per = ((nk_total + P.nsplit - 1) / P.nsplit + 1) & ~1;  // ... and every split's range too: the K loop runs tile pairs
+  const int kt0 = min(nk_total, split * nk_per), kt1 = min(nk_total, kt0 + nk_per);
   const int nsteps = 2 * max(kt1 - kt0, 0);  // even, 32 k each
 
   // the sixteen 1-KiB pieces this wave brings per 64-k tile: pieces 4w .. 4w+3 of each of the four half images, by LDS-DMA
@@ -284,7 +345,10 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(LaunchTable tab) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (dropped requests still count)
   }
   __syncthreads();
-  if (live) w4_epilogue_lean<(EPI & 1) != 0, (EPI & 4) != 0>(acc, P, smem, m0 + wr * WM, n0 + wc * WN, wave, lane);
+  if (live) {
+    if constexpr (EPI == 8) w4_epilogue_f32(acc, P, smem, m0 + wr * WM, n0 + wc * WN, split, wave, lane);
+    else w4_epilogue_lean<(EPI & 1) != 0, (EPI & 4) != 0>(acc, P, smem, m0 + wr * WM, n0 + wc * WN, wave, lane);
+  }
 }
 
 template <int EPI>
@@ -306,17 +370,23 @@ void launch_w4(const LaunchTable& tab, hipStream_t s) {
 // the launches this kernel takes: one problem, NT, no split, K a multiple of 128 and >= 256, bf16 C through the bare epilogue
 // (alpha, bias, folded LayerNorm, softmax partials — the LM head and the all-layer cross k/v projection)
 bool gemm_w4_takes(const LaunchTable& tab) {
-  if (tab.count != 1 || !table_is_plain(tab)) return false;
+  if (tab.count != 1) return false;
   const Problem& p = tab.p[0];
   const EpiArgs& e = p.epi;
   // the DMA addresses an operand through a buffer resource of 2^31 - 1 bytes with 32-bit lane offsets: larger operands stay on the
   // four-phase kernel (64-bit addresses)
   const long long lim = 0x7fffffffLL;
   if ((long long)p.M * p.lda * 2 >= lim || (long long)p.N * p.ldb * 2 >= lim) return false;
-  return p.nsplit == 1 && p.K >= 256 && p.K % 128 == 0 && !e.R && !e.drop_thr && !e.rowsum2 && !e.c_f32;
+  if (p.K < 256 || p.K % 128 != 0 || e.R || e.drop_thr || e.rowsum2 || e.act || e.Zout || e.dact || e.accumulate) return false;
+  if (((uintptr_t)e.C & 15) != 0) return false;
+  if (e.c_f32)  // fp32 C (one slab per split with split-K): alpha and bias only
+    return !e.rowstat && !e.ln_stats && (p.nsplit == 1 || p.split_stride > 0) && p.K / 64 / p.nsplit >= 2;
+  // bf16 C: bias, folded LayerNorm (whole 8-column groups only: its column terms are loaded 8 at a time), softmax partials
+  return p.nsplit == 1 && (e.ldc & 7) == 0 && (!e.ln_stats || p.N % 8 == 0);
 }
 void launch_gemm_w4(const LaunchTable& tab, hipStream_t s) {
   const EpiArgs& e = tab.p[0].epi;
+  if (e.c_f32) { launch_w4<8>(tab, s); return; }
   const int epi = 2 + (e.rowstat ? 1 : 0) + (e.ln_stats ? 4 : 0);
   switch (epi) {
     case 2: launch_w4<2>(tab, s); break;

@@ -59,6 +59,12 @@ class Engine:
         self._lnf = {}
         self._lnf_version = -1
         self._dw_stream = None
+        # LM-head backward as NT launches of the four-wave kernel (k-contiguous copies: dlogits^T from the CE backward, h^T, E^T);
+        # MIC_HEAD_NT=0: the k-major launches of rounds 1-4 (A/B)
+        import os as _os
+        self.head_nt = _os.environ.get("MIC_HEAD_NT", "1") != "0"
+        self._head_nt_state = None   # (dlogits^T, Kp) of the CE backward that has just run
+        self._ET_version, self._ET_event = -1, None
         self._dw_events = []
         self._dw_side = False  # True while launching on the dW stream
         self._ckv_block_name = None  # set while the all-layer cross k/v weight gradient (one launch) sits in the dW queue
@@ -228,6 +234,7 @@ class Engine:
         for cb in list(self.on_free):
             cb()
         self._bufs.clear()
+        self._ET_version, self._ET_event, self._head_nt_state = -1, None, None
         self._lnf = {}
         self._lnf_version = -1
 
@@ -610,7 +617,16 @@ class Engine:
             hf = self.buf("d.hf" if pack is not None else "d.hfc", Mcap, d)  # compacted final hidden states (pad rows zero)
             Mh = rows[1]
         Mhp = _rup(Mh, 64)
-        if self.dt == torch.bfloat16:  # final_logits_bias gradient = row sums of dlogits^T, fused into the dE GEMM
+        nt = self._head_nt_state
+        self._head_nt_state = None
+        if nt is not None:
+            # NT launches on the four-wave kernel: dE = dlogits^T . (h^T)^T over K = rows (zero-padded to a multiple of 128 by the CE
+            # backward; the bias gradient was summed there), fp32 straight into the gradient buffer
+            dT, Kp = nt
+            hfT = self.buf("d.hfT", d, dT.shape[1])
+            ops.transpose_bf16(hf, hfT, Mh, d, rows_pad=Kp)
+            ops.gemm(dT, hfT, P.g("shared"), P.Vpad, d, Kp)
+        elif self.dt == torch.bfloat16:  # final_logits_bias gradient = row sums of dlogits^T, fused into the dE GEMM
             ops.zero(P.g("flb"))        # (atomics; this segment sits in front of the pre-zeroed atomic region)
             ops.gemm(dlogits, hf, P.g("shared"), P.Vpad, d, Mhp, a_kmajor=True, b_kmajor=True, a_rowsum=P.g("flb"), rowsum_k=Mh)
         else:
@@ -621,7 +637,19 @@ class Engine:
         # report, behind it (GradReducer `defer`)
         self._done("shared")
         dhc = dhf if (rows is None or pack is not None) else self.buf("db.dhfc", Mcap, d)
-        if self.dt == torch.bfloat16 and P.Vpad >= 16384:
+        if nt is not None:
+            # dX = dlogits . (E^T)^T over K = Vpad: ceil(Mh / 256) x d / 256 output tiles, split over K so that one round of blocks
+            # fills the chip; one fp32 slab per split, summed and rounded to bf16 once
+            tiles = ((Mh + 255) // 256) * ((d + 255) // 256)
+            nsp = max(1, min(ops.get_cu_budget() // tiles, P.Vpad // 128 // 2))
+            d32 = self.buf("db.dhf32", nsp * _rup(Mcap, ROWPAD), d, torch.float32)
+            slab = _rup(Mcap, ROWPAD) * d
+            ops.gemm(dlogits, self.shared_T(), d32, Mh, d, P.Vpad, split_k=nsp, split_stride=slab if nsp > 1 else 0)
+            if nsp > 1:
+                ops.sum_slabs(d32, nsp, slab, dhc, Mh, d, d32.stride(0), dhc.stride(0))
+            else:
+                ops.cast2d(d32, dhc, Mh, d, d32.stride(0), dhc.stride(0))
+        elif self.dt == torch.bfloat16 and P.Vpad >= 16384:
             # [Mh, d] output, reduction over the whole vocabulary: far too few tiles to fill 256 CUs.  Split-K 32 with K-range
             # <-> XCD affinity (gemm.hip) into per-split fp32 slabs (no atomics), summed and rounded to bf16 once.
             nsp = 32  # 16..64 measure the same (+-0.1 ms/step); the gain over the atomic variant is the absence of atomics
@@ -760,8 +788,60 @@ class Engine:
             ops.ce_rows(logits, logits.stride(0), P.V, labels, mask, label_smoothing, lse, rl, M)
         ops.ce_reduce(rl, mask, loss, denom, M)
         if backward:
-            ops.ce_bwd(logits, logits.stride(0), P.V, P.Vpad, labels, mask, label_smoothing, lse, denom, M)
+            kcap = self._head_nt_kcap(logits)
+            if kcap:
+                # dlogits in place AND transposed [Vpad][Kp] (reduction padding rows M .. Kp zero), final_logits_bias gradient on the way
+                Kp = _rup(M, 128)
+                dT = self.buf("d.dlogitsT", P.Vpad, kcap)
+                ops.zero(P.g("flb"))
+                ops.ce_bwd_t(logits, logits.stride(0), P.V, P.Vpad, labels, mask, label_smoothing, lse, denom, M, dT, rows_pad=Kp, colsum=P.g("flb"))
+                self._head_nt_state = (dT, Kp)
+            else:
+                ops.ce_bwd(logits, logits.stride(0), P.V, P.Vpad, labels, mask, label_smoothing, lse, denom, M)
+                self._head_nt_state = None
         return loss
+
+    def _head_nt_kcap(self, logits) -> int:
+        """columns of the dlogits^T buffer (the capacity of the row dimension, a multiple of 128) when the head's backward runs as NT
+        launches of the four-wave kernel, else 0: bf16 storage, a vocabulary worth the copies, operands inside the 2^31-byte
+        window that kernel's buffer resources address"""
+        P = self.P
+        if not self.head_nt or self.dt != torch.bfloat16 or P.Vpad < 16384 or P.d % 128 != 0:
+            return 0
+        kcap = _rup(logits.shape[0], 128)
+        return kcap if P.Vpad * kcap * 2 < 0x7fffffff and logits.shape[0] * logits.stride(0) * 2 < 0x7fffffff else 0
+
+    def shared_T(self):
+        """E^T [d][Vpad] (bf16): the k-contiguous copy of the tied embedding that the head's dX GEMM streams (dX = dlogits E reduces
+        over the vocabulary).  Rebuilt when the weights changed (ParamStore.version) — by the Trainer on a side stream behind its
+        optimizer passes (`refresh_shared_T`), here on the spot otherwise."""
+        P = self.P
+        ET = self.buf("w.sharedT", P.d, P.Vpad)
+        ver = getattr(P, "version", 0)
+        if self._ET_version != ver:
+            ops.transpose_bf16(P.w("shared"), ET, P.Vpad, P.d)
+            self._ET_version, self._ET_event = ver, None
+        elif self._ET_event is not None:
+            torch.cuda.current_stream().wait_event(self._ET_event)
+            self._ET_event = None
+        return ET
+
+    def refresh_shared_T(self, side, version: int):
+        """Trainer, end of a step: rebuild E^T from the updated embedding on `side`, behind everything the current stream has
+        enqueued; the next step's head backward waits for it (shared_T).  `version`: the ParamStore.version the copy belongs to."""
+        if not self.head_nt or self.dt != torch.bfloat16 or "w.sharedT" not in {k[0] for k in self._bufs if isinstance(k, tuple)}:
+            return
+        P = self.P
+        ET = self.buf("w.sharedT", P.d, P.Vpad)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            with ops.pinned_stream():
+                ops.transpose_bf16(P.w("shared"), ET, P.Vpad, P.d)
+            done = torch.cuda.Event()
+            done.record(side)
+        self._ET_version, self._ET_event = version, done
 
     # ------------------------------------------------------------------ full passes
     def forward_logits(self, pixels, ids, pos_ids, key_mask, B, T, *, save=False, seed=None, trunc_int32=False, stats=False):

@@ -271,6 +271,20 @@ def ce_bwd(logits, ld, V, Vpad, labels, mask, ls, row_lse, denom, rows, loss_sca
                                float(loss_scale), _stream()), "mic_ce_bwd")
 
 
+def ce_bwd_t(logits, ld, V, Vpad, labels, mask, ls, row_lse, denom, rows, dlogits_t, rows_pad=0, colsum=None, loss_scale=1.0):
+    """ce_bwd on bf16 logits that also writes dlogits^T [Vpad][ld_t] (columns rows .. rows_pad zero) and adds the column sums of the
+    stored gradient to `colsum` (mic_ce_bwd_t)"""
+    L.check(L.lib().mic_ce_bwd_t(rows, V, Vpad, _p(logits), ld, _p(labels), _p(mask), float(ls), _p(row_lse), _p(denom), float(loss_scale),
+                                 _p(dlogits_t), dlogits_t.stride(0), int(rows_pad), _p(colsum), _stream()), "mic_ce_bwd_t")
+
+
+def transpose_bf16(src, dst, rows, cols, rows_pad=0):
+    """dst[c][r] = src[r][c] for the leading rows x cols of a bf16 matrix; dst's columns rows .. rows_pad (0: rows rounded up to 64) are zeroed"""
+    L.check(L.lib().mic_transpose_bf16(int(rows), int(rows_pad), int(cols), _p(src), src.stride(0), _p(dst), dst.stride(0), _stream()),
+            "mic_transpose_bf16")
+    return dst
+
+
 def colsum(x, out, rows, cols, ld, accumulate=False):
     L.check(L.lib().mic_colsum(_dt(x), rows, cols, _p(x), ld, _p(out), int(accumulate), _stream()), "mic_colsum")
 

@@ -655,6 +655,10 @@ class Trainer:
             ops.adamw(st.master, st.m, st.v, st.grad, None if st.lp is st.master else st.lp, self.hyper, self.b1, self.b2, self.eps,
                       self.wd, grad_scale=1.0 / self.world)
         m.invalidate_params_cache(by_optimizer=True)
+        if m.device.type == "cuda":
+            # the k-contiguous copy of the tied embedding for the NEXT step's head backward: behind this step's optimizer passes, on a
+            # stream of its own — it has the whole next forward pass to finish (engine.shared_T waits for it)
+            eng.refresh_shared_T(ops.role_stream(m.device, "aux"), st.version)
         self.step += 1
         self.metrics_buf[0:1].copy_(loss)
         self.metrics_buf[1:2].copy_(self.hyper[0:1])  # lr, device to device (a Python scalar assigned into a device tensor syncs)

@@ -921,3 +921,81 @@ def test_gemm_four_wave_kernel_repeats_bit_for_bit(dev, M, N, K):
             c, st = run()
             torch.cuda.synchronize()
         assert torch.equal(c, c0) and torch.equal(st, s0)
+
+
+# ---------------------------------------------------------------- round 5: the LM head's backward as NT launches
+@pytest.mark.parametrize("rows,cols,pad", [(64, 512, 0), (100, 1024, 128), (37, 72, 64), (2300, 1032, 2304)])
+def test_transpose_bf16(dev, rows, cols, pad):
+    """mic_transpose_bf16: dst[c][r] = src[r][c], bit for bit; columns rows .. rows_pad of dst zero, nothing written beyond"""
+    from mic_amd import ops
+
+    g = torch.Generator().manual_seed(rows + cols)
+    src = rnd((rows + 3, cols + 8), g, torch.bfloat16).to(dev)   # (a view with a leading dimension larger than `cols`)
+    rp = pad if pad else (rows + 63) // 64 * 64
+    dst = torch.full((cols, rp + 8), 7.0, dtype=torch.bfloat16, device=dev)
+    ops.transpose_bf16(src, dst, rows, cols, rows_pad=pad)
+    torch.cuda.synchronize()
+    assert torch.equal(dst[:, :rows], src[:rows, :cols].T)
+    assert (dst[:, rows:rp] == 0).all() and (dst[:, rp:] == 7.0).all()
+
+
+@pytest.mark.parametrize("ls", [0.0, 0.1])
+@pytest.mark.parametrize("rows,V,Vpad", [(24, 1003, 1024), (150, 5003, 5056), (70, 600, 640)])
+def test_cross_entropy_backward_with_transposed_copy(dev, ls, rows, V, Vpad):
+    """mic_ce_bwd_t = mic_ce_bwd in place (same bits), plus dlogits^T (zero reduction padding) and the column sums of the stored
+    gradient added to `colsum` (the final_logits_bias gradient)"""
+    from mic_amd import ops
+
+    g = torch.Generator().manual_seed(rows + V)
+    logits = torch.zeros((rows + 5, Vpad), dtype=torch.bfloat16)
+    logits[:rows, :V] = rnd((rows, V), g, torch.bfloat16, 3.0)
+    labels = torch.randint(0, V, (rows,), generator=g, dtype=torch.int32).to(dev)
+    mask = (torch.rand(rows, generator=g) > 0.3).to(torch.int32).to(dev)
+    a, b = logits.to(dev), logits.to(dev)
+    lse, rl = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    loss, denom = torch.empty(1, device=dev), torch.empty(1, device=dev)
+    ops.ce_rows(a, Vpad, V, labels, mask, ls, lse, rl, rows)
+    ops.ce_reduce(rl, mask, loss, denom, rows)
+    ops.ce_bwd(a, Vpad, V, Vpad, labels, mask, ls, lse, denom, rows)
+    rp = (rows + 127) // 128 * 128
+    dT = torch.full((Vpad, rp + 64), 3.0, dtype=torch.bfloat16, device=dev)
+    cs = torch.full((Vpad,), 0.5, dtype=torch.float32, device=dev)
+    ops.ce_bwd_t(b, Vpad, V, Vpad, labels, mask, ls, lse, denom, rows, dT, rows_pad=rp, colsum=cs)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)                                   # the in-place gradient: the same bits as mic_ce_bwd
+    assert torch.equal(dT[:, :rows], b[:rows].T)               # ... and transposed
+    assert (dT[:, rows:rp] == 0).all() and (dT[:, rp:] == 3.0).all()
+    ref = b[:rows].float().sum(0).cpu()
+    assert (cs.cpu() - 0.5 - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item()) + 2e-7
+    assert (b[rows:] == logits[rows:].to(dev)).all()           # rows behind `rows` untouched
+
+
+@pytest.mark.parametrize("M,N,K,nsp", [(4096, 4096, 256, 1), (2300, 6000, 384, 1), (2432, 1024, 64 * 96, 6), (2176, 1024, 64 * 50, 7),
+                                      (520, 1024, 64 * 128, 24)])
+def test_gemm_four_wave_kernel_fp32_and_split_k_slabs(dev, M, N, K, nsp):
+    """the four-wave kernel's fp32 epilogue: C32 = A B^T (NT) straight into fp32, and as split-K slabs (one per split, fully
+    overwritten, empty K ranges as zeros) summed by mic_sum_slabs — the LM head's dE and dX launches; bit-identical run to run"""
+    from mic_amd import ops
+
+    plan = ops.gemm_plan([(M, N, K)], split_k=nsp)
+    assert plan["tile"] == 256 and plan["phased"] == 2, plan
+    g = torch.Generator().manual_seed(M + N + K)
+    a = rnd((M, K), g, torch.bfloat16, 0.5).to(dev)
+    b = rnd((N, K), g, torch.bfloat16, 0.1).to(dev)
+    ref = a.float() @ b.float().T
+    Mp = (M + 63) // 64 * 64
+    slab = Mp * N
+    outs = []
+    for _ in range(2):
+        ws = torch.full((max(nsp, 1) * Mp, N), float("nan"), dtype=torch.float32, device=dev)
+        ops.gemm(a, b, ws, M, N, K, split_k=nsp if nsp > 1 else 0, split_stride=slab if nsp > 1 else 0)
+        if nsp > 1:
+            o = torch.empty((M, N), dtype=torch.float32, device=dev)
+            ops.sum_slabs(ws, nsp, slab, o, M, N, ws.stride(0), o.stride(0))
+        else:
+            o = ws[:M]
+        torch.cuda.synchronize()
+        assert torch.isfinite(o).all()
+        assert (o - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
+        outs.append(o.clone())
+    assert torch.equal(outs[0], outs[1])
