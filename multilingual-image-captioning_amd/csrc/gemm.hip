@@ -313,6 +313,19 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
   tab.total_blocks = blocks;
   for (int i = 0; i < count; ++i)
     MIC_CHECK(!args[i].rowsum2 || table_is_plain(tab), "mic_gemm_grouped: rowsum2 needs every problem of the launch on the bare / residual epilogue");
+  // The two-blocks-per-CU 256 x 128 kernel (gemm_d2.hip) takes the four-wave kernel's launches that carry softmax partials (the
+  // LM-head forward: K = 1024 tiles whose epilogue is a third of their time — under a second block's MFMAs it is cover).  Its K loop
+  // is slower than the four-wave kernel's (64-B DMA segments: bound by L2 requests), so the deep-K and bare launches stay there.
+  // MIC_GEMM_D2 (A/B): 0 = off; 1 = everything the four-wave kernel would take; 2 = every single-problem NT 256-tile launch its
+  // epilogue covers; 3 (default) = the launches with softmax partials
+  static const int d2_env = [] { const char* e = getenv("MIC_GEMM_D2"); return e ? atoi(e) : 3; }();
+  const bool nt1 = bm == 256 && !f8 && !args[0].a_kmajor && !args[0].b_kmajor && count == 1;
+  if (d2_env && nt1 && gemm_d2_takes(tab) && (d2_env == 2 || (pl.phased == 2 && gemm_w4_takes(tab))) && (d2_env != 3 || tab.p[0].epi.rowstat)) {
+    Problem& p = tab.p[0];
+    p.tiles_n = (p.N + 127) / 128;  // 256 x 128 tiles
+    tab.total_blocks = p.tiles_m * p.tiles_n * p.nsplit;
+    launch_gemm_d2(tab, s);
+  } else
   if (bm == 256 && pl.phased == 2 && gemm_w4_takes(tab)) launch_gemm_w4(tab, s);  // 4 waves x 128x128, bare epilogues (default on)
   else if (bm == 256 && pl.phased && tab.p[0].nsplit == 1) launch_gemm_phased(tab, args[0].a_kmajor, args[0].b_kmajor, table_is_plain(tab), s);  // LDS-DMA, phased
   else if (bm == 256) launch_gemm_t256(tab, args[0].a_kmajor, args[0].b_kmajor, s, f8);     // 256x256x64, 8 waves

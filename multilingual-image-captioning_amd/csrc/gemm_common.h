@@ -27,6 +27,9 @@ void launch_gemm_phased(const LaunchTable& tab, int akm, int bkm, bool plain, hi
 // gemm_w4.hip: 256x256 tiles on four waves (128x128 wave tiles, one wave per SIMD), LDS-DMA ring of 32-k steps; NT, single problem
 bool gemm_w4_takes(const LaunchTable& tab);
 void launch_gemm_w4(const LaunchTable& tab, hipStream_t s);
+// gemm_d2.hip: 256x128 tiles on four waves (128x64 wave tiles), two blocks per CU, LDS-DMA ring of 32-k steps; NT, single problem
+bool gemm_d2_takes(const LaunchTable& tab);
+void launch_gemm_d2(const LaunchTable& tab, hipStream_t s);
 // one translation unit per tile configuration of the main kernel (gemm_kernel.h): 256x256 / 128x128 (K-groups 1, 2) / 64x64 (1, 2, 4)
 bool table_is_plain(const LaunchTable& t);
 void launch_gemm_t256(const LaunchTable& tab, int akm, int bkm, hipStream_t s, int f8);
