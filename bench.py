@@ -560,6 +560,7 @@ def main():
         busy = sum(a.elapsed_time(b_) for a, b_ in tr.reducer.emulated_events)
         tr.reducer.emulate["timing"] = False
         emulation = {"world": args.emulate_main, "comm_dtype": "bf16" if tr.grad_comm_dtype is not None else "fp32", "comm_cus": tr.comm_cus,
+                     "reducer_host_ms_per_step": round(tr.reducer.host_s * 1e3, 3),  # host time inside GradReducer.progress / finish (last step)
                      "projected_allreduce_ms_per_step": round(tr.reducer.emulated_ms, 2), "collective_stream_busy_ms_per_step": round(busy, 2),
                      "projected_allreduce_ms_fp32": round(allreduce_ms(4.0 * model.store.numel, args.emulate_main), 2)}
 
@@ -754,6 +755,7 @@ def main():
                                         f"{n_loss:.0f} of {B * T} rows per step)" if (tr.pack_rows and args.dtype in ("bf16", "fp8") and not args.dense_captions) else f"all {B * T} positions"),
                        "lm_head": head, "gemm_dtype": "fp8 e4m3 (fwd) / e5m2 (grads) for QKV+FFN, bf16 elsewhere" if args.dtype == "fp8" else args.dtype},
             "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 3),
+            "reducer_host_ms_per_step": round(tr.reducer.host_s * 1e3, 3),  # of which inside GradReducer.progress / finish (last step: bucket events, exchanges, optimizer passes)
             "model_tflops_per_gpu": round(step_flops * args.steps / dt / 1e12, 1),
             "model_tflops_note": f"EXECUTED model FLOPs per step ({step_flops / 1e12:.2f} TF: dense {dense_flops / 1e12:.2f} TF of SURVEY 8d minus the LM-head "
                                  + ("and decoder-layer " if packed else "") + f"work on the {B * T - n_loss:.0f} padded label positions, whose loss weight is 0"

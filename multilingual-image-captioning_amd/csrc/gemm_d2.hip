@@ -21,6 +21,12 @@
 //     operands of a pass requested before its restage.  With a second block computing on the same CU the epilogue is cover, not
 //     a stall, so it can afford the general form.
 //   * Split-K writes one fp32 slab per split (split-major block order, as gemm_w4.hip).  Single-problem NT launches, K % 64 == 0.
+//   * Measured (profiles/NOTES_r5.md): 4096^3 977 TF/s against the four-wave kernel's 1277 — two resident blocks reach 69 % of the
+//     matrix pipe where one four-wave block reaches 66-78 %: whatever holds an LDS-fed bf16 K loop at ~2/3 of the pipe (the library's
+//     kernels sit at 72 % in cycles) is not the lack of a second instruction stream.  What the second block does buy is the epilogue:
+//     LM head with softmax partials 647 us against 636-639 in isolation, decoder step 2.35 against 2.42 ms in situ (+2.7 % captions/s),
+//     train step level.  A 192 x 128 variant on whole cache lines in two 40-KiB slots (0.42 L2 requests per clock instead of 0.75)
+//     ran its K loop 8 % faster (4096^3 1052 TF/s) and changed neither leg in situ: not kept.
 #include "gemm_common.h"
 
 namespace {
@@ -302,3 +308,4 @@ void launch_gemm_d2(const LaunchTable& tab, hipStream_t s) {
   if (tab.p[0].epi.rowstat) launch_d2<1>(tab, s);
   else launch_d2<0>(tab, s);
 }
+

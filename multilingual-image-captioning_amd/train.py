@@ -235,6 +235,7 @@ class GradReducer:
             self.emulated_ms = 0.0
             self.emulated_events = []
         self.on_ready = on_ready if self.cuda else None
+        self.host_s = 0.0
         self.next = 0
         self.handles = []
         self._pending: List[Tuple[int, int, object]] = []  # "next": exchange started, optimizer pass due at the next report
@@ -279,6 +280,7 @@ class GradReducer:
         return self.world > 1 or self.on_ready is not None or self.emulate is not None
 
     def start_step(self):
+        self.host_s = 0.0
         self.next = 0
         self.handles = []
         self._pending = []
@@ -310,6 +312,15 @@ class GradReducer:
         """Backward reports that every gradient with flat offset < offset_done is final."""
         if not self.active:
             return
+        import time
+
+        t0 = time.perf_counter()
+        try:
+            self._progress(offset_done)
+        finally:
+            self.host_s += time.perf_counter() - t0  # host time this step spent issuing exchanges / optimizer passes (bench.py reports it)
+
+    def _progress(self, offset_done: int):
         if self.cuda:
             self._issue_pending()
         while self.next < len(self.buckets) and self.buckets[self.next][1] <= offset_done:
@@ -348,6 +359,15 @@ class GradReducer:
         self.progress(self.grad.numel())
         if not self.active:
             return
+        import time
+
+        t0 = time.perf_counter()
+        try:
+            self._finish(before, after)
+        finally:
+            self.host_s += time.perf_counter() - t0
+
+    def _finish(self, before, after):
         if not self.cuda:
             for h in self.handles:
                 h.wait()

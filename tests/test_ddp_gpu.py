@@ -1,6 +1,7 @@
 """Data-parallel train step, world_size 2, on the GPU box's single MI355X: both ranks share cuda:0 and exchange gradients
 over gloo (RCCL needs one device per rank; the host/stream logic — bucketed all-reduce on the side stream as backward
-completes the flat gradient buffer, SUM + 1/world in AdamW, metric pmean — is identical).  Checked against the oracle:
+completes the flat gradient buffer, SUM + 1/world in AdamW, metric pmean — is identical).  On a node with >= 2 GPUs
+`MIC_DDP_BACKEND=nccl` runs the same tests over RCCL, one device per rank (tools/first_multi_gpu_run.sh).  Checked against the oracle:
 pmean of per-rank gradients of per-rank masked-mean losses (main.py:679, 698), then one AdamW step."""
 import os
 import sys
@@ -13,13 +14,30 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _init(rank, world):
+    """process group + this rank's device: gloo with every rank on cuda:0 (the one-GPU box), or MIC_DDP_BACKEND=nccl with one device
+    per rank (RCCL; the channel cap the Trainer's CU budget is read from is exported first)"""
+    import torch.distributed as dist
+
+    if os.environ.get("MIC_DDP_BACKEND", "gloo") == "nccl":
+        from mic_amd.train import configure_rccl
+
+        configure_rccl()
+        torch.cuda.set_device(rank)
+        dev = torch.device("cuda", rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        return dev
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    return torch.device("cuda:0")
+
+
 def _worker(rank, world, port, q, comm=None):
     import torch.distributed as dist
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = _init(rank, world)
     try:
         from util_small import batch, make_pair
 
@@ -28,7 +46,6 @@ def _worker(rank, world, port, q, comm=None):
         from mic_amd.params import flatten_tree
         from oracle import train_ref
 
-        dev = torch.device("cuda:0")
         rc, p, model = make_pair(torch.float32, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.0)
         lr_fn = create_learning_rate_fn(40, 4, 1, 0, 1e-3)
         tr = Trainer(model, lr_fn, weight_decay=0.01, seed=42, bucket_mb=0.25,  # small buckets: several fire mid-backward
@@ -111,14 +128,13 @@ def _packed_worker(rank, world, port, q, full=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = _init(rank, world)
     try:
         from util_small import batch, make_pair
 
         import mic_amd  # noqa: F401
         from mic_amd import Trainer, create_learning_rate_fn
 
-        dev = torch.device("cuda:0")
         if full:  # ViT-B/32 + mBART-large-50 size, 16 of the bench's ragged captions per rank (different valid-row counts per rank)
             import bench
             from mic_amd import CLIPVisionMBartConfig, FlaxCLIPVisionMBartForConditionalGeneration
