@@ -184,6 +184,15 @@ int mic_layernorm_bwd(int dtype, int rows, int width, const void* x, const float
                       const float* rstd, const void* dy, const void* dres, void* dx, float* dgamma, float* dbeta,
                       void* dxm, float dropout_p, uint32_t dropout_seed, float in_dropout_p, uint32_t in_dropout_seed,
                       void* stream);
+/* mic_layernorm_bwd with the gamma / beta gradients as per-block partial column sums (plain stores) instead of fp32 atomics:
+ * partials [2][mic_layernorm_bwd_blocks(rows)][width] fp32 (gamma sums first), fully overwritten.  mic_ln_param_grads adds the blocks
+ * up in block order — deterministic, and off the critical path: the atomics were a third of the kernel's time at 2.4 k rows. */
+int mic_layernorm_bwd_blocks(int rows);
+int mic_layernorm_bwd_partials(int dtype, int rows, int width, const void* x, const float* gamma, const float* mean,
+                               const float* rstd, const void* dy, const void* dres, void* dx, float* partials, void* dxm,
+                               float dropout_p, uint32_t dropout_seed, float in_dropout_p, uint32_t in_dropout_seed, void* stream);
+typedef struct { const float* partials; float* dgamma; float* dbeta; int nblk, width, accumulate; } mic_ln_param_item;  /* dgamma / dbeta may be NULL */
+int mic_ln_param_grads(const mic_ln_param_item* items, int count, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Attention core (flax dot_product_attention_weights): q scaled by 1/sqrt(D) first,

@@ -61,6 +61,10 @@ class GemmPlanInfo(C.Structure):
                 ("phased", C.c_int), ("cu_budget", C.c_int), ("tile_m", C.c_int)]
 
 
+class LnParamItem(C.Structure):
+    _fields_ = [("partials", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("nblk", C.c_int), ("width", C.c_int), ("accumulate", C.c_int)]
+
+
 class ImageItem(C.Structure):
     _fields_ = [("src", C.c_void_p), ("H", C.c_int), ("W", C.c_int), ("hwc", C.c_int)]
 
@@ -83,6 +87,9 @@ _SIGS = {
     "mic_sum_slabs": ([_i, _i, C.c_longlong, _i, _i, _p, _i, _p, _i, _p], C.c_int),
     "mic_layernorm_fwd": ([_i, _i, _i, _p, _p, _p, _f, _p, _p, _p, _f, _u32, _p], C.c_int),
     "mic_layernorm_bwd": ([_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _u32, _f, _u32, _p], C.c_int),
+    "mic_layernorm_bwd_blocks": ([_i], C.c_int),
+    "mic_layernorm_bwd_partials": ([_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _u32, _f, _u32, _p], C.c_int),
+    "mic_ln_param_grads": ([C.POINTER(LnParamItem), _i, _p], C.c_int),
     "mic_attn_fwd": ([_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p], C.c_int),
     "mic_attn_probs": ([_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p], C.c_int),
     "mic_attn_bwd": ([_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p], C.c_int),

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64 * NW, NCH <= 2 ? 4 : 2) void ln_bwd_kernel(int r
                                                      const T* __restrict__ dres, T* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      T* __restrict__ dxm, uint32_t thr_m, uint32_t seed_m, float scale_m,
-                                                     uint32_t thr_in, uint32_t seed_in, float scale_in) {
+                                                     uint32_t thr_in, uint32_t seed_in, float scale_in, float* __restrict__ partials) {
   __shared__ float red[NW][64 * 8 + 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = width >> 3;
@@ -150,11 +150,14 @@ __global__ __launch_bounds__(64 * NW, NCH <= 2 ? 4 : 2) void ln_bwd_kernel(int r
       float* dst = which ? dbeta : dgamma;
       for (int col = threadIdx.x; col < 512; col += 64 * NW) {
         const int gcol = c * 512 + col;  // = (lane' + c*64)*8 + i with lane'*8+i = col
-        if (gcol < width && dst) {
+        if (gcol < width && (dst || partials)) {
           float a = 0.f;
 #pragma unroll
           for (int w = 0; w < NW; ++w) a += red[w][col];
-          atomicAdd(dst + gcol, a);
+          // partials: this block's column sums as plain stores into [2][gridDim.x][width] (summed later, off the critical path, in a
+          // fixed order: mic_ln_param_grads) instead of 2 * width atomics per block — a third of this kernel's time at 2.4 k rows
+          if (partials) partials[((size_t)which * gridDim.x + blockIdx.x) * width + gcol] = a;
+          else atomicAdd(dst + gcol, a);
         }
       }
     }
@@ -180,22 +183,79 @@ extern "C" int mic_layernorm_fwd(int dtype, int rows, int width, const void* x, 
   return MIC_OK;
 }
 
+static int ln_bwd_blocks(int rows) {
+  const int nblk = (rows + LNB_WAVES - 1) / LNB_WAVES;
+  return nblk > 256 ? 256 : nblk;
+}
+extern "C" int mic_layernorm_bwd_blocks(int rows) { return ln_bwd_blocks(rows > 0 ? rows : 1); }
+static int ln_bwd_impl(int dtype, int rows, int width, const void* x, const float* gamma, const float* mean, const float* rstd,
+                       const void* dy, const void* dres, void* dx, float* dgamma, float* dbeta, void* dxm, float dropout_p,
+                       uint32_t dropout_seed, float in_dropout_p, uint32_t in_dropout_seed, float* partials, void* stream);
 extern "C" int mic_layernorm_bwd(int dtype, int rows, int width, const void* x, const float* gamma, const float* mean,
                                  const float* rstd, const void* dy, const void* dres, void* dx, float* dgamma,
                                  float* dbeta, void* dxm, float dropout_p, uint32_t dropout_seed, float in_dropout_p,
                                  uint32_t in_dropout_seed, void* stream) {
+  return ln_bwd_impl(dtype, rows, width, x, gamma, mean, rstd, dy, dres, dx, dgamma, dbeta, dxm, dropout_p, dropout_seed, in_dropout_p,
+                     in_dropout_seed, nullptr, stream);
+}
+extern "C" int mic_layernorm_bwd_partials(int dtype, int rows, int width, const void* x, const float* gamma, const float* mean,
+                                          const float* rstd, const void* dy, const void* dres, void* dx, float* partials, void* dxm,
+                                          float dropout_p, uint32_t dropout_seed, float in_dropout_p, uint32_t in_dropout_seed, void* stream) {
+  MIC_CHECK(partials != nullptr, "mic_layernorm_bwd_partials: null partials");
+  return ln_bwd_impl(dtype, rows, width, x, gamma, mean, rstd, dy, dres, dx, nullptr, nullptr, dxm, dropout_p, dropout_seed, in_dropout_p,
+                     in_dropout_seed, partials, stream);
+}
+// dgamma / dbeta from the block partials of mic_layernorm_bwd_partials: out[which][col] (+)= sum over blocks, in block order
+struct LnParamItem { const float* partials; float* dgamma; float* dbeta; int nblk, width, accumulate; };
+struct LnParamTable { int count; LnParamItem it[8]; };
+__global__ __launch_bounds__(256) void ln_param_grads_kernel(LnParamTable tab) {
+  const LnParamItem& I = tab.it[blockIdx.z];
+  const int which = blockIdx.y, col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= I.width) return;
+  float* dst = which ? I.dbeta : I.dgamma;
+  if (!dst) return;
+  const float* src = I.partials + (size_t)which * I.nblk * I.width + col;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int b = 0;
+  for (; b + 4 <= I.nblk; b += 4) {
+    a0 += src[(size_t)b * I.width]; a1 += src[(size_t)(b + 1) * I.width];
+    a2 += src[(size_t)(b + 2) * I.width]; a3 += src[(size_t)(b + 3) * I.width];
+  }
+  for (; b < I.nblk; ++b) a0 += src[(size_t)b * I.width];
+  const float a = (a0 + a1) + (a2 + a3);
+  dst[col] = I.accumulate ? dst[col] + a : a;
+}
+extern "C" int mic_ln_param_grads(const mic_ln_param_item* items, int count, void* stream) {
+  MIC_CHECK(items && count >= 1, "mic_ln_param_grads: bad args");
+  for (int i0 = 0; i0 < count; i0 += 8) {
+    LnParamTable tab;
+    tab.count = count - i0 < 8 ? count - i0 : 8;
+    int wmax = 0;
+    for (int i = 0; i < tab.count; ++i) {
+      const mic_ln_param_item& m = items[i0 + i];
+      MIC_CHECK(m.partials && m.nblk > 0 && m.width > 0, "mic_ln_param_grads: bad item %d", i0 + i);
+      tab.it[i] = LnParamItem{m.partials, m.dgamma, m.dbeta, m.nblk, m.width, m.accumulate};
+      wmax = m.width > wmax ? m.width : wmax;
+    }
+    hipLaunchKernelGGL(ln_param_grads_kernel, dim3((wmax + 255) / 256, 2, tab.count), dim3(256), 0, (hipStream_t)stream, tab);
+    MIC_LAUNCH_CHECK();
+  }
+  return MIC_OK;
+}
+static int ln_bwd_impl(int dtype, int rows, int width, const void* x, const float* gamma, const float* mean, const float* rstd,
+                       const void* dy, const void* dres, void* dx, float* dgamma, float* dbeta, void* dxm, float dropout_p,
+                       uint32_t dropout_seed, float in_dropout_p, uint32_t in_dropout_seed, float* partials, void* stream) {
   MIC_CHECK(rows > 0 && width > 0 && width % 8 == 0 && width <= 64 * 8 * LN_MAXC, "mic_layernorm_bwd: bad shape rows=%d width=%d", rows, width);
   MIC_CHECK(x && gamma && mean && rstd && dy && dx, "mic_layernorm_bwd: null pointer");
   // measured: 16-wave blocks 21.9 -> 20.9 us, more than 256 blocks slower (each block ends with 2*width fp32 atomics,
   // ~4 us of the ~20 us at 4096x1024) -- the kernel is latency-bound at two rows per wave, not bandwidth-bound
   const int NWS = LNB_WAVES;
-  int nblk = (rows + NWS - 1) / NWS;
-  if (nblk > 256) nblk = 256;
+  const int nblk = ln_bwd_blocks(rows);
   dim3 grid(nblk), block(64 * NWS);
   const uint32_t thr_m = dxm ? thr_of(dropout_p) : 0u, thr_in = thr_of(in_dropout_p);
   const float sm = 1.0f / (1.0f - dropout_p), si = 1.0f / (1.0f - in_dropout_p);
 #define LNB_LAUNCH(TT, NC) LNB_LAUNCH2(TT, NC, LNB_WAVES)
-#define LNB_LAUNCH2(TT, NC, NWW) hipLaunchKernelGGL((ln_bwd_kernel<TT, NC, NWW>), grid, block, 0, (hipStream_t)stream, rows, width, (const TT*)x, gamma, mean, rstd, (const TT*)dy, (const TT*)dres, (TT*)dx, dgamma, dbeta, (TT*)dxm, thr_m, dropout_seed, sm, thr_in, in_dropout_seed, si)
+#define LNB_LAUNCH2(TT, NC, NWW) hipLaunchKernelGGL((ln_bwd_kernel<TT, NC, NWW>), grid, block, 0, (hipStream_t)stream, rows, width, (const TT*)x, gamma, mean, rstd, (const TT*)dy, (const TT*)dres, (TT*)dx, dgamma, dbeta, (TT*)dxm, thr_m, dropout_seed, sm, thr_in, in_dropout_seed, si, partials)
   if (dtype == MIC_BF16) { if (width <= 1024) LNB_LAUNCH(uint16_t, 2); else LNB_LAUNCH(uint16_t, LN_MAXC); }
   else if (dtype == MIC_F32) { if (width <= 1024) LNB_LAUNCH(float, 2); else LNB_LAUNCH(float, LN_MAXC); }
 #undef LNB_LAUNCH

@@ -63,6 +63,10 @@ class Engine:
         # MIC_HEAD_NT=0: the k-major launches of rounds 1-4 (A/B)
         import os as _os
         self.head_nt = _os.environ.get("MIC_HEAD_NT", "1") != "0"
+        # LayerNorm backward: gamma / beta gradients as per-block partial sums reduced later with the layer's weight-gradient launches
+        # (no atomics on the critical path, a fixed summation order); MIC_LN_PARTIALS=0: fp32 atomics inside the kernel (A/B)
+        self.ln_partials = _os.environ.get("MIC_LN_PARTIALS", "1") != "0"
+        self._lnp_queue = []
         self._head_nt_state = None   # (dlogits^T, Kp) of the CE backward that has just run
         self._ET_version, self._ET_event = -1, None
         self._dw_events = []
@@ -333,6 +337,19 @@ class Engine:
         next layer's backward rewrites the other one), a single buffer otherwise"""
         return self.buf(f"{name}.{l & 1}" if self._dw_on() else name, rows, cols)
 
+    def ln_bwd(self, tag: str, l: int, x, ln: str, mean, rstd, dy, dx, rows: int, **kw):
+        """LayerNorm backward of the LayerNorm named `ln` (parameters ln + ".g" / ".b"): dx (and the kwargs' by-products) now, the
+        gamma / beta gradients either by atomics inside the kernel or — default — as block partials in a per-(call site, layer
+        parity) buffer, summed by the next flush_dw() (the buffer discipline of dyb())"""
+        P = self.P
+        if not self.ln_partials:
+            return ops.layernorm_bwd(x, P.f32(ln + ".g"), mean, rstd, dy, dx, P.g(ln + ".g"), P.g(ln + ".b"), rows=rows, **kw)
+        width = x.shape[-1]
+        part = self.buf(f"lnp.{tag}.{l & 1}", 2 * 256, width, torch.float32)  # [2][blocks <= 256][width]
+        ops.layernorm_bwd_partials(x, P.f32(ln + ".g"), mean, rstd, dy, dx, part, rows=rows, **kw)
+        self._lnp_queue.append((part, ops.layernorm_bwd_blocks(rows), width, P.g(ln + ".g"), P.g(ln + ".b"), False))
+        return dx
+
     def _dw_on(self) -> bool:
         return self.dw_overlap and not self.fp8
 
@@ -340,7 +357,7 @@ class Engine:
         """Launch the layer's queued weight-gradient GEMMs (and bias column sums) as grouped launches — on the dW stream when
         enabled: it waits for everything enqueued so far (the operands' producers), main goes on with the next layer and
         only waits for the dW launch of TWO layers back (the one that read the buffers the next layer is about to rewrite)."""
-        if not (self._cs_queue or self._dw_queue or (self.fp8 and self._dw8_queue)):
+        if not (self._cs_queue or self._dw_queue or self._lnp_queue or (self.fp8 and self._dw8_queue)):
             return
         side = None
         if self._dw_on():
@@ -372,11 +389,16 @@ class Engine:
 
     def dw_join(self):
         """end of backward: the step's stream waits for the dW stream (next forward rewrites the saved activations dW reads)"""
+        if self._lnp_queue:
+            self.flush_dw()  # LayerNorm parameter gradients queued behind the last layer's flush
         if self._dw_events:
             torch.cuda.current_stream().wait_event(self._dw_events[-1])
             self._dw_events = []
 
     def _flush_dw_launches(self):
+        if self._lnp_queue:
+            ops.ln_param_grads(self._lnp_queue)
+            self._lnp_queue = []
         if self._cs_queue:
             ops.colsum_grouped(self._cs_queue)
             self._cs_queue = []
@@ -469,7 +491,7 @@ class Engine:
             da = self.buf("vb.da", Mv, vd)
             self.linear_bwd(p + "fc1", a2, dz, Mv, dx=da, defer=True)
             dxm = self.dyb("vb.dxm", l, Mv, vd)
-            ops.layernorm_bwd(xm, P.f32(p + "ln2.g"), st2[0], st2[1], da, dxm, P.g(p + "ln2.g"), P.g(p + "ln2.b"), rows=Mv, dres=dx)
+            self.ln_bwd("v2", l, xm, p + "ln2", st2[0], st2[1], da, dxm, Mv, dres=dx)
             dctx = self.buf("vb.dctx", Mv, vd)
             self.linear_bwd(p + "o", ctx, dxm, Mv, dx=dctx, defer=True)
             dqkv = self.dyb("vb.dqkv", l, Mv, 3 * vd)
@@ -478,11 +500,11 @@ class Engine:
             self.linear_bwd(p + "qkv", a1, dqkv, Mv, dx=da, defer=True)
             self.flush_dw()  # before LN1 backward overwrites dx (the fc2 gradient operand)
             dx = self.dyb("vb.dx", l - 1, Mv, vd)  # the layer below's residual-stream gradient (= its fc2 dW operand)
-            ops.layernorm_bwd(x_in, P.f32(p + "ln1.g"), st1[0], st1[1], da, dx, P.g(p + "ln1.g"), P.g(p + "ln1.b"), rows=Mv, dres=dxm)
+            self.ln_bwd("v1", l, x_in, p + "ln1", st1[0], st1[1], da, dx, Mv, dres=dxm)
         emb = self.buf("v.emb", Mv, vd)
         st = self.buf("v.pre.stats", 2, _rup(Mv, ROWPAD), torch.float32)
         demb = self.buf("vb.demb", Mv, vd)
-        ops.layernorm_bwd(emb, P.f32("vit.pre_ln.g"), st[0], st[1], dx, demb, P.g("vit.pre_ln.g"), P.g("vit.pre_ln.b"), rows=Mv)
+        self.ln_bwd("vpre", 0, emb, "vit.pre_ln", st[0], st[1], dx, demb, Mv)
         dpe = self.buf("vb.dpe", Mp, vd)
         ops.vit_assemble_bwd(demb, dpe, P.g("vit.cls"), P.g("vit.pos"), B, S, vd, vd)
         pk = P.ps * P.ps * 3
@@ -668,8 +690,8 @@ class Engine:
         dxm = self.dyb("db.dxm_a", P.L - 1, Mcap, d)
         stf = self.buf("d.f.stats", 2, _rup(Mcap, ROWPAD), torch.float32)
         x_last = self.buf(f"d{P.L - 1}.x3", Mcap, d)
-        ops.layernorm_bwd(x_last, P.f32("dec.ln_f.g"), stf[0], stf[1], dhf, dx, P.g("dec.ln_f.g"), P.g("dec.ln_f.b"), rows=M,
-                          dxm=dxm, dropout_p=pd, dropout_seed=sd(12 + 3 * (P.L - 1)))
+        self.ln_bwd("f", 0, x_last, "dec.ln_f", stf[0], stf[1], dhf, dx, M,
+                    dxm=dxm, dropout_p=pd, dropout_seed=sd(12 + 3 * (P.L - 1)))
         dehs = self.buf("db.dehs", Mv, d)
         hoist = self.ckv_hoisted()
         kvcat = self.buf("d.ckvcat", Mv, P.L * 2 * d) if hoist else None
@@ -690,8 +712,8 @@ class Engine:
             da = self.buf("db.da", Mcap, d)
             self.linear_bwd(p + "fc1", a_ff, dz, M, dx=da, defer=True)
             dx2 = self.buf("db.dx2", Mcap, d)
-            ops.layernorm_bwd(x2, P.f32(p + "ln_ff.g"), stats[4], stats[5], da, dx2, P.g(p + "ln_ff.g"), P.g(p + "ln_ff.b"), rows=M,
-                              dres=dx, dxm=dxm_b, dropout_p=pd, dropout_seed=sd(11 + 3 * l))
+            self.ln_bwd("ff", l, x2, p + "ln_ff", stats[4], stats[5], da, dx2, M,
+                        dres=dx, dxm=dxm_b, dropout_p=pd, dropout_seed=sd(11 + 3 * l))
             # --- cross-attention branch
             dctx = self.buf("db.dctx", Mcap, d)
             self.linear_bwd(p + "co", cctx, dxm_b, M, dx=dctx, defer=True)
@@ -707,8 +729,8 @@ class Engine:
             if not hoist:
                 self.linear_bwd(p + "ckv", ehs, dkv, Mv, dx=dehs, dx_accumulate=(l != P.L - 1), defer=True)
             dx1 = self.buf("db.dx1", Mcap, d)
-            ops.layernorm_bwd(x1, P.f32(p + "ln_ca.g"), stats[2], stats[3], da, dx1, P.g(p + "ln_ca.g"), P.g(p + "ln_ca.b"), rows=M,
-                              dres=dx2, dxm=dxm_c, dropout_p=pd, dropout_seed=sd(10 + 3 * l))
+            self.ln_bwd("ca", l, x1, p + "ln_ca", stats[2], stats[3], da, dx1, M,
+                        dres=dx2, dxm=dxm_c, dropout_p=pd, dropout_seed=sd(10 + 3 * l))
             # --- self-attention branch
             self.linear_bwd(p + "so", ctx, dxm_c, M, dx=dctx, defer=True)
             dqkv = self.dyb("db.dqkv", l, Mcap, 3 * d)
@@ -723,11 +745,10 @@ class Engine:
             self.flush_dw()  # the layer's 7 weight-gradient GEMMs as one grouped launch (before dxm_a is rewritten)
             dxm = self.dyb("db.dxm_a", l - 1, Mcap, d)
             if l > 0:
-                ops.layernorm_bwd(x_in, P.f32(p + "ln_sa.g"), stats[0], stats[1], da, dx, P.g(p + "ln_sa.g"), P.g(p + "ln_sa.b"), rows=M,
-                                  dres=dx1, dxm=dxm, dropout_p=pd, dropout_seed=sd(12 + 3 * (l - 1)))
+                self.ln_bwd("sa", l, x_in, p + "ln_sa", stats[0], stats[1], da, dx, M,
+                            dres=dx1, dxm=dxm, dropout_p=pd, dropout_seed=sd(12 + 3 * (l - 1)))
             else:
-                ops.layernorm_bwd(x_in, P.f32(p + "ln_sa.g"), stats[0], stats[1], da, dx, P.g(p + "ln_sa.g"), P.g(p + "ln_sa.b"), rows=M,
-                                  dres=dx1)
+                self.ln_bwd("sa", l, x_in, p + "ln_sa", stats[0], stats[1], da, dx, M, dres=dx1)
         if hoist:
             # the cross-attention k/v projections of all layers at once: dW (+ bias row sums) = dkv^T ehs as one [L*2d][d] weight
             # gradient (on the dW stream), dehs = dkv W as one contraction over K = L*2d (split over K into fp32 slabs: 52 output
@@ -763,8 +784,8 @@ class Engine:
         h0 = self.buf("d.h0", Mcap, d)
         ste = self.buf("d.emb.stats", 2, _rup(Mcap, ROWPAD), torch.float32)
         dh0 = self.buf("db.dh0", Mcap, d)
-        ops.layernorm_bwd(h0, P.f32("dec.ln_emb.g"), ste[0], ste[1], dx, dh0, P.g("dec.ln_emb.g"), P.g("dec.ln_emb.b"), rows=M,
-                          in_dropout_p=pd, in_dropout_seed=sd(1))
+        self.ln_bwd("emb", 0, h0, "dec.ln_emb", ste[0], ste[1], dx, dh0, M,
+                    in_dropout_p=pd, in_dropout_seed=sd(1))
         if self.defer_embed:
             ops.embed_bwd(ids, pos_ids, dh0, self.embed_scale, None, P.g("dec.pos"), M, d)
             if pack is not None and M < Mcap:

@@ -185,6 +185,31 @@ def layernorm_bwd(x, gamma, mean, rstd, dy, dx, dgamma, dbeta, rows=None, dres=N
     return dx
 
 
+def layernorm_bwd_blocks(rows: int) -> int:
+    """blocks mic_layernorm_bwd launches for `rows` rows = rows of its partials buffer per (gamma | beta)"""
+    return int(L.lib().mic_layernorm_bwd_blocks(int(rows)))
+
+
+def layernorm_bwd_partials(x, gamma, mean, rstd, dy, dx, partials, rows=None, dres=None, dxm=None, dropout_p=0.0, dropout_seed=0,
+                           in_dropout_p=0.0, in_dropout_seed=0):
+    """layernorm_bwd whose gamma / beta gradients land as per-block partial sums in `partials` (fp32 [2][blocks][width], overwritten)
+    for a later `ln_param_grads` instead of atomics"""
+    rows = rows if rows is not None else x.shape[0]
+    L.check(L.lib().mic_layernorm_bwd_partials(_dt(x), rows, x.shape[-1], _p(x), _p(gamma), _p(mean), _p(rstd), _p(dy), _p(dres), _p(dx),
+                                               _p(partials), _p(dxm), float(dropout_p), int(dropout_seed) & 0xFFFFFFFF,
+                                               float(in_dropout_p), int(in_dropout_seed) & 0xFFFFFFFF, _stream()), "mic_layernorm_bwd_partials")
+    return dx
+
+
+def ln_param_grads(items):
+    """items: [(partials, nblk, width, dgamma, dbeta, accumulate)] -> dgamma / dbeta (+)= sum over the blocks' partials (one grouped launch
+    per 8 items)"""
+    arr = (L.LnParamItem * len(items))()
+    for a, (part, nblk, width, dg, db, acc) in zip(arr, items):
+        a.partials, a.dgamma, a.dbeta, a.nblk, a.width, a.accumulate = _p(part), _p(dg), _p(db), int(nblk), int(width), int(bool(acc))
+    L.check(L.lib().mic_ln_param_grads(arr, len(items), _stream()), "mic_ln_param_grads")
+
+
 def attn_fwd(q, k, v, out, B, H, Tq, Tk, *, ldq, ldk, ldv, ldo, key_mask=None, causal=False, lse=None):
     L.check(L.lib().mic_attn_fwd(_dt(q), B, H, Tq, Tk, _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), ldo, _p(key_mask), int(causal),
                                  _p(lse), _stream()), "mic_attn_fwd")

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, mic_amd
 from mic_amd import ops
 dev = torch.device("cuda:0")
-for rows, width in ((4096, 1024), (3200, 768)):
+for rows, width in ((2432, 1024), (4096, 1024), (3200, 768)):
     sets = []
     for _ in range(8):
         x = torch.randn(rows, width, device=dev).to(torch.bfloat16)
