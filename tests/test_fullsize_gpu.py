@@ -69,6 +69,15 @@ def test_fullsize_bf16_every_stage_within_1e3_of_bf16_storage_oracle(full):
     assert max(s[3] for s in stages) < 0.02
 
 
+def _tail(d, s):
+    """(99.9th percentile, rms) of |d| / s: the maximum over millions of elements is an extreme-value statistic — 3.1e-3 in one
+    evaluation order, 6.2e-3 in the next — the upper tail and the rms are properties of the error distribution"""
+    f = (d.flatten() / s).float()
+    if f.numel() > 4_000_000:
+        f = f[:: f.numel() // 4_000_000 + 1]
+    return torch.quantile(f, 0.999).item(), f.pow(2).mean().sqrt().item()
+
+
 def _self_distance(fn):
     """distance between two valid evaluation orders of the bf16-storage oracle: fp32 vs float64 accumulation of every Linear"""
     from oracle import model_ref_bf16 as E
@@ -103,8 +112,11 @@ def test_fullsize_bf16_logits_as_close_to_the_bf16_storage_oracle_as_the_oracle_
     own = ((d_self.max() / s).item(), (d_self.mean() / s).item())
     print(f"[fullsize bf16 logits, stored vs stored] HIP vs oracle: max {hip[0]:.2e} mean {hip[1]:.2e}; oracle(f32 acc) vs oracle(f64 acc): "
           f"max {own[0]:.2e} mean {own[1]:.2e}")
+    t_hip, t_own = _tail(d_hip, s), _tail(d_self, s)
+    print(f"[fullsize bf16 logits] (q99.9, rms) of |d| / scale: HIP vs oracle {t_hip[0]:.2e} {t_hip[1]:.2e}, oracle vs itself {t_own[0]:.2e} {t_own[1]:.2e}")
     assert own[0] > 1e-3, own
     assert hip[0] < 2.0 ** -7 + 1e-3 and hip[1] < 1.5 * own[1], (hip, own)
+    assert t_hip[0] < 1.3 * t_own[0] and t_hip[1] < 1.3 * t_own[1], (t_hip, t_own)
 
 
 @pytest.mark.parametrize("fold", [False, True])
@@ -141,9 +153,14 @@ def test_fullsize_bf16_cached_decode_as_close_to_the_bf16_storage_oracle_as_the_
         s = ref.abs().max()
         d_hip, d_self = (got - E.rb(ref)).abs(), (E.rb(ref64) - E.rb(ref)).abs()
         hip, own = ((d_hip.max() / s).item(), (d_hip.mean() / s).item()), ((d_self.max() / s).item(), (d_self.mean() / s).item())
-        print(f"[fullsize bf16 cached decode fold={fold}] HIP vs oracle: max {hip[0]:.2e} mean {hip[1]:.2e}; oracle vs itself (f64 acc): "
-              f"max {own[0]:.2e} mean {own[1]:.2e}")
+        t_hip, t_own = _tail(d_hip, s), _tail(d_self, s)
+        print(f"[fullsize bf16 cached decode fold={fold}] HIP vs oracle: max {hip[0]:.2e} mean {hip[1]:.2e} q99.9 {t_hip[0]:.2e} rms {t_hip[1]:.2e}; "
+              f"oracle vs itself (f64 acc): max {own[0]:.2e} mean {own[1]:.2e} q99.9 {t_own[0]:.2e} rms {t_own[1]:.2e}")
         assert hip[0] < 2.0 ** -7 + 1e-3 and hip[1] < 1.5 * own[1], (hip, own)
+        # the maximum over 2 M logits is an extreme-value statistic (round 4 read 6.2e-3 here against a self-distance of 3.1e-3, and
+        # 5.9e-3 against 5.9e-3 in the teacher-forced test): what is pinned is the error DISTRIBUTION — its upper tail and its rms
+        # are the oracle's own
+        assert t_hip[0] < 1.3 * t_own[0] and t_hip[1] < 1.3 * t_own[1], (t_hip, t_own)
     finally:
         model.engine.decode_ln_fold = keep
 

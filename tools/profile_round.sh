@@ -1,5 +1,5 @@
 R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp
-O=$R/gpurun_out/r4prof; mkdir -p $O
+O=$R/gpurun_out/r5prof; mkdir -p $O
 TR="--steps 1 --warmup 1 --no-generate --no-cpu-baseline --no-dense-leg --no-roofline --emulate-comm 0"
 # train: kernel trace with the default overlap (dW / optimizer streams) and serial
 rocprofv3 --kernel-trace --output-format csv -d $O/train_kt -- python3 $R/bench.py --steps 3 --warmup 1 --no-generate --no-cpu-baseline --no-dense-leg --no-roofline --emulate-comm 0 > $O/train_kt.log 2>&1
@@ -15,14 +15,14 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/gen_fetch --
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/gen_write -- python3 $R/bench.py --generate-only --no-roofline > $O/gen_write.log 2>&1
 cd $R
 f() { ls $O/$1/*/*$2 | head -1; }
-python tools/rocpd_stats.py $(f train_kt kernel_trace.csv) 4 > $O/r4_train_kernel_stats_overlapped.txt
-python tools/rocpd_stats.py $(f train_kt_serial kernel_trace.csv) 4 > $O/r4_train_kernel_stats_serial.txt
-python tools/pmc_traffic.py $(f train_fetch counter_collection.csv) $(f train_write counter_collection.csv) 2 $O/r4_train_pmc_hbm_traffic.json > $O/r4_train_pmc_hbm_traffic.txt
-python tools/pmc_mfma.py $(f train_mfma counter_collection.csv) > $O/r4_train_pmc_mfma_lds.txt
-python tools/rocpd_stats.py $(f gen_kt kernel_trace.csv) 378 > $O/r4_generate_kernel_stats.txt
-python tools/pmc_traffic_gen.py $(f gen_fetch counter_collection.csv) $(f gen_write counter_collection.csv) 378 $O/r4_generate_pmc_hbm_traffic.json > $O/r4_generate_pmc_hbm_traffic.txt
+python tools/rocpd_stats.py $(f train_kt kernel_trace.csv) 4 > $O/r5_train_kernel_stats_overlapped.txt
+python tools/rocpd_stats.py $(f train_kt_serial kernel_trace.csv) 4 > $O/r5_train_kernel_stats_serial.txt
+python tools/pmc_traffic.py $(f train_fetch counter_collection.csv) $(f train_write counter_collection.csv) 2 $O/r5_train_pmc_hbm_traffic.json > $O/r5_train_pmc_hbm_traffic.txt
+python tools/pmc_mfma.py $(f train_mfma counter_collection.csv) > $O/r5_train_pmc_mfma_lds.txt
+python tools/rocpd_stats.py $(f gen_kt kernel_trace.csv) 378 > $O/r5_generate_kernel_stats.txt
+python tools/pmc_traffic_gen.py $(f gen_fetch counter_collection.csv) $(f gen_write counter_collection.csv) 378 $O/r5_generate_pmc_hbm_traffic.json > $O/r5_generate_pmc_hbm_traffic.txt
 # keep only the summaries and the kernel-trace csv of the two main runs (the merge-back limit is 64 MiB)
-cp $(f train_kt_serial kernel_trace.csv) $O/r4_train_rocprofv3_kernel_trace_serial.csv
-cp $(f gen_kt kernel_trace.csv) $O/r4_generate_rocprofv3_kernel_trace.csv
+cp $(f train_kt_serial kernel_trace.csv) $O/r5_train_rocprofv3_kernel_trace_serial.csv
+cp $(f gen_kt kernel_trace.csv) $O/r5_generate_rocprofv3_kernel_trace.csv
 rm -rf $O/train_kt $O/train_kt_serial $O/train_fetch $O/train_write $O/train_mfma $O/gen_kt $O/gen_fetch $O/gen_write
-ls -la $O; head -5 $O/r4_train_pmc_hbm_traffic.txt; cat $O/r4_train_pmc_hbm_traffic.json; cat $O/r4_generate_pmc_hbm_traffic.json; head -12 $O/r4_train_pmc_mfma_lds.txt
+ls -la $O; head -5 $O/r5_train_pmc_hbm_traffic.txt; cat $O/r5_train_pmc_hbm_traffic.json; cat $O/r5_generate_pmc_hbm_traffic.json; head -12 $O/r5_train_pmc_mfma_lds.txt
