@@ -32,9 +32,6 @@
 
 namespace {
 
-#ifndef W4_SPREAD
-#define W4_SPREAD 0  // where the LDS-DMA requests of a tile sit among its MFMA gaps (A/B builds: -DW4_SPREAD=1|2)
-#endif
 constexpr int W4_BK = 64, W4_HIMG = 128 * W4_BK * 2, W4_SLOT = 4 * W4_HIMG;  // 64-k tiles: half image 16 KiB, slot 64 KiB
 
 // byte offset of this lane's source (k = 0 of the split) for 1-KiB piece q (8 rows x 128 B = whole lines) of a half image whose row 0
@@ -292,7 +289,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(LaunchTable tab) {
 //              wave's pieces of tile T+1 have landed} s_barrier — tile T+1 is readable, this tile's slot is dead
 //   quarters 1, 2: read tile T+1's kk = 0 / kk = 1 fragments (first 8 gaps of the quarter) into the registers the finished quarters
 //              freed; one LDS-DMA piece of tile T+2 into the dead slot in every other gap (an LDS-DMA piece costs 60-100 cycles of
-//              issue time: never two in a row)
+//              issue time: never two in a row; spreading the sixteen pieces over quarters 1-3 or every third gap measured the same
+//              107.5-108.0 us at 4096^3, profiles/NOTES_r5.md section 4)
 //   quarter 3: read tile T+1's kk = 2 fragments
 #define W4_TILE(C)                                                                                                             \
   do {                                                                                                                         \
@@ -307,14 +305,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(LaunchTable tab) {
       const int rk_ = (q_ + 3) & 3, rs_ = q_ == 0 ? (C) : 1 - (C);  /* kk and slot of this quarter's fragment reads */          \
       if (x_ < 4) fa[x_][rk_] = read_frag<false, W4_BK, 128>(fa_ + rs_ * W4_SLOT, x_ * 32, rk_, lane);                         \
       else if (x_ < 8) fb[x_ - 4][rk_] = read_frag<false, W4_BK, 128>(fb_ + rs_ * W4_SLOT, (x_ - 4) * 32, rk_, lane);          \
-      if (W4_SPREAD == 0) {                                                                                                    \
-        if ((q_ == 1 || q_ == 2) && (x_ & 1) == 1) W4_DMA(t + (C) + 2, C, (q_ - 1) * 8 + (x_ >> 1));                           \
-      } else if (W4_SPREAD == 1) { /* 5 + 5 + 6 pieces over quarters 1-3, in the gaps behind the fragment reads */            \
-        if ((q_ == 1 || q_ == 2) && (x_ & 1) == 1 && x_ >= 7) W4_DMA(t + (C) + 2, C, (q_ - 1) * 5 + ((x_ - 7) >> 1));          \
-        if (q_ == 3 && (x_ & 1) == 1 && x_ >= 5) W4_DMA(t + (C) + 2, C, 10 + ((x_ - 5) >> 1));                                 \
-      } else { /* 6 + 5 + 5: one piece every third gap of quarters 1-3 */                                                     \
-        if (q_ >= 1 && ((q_ - 1) * 16 + x_) % 3 == 0) W4_DMA(t + (C) + 2, C, ((q_ - 1) * 16 + x_) / 3);                        \
-      }                                                                                                                        \
+      if ((q_ == 1 || q_ == 2) && (x_ & 1) == 1) W4_DMA(t + (C) + 2, C, (q_ - 1) * 8 + (x_ >> 1));                             \
       __builtin_amdgcn_sched_barrier(0);                                                                                       \
     }                                                                                                                          \
   } while (0)
