@@ -289,7 +289,7 @@ def bench_generate(model, cfg, dev, batch=256, langs=(250004, 250008, 250003, 25
     # the dominant kernel class of a decoder step BY TIME is the MFMA GEMM (LM head + the layers' projections): that is the
     # leg's `roofline`; the decode attention (HBM-bound) and the whole step are reported beside it
     peak = PEAK_TFLOPS["bf16"] if model.dtype == torch.bfloat16 else PEAK_TFLOPS["f32"]
-    res["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel + gemm_w4_kernel (every GEMM launch of a decoder step: LM head + layer projections)",
+    res["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel + gemm_d2_kernel (every GEMM launch of a decoder step: LM head + layer projections)",
                        "achieved": round((hf + gf) / (ht + gt) / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
                        "frac": round((hf + gf) / (ht + gt) / 1e12 / peak, 4), "traffic": None,
                        "ms_per_step": round((ht + gt) / nst * 1e3, 3), "launches_per_step": round((hn + gn) / nst, 1),
@@ -634,7 +634,7 @@ def main():
         flops = sum(r[0] for r in recs)
         ms = sum(r[1].elapsed_time(r[2]) for r in recs)
         ach = flops / (ms * 1e-3) / 1e12
-        kname = {"bf16": "gemm_bf16_kernel + gemm_w4_kernel (every GEMM launch of the step)", "f32": "gemm_f32_kernel", "fp8": "gemm_bf16_kernel + gemm_fp8_kernel"}[args.dtype]
+        kname = {"bf16": "gemm_bf16_kernel + gemm_w4_kernel + gemm_d2_kernel (every GEMM launch of the step)", "f32": "gemm_f32_kernel", "fp8": "gemm_bf16_kernel + gemm_fp8_kernel"}[args.dtype]
         roofline = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": len(recs), "gemm_ms_per_step": round(ms, 3),
                     "gemm_gflop_per_step": round(flops / 1e9, 1)}

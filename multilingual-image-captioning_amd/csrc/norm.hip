@@ -208,22 +208,37 @@ extern "C" int mic_layernorm_bwd_partials(int dtype, int rows, int width, const 
 // dgamma / dbeta from the block partials of mic_layernorm_bwd_partials: out[which][col] (+)= sum over blocks, in block order
 struct LnParamItem { const float* partials; float* dgamma; float* dbeta; int nblk, width, accumulate; };
 struct LnParamTable { int count; LnParamItem it[8]; };
+// one block = 32 columns x 8 row lanes: every lane sums nblk / 8 partial rows (sixteen independent loads in flight per trip: with
+// one thread per column walking all 256 rows the kernel was a 24-us latency chain), the eight lanes meet in LDS in a fixed order
 __global__ __launch_bounds__(256) void ln_param_grads_kernel(LnParamTable tab) {
+  __shared__ float red[8][33];
   const LnParamItem& I = tab.it[blockIdx.z];
-  const int which = blockIdx.y, col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= I.width) return;
+  const int which = blockIdx.y, c = threadIdx.x & 31, r = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + c;
   float* dst = which ? I.dbeta : I.dgamma;
-  if (!dst) return;
-  const float* src = I.partials + (size_t)which * I.nblk * I.width + col;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int b = 0;
-  for (; b + 4 <= I.nblk; b += 4) {
-    a0 += src[(size_t)b * I.width]; a1 += src[(size_t)(b + 1) * I.width];
-    a2 += src[(size_t)(b + 2) * I.width]; a3 += src[(size_t)(b + 3) * I.width];
+  if (blockIdx.x * 32 >= I.width || !dst) return;  // (block-uniform)
+  float a = 0.f;
+  if (col < I.width) {
+    const float* src = I.partials + (size_t)which * I.nblk * I.width + col;
+    for (int b0 = r; b0 < I.nblk; b0 += 8 * 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int b = b0 + 8 * u;
+        v[u] = b < I.nblk ? src[(size_t)b * I.width] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) a += v[u];
+    }
   }
-  for (; b < I.nblk; ++b) a0 += src[(size_t)b * I.width];
-  const float a = (a0 + a1) + (a2 + a3);
-  dst[col] = I.accumulate ? dst[col] + a : a;
+  red[r][c] = a;
+  __syncthreads();
+  if (r == 0 && col < I.width) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][c];
+    dst[col] = I.accumulate ? dst[col] + t : t;
+  }
 }
 extern "C" int mic_ln_param_grads(const mic_ln_param_item* items, int count, void* stream) {
   MIC_CHECK(items && count >= 1, "mic_ln_param_grads: bad args");
@@ -237,7 +252,7 @@ extern "C" int mic_ln_param_grads(const mic_ln_param_item* items, int count, voi
       tab.it[i] = LnParamItem{m.partials, m.dgamma, m.dbeta, m.nblk, m.width, m.accumulate};
       wmax = m.width > wmax ? m.width : wmax;
     }
-    hipLaunchKernelGGL(ln_param_grads_kernel, dim3((wmax + 255) / 256, 2, tab.count), dim3(256), 0, (hipStream_t)stream, tab);
+    hipLaunchKernelGGL(ln_param_grads_kernel, dim3((wmax + 31) / 32, 2, tab.count), dim3(256), 0, (hipStream_t)stream, tab);
     MIC_LAUNCH_CHECK();
   }
   return MIC_OK;

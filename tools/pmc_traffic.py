@@ -50,7 +50,7 @@ if len(sys.argv) > 4:
     n = sum(max(f[k][0], w[k][0]) for k in g) / steps
     fb = sum(f[k][1] for k in g) * KB * cf / steps
     wb = sum(w[k][1] for k in g) * KB * cw / steps
-    json.dump({"kernel": "gemm_bf16_kernel + gemm_w4_kernel + gemm_phased_kernel", "launches_per_step": n, "fetch_GB_per_step": round(fb / 1e9, 3),
+    json.dump({"kernel": "gemm_bf16_kernel + gemm_w4_kernel + gemm_d2_kernel + gemm_phased_kernel", "launches_per_step": n, "fetch_GB_per_step": round(fb / 1e9, 3),
                "write_GB_per_step": round(wb / 1e9, 3), "bytes_per_launch": int((fb + wb) / max(n, 1)),
                "calibration": {"fetch_factor": round(cf, 3), "write_factor": round(cw, 3), "on": "adamw_kernel (16 B read + 14 B written per element)"},
                "total_fetch_GB_per_step": round(tf / 1e9, 3), "total_write_GB_per_step": round(tw / 1e9, 3)}, open(sys.argv[4], "w"), indent=1)

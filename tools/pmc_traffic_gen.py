@@ -43,5 +43,5 @@ if len(sys.argv) > 4:
         return {"launches_per_step": round(n / steps, 2), "bytes_per_launch": int(sum(v[1] + v[2] for v in sel) / max(n, 1)),
                 "fetch_MB_per_step": round(sum(v[1] for v in sel) / steps / 1e6, 2), "write_MB_per_step": round(sum(v[2] for v in sel) / steps / 1e6, 2)}
     json.dump({"attention": dict(kernel="attn_decode_kernel + attn_decode_group_kernel", **group(lambda k: k.startswith("attn_decode"))),
-               "gemm": dict(kernel="gemm_bf16_kernel + gemm_w4_kernel + gemm_phased_kernel", **group(lambda k: k.startswith("gemm_"))),
+               "gemm": dict(kernel="gemm_bf16_kernel + gemm_w4_kernel + gemm_d2_kernel + gemm_phased_kernel", **group(lambda k: k.startswith("gemm_"))),
                "total_GB_per_decoder_step": round((tf + tw) / steps / 1e9, 3)}, open(sys.argv[4], "w"), indent=1)
