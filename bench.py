@@ -511,6 +511,7 @@ def main():
     for i in range(args.steps):
         out = tr.train_step(dbatches[i % 2])
     t_issue = time.perf_counter() - t0  # the host's share: all K steps queued (nothing in a step waits for the GPU)
+    reducer_host_ms = tr.reducer.host_s * 1e3  # ... of which inside GradReducer.progress / finish, last timed step
     barrier()
     dt = time.perf_counter() - t0
     loss = float(out["loss"])
@@ -755,7 +756,7 @@ def main():
                                         f"{n_loss:.0f} of {B * T} rows per step)" if (tr.pack_rows and args.dtype in ("bf16", "fp8") and not args.dense_captions) else f"all {B * T} positions"),
                        "lm_head": head, "gemm_dtype": "fp8 e4m3 (fwd) / e5m2 (grads) for QKV+FFN, bf16 elsewhere" if args.dtype == "fp8" else args.dtype},
             "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 3),
-            "reducer_host_ms_per_step": round(tr.reducer.host_s * 1e3, 3),  # of which inside GradReducer.progress / finish (last step: bucket events, exchanges, optimizer passes)
+            "reducer_host_ms_per_step": round(reducer_host_ms, 3),  # of which inside GradReducer.progress / finish (last timed step: bucket events, exchanges, optimizer passes)
             "model_tflops_per_gpu": round(step_flops * args.steps / dt / 1e12, 1),
             "model_tflops_note": f"EXECUTED model FLOPs per step ({step_flops / 1e12:.2f} TF: dense {dense_flops / 1e12:.2f} TF of SURVEY 8d minus the LM-head "
                                  + ("and decoder-layer " if packed else "") + f"work on the {B * T - n_loss:.0f} padded label positions, whose loss weight is 0"

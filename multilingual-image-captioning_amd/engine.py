@@ -850,10 +850,10 @@ class Engine:
     def refresh_shared_T(self, side, version: int):
         """Trainer, end of a step: rebuild E^T from the updated embedding on `side`, behind everything the current stream has
         enqueued; the next step's head backward waits for it (shared_T).  `version`: the ParamStore.version the copy belongs to."""
-        if not self.head_nt or self.dt != torch.bfloat16 or "w.sharedT" not in {k[0] for k in self._bufs if isinstance(k, tuple)}:
-            return
         P = self.P
-        ET = self.buf("w.sharedT", P.d, P.Vpad)
+        ET = self._bufs.get(("w.sharedT", P.d, P.Vpad, self.dt))  # (only once a head backward has built it)
+        if not self.head_nt or self.dt != torch.bfloat16 or ET is None:
+            return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         with torch.cuda.stream(side):

@@ -674,3 +674,48 @@ def test_fullsize_packed_rows_against_the_fp32_oracle_batch8(full, dev):
     assert not bad, sorted(bad.items(), key=lambda kv: kv[1])[:6]
     assert allc > 0.995, allc
     model.engine.free_buffers()
+
+
+def test_fullsize_head_backward_nt_launches_equal_the_kmajor_launches(full):
+    """round 5: the LM head's backward as NT launches of the four-wave kernel over k-contiguous copies (dlogits^T from the transposing
+    CE backward, h^T, E^T) against the k-major launches of rounds 1-4 (`Engine.head_nt = False`) on the same weights and batch, at
+    full size (the reduced test models have too small a vocabulary to take the NT path): same loss bits (the forward is the same), the
+    logits-bias gradient (column sums of the same bf16 dlogits, different summation order), the tied embedding's gradient and — through
+    dX — a decoder and a ViT weight gradient.  Also: E^T follows a weight update (ParamStore.version)."""
+    rc, p, models, (px, labels, mask, dec_in), _ = full
+    model = models[torch.bfloat16]
+    eng, st = model.engine, model.store
+    keep = eng.head_nt
+    res = {}
+    try:
+        for nt in (True, False):
+            eng.head_nt = nt
+            res[nt] = _grads(model, px, labels, mask, dec_in, compact=True)
+        assert eng._bufs.get(("w.sharedT", st.d, st.Vpad, torch.bfloat16)) is not None  # the NT pass built E^T
+        assert res[True][0] == res[False][0]
+        # rows of the embedding no decoder input id touches hold dE alone: the two launches agree to fp32 summation order there
+        sh = st.segs["shared"]
+        untouched = torch.ones(st.Vpad, dtype=torch.bool)
+        untouched[dec_in.reshape(-1)] = False
+        ga, gb = (res[k][1][sh.offset: sh.offset + sh.numel].view(st.Vpad, st.d)[untouched.to(res[k][1].device)] for k in (True, False))
+        assert ((ga - gb).abs().max() / gb.abs().max()).item() < 2e-5
+        # (the tied embedding's gradient = dE, fp32 summation order only, + the input-embedding rows scattered in at the END of the
+        # bf16 backward chain: those rows carry dX's rounding differences like every weight gradient behind the head)
+        for name, tol in (("flb", 2e-5), ("shared", 3e-2), ("dec11.fc2.w", 1e-2), ("dec0.qkv.w", 1e-2), ("vit0.fc1.w", 2e-2)):
+            s = st.segs[name]
+            a, b = res[True][1][s.offset: s.offset + s.numel], res[False][1][s.offset: s.offset + s.numel]
+            e = ((a - b).abs().max() / b.abs().max()).item()
+            assert e < tol, (name, e)  # fp32 summation order up to dX; behind it bf16 roundings of dh that fall the other way
+        # E^T is rebuilt when the weights move: perturb the embedding's compute copy, bump the version, compare with a fresh transpose
+        eng.head_nt = True
+        w = st.w("shared")
+        w[:16].mul_(2.0)
+        model.invalidate_params_cache()
+        ET = eng.shared_T()
+        torch.cuda.synchronize()
+        assert torch.equal(ET[:, : st.Vpad], w.T)
+    finally:
+        eng.head_nt = keep
+        from mic_amd.params import unflatten_tree
+
+        model.params = unflatten_tree({k: v.numpy() for k, v in p.items()})  # (the fixture is shared: put the weights back)
