@@ -999,3 +999,39 @@ def test_gemm_four_wave_kernel_fp32_and_split_k_slabs(dev, M, N, K, nsp):
         assert (o - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
         outs.append(o.clone())
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("rows,width", [(2432, 1024), (3200, 768), (37, 72), (5, 2048)])
+def test_layernorm_bwd_partials_and_param_grads(dev, dtype, rows, width):
+    """mic_layernorm_bwd_partials + mic_ln_param_grads = mic_layernorm_bwd: the same dx / dxm bits, gamma / beta gradients equal to
+    the atomics' to fp32 summation order — and the same bits from run to run (block partials added in block order), overwrite and
+    accumulate modes, several LayerNorms in one grouped launch"""
+    from mic_amd import ops
+
+    g = torch.Generator().manual_seed(rows * 3 + width)
+    x, dy, dres = (rnd((rows, width), g, dtype, 2.0).to(dev) for _ in range(3))
+    gamma = (1 + 0.1 * torch.randn(width, generator=g)).to(dev)
+    mean, rstd = x.float().mean(1), (x.float().var(1, unbiased=False) + 1e-5).rsqrt()
+    kw = dict(dres=dres, dropout_p=0.1, dropout_seed=9)
+    dx0, dxm0 = torch.empty_like(x), torch.empty_like(x)
+    dg0, db0 = torch.zeros(width, device=dev), torch.zeros(width, device=dev)
+    ops.layernorm_bwd(x, gamma, mean, rstd, dy, dx0, dg0, db0, dxm=dxm0, **kw)
+    nblk = ops.layernorm_bwd_blocks(rows)
+    assert 1 <= nblk <= 256
+    outs = []
+    for rep in range(2):
+        part = torch.full((2 * nblk, width), float("nan"), device=dev)  # fully overwritten
+        dx1, dxm1 = torch.empty_like(x), torch.empty_like(x)
+        ops.layernorm_bwd_partials(x, gamma, mean, rstd, dy, dx1, part, dxm=dxm1, **kw)
+        dg1, db1 = torch.full((width,), 7.0, device=dev), torch.full((width,), 7.0, device=dev)
+        dg2, db2 = torch.full((width,), 1.0, device=dev), torch.full((width,), 1.0, device=dev)
+        ops.ln_param_grads([(part, nblk, width, dg1, db1, False), (part, nblk, width, dg2, None, True), (part, nblk, width, None, db2, True)])
+        torch.cuda.synchronize()
+        assert torch.equal(dx1, dx0) and torch.equal(dxm1, dxm0)
+        sc = max(dg0.abs().max().item(), 1e-6)
+        assert (dg1 - dg0).abs().max().item() < 1e-5 * sc + 1e-6 and (db1 - db0).abs().max().item() < 1e-5 * max(db0.abs().max().item(), 1e-6) + 1e-6
+        assert torch.equal(dg2, dg1 + 1.0) or (dg2 - dg1 - 1.0).abs().max().item() < 1e-6 * sc + 1e-6  # accumulate
+        assert (db2 - db1 - 1.0).abs().max().item() < 1e-6 * max(db1.abs().max().item(), 1.0)
+        outs.append((dg1.clone(), db1.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])  # deterministic
