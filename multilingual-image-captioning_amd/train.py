@@ -509,6 +509,7 @@ class Trainer:
                                    ready_when=when, comm_dtype=self.grad_comm_dtype, opt_cus=opt_cus,
                                    emulate=dict(world=emu_world, cus=self.comm_cus or COMM_CUS_DEFAULT, comm_bytes=cb) if emu_world > 1 else None)
         self.metrics_buf = torch.zeros(2, dtype=torch.float32, device=model.device)
+        self._pos = {}
 
     def _adamw_slice(self, b: int, e: int):
         """AdamW on flat slice [b, e) — runs on the reducer's side stream right after that bucket's all-reduce.  The part of the
@@ -573,7 +574,9 @@ class Trainer:
         mask = m._dev(batch["attention_mask"], torch.int32)
         dec_in = m._dev(batch["decoder_input_ids"], torch.int32)
         B, T = labels.shape
-        pos = torch.arange(T, dtype=torch.int32, device=m.device)[None].expand(B, T).contiguous()
+        pos = self._pos.get((B, T))  # position ids 0 .. T-1 per sequence: built once per batch shape (two launches per step otherwise)
+        if pos is None:
+            pos = self._pos[(B, T)] = torch.arange(T, dtype=torch.int32, device=m.device)[None].expand(B, T).contiguous()
         rows = row_labels = None
         pk = batch.get("packed_rows") if self.pack_rows else None
         if self.compact_head:
