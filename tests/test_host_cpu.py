@@ -372,6 +372,24 @@ def _ddp_worker(rank, world, port, q):
     red.finish()
     expect = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
     ok = torch.equal(g, expect) and red.next == len(buckets) and sum(fired) == len(buckets) and ok16
+    # the host side of one step's exchange at the bucket count of the real layout (25): what GradReducer.progress / finish cost the
+    # issuing thread (bench.py puts the figure next to host_issue_ms_per_step; over RCCL the enqueue is asynchronous like this one)
+    n25 = 25 * 4096
+    g25 = torch.ones(n25) * (rank + 1)
+    r25 = GradReducer(g25, [(i * 4096, (i + 1) * 4096) for i in range(25)])
+    issue, total = [], []
+    for _ in range(5):
+        g25.fill_(float(rank + 1))
+        r25.start_step()
+        for i in range(25):
+            r25.progress((i + 1) * 4096)
+        issue.append(r25.host_s * 1e3)   # 25 asynchronous collectives issued
+        r25.finish()                      # (CPU tensors: finish() also WAITS for the collectives; on the GPU it only enqueues)
+        total.append(r25.host_s * 1e3)
+    ok = ok and torch.equal(g25, torch.ones(n25) * sum(r + 1 for r in range(world))) and 0.0 < min(issue) < min(total) < 200.0
+    if rank == 0:
+        print(f"[reducer host side, gloo world {world}, 25 buckets] issue {min(issue):.3f} ms per step, with the waits {min(total):.3f} ms "
+              "(best of 5)", flush=True)
     # pmean of per-rank masked means (main.py:679, 698): mean of means, not a token-weighted global mean
     m = torch.tensor([float(rank + 1), 0.0])
     dist.all_reduce(m)
