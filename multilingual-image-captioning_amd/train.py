@@ -683,6 +683,10 @@ class Trainer:
             # stream of its own — it has the whole next forward pass to finish (engine.shared_T waits for it)
             eng.refresh_shared_T(ops.role_stream(m.device, "aux"), st.version)
         self.step += 1
+        if self.world == 1:
+            # one launch instead of three (two copies + a clone) in the gap between two steps; fresh storage per step (callers keep these)
+            out = torch.cat((loss.reshape(1), self.hyper[0:1]))
+            return {"loss": out[0], "learning_rate": out[1]}
         self.metrics_buf[0:1].copy_(loss)
         self.metrics_buf[1:2].copy_(self.hyper[0:1])  # lr, device to device (a Python scalar assigned into a device tensor syncs)
         return self._pmean_metrics()
