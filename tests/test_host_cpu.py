@@ -526,3 +526,17 @@ def test_bleu_known_answers():
     dec = lambda rows: [" ".join(vocab[t] for t in row if t in vocab) for row in rows]
     m = compute_metrics([[2, 5, 6, 7, 8, 2, 1]], [[250004, 5, 6, 7, 8, 2, 1]], dec)
     assert m == {"BLEU-1": 1.0, "BLEU-2": 1.0, "BLEU-3": 1.0, "BLEU-4": 1.0}
+
+
+def test_tool_scripts_parse():
+    """the shell scripts under tools/ (profiling passes, A/B drivers, the first-multi-GPU-lease script nobody has been able to run yet)
+    at least parse, and the Python tools compile"""
+    import glob
+    import py_compile
+    import subprocess
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "tools", "*.sh"))):
+        r = subprocess.run(["bash", "-n", f], capture_output=True, text=True)
+        assert r.returncode == 0, (f, r.stderr)
+    for f in sorted(glob.glob(os.path.join(ROOT, "tools", "*.py"))):
+        py_compile.compile(f, doraise=True)
