@@ -290,7 +290,8 @@ int mic_ce_bwd_t(int rows, int V, int Vpad, void* logits, int ld, const int32_t*
                  const float* row_lse, const float* denom, float loss_scale, void* dlogits_t, int ld_t, int rows_pad, float* colsum,
                  void* stream);
 /* dst[c][r] = src[r][c] (bf16), r < rows, c < cols; dst columns rows .. rows_pad (a multiple of 64; 0 = rows rounded up to 64) are
- * written as zeros (the padding of a GEMM's reduction dimension).  cols, ld_src, ld_dst multiples of 8; ld_dst >= rows_pad; 16-B
+ * written as zeros (the padding of a GEMM's reduction dimension).  Makes h^T and E^T, the k-contiguous operands of the tied head's
+ * backward (modeling:170-174; the reference leaves operand layouts to XLA).  cols, ld_src, ld_dst multiples of 8; ld_dst >= rows_pad; 16-B
  * aligned operands. */
 int mic_transpose_bf16(int rows, int rows_pad, int cols, const void* src, int ld_src, void* dst, int ld_dst, void* stream);
 
