@@ -123,10 +123,10 @@ def _cpu_oracle_params():
     return _CPU_PARAMS["rc"], _CPU_PARAMS["p"]
 
 
-def cpu_baseline_train(budget_s=10.0):
+def cpu_baseline_train(budget_s=14.0, B=4, min_timed=3):
     """The oracle (torch-CPU fp32 restatement of the reference path; NOT Flax) on this box's host cores: train step
-    (fwd + bwd + AdamW) images/s at B=8 on the full-size model.  Bounded sample: one warm-up iteration, then timed iterations
-    until `budget_s` of timed work (both CPU legs together stay near 30 s; the sample actually taken is stated)."""
+    (fwd + bwd + AdamW) images/s at B=4 on the full-size model.  Bounded sample: one warm-up iteration, then at least `min_timed`
+    timed iterations and as many more as fit into `budget_s` of timed work; the spread of the per-iteration rates is stated."""
     import torch
 
     from oracle import train_ref
@@ -137,10 +137,10 @@ def cpu_baseline_train(budget_s=10.0):
     p = dict(p0)
     m = {k: torch.zeros_like(v) for k, v in p.items()}
     v2 = {k: torch.zeros_like(v) for k, v in p.items()}
-    b = synth_batch(8, 64, rc.vocab_size, rc.image_size, 7)
+    b = synth_batch(B, 64, rc.vocab_size, rc.image_size, 7)
     t = {k: torch.from_numpy(v) for k, v in b.items()}
-    n, t_used, warm, n_warm = 0, 0.0, 0, 1
-    for it in range(11):
+    times, warm, n_warm = [], 0, 1
+    for it in range(12):
         t0 = time.time()
         _, g = train_ref.loss_and_grads(rc, p, t["pixel_values"], t["input_ids"], t["attention_mask"], t["decoder_input_ids"])
         with torch.no_grad():
@@ -151,18 +151,20 @@ def cpu_baseline_train(budget_s=10.0):
         if it < n_warm:
             warm += 1
             continue
-        n += 8
-        t_used += dt
-        if t_used + dt > budget_s:
+        times.append(dt)
+        if len(times) >= min_timed and sum(times) + dt > budget_s:
             break
-    return {"value": round(n / t_used, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"oracle (torch-CPU fp32 restatement, not Flax) train step fwd+bwd+AdamW, full-size model, B=8, "
-                      f"{warm} warm-up + {n // 8} timed iterations (cut at {budget_s:.0f} s of timed work), {cores} threads of {os.cpu_count()} logical CPUs"}
+    rates = [B / x for x in times]
+    return {"value": round(B * len(times) / sum(times), 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "min": round(min(rates), 3), "max": round(max(rates), 3), "timed_iterations": len(times),
+            "sample": f"oracle (torch-CPU fp32 restatement, not Flax) train step fwd+bwd+AdamW, full-size model, B={B}, "
+                      f"{warm} warm-up + {len(times)} timed iterations ({sum(times):.1f} s of timed work; value = images / total time, min / max = "
+                      f"slowest / fastest iteration), {cores} threads of {os.cpu_count()} logical CPUs"}
 
 
-def cpu_baseline_beam(budget_s=10.0):
-    """Beam-4 captions/s of the oracle at B=8 (evaluation.py:80-94 shape: num_beams 4, max_length 64, forced BOS), one call.
-    Bounded: when the first 3 decoder steps predict more than `budget_s` for 63 steps, max_length is shortened and said so."""
+def cpu_baseline_beam(budget_s=14.0):
+    """Beam-4 captions/s of the oracle at B=8 (evaluation.py:80-94 shape: num_beams 4, max_length 64, forced BOS), two timed calls.
+    Bounded: when the first 3 decoder steps predict more than `budget_s` for the two calls, max_length is shortened and said so."""
     import numpy as np
     import torch
 
@@ -189,14 +191,21 @@ def cpu_baseline_beam(budget_s=10.0):
     t4, _ = run(4)  # warm-up and probe: encoder + 3 steps
     note(f"cpu baseline (beam-4) probe of 3 steps: {t4:.1f} s")
     # the first steps of a call are the cheap ones (measured on the pool's hosts: 0.2 s per step in the probe, 0.67 s per step over
-    # a 49-step call): budget with 3.3 x the probe's figure
+    # a 49-step call): budget with 3.3 x the probe's figure.  TWO timed calls share the budget, so the line carries a spread.
     per_step = 3.3 * t4 / 4.0
-    L = 64 if per_step * 63 <= budget_s else max(6, int(budget_s / per_step))
-    dt, steps = run(L)
-    scale = 63.0 / steps  # captions/s for the full 63-step caption, extrapolated linearly when shortened
-    return {"value": round(B / (dt * scale), 4), "unit": "captions/sec", "cores": cores, "kind": "port",
-            "sample": f"oracle (torch-CPU fp32 restatement, not Flax) beam-4 generate, full-size model, B=8, max_length {L} "
-                      f"({steps} decoder steps in {dt:.1f} s" + ("" if L == 64 else ", scaled to 63 steps") + f"), 1 call after a 3-step warm-up, {cores} threads of {os.cpu_count()} logical CPUs"}
+    calls = 2
+    L = 64 if per_step * 63 * calls <= budget_s else max(6, int(budget_s / calls / per_step))
+    vals, tot_t, tot_steps = [], 0.0, 0
+    for _ in range(calls):
+        dt, steps = run(L)
+        note(f"cpu baseline (beam-4) call of {steps} steps: {dt:.1f} s")
+        vals.append(B / (dt * 63.0 / steps))  # captions/s for the full 63-step caption, extrapolated linearly when shortened
+        tot_t, tot_steps = tot_t + dt, tot_steps + steps
+    return {"value": round(calls * B / (tot_t * 63.0 * calls / tot_steps), 4), "unit": "captions/sec", "cores": cores, "kind": "port",
+            "min": round(min(vals), 4), "max": round(max(vals), 4), "timed_calls": calls,
+            "sample": f"oracle (torch-CPU fp32 restatement, not Flax) beam-4 generate, full-size model, B={B}, max_length {L} "
+                      f"({calls} timed calls of {tot_steps // calls} decoder steps, {tot_t:.1f} s together" + ("" if L == 64 else ", scaled to 63 steps")
+                      + f"; min / max = the two calls), after a 3-step warm-up call, {cores} threads of {os.cpu_count()} logical CPUs"}
 
 
 # ---------------------------------------------------------------------------------------------- beam-4 leg
@@ -354,7 +363,7 @@ def pmc_traffic(argv, kernel_prefix="gemm_"):
         env = {k: v for k, v in os.environ.items() if k not in drop and not k.startswith(("MASTER_", "TORCHELASTIC_"))}
         env["TMPDIR"] = "/tmp"
         cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__)] + \
-              child_argv + ["--steps", "1", "--warmup", "1", "--no-roofline", "--no-generate", "--no-cpu-baseline", "--no-dense-leg", "--emulate-comm", "0"]
+              child_argv + ["--steps", "1", "--warmup", "1", "--no-roofline", "--no-generate", "--no-cpu-baseline", "--no-dense-leg", "--no-extra-legs", "--emulate-comm", "0"]
         subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
         n = 0
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -393,6 +402,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-generate", action="store_true", help="skip the beam-4 captions/sec leg")
     ap.add_argument("--no-dense-leg", action="store_true", help="skip the short dense-caption timing reported beside the headline")
+    ap.add_argument("--no-fp8-leg", action="store_true", help="skip the configs[4] (fp8 GEMMs) step timed in a child process beside the bf16 headline")
+    ap.add_argument("--no-extra-legs", action="store_true", help="profiling / A-B aid: only the timed region (no idle-GPU issue timing, no host-batch "
+                    "(h2d_inclusive) leg, no fp8 leg) — the step count of a kernel trace is then exactly warmup + steps")
     ap.add_argument("--gen-batch", type=int, default=256)
     ap.add_argument("--generate-only", action="store_true", help="profiling aid: only the beam-4 leg")
     ap.add_argument("--pmc-traffic", action="store_true", help="measure roofline.traffic now (two rocprofv3 child passes, ~2 min)")
@@ -521,6 +533,75 @@ def main():
         dt = float(tmax.item())
     images_per_sec = world * B * args.steps / dt
 
+    # host time to ISSUE one step with the GPU idle (queue empty at the start: no back-pressure; `host_loop_ms_per_step` above is the
+    # figure of a loop whose queue is full, i.e. it mostly measures the GPU): median of 3, each behind a device sync
+    issue_idle = []
+    for i in range(0 if args.no_extra_legs else 3):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        tr.train_step(dbatches[i % 2])
+        issue_idle.append(time.perf_counter() - t1)
+    barrier()
+    issue_idle_ms = sorted(issue_idle)[1] * 1e3 if issue_idle else None
+
+    # the step as main.py:773-775 pays it: the batch arrives in HOST memory every iteration.  Pinned host buffers, the copy of batch
+    # i+1 on a copy stream beside step i (two device slots), the step waits for its own batch's event.  Reported beside the
+    # headline (`value` keeps the inputs resident, as the bench contract asks); never part of `value`.
+    h2d = None
+    if not args.emulate_main and not args.no_extra_legs:
+        pinned = []
+        for b, db in zip(batches, dbatches):
+            hp = {k: torch.from_numpy(v).pin_memory() for k, v in b.items()}
+            for k in ("loss_rows", "packed_rows"):
+                if k in db:
+                    hp[k] = tuple(t.cpu().pin_memory() for t in db[k])
+            pinned.append(hp)
+        slots = [{k: (tuple(torch.empty_like(t, device=dev) for t in v) if isinstance(v, tuple) else torch.empty_like(v, device=dev))
+                  for k, v in hp.items()} for hp in pinned]
+        copy_stream = torch.cuda.Stream(device=dev)
+        done = [None, None]
+
+        def stage(i):
+            with torch.cuda.stream(copy_stream):
+                if done[i % 2] is not None:
+                    copy_stream.wait_event(done[i % 2])  # the step that last read this slot
+                for k, v in pinned[i % 2].items():
+                    if isinstance(v, tuple):
+                        for dst, src in zip(slots[i % 2][k], v):
+                            dst.copy_(src, non_blocking=True)
+                    else:
+                        slots[i % 2][k].copy_(v, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            return ev
+
+        def inclusive(nsteps):
+            ev = stage(0)
+            for i in range(nsteps):
+                torch.cuda.current_stream().wait_event(ev)
+                if i + 1 < nsteps:
+                    ev = stage(i + 1)
+                tr.train_step(slots[i % 2])
+                d = torch.cuda.Event()
+                d.record()
+                done[i % 2] = d
+
+        inclusive(2)
+        barrier()
+        t1 = time.perf_counter()
+        inclusive(args.steps)
+        barrier()
+        hdt = time.perf_counter() - t1
+        if world > 1:
+            tmax = torch.tensor([hdt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            hdt = float(tmax.item())
+        mb = sum(v.numel() * v.element_size() for v in pinned[0].values() if not isinstance(v, tuple)) / 1e6
+        h2d = {"ms_per_step": round(hdt / args.steps * 1e3, 3), "images_per_sec": round(world * B * args.steps / hdt, 1), "steps": args.steps,
+               "note": f"the same step with every batch copied from pinned host memory inside the timed loop ({mb:.1f} MB per step; main.py:773-775 "
+                       "shards the host batch onto the devices every iteration): batch i+1 travels on a copy stream beside step i"}
+        del slots, pinned
+
     # the same step on dense captions (every caption 62 tokens: no padded label positions, the configuration BASELINE.md §4's
     # "padding not discounted" FLOP count describes) — a second, shorter timed region on every rank, reported beside the headline
     dense, db2 = None, None
@@ -638,7 +719,10 @@ def main():
         kname = {"bf16": "gemm_bf16_kernel + gemm_w4_kernel + gemm_d2_kernel (every GEMM launch of the step)", "f32": "gemm_f32_kernel", "fp8": "gemm_bf16_kernel + gemm_fp8_kernel"}[args.dtype]
         roofline = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": len(recs), "gemm_ms_per_step": round(ms, 3),
-                    "gemm_gflop_per_step": round(flops / 1e9, 1)}
+                    "gemm_gflop_per_step": round(flops / 1e9, 1),
+                    # the whole step against the same peak: every executed GEMM FLOP of the instrumented step over the TIMED ms_per_step
+                    # (attention, LayerNorm, loss, optimizer and every gap count as time, not as work)
+                    "whole_step_frac": round(flops / (dt / args.steps) / 1e12 / peak, 4)}
         if dense is not None and "roofline_frac" in dense:
             roofline["note"] = ("with packed decoder rows the executed GEMM FLOPs fall faster than the GEMM time (the one-round launches of "
                                 "the N = 1024 projections are latency-bound: fewer tiles, same duration), so this fraction sits below the "
@@ -717,7 +801,7 @@ def main():
         env = {k: v for k, v in os.environ.items() if k not in drop and not k.startswith(("MASTER_", "TORCHELASTIC_"))}
         for ew in emu_worlds:
             cmd = [sys.executable, os.path.abspath(__file__), "--emulate-main", str(ew), "--emulate-comm", "0", "--steps", "6", "--warmup", "3",
-                   "--no-generate", "--no-cpu-baseline", "--no-roofline", "--no-dense-leg", "--dtype", args.dtype, "--grad-comm", args.grad_comm,
+                   "--no-generate", "--no-cpu-baseline", "--no-roofline", "--no-dense-leg", "--no-extra-legs", "--dtype", args.dtype, "--grad-comm", args.grad_comm,
                    "--batch", str(args.batch)] + (["--small"] if args.small else []) + (["--comm-cus", str(args.comm_cus)] if args.comm_cus is not None else [])
             try:
                 r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -727,6 +811,26 @@ def main():
                 emulated["worlds"][str(ew)] = {"ms_per_step": cd["ms_per_step"], "images_per_sec_per_gpu": cd["value"], **e}
             except Exception as ex:  # a reported figure, never a dependency of the headline number
                 emulated["worlds"][str(ew)] = {"ms_per_step": None, "error": f"{type(ex).__name__}: {ex}"[:300]}
+
+    # configs[4] beside the headline: the same step with the QKV / FFN projections as fp8 GEMMs, in a fresh child process (one Trainer
+    # per process, like a data-parallel rank), so the driver's record carries it
+    fp8_leg = None
+    if rank == 0 and world == 1 and args.dtype == "bf16" and not args.no_fp8_leg and not args.no_extra_legs and not args.small and not args.emulate_main and not args.dense_captions:
+        note("fp8 leg (child process)")
+        torch.cuda.synchronize()
+        drop = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE")
+        env = {k: v for k, v in os.environ.items() if k not in drop and not k.startswith(("MASTER_", "TORCHELASTIC_"))}
+        cmd = [sys.executable, os.path.abspath(__file__), "--dtype", "fp8", "--steps", str(args.steps), "--warmup", str(max(args.warmup, 3)), "--no-generate",
+               "--no-cpu-baseline", "--no-dense-leg", "--no-extra-legs", "--emulate-comm", "0", "--batch", str(args.batch)] + (["--no-roofline"] if args.no_roofline else [])
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+            cd = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+            fp8_leg = {"metric": "train images/sec, configs[4]: QKV / FFN projections of both towers as OCP fp8 GEMMs (e4m3 forward, e5m2 gradients, delayed "
+                                 "per-tensor scaling, fp32 accumulate), everything else as in the headline step",
+                       "value": cd["value"], "unit": "images/sec", "ms_per_step": cd["ms_per_step"], "steps": cd["steps"], "final_loss": cd["final_loss"],
+                       "vs_bf16_same_box": round(cd["value"] / images_per_sec, 4), "roofline": cd.get("roofline")}
+        except Exception as ex:  # a reported figure, never a dependency of the headline number
+            fp8_leg = {"value": None, "error": f"{type(ex).__name__}: {ex}"[:300]}
 
     if rank == 0:
         # executed work: the LM head (forward, dE, dX: 3 x 2 x rows x V x d) runs only on the label positions that carry loss
@@ -755,7 +859,9 @@ def main():
                        "decoder_rows": ("valid caption positions only (packed rows: padded positions neither carry loss nor are attended to — exact; "
                                         f"{n_loss:.0f} of {B * T} rows per step)" if (tr.pack_rows and args.dtype in ("bf16", "fp8") and not args.dense_captions) else f"all {B * T} positions"),
                        "lm_head": head, "gemm_dtype": "fp8 e4m3 (fwd) / e5m2 (grads) for QKV+FFN, bf16 elsewhere" if args.dtype == "fp8" else args.dtype},
-            "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 3),
+            "host_issue_ms_per_step": None if issue_idle_ms is None else round(issue_idle_ms, 3),  # host time to enqueue ONE step on an idle GPU (median of 3): the host's real share
+            "host_loop_ms_per_step": round(t_issue / args.steps * 1e3, 3),  # the timed loop's host side with the queue full (back-pressured by the GPU: NOT the host's cost)
+            "h2d_inclusive": h2d,
             "reducer_host_ms_per_step": round(reducer_host_ms, 3),  # of which inside GradReducer.progress / finish (last timed step: bucket events, exchanges, optimizer passes)
             "model_tflops_per_gpu": round(step_flops * args.steps / dt / 1e12, 1),
             "model_tflops_note": f"EXECUTED model FLOPs per step ({step_flops / 1e12:.2f} TF: dense {dense_flops / 1e12:.2f} TF of SURVEY 8d minus the LM-head "
@@ -763,7 +869,7 @@ def main():
                                  + (" and which no valid position attends to" if packed else "") + ") / ms_per_step; dense_equivalent divides the full dense count "
                                  "by the same time (NOT executed work); dense_captions is the measured step when every position carries loss",
             "dense_equivalent_tflops_per_gpu": round(dense_flops * args.steps / dt / 1e12, 1),
-            "dense_captions": dense,
+            "dense_captions": dense, "fp8_train": fp8_leg,
             "comm_emulated": emulated, "emulation": emulation,
             "final_loss": round(loss, 4),
             "roofline": roofline, "cpu_baseline": cpu, "beam4_generate": gen,

@@ -10,9 +10,18 @@
  *
  * Conventions
  *  - All pointers are caller-owned DEVICE pointers; outputs and workspaces are caller-allocated.
- *  - Every call is asynchronous on `stream` (a hipStream_t passed as void*); no global mutable state,
- *    re-entrant across streams/threads.  Return 0 on success, negative MIC_E* on bad arguments
- *    (never throws, never exits); mic_last_error() gives a thread-local message.
+ *  - Every call is asynchronous on `stream` (a hipStream_t passed as void*) and re-entrant across streams and
+ *    threads.  State the library keeps between calls, all of it host-side planning state (no device memory):
+ *      (1) the GEMM tile planner's CU budget — THREAD-LOCAL, set by mic_set_cu_budget (0 = default), read by
+ *          the mic_gemm* calls of the same thread and by mic_get_cu_budget / mic_gemm_plan;
+ *      (2) A/B switches read ONCE per process from the environment at the first GEMM call and latched:
+ *          MIC_FREE_CUS, MIC_GEMM_TILE, MIC_TINY_BELOW, MIC_GEMM_QUANT, MIC_GEMM_T192, MIC_GEMM_PHASED,
+ *          MIC_GEMM_W4, MIC_GEMM_D2, MIC_GEMM_KG, MIC_GEMM_KG128, MIC_GEMM_PERSIST (tools/README.md; the
+ *          defaults are the measured best, nothing on the product path sets them);
+ *      (3) per-device one-time attributes of the kernels (dynamic-LDS size) and the thread-local
+ *          mic_last_error() message.
+ *    Nothing else: no caches of caller pointers, no hidden workspaces, no streams of its own.
+ *    Return 0 on success, negative MIC_E* on bad arguments (never throws, never exits).
  *  - Activations are row-major [rows][width]; `dtype` selects the storage type of activations
  *    (MIC_BF16 = bf16 storage, fp32 accumulate/statistics;  MIC_F32 = the reference's default dtype).
  *  - Linear weights are stored [out][in] (k-contiguous); LayerNorm / bias vectors and optimizer state fp32.

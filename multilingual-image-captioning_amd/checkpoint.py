@@ -1,7 +1,8 @@
 """Checkpoint wire format of the reference: `flax_model.msgpack` (flax.serialization.to_bytes/from_bytes:
-msgpack with ndarray ext-type 1 = (shape, dtype name, raw bytes)) + `config.json`
-(`modeling_clip_vision_utils.py:323-333, 441-445`).  flax is not installed here; the format is restated from its
-published serializer and round-trip tested (tests/test_host_cpu.py).  Also here: PyTorch-checkpoint ingestion for
+msgpack with ext-type 1 = ndarray (shape, dtype name, raw bytes), 2 = Python complex, 3 = numpy scalar, and leaves above 2^30
+bytes cut into `__msgpack_chunked_array__` dicts) + `config.json` (`modeling_clip_vision_utils.py:323-333, 441-445`).  flax is
+not installed here; the format is restated from its published serializer, pinned on hand-assembled bytes and round-trip
+tested (tests/test_host_cpu.py).  Also here: PyTorch-checkpoint ingestion for
 `mbart_from_pt=True` (`modeling_clip_vision_utils.py:318-321`, `main.py:426`) and the optimizer/step files of
 `save_model_checkpoint(with_opt=True)` / `restore_model_checkpoint` (`main.py:299-345`)."""
 from __future__ import annotations
@@ -13,41 +14,92 @@ from types import SimpleNamespace
 import msgpack
 import numpy as np
 
-_EXT_NDARRAY = 1
+# flax.serialization's msgpack extension types (its `_MsgpackExtType`): an ndarray as (shape, dtype name, C-order bytes); a Python
+# complex as (real, imag); a numpy scalar as a 0-d ndarray payload that the reader unwraps with `ar[()]`
+_EXT_NDARRAY, _EXT_NATIVE_COMPLEX, _EXT_NPSCALAR = 1, 2, 3
+# leaves above this many BYTES travel as {"__msgpack_chunked_array__": True, "shape": {"0": ..}, "chunks": {"0": ndarray, ..}} (msgpack's
+# bin format ends at 2^32 - 1 bytes; flax cuts at 2^30).  The 250 054 x 1024 fp32 embedding is 1.02e9 bytes: just under, one piece.
+MAX_CHUNK_SIZE = 2 ** 30
+_CHUNK_KEY = "__msgpack_chunked_array__"
 
 
-def _np_dtype(name: str):
-    if name == "bfloat16":
-        return None
-    return np.dtype(name)
+def _ndarray_payload(a: np.ndarray) -> bytes:
+    if a.dtype.hasobject:
+        raise ValueError("object arrays cannot be serialised")
+    return msgpack.packb((list(a.shape), a.dtype.name, a.tobytes("C")), use_bin_type=True)
+
+
+def _ndarray_from_payload(data: bytes):
+    shape, dtype_name, buf = msgpack.unpackb(data, raw=False)
+    if dtype_name == "bfloat16":  # numpy has no bfloat16: widen (exact) to float32
+        u = np.frombuffer(buf, dtype=np.uint16).astype(np.uint32) << 16
+        return u.view(np.float32).reshape(shape)
+    return np.frombuffer(buf, dtype=np.dtype(dtype_name)).reshape(shape).copy()
 
 
 def _encode(obj):
-    if isinstance(obj, np.ndarray) or np.isscalar(obj) and not isinstance(obj, (int, float, bool, str, bytes)):
-        a = np.asarray(obj)
-        payload = msgpack.packb((list(a.shape), a.dtype.name, a.tobytes()), use_bin_type=True)
-        return msgpack.ExtType(_EXT_NDARRAY, payload)
+    if isinstance(obj, np.ndarray):
+        return msgpack.ExtType(_EXT_NDARRAY, _ndarray_payload(obj))
+    if isinstance(obj, np.generic):
+        return msgpack.ExtType(_EXT_NPSCALAR, _ndarray_payload(np.asarray(obj)))
+    if isinstance(obj, complex):
+        return msgpack.ExtType(_EXT_NATIVE_COMPLEX, msgpack.packb((obj.real, obj.imag)))
     raise TypeError(f"cannot serialise {type(obj)}")
 
 
 def _decode(code, data):
     if code == _EXT_NDARRAY:
-        shape, dtype_name, buf = msgpack.unpackb(data, raw=False)
-        if dtype_name == "bfloat16":
-            u = np.frombuffer(buf, dtype=np.uint16).astype(np.uint32) << 16
-            return u.view(np.float32).reshape(shape)
-        return np.frombuffer(buf, dtype=np.dtype(dtype_name)).reshape(shape).copy()
+        return _ndarray_from_payload(data)
+    if code == _EXT_NATIVE_COMPLEX:
+        re, im = msgpack.unpackb(data)
+        return complex(re, im)
+    if code == _EXT_NPSCALAR:
+        return _ndarray_from_payload(data)[()]
     return msgpack.ExtType(code, data)
+
+
+def _chunk(a: np.ndarray, max_bytes: int):
+    n = max(1, int(max_bytes / a.dtype.itemsize))
+    flat = a.reshape(-1)
+    return {_CHUNK_KEY: True, "shape": {str(i): int(x) for i, x in enumerate(a.shape)},
+            "chunks": {str(i): flat[b: b + n] for i, b in enumerate(range(0, flat.size, n))}}
+
+
+def _chunk_leaves(tree, max_bytes: int):
+    if isinstance(tree, dict):
+        return {k: _chunk_leaves(v, max_bytes) for k, v in tree.items()}
+    if isinstance(tree, np.ndarray) and tree.size * tree.dtype.itemsize > max_bytes:
+        return _chunk(tree, max_bytes)
+    return tree
+
+
+def _unchunk_leaves(tree):
+    if not isinstance(tree, dict):
+        return tree
+    if _CHUNK_KEY in tree:
+        shape = tuple(tree["shape"][str(i)] for i in range(len(tree["shape"])))
+        return np.concatenate([tree["chunks"][str(i)] for i in range(len(tree["chunks"]))]).reshape(shape)
+    return {k: _unchunk_leaves(v) for k, v in tree.items()}
+
+
+def to_bytes(tree, max_chunk_bytes: int = MAX_CHUNK_SIZE) -> bytes:
+    """`flax.serialization.msgpack_serialize` of a nested dict of numpy leaves"""
+    return msgpack.packb(_chunk_leaves(tree, max_chunk_bytes), default=_encode, use_bin_type=True, strict_types=True)
+
+
+def from_bytes(data: bytes):
+    """`flax.serialization.msgpack_restore`: ext types 1 / 2 / 3 and chunked leaves"""
+    return _unchunk_leaves(msgpack.unpackb(data, ext_hook=_decode, raw=False, strict_map_key=False))
 
 
 def save_flax_msgpack(path: str, tree) -> None:
     with open(path, "wb") as f:
-        f.write(msgpack.packb(tree, default=_encode, use_bin_type=True, strict_types=False))
+        f.write(to_bytes(tree))
 
 
 def load_flax_msgpack(path: str):
     with open(path, "rb") as f:
-        return msgpack.unpackb(f.read(), ext_hook=_decode, raw=False, strict_map_key=False)
+        return from_bytes(f.read())
 
 
 # ---------------------------------------------------------------------------------------------- PyTorch checkpoints

@@ -160,7 +160,7 @@ static bool any_rowsum_early(const mic_gemm_args* args, int count) {
 // device (256 on MI355X); a data-parallel job whose collectives occupy CUs (RCCL's channels are persistent blocks, one CU each)
 // lowers it — `mic_set_cu_budget`, or MIC_FREE_CUS in the environment — so that a launch sized for 256 free CUs re-plans
 // (fewer K-groups, i.e. more blocks per CU) instead of spilling a few blocks into a second round.
-static int g_cu_budget = 0;
+static thread_local int g_cu_budget = 0;  // per calling thread: two host threads driving two streams plan independently
 int mic_cu_budget_now() {
   static const int env = [] { const char* e = getenv("MIC_FREE_CUS"); return e ? atoi(e) : 0; }();
   int c = g_cu_budget > 0 ? g_cu_budget : (env > 0 ? env : 256);

@@ -664,8 +664,15 @@ class Engine:
             # fills the chip; one fp32 slab per split, summed and rounded to bf16 once
             tiles = ((Mh + 255) // 256) * ((d + 255) // 256)
             nsp = max(1, min(ops.get_cu_budget() // tiles, P.Vpad // 128 // 2))
-            d32 = self.buf("db.dhf32", nsp * _rup(Mcap, ROWPAD), d, torch.float32)
-            slab = _rup(Mcap, ROWPAD) * d
+            # ONE workspace whatever this batch's row count: a slab is as tall as the valid rows (rounded to the tile), and
+            # nsp * slab rows <= budget / (d / 256) tile rows — a buffer keyed on nsp would add ~100 MB per distinct split seen
+            # during training on ragged batches.  (The split itself follows Mh: the fp32 summation order of dX is a function of
+            # the batch's row count, like every tile choice of the planner.)
+            slab_rows = _rup(Mh, 256)
+            cap_rows = max(_rup(Mcap, 256), (256 // max(1, (d + 255) // 256)) * 256)
+            d32 = self.buf("db.dhf32", cap_rows, d, torch.float32)
+            assert nsp * slab_rows <= d32.shape[0], (nsp, slab_rows, d32.shape)
+            slab = slab_rows * d
             ops.gemm(dlogits, self.shared_T(), d32, Mh, d, P.Vpad, split_k=nsp, split_stride=slab if nsp > 1 else 0)
             if nsp > 1:
                 ops.sum_slabs(d32, nsp, slab, dhc, Mh, d, d32.stride(0), dhc.stride(0))
@@ -840,6 +847,8 @@ class Engine:
         ET = self.buf("w.sharedT", P.d, P.Vpad)
         ver = getattr(P, "version", 0)
         if self._ET_version != ver:
+            if self._ET_event is not None:  # a side-stream refresh of an older version may still be writing this buffer
+                torch.cuda.current_stream().wait_event(self._ET_event)
             ops.transpose_bf16(P.w("shared"), ET, P.Vpad, P.d)
             self._ET_version, self._ET_event = ver, None
         elif self._ET_event is not None:

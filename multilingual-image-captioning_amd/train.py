@@ -163,20 +163,42 @@ def rccl_channel_cap() -> int:
         return 0
 
 
-def allreduce_ms(nbytes: float, world: int, link_gbps: float = XGMI_LINK_GBPS) -> float:
-    """ring all-reduce of `nbytes` per rank over the world-1 xGMI links of a GPU: every rank sends and receives 2 (world-1)/world
-    of its bytes, spread over world-1 links"""
+XGMI_LINK_PEAK_GBPS = 153.0  # per peer link as the hardware guide and SURVEY §5 quote it (the optimistic end of the projection)
+
+
+def allreduce_ms(nbytes: float, world: int, link_gbps: float = XGMI_LINK_GBPS, algo: str = "all_links") -> float:
+    """PROJECTED all-reduce time of `nbytes` per rank among `world` fully connected GPUs (no N > 1 hardware run has been possible:
+    a byte-count model, not a measurement).
+    algo="all_links" (default): every rank sends and receives 2 (world-1)/world of its bytes spread over its world-1 peer links —
+      what a direct reduce-scatter + all-gather does, and what world-1 concurrent rings do: 2 nbytes / (world * link).
+    algo="ring_one_link": a single classic ring, one link per direction: 2 (world-1)/world * nbytes / link.
+    `link_gbps`: XGMI_LINK_GBPS (64, the conservative default: what RCCL rings have been seen to get out of one link) or
+    XGMI_LINK_PEAK_GBPS (153, SURVEY §5's direct RS + AG figure: 3.6 ms for the 2.19 GB fp32 gradient at N = 8)."""
     if world <= 1:
         return 0.0
-    return 2.0 * (world - 1) / world * nbytes / ((world - 1) * link_gbps * 1e9) * 1e3
+    if algo == "ring_one_link":
+        return 2.0 * (world - 1) / world * nbytes / (link_gbps * 1e9) * 1e3
+    if algo != "all_links":
+        raise ValueError(f"unknown all-reduce model {algo!r}")
+    return 2.0 * nbytes / (world * link_gbps * 1e9) * 1e3
 
 
-def choose_comm_dtype(world: int, numel: int, window_ms: float = BACKWARD_WINDOW_MS) -> Optional[torch.dtype]:
+def allreduce_projections(nbytes: float, world: int) -> Dict[str, float]:
+    """the bracket the byte-count model gives: pessimistic (all links at 64 GB/s — what `choose_comm_dtype` and the emulated
+    exchange use), optimistic (direct reduce-scatter + all-gather over all links at 153 GB/s) and a single ring"""
+    return {"all_links_64GBps_ms": round(allreduce_ms(nbytes, world), 2),
+            "direct_rs_ag_153GBps_ms": round(allreduce_ms(nbytes, world, XGMI_LINK_PEAK_GBPS), 2),
+            "single_ring_153GBps_ms": round(allreduce_ms(nbytes, world, XGMI_LINK_PEAK_GBPS, "ring_one_link"), 2)}
+
+
+def choose_comm_dtype(world: int, numel: int, window_ms: float = BACKWARD_WINDOW_MS, link_gbps: float = XGMI_LINK_GBPS) -> Optional[torch.dtype]:
     """`grad_comm_dtype="auto"`: fp32 — the reference's `lax.pmean` of fp32 gradients (main.py:698) — wherever the projected fp32
     exchange fits under backward, bf16 where it would not (the step would be communication-bound; a bf16 sum changes pmean's
-    arithmetic by one rounding per rank and element, tests/test_ddp_gpu.py).  By the byte counts of the 547 M-parameter model:
-    N = 2: 34 ms, N = 4: 17 ms -> bf16 (17 / 8.5 ms); N = 8: 8.5 ms -> fp32."""
-    if world <= 1 or allreduce_ms(4.0 * numel, world) <= window_ms:
+    arithmetic by one rounding per rank and element, tests/test_ddp_gpu.py).  By the byte counts of the 547 M-parameter model at
+    the conservative 64 GB/s per link: N = 2: 34 ms, N = 4: 17 ms -> bf16 (17 / 8.5 ms); N = 8: 8.5 ms -> fp32.  With
+    `link_gbps=XGMI_LINK_PEAK_GBPS` (direct reduce-scatter + all-gather at 153 GB/s: 14.3 / 7.2 / 3.6 ms) only N = 2 is over the
+    window; pass the link rate RCCL was MEASURED at once a multi-GPU node has run tools/first_multi_gpu_run.sh."""
+    if world <= 1 or allreduce_ms(4.0 * numel, world, link_gbps) <= window_ms:
         return None
     return torch.bfloat16
 

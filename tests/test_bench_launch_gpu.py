@@ -75,3 +75,7 @@ def test_bench_default_line_carries_the_dense_caption_step(dev):
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert "ragged" in d["data"] and d["dense_captions"] is None and "dense_equivalent_tflops_per_gpu" in d
+    # beside the headline (inputs resident): the host's issue time of one step on an idle GPU, and the step with the batch copied from
+    # pinned host memory inside the loop (main.py:773-775)
+    assert 0 < d["host_issue_ms_per_step"] and d["host_loop_ms_per_step"] > 0
+    assert d["h2d_inclusive"]["ms_per_step"] > 0 and d["h2d_inclusive"]["steps"] == 2 and d["fp8_train"] is None  # (fp8 leg: full size only)

@@ -109,6 +109,61 @@ def test_checkpoint_msgpack_roundtrip(tmp_path):
     assert shape == [1, 5] and dtype_name == "float32" and len(buf) == 20
 
 
+def test_checkpoint_flax_wire_format_known_answer():
+    """byte-level known answer, hand-assembled from the msgpack specification and flax.serialization's published rules (NOT a
+    round trip through this build's writer): a map with an ndarray (ext 1), a numpy scalar (ext 3), a Python complex (ext 2), a
+    bfloat16 leaf and a chunked leaf (`__msgpack_chunked_array__`), read by `from_bytes`; then the writer reproduces the bytes of
+    the part it can produce."""
+    import struct
+
+    from mic_amd.checkpoint import from_bytes, to_bytes
+
+    def fixstr(t):
+        assert len(t) < 32
+        return bytes([0xA0 | len(t)]) + t.encode()
+
+    def nd_payload(shape, dtype_name, raw):  # fixarray(3): [fixarray(shape) of positive fixints, fixstr dtype, bin8 data]
+        assert len(raw) < 256 and all(0 <= x < 128 for x in shape)
+        return bytes([0x93, 0x90 | len(shape)]) + bytes(shape) + fixstr(dtype_name) + bytes([0xC4, len(raw)]) + raw
+
+    def ext8(code, payload):  # ext 8: 0xc7, length, type, data
+        assert len(payload) < 256 and len(payload) not in (1, 2, 4, 8, 16)
+        return bytes([0xC7, len(payload), code]) + payload
+
+    a_raw = struct.pack("<4h", 1, 2, 3, 4)
+    kernel = ext8(1, nd_payload([2, 2], "int16", a_raw))
+    scal_p = nd_payload([], "float32", struct.pack("<f", 1.5))
+    assert len(scal_p) == 16
+    scalar = bytes([0xD8, 3]) + scal_p                                    # fixext 16, type 3 (numpy scalar)
+    cplx_p = bytes([0x92, 0xCB]) + struct.pack(">d", 1.0) + bytes([0xCB]) + struct.pack(">d", -2.0)  # [float64 1.0, float64 -2.0]
+    cplx = ext8(2, cplx_p)
+    bf = ext8(1, nd_payload([3], "bfloat16", struct.pack("<3H", 0x3F80, 0xC000, 0x3DCD)))  # 1.0, -2.0, 0.10009765625
+    ch0 = ext8(1, nd_payload([3], "float32", struct.pack("<3f", 0.0, 1.0, 2.0)))
+    ch1 = ext8(1, nd_payload([3], "float32", struct.pack("<3f", 3.0, 4.0, 5.0)))
+    chunked = (bytes([0x83]) + fixstr("__msgpack_chunked_array__") + bytes([0xC3])            # fixmap(3): flag true
+               + fixstr("shape") + bytes([0x82]) + fixstr("0") + bytes([2]) + fixstr("1") + bytes([3])
+               + fixstr("chunks") + bytes([0x82]) + fixstr("0") + ch0 + fixstr("1") + ch1)
+    blob = (bytes([0x85]) + fixstr("kernel") + kernel + fixstr("count") + scalar + fixstr("z") + cplx + fixstr("h") + bf
+            + fixstr("big") + chunked)
+    t = from_bytes(blob)
+    assert t["kernel"].dtype == np.int16 and np.array_equal(t["kernel"], [[1, 2], [3, 4]])
+    assert isinstance(t["count"], np.float32) and t["count"] == np.float32(1.5)  # unwrapped with ar[()], not a 0-d array
+    assert t["z"] == complex(1.0, -2.0)
+    assert t["h"].dtype == np.float32 and np.array_equal(t["h"], np.array([1.0, -2.0, 0.10009765625], dtype=np.float32))
+    assert t["big"].shape == (2, 3) and np.array_equal(t["big"], np.arange(6, dtype=np.float32).reshape(2, 3))
+    # the writer: same bytes for the leaves numpy can hold (no bfloat16), chunking at a 12-byte limit like flax's at 2^30
+    tree = {"kernel": np.array([[1, 2], [3, 4]], dtype=np.int16), "count": np.float32(1.5), "z": complex(1.0, -2.0),
+            "big": np.arange(6, dtype=np.float32).reshape(2, 3)}
+    want = (bytes([0x84]) + fixstr("kernel") + kernel + fixstr("count") + scalar + fixstr("z") + cplx + fixstr("big") + chunked)
+    assert to_bytes(tree, max_chunk_bytes=12) == want
+    # under the limit a leaf stays one ext-1 record; a 0-d ndarray (optax `count` after device_get) is ext 1 with an empty shape
+    one = to_bytes({"big": tree["big"], "c": np.asarray(7, dtype=np.int32)})
+    assert one == bytes([0x82]) + fixstr("big") + ext8(1, nd_payload([2, 3], "float32", struct.pack("<6f", *range(6)))) + fixstr("c") + \
+        ext8(1, nd_payload([], "int32", struct.pack("<i", 7)))
+    back = from_bytes(one)
+    assert back["c"].shape == () and int(back["c"]) == 7
+
+
 def test_host_helpers_equal_oracle():
     from mic_amd import create_learning_rate_fn, shift_tokens_right
     from oracle import train_ref

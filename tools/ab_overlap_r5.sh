@@ -5,7 +5,7 @@ OUT=gpurun_out/r5ab/overlap.txt
 : > $OUT
 run() {  # label, env assignments...
   label="$1"; shift
-  line=$(env "$@" python bench.py --steps 20 --warmup 5 --no-generate --no-cpu-baseline --no-roofline --no-dense-leg --emulate-comm 0 2>/dev/null | grep '^{' | head -1)
+  line=$(env "$@" python bench.py --steps 20 --warmup 5 --no-generate --no-cpu-baseline --no-roofline --no-dense-leg --no-extra-legs --emulate-comm 0 2>/dev/null | grep '^{' | head -1)
   echo "$label $(python -c "import json,sys; d=json.loads(sys.argv[1]); print(d['ms_per_step'], d['value'])" "$line")" | tee -a $OUT
 }
 run base            MIC_NOP=1

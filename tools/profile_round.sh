@@ -1,10 +1,10 @@
 R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/r5prof; mkdir -p $O
-TR="--steps 1 --warmup 1 --no-generate --no-cpu-baseline --no-dense-leg --no-roofline --emulate-comm 0"
+TR="--steps 1 --warmup 1 --no-generate --no-cpu-baseline --no-dense-leg --no-extra-legs --no-roofline --emulate-comm 0"
 # train: kernel trace with the default overlap (dW / optimizer streams) and serial
-rocprofv3 --kernel-trace --output-format csv -d $O/train_kt -- python3 $R/bench.py --steps 3 --warmup 1 --no-generate --no-cpu-baseline --no-dense-leg --no-roofline --emulate-comm 0 > $O/train_kt.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/train_kt -- python3 $R/bench.py --steps 3 --warmup 1 --no-generate --no-cpu-baseline --no-dense-leg --no-extra-legs --no-roofline --emulate-comm 0 > $O/train_kt.log 2>&1
 export MIC_DW_OVERLAP=0 MIC_OPT_OVERLAP=0
-rocprofv3 --kernel-trace --output-format csv -d $O/train_kt_serial -- python3 $R/bench.py --steps 3 --warmup 1 --no-generate --no-cpu-baseline --no-dense-leg --no-roofline --emulate-comm 0 > $O/train_kt_serial.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/train_kt_serial -- python3 $R/bench.py --steps 3 --warmup 1 --no-generate --no-cpu-baseline --no-dense-leg --no-extra-legs --no-roofline --emulate-comm 0 > $O/train_kt_serial.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/train_fetch -- python3 $R/bench.py $TR > $O/train_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/train_write -- python3 $R/bench.py $TR > $O/train_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/train_mfma -- python3 $R/bench.py $TR > $O/train_mfma.log 2>&1
