@@ -90,7 +90,8 @@ static int fill_epi(const mic_gemm_args* a, EpiArgs& e) {
   MIC_CHECK(a->dtype == MIC_BF16 || a->dtype == MIC_F32 || a->dtype == MIC_FP8, "mic_gemm: bad dtype %d", a->dtype);
   if (a->dtype == MIC_FP8) {
     MIC_CHECK(a->c_dtype == MIC_BF16 || a->c_dtype == MIC_F32, "mic_gemm(fp8): C is bf16 or f32");
-    MIC_CHECK(!a->a_kmajor && !a->b_kmajor, "mic_gemm(fp8): both operands must be k-contiguous (mic_fp8_quantize writes the transposed copies)");
+    MIC_CHECK(a->a_kmajor == a->b_kmajor, "mic_gemm(fp8): both operands k-contiguous (NT) or both k-major (TN, the weight-gradient GEMM)");
+    if (a->a_kmajor) MIC_CHECK(a->M % 16 == 0 && a->N % 16 == 0 && a->split_k <= 1, "mic_gemm(fp8, k-major): M and N must be multiples of 16");
     MIC_CHECK((a->a_fmt == MIC_E4M3 || a->a_fmt == MIC_E5M2) && a->b_fmt == MIC_E4M3, "mic_gemm(fp8): A is e4m3 or e5m2, B is e4m3");
     MIC_CHECK(a->K % 128 == 0, "mic_gemm(fp8): K=%d must be a multiple of 128 (zero-pad the reduction dim)", a->K);
     MIC_CHECK(a->lda % 16 == 0 && a->ldb % 16 == 0, "mic_gemm(fp8): lda/ldb must be multiples of 16 bytes");
@@ -202,6 +203,7 @@ static GemmPlan plan_bf16(const mic_gemm_args* args, int count) {
     if (c128 < c256) bm = 128;
   }
   if (force == 256 || force == 128 || force == 64) bm = force;
+  if (args[0].dtype == MIC_FP8 && args[0].a_kmajor && bm < 128) bm = 128;  // fp8 k-major images are 128 wide
   for (int i = 0; i < count; ++i)
     if (args[i].rowstat) bm = 256;  // softmax partials per 64-column granule = the wave tile width of this configuration
   // 192 x 128 tiles for the single-problem NT / NN launches whose 128 x 128 tiles would need a second round of the 2-per-CU slots
@@ -290,8 +292,9 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
     p.A = (const uint16_t*)args[i].A; p.B = (const uint16_t*)args[i].B;
     p.lda = args[i].lda; p.ldb = args[i].ldb; p.M = args[i].M; p.N = args[i].N; p.K = args[i].K;
     p.sa = p.sb = nullptr;
-    if (f8) {  // the kernel counts K and the leading dimensions in 2-byte units
-      p.lda /= 2; p.ldb /= 2; p.K /= 2;
+    if (f8) {  // the kernel counts K and the leading dimensions of k-contiguous operands in 2-byte units (k-major: ld in bytes)
+      if (!args[i].a_kmajor) { p.lda /= 2; p.ldb /= 2; }
+      p.K /= 2;
       p.sa = args[i].a_scale_inv; p.sb = args[i].b_scale_inv;
     }
     p.tiles_m = (p.M + bm_m - 1) / bm_m; p.tiles_n = (p.N + bm - 1) / bm;
@@ -304,8 +307,8 @@ static int launch_bf16(const mic_gemm_args* args, int count, hipStream_t s) {
     MIC_CHECK(!args[i].a_rowsum || args[i].a_kmajor, "mic_gemm: a_rowsum needs a_kmajor (A = dy^T of the weight-gradient GEMM)");
     p.a_rowsum = args[i].a_rowsum;
     p.rowsum_k = args[i].rowsum_k > 0 ? args[i].rowsum_k : p.K;
-    MIC_CHECK(args[i].k_valid >= 0 && (args[i].k_valid == 0 || (args[i].a_kmajor && args[i].b_kmajor && !f8)),
-              "mic_gemm: k_valid is a feature of the bf16 k-major x k-major (weight-gradient) launches");
+    MIC_CHECK(args[i].k_valid >= 0 && (args[i].k_valid == 0 || (args[i].a_kmajor && args[i].b_kmajor)),
+              "mic_gemm: k_valid is a feature of the k-major x k-major (weight-gradient) launches");
     p.k_valid = args[i].k_valid > 0 ? args[i].k_valid : 0x7fffffff;
     p.block_begin = blocks;
     blocks += p.tiles_m * p.tiles_n * p.nsplit;

@@ -135,6 +135,51 @@ __device__ __forceinline__ i32x8 read_frag8(const char* lds_tile, int xb, int mm
   return r;
 }
 
+// fp8 K-MAJOR operands (the weight-gradient GEMM dW = dy^T x reads dy and x as the producers wrote them, [rows = k][features = x],
+// one byte per element: no transposed copies).  Image = [128 k][128 x] bytes: k-rows of 128 B, 16-B chunk c of row k stored at
+// c ^ (((k >> 1) & 3) << 1).  Fragments by ds_read_b64_tr_b8 (tools/probe_tr8.hip: a 16-lane group reads an 8 (k) x 16 (x) byte block,
+// lanes 2j / 2j+1 supply the two 8-byte halves of row j, lane l receives column l = 8 consecutive k of ONE x): four of them give a
+// lane the 32 consecutive k of x = xb + (lane & 31) that v_mfma_scale_f32_32x32x64_f8f6f4 wants (k half = lane >> 5, as in
+// read_frag8).  A half-wave's two groups touch 8 rows x 2 chunks = 16 distinct 16-B slots of the 256-B bank row: conflict-free.
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+template <int NWAVES>
+struct Half8Stager {
+  static constexpr int NINST = 16, PER = NINST / NWAVES;  // 1 KiB pieces (8 k-rows) per image
+  static_assert(PER >= 1, "too many waves for this image");
+  // src: bytes [K rows][ld bytes]; x0 / lim in elements (= bytes), k0 in 2-byte units like every K of the fp8 launches (rows = 2 k0)
+  static __device__ __forceinline__ void load(u32x4 (&r)[PER], const uint16_t* __restrict__ src, int ld, int x0, int k0, int lim, int wave, int lane) {
+    const uint8_t* s8 = reinterpret_cast<const uint8_t*>(src);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int row = (wave * PER + i) * 8 + (lane >> 3), c = lane & 7;
+      int gx = x0 + c * 16;
+      gx = gx < lim ? gx : 0;
+      r[i] = *reinterpret_cast<const u32x4*>(s8 + (size_t)(2 * k0 + row) * ld + gx);
+    }
+  }
+  static __device__ __forceinline__ void store(const u32x4 (&r)[PER], char* lds_tile, int wave, int lane, int k_rows_valid = 0x7fffffff) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int row = (wave * PER + i) * 8 + (lane >> 3), c = lane & 7;
+      u32x4 v = r[i];
+      if (row >= k_rows_valid) v = u32x4{0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(lds_tile + row * 128 + ((c ^ (((row >> 1) & 3) << 1)) << 4)) = v;
+    }
+  }
+};
+__device__ __forceinline__ i32x8 read_frag8_tr(const char* lds_tile, int xb, int mm, int lane) {
+  const int g = lane >> 4, p = lane & 15;
+  const int x = xb + 16 * (g & 1) + 8 * (p & 1);
+  const int k = mm * 64 + 32 * (g >> 1) + (p >> 1);  // + 8 r for read r: (k >> 1) & 3 does not depend on r, the four reads are 1 KiB apart
+  const char* a = lds_tile + k * 128 + ((((x >> 4) ^ (((k >> 1) & 3) << 1)) << 4) | (x & 15));
+  const i32x2 r0 = __builtin_amdgcn_ds_read_tr8_b64_v2i32(LDS_PTR(i32x2, a));
+  const i32x2 r1 = __builtin_amdgcn_ds_read_tr8_b64_v2i32(LDS_PTR(i32x2, a + 1024));
+  const i32x2 r2 = __builtin_amdgcn_ds_read_tr8_b64_v2i32(LDS_PTR(i32x2, a + 2048));
+  const i32x2 r3 = __builtin_amdgcn_ds_read_tr8_b64_v2i32(LDS_PTR(i32x2, a + 3072));
+  i32x8 r = {r0[0], r0[1], r1[0], r1[1], r2[0], r2[1], r3[0], r3[1]};
+  return r;
+}
+
 __device__ __forceinline__ void tile_coords(int lid, int tiles_m, int tiles_n, int& tm, int& tn) {
   const int GROUP_M = 8;  // GROUP_M-tall column panels
   const int per_group = GROUP_M * tiles_n;

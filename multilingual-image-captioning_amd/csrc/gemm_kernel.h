@@ -2,6 +2,7 @@
 // tile configuration: gemm_t256.hip, gemm_t128.hip, gemm_t64.hip — the ~70 instantiations compile in parallel).
 #pragma once
 #include "gemm_common.h"
+#include <type_traits>
 
 // Wave tile WM x WN (WM in {32,64,128}, WN in {32,64}); 2 waves along M, WNW along N.  BM = 2*WM, BN = WN*WNW.
 //   <32,32,2>  64x64,   4 waves : launches too small to give every CU a 128x128 tile; 32 KiB LDS, several blocks per CU
@@ -23,7 +24,9 @@
 //   sizes below stay in 2-byte units (K, lda, ldb = bytes / 2), so the staging code is shared.
 template <int WM, int WN, int WNW, int BKT, bool AK, bool BKM, int KG = 1, bool PLAIN = false, int F8 = 0>
 __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kernel(LaunchTable tab) {
-  static_assert(F8 == 0 || (!AK && !BKM && BKT == 64), "fp8: k-contiguous operands, 128-byte stages");
+  static_assert(F8 == 0 || (AK == BKM && BKT == 64), "fp8: NT (both operands k-contiguous) or TN (both k-major), 128-k stages");
+  constexpr bool F8T = F8 != 0 && AK;  // fp8 weight-gradient launches: [128 k][128 x] byte images, ds_read_b64_tr_b8 fragments
+  static_assert(!F8T || (WM % 64 == 0 && WN * WNW % 128 == 0), "fp8 TN: 128-wide images (128x128 / 256x256 tiles)");
   constexpr int BM = 2 * WM, BN = WN * WNW, NWAVES = 2 * WNW, NTHREADS = 64 * NWAVES * KG;
   // rows per staged image: 128, or 64 for the 64-wide tiles and for BM = 192 (three 64-row images side by side: a wave's 96 rows
   // start at row 0 or 96 and run across image boundaries — images of a k-contiguous operand are contiguous 128-B rows whose
@@ -33,8 +36,8 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
   constexpr int HALF_A = UA * BKT * 2, HALF_B = UB * BKT * 2;
   constexpr int NHA = BM / UA, NHB = BN / UB, STAGE = NHA * HALF_A + NHB * HALF_B, AI = WM / 32, NJ = WN / 32, KSTEPS = BKT / 16;
   constexpr int STAGE_AT = 0;  // k-step in front of which the next tile's LDS writes / global loads are issued (1..3 measured equal)
-  using SA = HalfStager<AK, NWAVES, BKT, UA>;
-  using SB = HalfStager<BKM, NWAVES, BKT, UB>;
+  using SA = std::conditional_t<F8T, Half8Stager<NWAVES>, HalfStager<AK, NWAVES, BKT, UA>>;
+  using SB = std::conditional_t<F8T, Half8Stager<NWAVES>, HalfStager<BKM, NWAVES, BKT, UB>>;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A halves | B halves]
   const int tid = threadIdx.x, lane = tid & 63, wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kg = wave_all / NWAVES, wave = wave_all % NWAVES;  // K-group, wave within the group
@@ -111,10 +114,11 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
   };
   // weight-gradient launches (both operands k-major, see mic_gemm_args.k_valid): reduction rows k >= k_valid are written to LDS
   // as zeros; `t` = the K-tile being written
-  constexpr bool KV = AK && BKM && F8 == 0;
+  constexpr bool KV = AK && BKM;
+  constexpr int KROWS = F8T ? 2 * BKT : BKT;  // reduction rows per K-tile (fp8: K counts 2-byte units)
   const int k_valid = KV ? P.k_valid : 0x7fffffff;
   auto write_lds = [&](char* buf, int t) __attribute__((always_inline)) {
-    const int kr = KV ? k_valid - (kt0 + t) * BKT : 0x7fffffff;  // valid rows of this K-tile (>= BKT: all)
+    const int kr = KV ? k_valid - (kt0 + t) * KROWS : 0x7fffffff;  // valid rows of this K-tile (>= KROWS: all)
 #pragma unroll
     for (int h = 0; h < NHA; ++h) SA::store(ra[h], buf + h * HALF_A, wave, lane, kr);
 #pragma unroll
@@ -146,9 +150,9 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
 #pragma unroll
         for (int mm = 0; mm < 2; ++mm) {
 #pragma unroll
-          for (int i = 0; i < AI; ++i) a8[mm][i] = read_frag8(At, a_off + i * 32, mm, lane);
+          for (int i = 0; i < AI; ++i) a8[mm][i] = F8T ? read_frag8_tr(At, a_off + i * 32, mm, lane) : read_frag8(At, a_off + i * 32, mm, lane);
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) b8[mm][j] = read_frag8(Bt, b_off + j * 32, mm, lane);
+          for (int j = 0; j < NJ; ++j) b8[mm][j] = F8T ? read_frag8_tr(Bt, b_off + j * 32, mm, lane) : read_frag8(Bt, b_off + j * 32, mm, lane);
         }
 #pragma unroll
         for (int mm = 0; mm < 2; ++mm)
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
             for (int j = 0; j < NJ; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[mm][i], b8[mm][j], acc[i][j], F8 == 2 ? 1 : 0, 0, 0, 0x7f7f7f7f, 0,
                                                                           0x7f7f7f7f);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * 2 * (AI + NJ), 0);  // two 16-B reads per fragment
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * (F8T ? 4 : 2) * (AI + NJ), 0);  // two 16-B reads (TN: four transposing 8-B reads) per fragment
         __builtin_amdgcn_sched_group_barrier(0x008, 2 * AI * NJ, 0);
       } else if constexpr (F8 != 0) {
 #pragma unroll
@@ -169,9 +173,9 @@ __global__ __launch_bounds__(128 * WNW * KG, KG > 1 ? 1 : 2) void gemm_bf16_kern
           }
           i32x8 a8[AI], b8[NJ];
 #pragma unroll
-          for (int i = 0; i < AI; ++i) a8[i] = read_frag8(At, a_off + i * 32, mm, lane);
+          for (int i = 0; i < AI; ++i) a8[i] = F8T ? read_frag8_tr(At, a_off + i * 32, mm, lane) : read_frag8(At, a_off + i * 32, mm, lane);
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) b8[j] = read_frag8(Bt, b_off + j * 32, mm, lane);
+          for (int j = 0; j < NJ; ++j) b8[j] = F8T ? read_frag8_tr(Bt, b_off + j * 32, mm, lane) : read_frag8(Bt, b_off + j * 32, mm, lane);
 #pragma unroll
           for (int i = 0; i < AI; ++i)
 #pragma unroll
@@ -342,7 +346,12 @@ static inline void launch_cfg_p(const LaunchTable& tab, int akm, int bkm, hipStr
     hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, WNW, BKT, AKM, BKMM, KG, PLAIN, F8>), grid, block, lds, s, tab);                 \
   } while (0)
   if constexpr (F8 != 0) {
-    LAUNCH(false, false);
+    if constexpr ((2 * WM) % 128 == 0 && (WN * WNW) % 128 == 0) {  // 128x128 / 256x256 tiles also carry the TN (weight-gradient) form
+      if (akm && bkm) LAUNCH(true, true);
+      else LAUNCH(false, false);
+    } else {
+      LAUNCH(false, false);
+    }
   } else if constexpr (WM == 96) {  // BM = 192: k-contiguous A only
     if (!bkm) LAUNCH(false, false);
     else LAUNCH(false, true);
@@ -359,11 +368,11 @@ template <int WM, int WN, int WNW, int BKT, int KG = 1>
 static inline void launch_cfg(const LaunchTable& tab, int akm, int bkm, hipStream_t s, int f8 = 0) {
   const bool plain = table_is_plain(tab);
   if (f8 == 1) {
-    if (plain) launch_cfg_p<WM, WN, WNW, BKT, KG, true, 1>(tab, 0, 0, s);
-    else launch_cfg_p<WM, WN, WNW, BKT, KG, false, 1>(tab, 0, 0, s);
+    if (plain) launch_cfg_p<WM, WN, WNW, BKT, KG, true, 1>(tab, akm, bkm, s);
+    else launch_cfg_p<WM, WN, WNW, BKT, KG, false, 1>(tab, akm, bkm, s);
   } else if (f8 == 2) {
-    if (plain) launch_cfg_p<WM, WN, WNW, BKT, KG, true, 2>(tab, 0, 0, s);
-    else launch_cfg_p<WM, WN, WNW, BKT, KG, false, 2>(tab, 0, 0, s);
+    if (plain) launch_cfg_p<WM, WN, WNW, BKT, KG, true, 2>(tab, akm, bkm, s);
+    else launch_cfg_p<WM, WN, WNW, BKT, KG, false, 2>(tab, akm, bkm, s);
   } else if (plain) launch_cfg_p<WM, WN, WNW, BKT, KG, true>(tab, akm, bkm, s);
   else launch_cfg_p<WM, WN, WNW, BKT, KG, false>(tab, akm, bkm, s);
 }

@@ -101,6 +101,50 @@ def test_fp8_gemm_equals_dequantised_matmul(dev, afmt, M, N, K, cdt):
     assert rel < (0.05 if afmt == torch.float8_e4m3fn else 0.09), rel
 
 
+@pytest.mark.parametrize("afmt", [torch.float8_e4m3fn, torch.float8_e5m2])
+@pytest.mark.parametrize("M,N,K,kv", [(1024, 1024, 2432, 2404), (3072, 1024, 4096, 0), (128, 256, 128, 100), (4096, 1024, 2560, 2433),
+                                      (768, 3072, 3200, 0), (144, 272, 384, 300)])
+def test_fp8_gemm_kmajor_weight_gradient_form(dev, afmt, M, N, K, kv):
+    """dW[M][N] = sum over rows k < k_valid of dy[k][M] x[k][N]: both fp8 operands K-MAJOR (as their producers wrote them, no
+    transposed copies; fragments through ds_read_b64_tr_b8), fp32 output, rows at and behind k_valid count as zero whatever they
+    hold (packed batches leave stale rows there).  128 x 128 tiles with one / two K-groups and 256 x 256 tiles; exact up to fp32
+    accumulation order against an fp32 matmul of the dequantised operands; grouped like a layer's weight gradients."""
+    from mic_amd import ops
+
+    g = torch.Generator().manual_seed(M + N + K)
+    dy = (torch.randn(K, M, generator=g) * 0.3).to(torch.bfloat16)
+    x = (torch.randn(K, N, generator=g) * 2).to(torch.bfloat16)
+    qa, _, sa = _quant_ref(dy, afmt)
+    qb, _, sb = _quant_ref(x, torch.float8_e4m3fn)
+    valid = kv if kv else K
+    ra, rb = qa.float().clone(), qb.float().clone()
+    ra[valid:], rb[valid:] = 0, 0
+    ref = (ra.T @ rb) * (sa * sb)
+    sa_d, sb_d = torch.tensor([sa], device=dev), torch.tensor([sb], device=dev)
+    out = torch.full((M, N), 7.0, dtype=torch.float32, device=dev)
+    ops.gemm(qa.to(dev), qb.to(dev), out, M, N, K, a_kmajor=True, b_kmajor=True, a_scale_inv=sa_d, b_scale_inv=sb_d, k_valid=kv)
+    torch.cuda.synchronize()
+    err = ((out.cpu() - ref).abs().max() / ref.abs().max()).item()
+    assert err < 1e-4, err
+    # grouped with a second problem of another shape (one launch, the planner sees both)
+    M2, N2 = 256, 1024
+    dy2 = (torch.randn(K, M2, generator=g) * 0.1).to(torch.bfloat16)
+    qa2, _, sa2 = _quant_ref(dy2, afmt)
+    ra2 = qa2.float().clone()
+    ra2[valid:] = 0
+    N2 = min(N2, N)
+    ref2 = (ra2.T @ rb[:, :N2]) * (sa2 * sb)
+    sa2_d = torch.tensor([sa2], device=dev)
+    out1 = torch.zeros((M, N), dtype=torch.float32, device=dev)
+    out2 = torch.zeros((M2, N2), dtype=torch.float32, device=dev)
+    qa_d, qb_d, qa2_d = qa.to(dev), qb.to(dev), qa2.to(dev)
+    ops.gemm_grouped([ops.gemm_args(qa_d, qb_d, out1, M, N, K, a_kmajor=True, b_kmajor=True, a_scale_inv=sa_d, b_scale_inv=sb_d, k_valid=kv),
+                      ops.gemm_args(qa2_d, qb_d, out2, M2, N2, K, a_kmajor=True, b_kmajor=True, a_scale_inv=sa2_d, b_scale_inv=sb_d, k_valid=kv)])
+    torch.cuda.synchronize()
+    assert ((out1.cpu() - ref).abs().max() / ref.abs().max()).item() < 1e-4
+    assert ((out2.cpu() - ref2).abs().max() / ref2.abs().max()).item() < 1e-4
+
+
 def test_fp8_gemm_epilogue_grouped_and_errors(dev):
     from mic_amd import _lib as L
     from mic_amd import ops
@@ -141,7 +185,7 @@ def test_fp8_gemm_epilogue_grouped_and_errors(dev):
         assert ((o.cpu() - r).abs().max() / r.abs().max()).item() < 1e-4
     with pytest.raises(L.MicError, match="multiple of 128"):
         ops.gemm(qa.to(dev)[:, :64], qb.to(dev)[:, :64], out, M, N, 64, a_scale_inv=sa_d, b_scale_inv=sb_d)
-    with pytest.raises(L.MicError, match="k-contiguous"):
+    with pytest.raises(L.MicError, match="both k-major"):  # NN / mixed layouts do not exist in fp8: NT or TN
         ops.gemm(qa.to(dev), qb.to(dev), out, M, N, K, b_kmajor=True, a_scale_inv=sa_d, b_scale_inv=sb_d)
 
 
