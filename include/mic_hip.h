@@ -94,7 +94,9 @@ typedef struct {
                               kernel holds anyway — no extra pass over dy */
   int rowsum_k;            /* valid reduction rows for a_rowsum (0 = K) */
   /* dtype == MIC_FP8 (BASELINE configs[4]; the reference has no counterpart, its dtypes are main.py:96-101): A and B are OCP
-   * fp8 bytes, both k-contiguous (a_kmajor = b_kmajor = 0), K % 128 == 0, lda/ldb in bytes and multiples of 16; R / Zin / Zout
+   * fp8 bytes, both k-contiguous (a_kmajor = b_kmajor = 0) or both K-MAJOR (a_kmajor = b_kmajor = 1: the weight-gradient form
+   * dW = dy^T x on dy [K][M] and x [K][N] as their producers wrote them, M % 16 == N % 16 == 0, k_valid as for bf16; fragments by
+   * ds_read_b64_tr_b8), K % 128 == 0, lda/ldb in bytes and multiples of 16; R / Zin / Zout
    * are bf16, C is c_dtype (bf16 or f32).  v = acc * a_scale_inv[0] * b_scale_inv[0] (device scalars written by
    * mic_fp8_quantize: the per-tensor dequantisation factors) before bias.  v_mfma_scale_f32_32x32x64_f8f6f4 with unit block
    * scales: fp32 accumulate at twice the bf16 MFMA rate, half the operand bytes. */
@@ -122,6 +124,11 @@ typedef struct {
    * both operands count as zero (0 = all K rows are valid).  K stays a multiple of 64; the buffers need not keep their rows
    * [k_valid, K) zeroed — with variable-length (packed) batches the number of valid rows changes from step to step. */
   int k_valid;
+  /* dtype == MIC_FP8 with c_dtype == MIC_FP8: fused emission (mic_fp8_out below) — the epilogue's result leaves as fp8 bytes
+   * (C, ldc in bytes) under the OUTPUT tensor's delayed scale: c_q8_state [2] (amax of the previous pass read, 1 / scale written),
+   * c_q8_amax this pass's partial maxima (or NULL), c_q8_fmt MIC_E4M3 / MIC_E5M2.  Activation / dact epilogues of NT launches
+   * (GELU(FFN-in) -> the e4m3 operand of FFN-out; dGELU-scaled dX of FFN-out -> the e5m2 dy of FFN-in's backward). */
+  float* c_q8_state; float* c_q8_amax; int c_q8_fmt;
 } mic_gemm_args;
 int mic_gemm(const mic_gemm_args* a, void* stream);
 /* dst[r][c] (dst_dtype) = sum over s < n_slabs of src[s * slab_stride + r * ld_src + c] (fp32): the second half of a
@@ -179,6 +186,19 @@ int mic_fp8_quantize(const mic_fp8_item* items, int count, void* stream);
 int mic_fp8_amax_partials(void);
 int mic_fp8_roll_amax(float* state, int stride_floats, float* partials, int count, void* stream);
 
+/* Fused fp8 emission under delayed scaling: the PRODUCER of an fp8 GEMM operand writes the bytes itself — q[r][c] =
+ * fp8(round_bf16(x[r][c]) * FMAX / state[0]) with state[0] the amax the tensor had in the previous pass (mic_fp8_roll_amax), records
+ * this pass's max |x| in amax_next (as mic_fp8_quantize does under delayed scaling) and writes state[1] = state[0] / FMAX, the
+ * dequantisation factor mic_gemm multiplies back.  Same bytes as producer + mic_fp8_quantize on the same scale; one launch less per
+ * tensor (the step had 181 of them).  Producers: mic_layernorm_fwd_q8, mic_layernorm_bwd_partials_q8, mic_attn_bwd_q8 /
+ * mic_attn_bwd_packed_q8 and the epilogue of an fp8 mic_gemm (mic_gemm_args.c_q8).  No reference counterpart (configs[4]). */
+typedef struct {
+  void* q; int ldq;      /* fp8 bytes [rows][ldq], ldq % 8 == 0, 8-B aligned */
+  float* state;          /* [2]: amax of the previous pass (read), 1 / scale (written) */
+  float* amax_next;      /* [mic_fp8_amax_partials()] partial maxima of this pass (atomic max) or NULL */
+  int fmt;               /* MIC_E4M3 / MIC_E5M2 */
+} mic_fp8_out;
+
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm (flax nn.LayerNorm: biased variance, fp32 statistics; 3P).
  *   fwd: y = (x-mean)*rstd*gamma + beta, then optional dropout; saves mean/rstd [rows] (may be NULL).
@@ -200,6 +220,16 @@ int mic_layernorm_bwd_blocks(int rows);
 int mic_layernorm_bwd_partials(int dtype, int rows, int width, const void* x, const float* gamma, const float* mean,
                                const float* rstd, const void* dy, const void* dres, void* dx, float* partials, void* dxm,
                                float dropout_p, uint32_t dropout_seed, float in_dropout_p, uint32_t in_dropout_seed, void* stream);
+/* bf16 storage, fused fp8 emission (mic_fp8_out above).  fwd: the normalised rows as e4m3 bytes beside y, or — y == NULL — instead
+ * of it (the operand of an fp8 q/k/v / FFN-in projection; LayerNorm's backward needs x and the statistics, not y).  bwd: q8_of_dx =
+ * 0: the dropout-masked gradient dxm as fp8 (dxm == NULL: only as fp8) — the dy of the fp8 FFN-out projection of the layer below;
+ * 1: dx itself also as fp8 (the ViT has no dropout: its residual-stream gradient is that dy). */
+int mic_layernorm_fwd_q8(int rows, int width, const void* x, const float* gamma, const float* beta, float eps, void* y, float* mean,
+                         float* rstd, float dropout_p, uint32_t dropout_seed, const mic_fp8_out* q8, void* stream);
+int mic_layernorm_bwd_partials_q8(int rows, int width, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                  const void* dy, const void* dres, void* dx, float* partials, void* dxm, float dropout_p,
+                                  uint32_t dropout_seed, float in_dropout_p, uint32_t in_dropout_seed, const mic_fp8_out* q8,
+                                  int q8_of_dx, void* stream);
 typedef struct { const float* partials; float* dgamma; float* dbeta; int nblk, width, accumulate; } mic_ln_param_item;  /* dgamma / dbeta may be NULL */
 int mic_ln_param_grads(const mic_ln_param_item* items, int count, void* stream);
 
@@ -236,6 +266,12 @@ int mic_attn_bwd_packed(int dtype, int B, int H, int Tq_max, int Tk, const int32
                         const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* out, int ldo,
                         const void* dout, int lddo, const float* lse, int causal, void* dq, int lddq, void* dk, int lddk,
                         void* dv, int lddv, void* stream);
+/* mic_attn_bwd / mic_attn_bwd_packed (q_off == NULL: dense rows) of the bf16 single-tile kernel with dQ / dK / dV written as fp8
+ * bytes under delayed scaling (mic_fp8_out): dq8 describes dQ's byte matrix and tensor, dk8 dK's; dV (dv8) shares dK's leading
+ * dimension, scale and amax table — dK and dV are the two halves of ONE [rows][2d] (or, with dQ, [rows][3d]) gradient tensor. */
+int mic_attn_bwd_q8(int B, int H, int Tq, int Tk, const int32_t* q_off, const int32_t* q_len, int kv_packed, const void* q, int ldq,
+                    const void* k, int ldk, const void* v, int ldv, const void* out, int ldo, const void* dout, int lddo, const float* lse,
+                    const int32_t* key_mask, int causal, const mic_fp8_out* dq8, const mic_fp8_out* dk8, void* dv8, void* stream);
 
 /* Decode-time self-attention over the static max_len-slot cache (3P _concatenate_to_cache; modeling:249-282;
  * SURVEY App. B7): one query per row, validity slot <= cur (cache_index).  The cache is NOT physically
@@ -312,6 +348,10 @@ int mic_colsum(int dtype, int rows, int cols, const void* x, int ld, float* out,
 /* several column sums (always accumulating into caller-zeroed outputs) in one launch per 8 items */
 typedef struct { const void* x; float* out; int rows, cols, ld; } mic_colsum_item;
 int mic_colsum_grouped(int dtype, const mic_colsum_item* items, int count, void* stream);
+/* the same over fp8 tensors (fused emission): out[c] += scale_inv[0] * sum_r fp8(x[r][c]) — the bias gradient of an fp8 projection from
+ * the bytes its dy exists as; cols, ld multiples of 8 */
+typedef struct { const void* x; float* out; const float* scale_inv; int rows, cols, ld, fmt; } mic_colsum_q8_item;
+int mic_colsum_q8_grouped(const mic_colsum_q8_item* items, int count, void* stream);
 /* keep-mask (uint8, 1 = keep) that the fused dropout epilogues use for (seed, p) over n elements */
 int mic_dropout_mask(uint8_t* out, int64_t n, float p, uint32_t seed, void* stream);
 int mic_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);

@@ -33,6 +33,7 @@ class GemmArgs(C.Structure):
         ("rowstat", C.c_void_p), ("rowstat_ld", C.c_int), ("rowstat_nvalid", C.c_int),
         ("a_ln_stats", C.c_void_p), ("a_ln_colsum", C.c_void_p), ("a_ln_width", C.c_int), ("a_ln_eps", C.c_float),
         ("rowsum2", C.c_void_p), ("k_valid", C.c_int),
+        ("c_q8_state", C.c_void_p), ("c_q8_amax", C.c_void_p), ("c_q8_fmt", C.c_int),
     ]
 
 
@@ -40,6 +41,14 @@ class Fp8Item(C.Structure):
     _fields_ = [("src", C.c_void_p), ("ld", C.c_int), ("rows", C.c_int), ("cols", C.c_int), ("rows_pad", C.c_int),
                 ("q", C.c_void_p), ("ldq", C.c_int), ("qT", C.c_void_p), ("ldqT", C.c_int), ("state", C.c_void_p), ("amax_next", C.c_void_p),
                 ("fmt", C.c_int)]
+
+
+class Fp8Out(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("ldq", C.c_int), ("state", C.c_void_p), ("amax_next", C.c_void_p), ("fmt", C.c_int)]
+
+
+class ColsumQ8Item(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("scale_inv", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("ld", C.c_int), ("fmt", C.c_int)]
 
 
 class ColsumItem(C.Structure):
@@ -90,6 +99,10 @@ _SIGS = {
     "mic_layernorm_bwd_blocks": ([_i], C.c_int),
     "mic_layernorm_bwd_partials": ([_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _u32, _f, _u32, _p], C.c_int),
     "mic_ln_param_grads": ([C.POINTER(LnParamItem), _i, _p], C.c_int),
+    "mic_layernorm_fwd_q8": ([_i, _i, _p, _p, _p, _f, _p, _p, _p, _f, _u32, C.POINTER(Fp8Out), _p], C.c_int),
+    "mic_layernorm_bwd_partials_q8": ([_i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _u32, _f, _u32, C.POINTER(Fp8Out), _i, _p], C.c_int),
+    "mic_attn_bwd_q8": ([_i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, C.POINTER(Fp8Out), C.POINTER(Fp8Out), _p, _p], C.c_int),
+    "mic_colsum_q8_grouped": ([C.POINTER(ColsumQ8Item), _i, _p], C.c_int),
     "mic_attn_fwd": ([_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p], C.c_int),
     "mic_attn_probs": ([_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p], C.c_int),
     "mic_attn_bwd": ([_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p], C.c_int),

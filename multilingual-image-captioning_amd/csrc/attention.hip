@@ -210,13 +210,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int H, int Tq_max, int Tk
 // 4x the waves per CU and 1/4 of the serial MFMA/LDS chain per wave.  Phase 1: wave w owns the (ib, jb) = (w>>1, w&1)
 // quadrant of S^T / dP^T and writes its quadrant of the P and dS tiles.  Phase 2: wave w owns output block
 // (w>>1, w&1) of dQ, dK and dV.
-template <typename T>
+// Q8 (bf16 storage): dQ / dK / dV leave as e5m2 BYTES under their tensors' delayed scales (common.h: Q8Out; dq / dk / dv then point
+// at byte matrices, lddq / lddk / lddv count bytes) — the dy operands of the fp8 q/k/v projections' backward GEMMs.  q8q: dQ's
+// tensor; q8kv: the tensor dK and dV belong to (self-attention: the same fused [rows][3d] gradient as dQ).
+template <typename T, bool Q8 = false>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(int H, int Tq_max, int Tk_max, const T* __restrict__ q, int ldq,
                                                        const T* __restrict__ k, int ldk, const T* __restrict__ v, int ldv,
                                                        const T* __restrict__ out, int ldo, const T* __restrict__ dout, int lddo,
                                                        const float* __restrict__ lse_in, const int32_t* __restrict__ key_mask,
                                                        int causal, T* __restrict__ dq, int lddq, T* __restrict__ dk, int lddk,
-                                                       T* __restrict__ dv, int lddv, PackedRows pk) {
+                                                       T* __restrict__ dv, int lddv, PackedRows pk, Q8Out q8q, Q8Out q8kv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TB = Tile<T>::BYTES;
   // five tiles (40 KiB in bf16: FOUR workgroups per CU, so the 1024 (batch, head) problems of a decoder layer at batch 64 are one
@@ -299,6 +302,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(int H, int Tq_max, int Tk
   {
     const int xb = wave >> 1, db = wave & 1;
     const int d = db * 32 + (lane & 31);
+    Q8Ctx cq, ckv;
+    if constexpr (Q8) {
+      cq = q8_begin(q8q, blockIdx.x == 0 && tid == 0);
+      ckv = q8_begin(q8kv, blockIdx.x == 0 && tid == 0);
+    }
     if (xb < nib) {
       f32x16 a;
       zero16(a);
@@ -306,7 +314,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(int H, int Tq_max, int Tk
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = xb * 32 + acc_row(r, lane);
-        if (i < Tq) ElemT<T>::st(dq + (q0 + i) * lddq + h * 64 + d, a[r]);
+        if (i < Tq) {
+          if constexpr (Q8) reinterpret_cast<uint8_t*>(dq)[(q0 + i) * lddq + h * 64 + d] = q8_pack1(cq, round_to<T>(a[r]), q8q.fmt);
+          else ElemT<T>::st(dq + (q0 + i) * lddq + h * 64 + d, a[r]);
+        }
       }
     }
     if (xb < njb) {
@@ -318,10 +329,20 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(int H, int Tq_max, int Tk
       for (int r = 0; r < 16; ++r) {
         const int j = xb * 32 + acc_row(r, lane);
         if (j < Tk) {
-          ElemT<T>::st(dk + (k0 + j) * lddk + h * 64 + d, a[r]);
-          ElemT<T>::st(dv + (k0 + j) * lddv + h * 64 + d, c[r]);
+          if constexpr (Q8) {
+            reinterpret_cast<uint8_t*>(dk)[(k0 + j) * lddk + h * 64 + d] = q8_pack1(ckv, round_to<T>(a[r]), q8kv.fmt);
+            reinterpret_cast<uint8_t*>(dv)[(k0 + j) * lddv + h * 64 + d] = q8_pack1(ckv, round_to<T>(c[r]), q8kv.fmt);
+          } else {
+            ElemT<T>::st(dk + (k0 + j) * lddk + h * 64 + d, a[r]);
+            ElemT<T>::st(dv + (k0 + j) * lddv + h * 64 + d, c[r]);
+          }
         }
       }
+    }
+    if constexpr (Q8) {
+      // (when dQ and dK / dV are one tensor both contexts carry the same scale: two atomics into the same table)
+      q8_end_wave(q8q, cq, blockIdx.x * 4 + wave);
+      q8_end_wave(q8kv, ckv, blockIdx.x * 4 + wave);
     }
   }
 }
@@ -688,11 +709,11 @@ extern "C" int mic_attn_bwd(int dtype, int B, int H, int Tq, int Tk, const void*
   dim3 grid(B * H), block(256);
   if (dtype == MIC_BF16) {
     const size_t lds = 5 * Tile<uint16_t>::BYTES;
-    hipLaunchKernelGGL(attn_bwd_kernel<uint16_t>, grid, block, lds, (hipStream_t)stream, H, Tq, Tk, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk, (const uint16_t*)v, ldv, (const uint16_t*)out, ldo, (const uint16_t*)dout, lddo, lse, key_mask, causal, (uint16_t*)dq, lddq, (uint16_t*)dk, lddk, (uint16_t*)dv, lddv, PackedRows{nullptr, nullptr, 0});
+    hipLaunchKernelGGL(attn_bwd_kernel<uint16_t>, grid, block, lds, (hipStream_t)stream, H, Tq, Tk, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk, (const uint16_t*)v, ldv, (const uint16_t*)out, ldo, (const uint16_t*)dout, lddo, lse, key_mask, causal, (uint16_t*)dq, lddq, (uint16_t*)dk, lddk, (uint16_t*)dv, lddv, PackedRows{nullptr, nullptr, 0}, Q8Out{}, Q8Out{});
   } else if (dtype == MIC_F32) {
     const size_t lds = 5 * Tile<float>::BYTES;
     if (int rc = set_lds(attn_bwd_kernel<float>, lds)) return rc;
-    hipLaunchKernelGGL(attn_bwd_kernel<float>, grid, block, lds, (hipStream_t)stream, H, Tq, Tk, (const float*)q, ldq, (const float*)k, ldk, (const float*)v, ldv, (const float*)out, ldo, (const float*)dout, lddo, lse, key_mask, causal, (float*)dq, lddq, (float*)dk, lddk, (float*)dv, lddv, PackedRows{nullptr, nullptr, 0});
+    hipLaunchKernelGGL(attn_bwd_kernel<float>, grid, block, lds, (hipStream_t)stream, H, Tq, Tk, (const float*)q, ldq, (const float*)k, ldk, (const float*)v, ldv, (const float*)out, ldo, (const float*)dout, lddo, lse, key_mask, causal, (float*)dq, lddq, (float*)dk, lddk, (float*)dv, lddv, PackedRows{nullptr, nullptr, 0}, Q8Out{}, Q8Out{});
   } else MIC_CHECK(false, "mic_attn_bwd: bad dtype");
   MIC_LAUNCH_CHECK();
   return MIC_OK;
@@ -730,12 +751,33 @@ extern "C" int mic_attn_bwd_packed(int dtype, int B, int H, int Tq_max, int Tk, 
   dim3 grid(B * H), block(256);
   if (dtype == MIC_BF16) {
     const size_t lds = 5 * Tile<uint16_t>::BYTES;
-    hipLaunchKernelGGL(attn_bwd_kernel<uint16_t>, grid, block, lds, (hipStream_t)stream, H, Tq_max, Tk, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk, (const uint16_t*)v, ldv, (const uint16_t*)out, ldo, (const uint16_t*)dout, lddo, lse, nullptr, causal, (uint16_t*)dq, lddq, (uint16_t*)dk, lddk, (uint16_t*)dv, lddv, pk);
+    hipLaunchKernelGGL(attn_bwd_kernel<uint16_t>, grid, block, lds, (hipStream_t)stream, H, Tq_max, Tk, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk, (const uint16_t*)v, ldv, (const uint16_t*)out, ldo, (const uint16_t*)dout, lddo, lse, nullptr, causal, (uint16_t*)dq, lddq, (uint16_t*)dk, lddk, (uint16_t*)dv, lddv, pk, Q8Out{}, Q8Out{});
   } else if (dtype == MIC_F32) {
     const size_t lds = 5 * Tile<float>::BYTES;
     if (int rc = set_lds(attn_bwd_kernel<float>, lds)) return rc;
-    hipLaunchKernelGGL(attn_bwd_kernel<float>, grid, block, lds, (hipStream_t)stream, H, Tq_max, Tk, (const float*)q, ldq, (const float*)k, ldk, (const float*)v, ldv, (const float*)out, ldo, (const float*)dout, lddo, lse, nullptr, causal, (float*)dq, lddq, (float*)dk, lddk, (float*)dv, lddv, pk);
+    hipLaunchKernelGGL(attn_bwd_kernel<float>, grid, block, lds, (hipStream_t)stream, H, Tq_max, Tk, (const float*)q, ldq, (const float*)k, ldk, (const float*)v, ldv, (const float*)out, ldo, (const float*)dout, lddo, lse, nullptr, causal, (float*)dq, lddq, (float*)dk, lddk, (float*)dv, lddv, pk, Q8Out{}, Q8Out{});
   } else MIC_CHECK(false, "mic_attn_bwd_packed: bad dtype");
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}
+
+// fused fp8 emission of dQ / dK / dV (bf16 storage, one 64x64 tile per sequence; dense rows with q_off == NULL, packed rows otherwise)
+extern "C" int mic_attn_bwd_q8(int B, int H, int Tq, int Tk, const int32_t* q_off, const int32_t* q_len, int kv_packed, const void* q,
+                               int ldq, const void* k, int ldk, const void* v, int ldv, const void* out, int ldo, const void* dout, int lddo,
+                               const float* lse, const int32_t* key_mask, int causal, const mic_fp8_out* dq8, const mic_fp8_out* dk8,
+                               void* dv8, void* stream) {
+  MIC_CHECK(B > 0 && H > 0 && Tq > 0 && Tq <= 64 && Tk > 0 && Tk <= 64, "mic_attn_bwd_q8: one 64x64 tile per sequence (Tq=%d Tk=%d)", Tq, Tk);
+  MIC_CHECK(q && k && v && out && dout && lse && dq8 && dk8 && dv8 && (!q_off == !q_len), "mic_attn_bwd_q8: null pointer");
+  MIC_CHECK(dq8->q && dq8->state && dk8->q && dk8->state && dq8->fmt == dk8->fmt && (dq8->fmt == MIC_E4M3 || dq8->fmt == MIC_E5M2),
+            "mic_attn_bwd_q8: bad fp8 outputs");
+  MIC_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0, "mic_attn_bwd_q8: row strides must keep 16-B alignment");
+  const PackedRows pk{q_off, q_len, kv_packed};
+  const Q8Out oq{(uint8_t*)dq8->q, dq8->ldq, dq8->state, dq8->amax_next, dq8->fmt}, okv{(uint8_t*)dk8->q, dk8->ldq, dk8->state, dk8->amax_next, dk8->fmt};
+  dim3 grid(B * H), block(256);
+  const size_t lds = 5 * Tile<uint16_t>::BYTES;
+  hipLaunchKernelGGL((attn_bwd_kernel<uint16_t, true>), grid, block, lds, (hipStream_t)stream, H, Tq, Tk, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk,
+                     (const uint16_t*)v, ldv, (const uint16_t*)out, ldo, (const uint16_t*)dout, lddo, lse, key_mask, causal, (uint16_t*)dq8->q, dq8->ldq,
+                     (uint16_t*)dk8->q, dk8->ldq, (uint16_t*)dv8, dk8->ldq, pk, oq, okv);
   MIC_LAUNCH_CHECK();
   return MIC_OK;
 }

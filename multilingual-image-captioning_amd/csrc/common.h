@@ -155,6 +155,59 @@ __device__ __forceinline__ uint32_t mic_hash(uint32_t seed, uint32_t idx) {
 __device__ __forceinline__ uint32_t dropout_threshold(float p) { return (uint32_t)fminf(p * 4294967296.0f, 4294967295.0f); }
 __device__ __forceinline__ bool dropout_keep(uint32_t seed, uint32_t idx, uint32_t thr) { return mic_hash(seed, idx) >= thr; }
 
+// ---- fused fp8 emission under DELAYED per-tensor scaling (BASELINE configs[4]): a producer kernel (LayerNorm forward / backward,
+// the GELU / dGELU GEMM epilogues, attention backward) writes its result as OCP fp8 bytes itself, with the scale derived from the
+// amax this tensor had in the PREVIOUS pass (state[0], rolled by mic_fp8_roll_amax), records this pass's max |x| in the tensor's
+// table of partial maxima and leaves the dequantisation factor in state[1] — what mic_fp8_quantize did in a launch of its own
+// (181 launches per train step).  Values are rounded to the storage type (bf16) first, so the bytes equal those of the two-kernel
+// path on the same scale.
+#define FP8_AMAX_PARTIALS 1024  // per-tensor partial maxima: one atomic per wave, spread over the table (1024 atomics on ONE address cost ~12 us)
+struct Q8Out { uint8_t* q; int ldq; float* state; float* amax_next; int fmt; };
+struct Q8Ctx { float scale, fmax, amax; };
+__device__ __forceinline__ uint32_t cvt4_fp8(const float* v, int fmt) {  // 4 floats -> 4 fp8 bytes (RNE, OCP encodings on gfx950)
+  int w = 0;
+  if (fmt == MIC_E4M3) {
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+  } else {
+    w = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], w, false);
+    w = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], w, true);
+  }
+  return (uint32_t)w;
+}
+__device__ __forceinline__ Q8Ctx q8_begin(const Q8Out& o, bool first_thread) {
+  Q8Ctx c;
+  c.fmax = o.fmt == MIC_E4M3 ? 448.0f : 57344.0f;
+  const float amax = o.state[0];
+  c.scale = amax > 0.f ? c.fmax / amax : 1.0f;
+  c.amax = 0.f;
+  if (first_thread) o.state[1] = amax > 0.f ? amax / c.fmax : 1.0f;
+  return c;
+}
+// 8 values (already rounded to the storage type) -> 8 fp8 bytes; the context keeps the running max |x|
+__device__ __forceinline__ uint2 q8_pack8(Q8Ctx& c, const float* v, int fmt) {
+  float t[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    c.amax = fmaxf(c.amax, fabsf(v[i]));
+    t[i] = fminf(fmaxf(v[i] * c.scale, -c.fmax), c.fmax);
+  }
+  return make_uint2(cvt4_fp8(t, fmt), cvt4_fp8(t + 4, fmt));
+}
+__device__ __forceinline__ uint8_t q8_pack1(Q8Ctx& c, float v, int fmt) {
+  c.amax = fmaxf(c.amax, fabsf(v));
+  const float t = fminf(fmaxf(v * c.scale, -c.fmax), c.fmax);
+  int w = 0;
+  w = fmt == MIC_E4M3 ? __builtin_amdgcn_cvt_pk_fp8_f32(t, 0.f, w, false) : __builtin_amdgcn_cvt_pk_bf8_f32(t, 0.f, w, false);
+  return (uint8_t)(w & 0xff);
+}
+// every lane of the wave calls this once, after its last pack: one atomic max per wave (non-negative floats order as ints)
+__device__ __forceinline__ void q8_end_wave(const Q8Out& o, const Q8Ctx& c, int wave_id) {
+  const float m = wave_max(c.amax);
+  if ((threadIdx.x & 63) == 0 && m > 0.f && o.amax_next)
+    atomicMax(reinterpret_cast<int*>(o.amax_next + (wave_id & (FP8_AMAX_PARTIALS - 1))), __float_as_int(m));
+}
+
 // ---- activations
 // The FFN activations run once per element inside GEMM epilogues, where the VALU is the bottleneck: each is written for the
 // fewest instructions — one v_exp_f32 (base 2, constants pre-multiplied by -log2 e) and one v_rcp_f32 each way.
@@ -217,6 +270,10 @@ struct EpiArgs {
   // the column tiles add up to the same bits in any order (run-to-run and batch-permutation determinism of generate).
   const long long* ln_stats; const float* ln_g; const float* ln_bias; float ln_inv_d, ln_eps;
   long long* rowsum2;
+  // fp8 GEMMs only: C leaves as fp8 bytes under the output tensor's delayed scale (c_q8 = 1 + MIC_E4M3 / MIC_E5M2; ldc in bytes),
+  // see Q8Out above — the GELU output of the FFN-in projection (next: the fp8 FFN-out projection) and the dGELU-scaled dX of
+  // FFN-out (next: FFN-in's backward GEMMs)
+  int c_q8; float* q8_state; float* q8_amax;
 };
 template <typename T>
 __device__ __forceinline__ void epilogue_store(const EpiArgs& e, int m, int n, float v) {
@@ -271,7 +328,8 @@ __device__ __forceinline__ void epilogue_prefetch8(const EpiArgs& e, int m, int 
   else if (e.accumulate && !e.c_f32) zc = *reinterpret_cast<const u32x4*>((const uint16_t*)e.C + (size_t)m * e.ldc + n);
   if (e.R) r = *reinterpret_cast<const u32x4*>((const uint16_t*)e.R + (size_t)m * e.ldr + n);
 }
-__device__ __forceinline__ void epilogue_store8_pre(const EpiArgs& e, int m, int n, float* v, u32x4 zc, u32x4 rq) {
+template <bool Q8 = false>
+__device__ __forceinline__ void epilogue_store8_pre(const EpiArgs& e, int m, int n, float* v, u32x4 zc, u32x4 rq, Q8Ctx* qc = nullptr) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] *= e.alpha;
   if (e.bias) {
@@ -316,6 +374,14 @@ __device__ __forceinline__ void epilogue_store8_pre(const EpiArgs& e, int m, int
     unpack8(rq, r);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] += r[i];
+  }
+  if constexpr (Q8) {
+    if (e.c_q8) {  // (host side: no accumulate, not fp32)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = round_to<uint16_t>(v[i]);
+      *reinterpret_cast<uint2*>((uint8_t*)e.C + (size_t)m * e.ldc + n) = q8_pack8(*qc, v, e.c_q8 - 1);
+      return;
+    }
   }
   if (e.c_f32) {
     float* c = (float*)e.C + (size_t)m * e.ldc + n;

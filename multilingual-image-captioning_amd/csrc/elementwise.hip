@@ -503,6 +503,74 @@ static int colsum_launch(int dtype, const mic_colsum_item* items, int count, voi
     hipLaunchKernelGGL(colsum_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tab);
   });
 }
+// the same for fp8 tensors (fused emission, BASELINE configs[4]): out[c] += scale_inv * sum_r fp8(x[r][c]) — the bias gradient of an fp8
+// projection from the e5m2 bytes its dy exists as (no bf16 copy is written any more).  Thread = 8 columns (one 8-B load per row).
+struct Colsum8Item { const uint8_t* x; float* out; const float* scale_inv; int rows, cols, ld, fmt, gx, gy, block_begin; };
+struct Colsum8Table { int count; Colsum8Item it[COLSUM_MAX]; };
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void colsum_q8_kernel(Colsum8Table tab) {
+  __shared__ float red[8][256 + 8];
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < COLSUM_MAX; ++i)
+    if (i < tab.count && (int)blockIdx.x >= tab.it[i].block_begin) pi = i;
+  const Colsum8Item& I = tab.it[pi];
+  const int local = blockIdx.x - I.block_begin;
+  const int bx = local % I.gx, by = local / I.gx;
+  const int cc = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c0 = bx * 256 + cc * 8;
+  const int rows_per = (I.rows + I.gy - 1) / I.gy;
+  const int r0 = by * rows_per, r1 = min(I.rows, r0 + rows_per);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c0 < I.cols) {  // cols % 8 == 0 (host check)
+    for (int r = r0 + rl; r < r1; r += 8) {
+      const uint2 u = *reinterpret_cast<const uint2*>(I.x + (size_t)r * I.ld + c0);
+      const int w[2] = {(int)u.x, (int)u.y};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x2v lo, hi;
+        if (I.fmt == MIC_E4M3) { lo = __builtin_amdgcn_cvt_pk_f32_fp8(w[h], false); hi = __builtin_amdgcn_cvt_pk_f32_fp8(w[h], true); }
+        else { lo = __builtin_amdgcn_cvt_pk_f32_bf8(w[h], false); hi = __builtin_amdgcn_cvt_pk_f32_bf8(w[h], true); }
+        acc[4 * h + 0] += lo[0]; acc[4 * h + 1] += lo[1]; acc[4 * h + 2] += hi[0]; acc[4 * h + 3] += hi[1];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[rl][cc * 8 + i] = acc[i];
+  __syncthreads();
+  const int c = bx * 256 + threadIdx.x;
+  if (c < I.cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t += red[j][threadIdx.x];
+    atomicAdd(I.out + c, t * I.scale_inv[0]);
+  }
+}
+extern "C" int mic_colsum_q8_grouped(const mic_colsum_q8_item* items, int count, void* stream) {
+  MIC_CHECK(items && count >= 1, "mic_colsum_q8_grouped: bad args");
+  for (int i0 = 0; i0 < count; i0 += COLSUM_MAX) {
+    Colsum8Table tab;
+    tab.count = count - i0 < COLSUM_MAX ? count - i0 : COLSUM_MAX;
+    int blocks = 0;
+    for (int i = 0; i < tab.count; ++i) {
+      const mic_colsum_q8_item& a = items[i0 + i];
+      MIC_CHECK(a.rows > 0 && a.cols > 0 && a.x && a.out && a.scale_inv, "mic_colsum_q8_grouped: bad item %d", i0 + i);
+      MIC_CHECK(a.cols % 8 == 0 && a.ld % 8 == 0 && ((uintptr_t)a.x & 7) == 0 && (a.fmt == MIC_E4M3 || a.fmt == MIC_E5M2), "mic_colsum_q8_grouped: cols, ld multiples of 8; fmt");
+      Colsum8Item& t = tab.it[i];
+      t.x = (const uint8_t*)a.x; t.out = a.out; t.scale_inv = a.scale_inv; t.rows = a.rows; t.cols = a.cols; t.ld = a.ld; t.fmt = a.fmt;
+      t.gx = (a.cols + 255) / 256;
+      int gy = (a.rows + 63) / 64;
+      const int cap = (1024 + t.gx - 1) / t.gx;
+      if (gy > cap) gy = cap;
+      t.gy = gy < 1 ? 1 : gy;
+      t.block_begin = blocks;
+      blocks += t.gx * t.gy;
+    }
+    hipLaunchKernelGGL(colsum_q8_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tab);
+    MIC_LAUNCH_CHECK();
+  }
+  return MIC_OK;
+}
 extern "C" int mic_colsum(int dtype, int rows, int cols, const void* x, int ld, float* out, int accumulate, void* stream) {
   MIC_CHECK(rows > 0 && cols > 0 && x && out, "mic_colsum: bad args");
   if (!accumulate) hipMemsetAsync(out, 0, sizeof(float) * cols, (hipStream_t)stream);

@@ -82,20 +82,6 @@ __global__ __launch_bounds__(256) void fp8_amax_kernel(QTable tab, int tiles_per
   if (cur_state) flush();
 }
 
-__device__ __forceinline__ uint32_t cvt4(const float* v, int fmt) {  // 4 floats -> 4 fp8 bytes (RNE, OCP encodings on gfx950)
-  int w = 0;
-  if (fmt == MIC_E4M3) {
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
-  } else {
-    w = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], w, false);
-    w = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], w, true);
-  }
-  return (uint32_t)w;
-}
-
-#define FP8_AMAX_PARTIALS 1024  // delayed scaling: per-tensor partial maxima (tile t lands in entry t % 1024): one atomic per
-                                // block, spread over 1024 addresses — 1024 atomics on ONE address cost ~12 us (L2 serialises them)
 // 128 (rows) x 64 (cols) tiles: thread t covers 8 columns (t & 7) of rows (t >> 3) + 32 h, h < 4 — four 16-B loads in flight per
 // thread, 128-B row segments in, 64-B segments of q and full 128-B lines of qT out (the 64 x 64 version measured 11 us for a
 // 4096 x 1024 tensor, 1.5 TB/s: too little work per block).
@@ -129,7 +115,7 @@ __global__ __launch_bounds__(256) void fp8_quantize_kernel(QTable tab) {
       m = fmaxf(m, fabsf(x));
       v[h][e] = fminf(fmaxf(x * scale, -fmax), fmax);
     }
-    const uint32_t lo = cvt4(v[h], I.fmt), hi = cvt4(v[h] + 4, I.fmt);
+    const uint32_t lo = cvt4_fp8(v[h], I.fmt), hi = cvt4_fp8(v[h] + 4, I.fmt);
     if (I.q && r < I.rows && c < I.cols) *reinterpret_cast<uint2*>(I.q + (size_t)r * I.ldq + c) = make_uint2(lo, hi);
     if (I.qT) {
 #pragma unroll

@@ -89,7 +89,14 @@ static int fill_epi(const mic_gemm_args* a, EpiArgs& e) {
   MIC_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "mic_gemm: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
   MIC_CHECK(a->dtype == MIC_BF16 || a->dtype == MIC_F32 || a->dtype == MIC_FP8, "mic_gemm: bad dtype %d", a->dtype);
   if (a->dtype == MIC_FP8) {
-    MIC_CHECK(a->c_dtype == MIC_BF16 || a->c_dtype == MIC_F32, "mic_gemm(fp8): C is bf16 or f32");
+    MIC_CHECK(a->c_dtype == MIC_BF16 || a->c_dtype == MIC_F32 || a->c_dtype == MIC_FP8, "mic_gemm(fp8): C is bf16, f32 or (fused emission) fp8");
+    if (a->c_dtype == MIC_FP8) {
+      // the epilogue quantises its result under the output tensor's delayed scale: the vector store path of the non-PLAIN epilogue
+      MIC_CHECK(a->c_q8_state && (a->c_q8_fmt == MIC_E4M3 || a->c_q8_fmt == MIC_E5M2), "mic_gemm(fp8 C): c_q8_state / c_q8_fmt");
+      MIC_CHECK((a->act || a->dact || a->Zout) && !a->accumulate && a->split_k <= 1 && !a->a_kmajor, "mic_gemm(fp8 C): an activation / dact epilogue of an NT launch, no accumulate / split-K");
+      MIC_CHECK(a->N % 8 == 0 && a->ldc % 8 == 0 && ((uintptr_t)a->C & 7) == 0 && (!a->Zout || a->ldz % 8 == 0) && (!a->Zin || a->ldz % 8 == 0) && (!a->R || a->ldr % 8 == 0),
+                "mic_gemm(fp8 C): N, ldc, ldz, ldr multiples of 8");
+    }
     MIC_CHECK(a->a_kmajor == a->b_kmajor, "mic_gemm(fp8): both operands k-contiguous (NT) or both k-major (TN, the weight-gradient GEMM)");
     if (a->a_kmajor) MIC_CHECK(a->M % 16 == 0 && a->N % 16 == 0 && a->split_k <= 1, "mic_gemm(fp8, k-major): M and N must be multiples of 16");
     MIC_CHECK((a->a_fmt == MIC_E4M3 || a->a_fmt == MIC_E5M2) && a->b_fmt == MIC_E4M3, "mic_gemm(fp8): A is e4m3 or e5m2, B is e4m3");
@@ -101,7 +108,9 @@ static int fill_epi(const mic_gemm_args* a, EpiArgs& e) {
   MIC_CHECK(a->c_dtype == a->dtype || a->c_dtype == MIC_F32, "mic_gemm: c_dtype must be dtype or f32");
   MIC_CHECK(!(a->dact && !a->Zin), "mic_gemm: dact needs Zin");
   MIC_CHECK(a->dropout_p >= 0.f && a->dropout_p < 1.f, "mic_gemm: dropout_p out of range");
+  MIC_CHECK(a->c_dtype != MIC_FP8 || a->dtype == MIC_FP8, "mic_gemm: an fp8 C belongs to the fp8 GEMMs");
   e.C = a->C; e.ldc = a->ldc; e.c_f32 = (a->c_dtype == MIC_F32);
+  e.c_q8 = a->c_dtype == MIC_FP8 ? 1 + a->c_q8_fmt : 0; e.q8_state = a->c_q8_state; e.q8_amax = a->c_q8_amax;
   e.bias = a->bias; e.act = a->act; e.Zout = a->Zout; e.ldz = a->ldz; e.Zin = a->Zin; e.dact = a->dact;
   e.R = a->R; e.ldr = a->ldr; e.accumulate = a->accumulate;
   e.drop_thr = a->dropout_p > 0.f ? (uint32_t)fminf(a->dropout_p * 4294967296.0f, 4294967295.0f) : 0u;
@@ -204,6 +213,8 @@ static GemmPlan plan_bf16(const mic_gemm_args* args, int count) {
   }
   if (force == 256 || force == 128 || force == 64) bm = force;
   if (args[0].dtype == MIC_FP8 && args[0].a_kmajor && bm < 128) bm = 128;  // fp8 k-major images are 128 wide
+  for (int i = 0; i < count; ++i)
+    if (args[i].c_dtype == MIC_FP8 && bm == 256) bm = 128;  // the fp8-emitting epilogue lives in the 128 / 64 tile kernels
   for (int i = 0; i < count; ++i)
     if (args[i].rowstat) bm = 256;  // softmax partials per 64-column granule = the wave tile width of this configuration
   // 192 x 128 tiles for the single-problem NT / NN launches whose 128 x 128 tiles would need a second round of the 2-per-CU slots

@@ -238,6 +238,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], c
   constexpr int NIT = (NGRP + NTHREADS - 1) / NTHREADS;   // ... per thread
   float* Cw = reinterpret_cast<float*>(smem) + wave * REGION;
   const bool pre = !is_split && epilogue_pre_ok(E) && epilogue_vec_ok(E, 8);
+  Q8Ctx q8c{1.0f, 448.0f, 0.0f};  // fp8 output (fp8 GEMMs, non-PLAIN launches only): scale from the tensor's delayed amax, running max |x|
+  constexpr bool Q8EPI = F8 != 0 && !PLAIN && WM <= 64;  // (the 256 x 256 kernels have no registers for it: the planner keeps fp8-C launches off them)
+  if constexpr (Q8EPI) {
+    if (E.c_q8) q8c = q8_begin(Q8Out{(uint8_t*)E.C, E.ldc, E.q8_state, E.q8_amax, E.c_q8 - 1}, blockIdx.x == 0 && tid == 0);
+  }
   // one pass per RP rows of the wave tile (body: gemm_epilogue_pass.inc).  The pass index selects accumulator registers, so it must
   // end up a constant: up to two passes the loop is unrolled by the compiler (the code every kernel had before the 96-row wave
   // tile, same register allocation); with three or four passes `#pragma unroll` gave up, the index stayed a run-time value and the
@@ -265,4 +270,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], c
     }
   }
 #undef MIC_EPILOGUE_PASS_K
+  if constexpr (Q8EPI) {
+    if (E.c_q8) q8_end_wave(Q8Out{(uint8_t*)E.C, E.ldc, E.q8_state, E.q8_amax, E.c_q8 - 1}, q8c, blockIdx.x * (NWAVES * KG) + wave + kg * NWAVES);
+  }
 }

@@ -4,15 +4,19 @@
 
 #define LN_MAXC 4  // 16-B chunks of 8 elements per lane: width <= 64*8*4 = 2048
 
-template <typename T>
+// Q8 (bf16 storage): the normalised row ALSO (or, y == nullptr, only) goes out as fp8 bytes under the tensor's delayed scale
+// (common.h: Q8Out) — the operand of an fp8 projection; the quantiser launch behind this kernel disappears.
+template <typename T, bool Q8 = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int width, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, T* __restrict__ y, float* __restrict__ mean_out,
                                                      float* __restrict__ rstd_out, uint32_t thr, uint32_t seed,
-                                                     float dscale) {
+                                                     float dscale, Q8Out q8) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
   if (row >= rows) return;
+  Q8Ctx qc;
+  if constexpr (Q8) qc = q8_begin(q8, blockIdx.x == 0 && threadIdx.x == 0);
   const int nchunk = width >> 3;
   const T* xr = x + (size_t)row * width;
   float v[LN_MAXC][8];
@@ -54,9 +58,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int width, const 
         o[i] = (v[c][i] - mean) * rstd * g[i] + b[i];
         if (thr) o[i] = dropout_keep(seed, (uint32_t)row * (uint32_t)width + (uint32_t)(ch * 8 + i), thr) ? o[i] * dscale : 0.f;
       }
-      st8(yr + ch * 8, o);
+      if (!Q8 || y) st8(yr + ch * 8, o);
+      if constexpr (Q8) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = round_to<T>(o[i]);
+        *reinterpret_cast<uint2*>(q8.q + (size_t)row * q8.ldq + ch * 8) = q8_pack8(qc, o, q8.fmt);
+      }
     }
   }
+  if constexpr (Q8) q8_end_wave(q8, qc, row);
 }
 
 // dx = (dres) + rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat));  dgamma += dy*xhat, dbeta += dy.
@@ -65,17 +75,23 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int width, const 
 #define LNB_WAVES 8  // waves per backward block: atomics scale with the BLOCK count, latency hiding with the WAVE count
 // NCH = 16-B chunks per lane (width <= 512*NCH): width <= 1024 runs with NCH = 2, half the registers of the generic
 // NCH = 4 build, so twice the waves fit a SIMD — this kernel lives on memory-level parallelism.
-template <typename T, int NCH, int NW>
-__global__ __launch_bounds__(64 * NW, NCH <= 2 ? 4 : 2) void ln_bwd_kernel(int rows, int width, const T* __restrict__ x,
+// Q8: 0 = off; 1 = dxm (the dropout-masked gradient entering the residual branch) also / only (dxm == nullptr) as fp8 bytes;
+// 2 = dx itself also as fp8 bytes (the ViT's residual-stream gradient is the FFN-out projection's dy) — e5m2 under the tensor's
+// delayed scale (common.h: Q8Out).
+template <typename T, int NCH, int NW, int Q8 = 0>
+__global__ __launch_bounds__(64 * NW, NCH <= 2 ? (Q8 ? 3 : 4) : 2) void ln_bwd_kernel(int rows, int width, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const T* __restrict__ dy,
                                                      const T* __restrict__ dres, T* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      T* __restrict__ dxm, uint32_t thr_m, uint32_t seed_m, float scale_m,
-                                                     uint32_t thr_in, uint32_t seed_in, float scale_in, float* __restrict__ partials) {
+                                                     uint32_t thr_in, uint32_t seed_in, float scale_in, float* __restrict__ partials,
+                                                     Q8Out q8) {
   __shared__ float red[NW][64 * 8 + 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = width >> 3;
+  Q8Ctx qc;
+  if constexpr (Q8 != 0) qc = q8_begin(q8, blockIdx.x == 0 && threadIdx.x == 0);
   float dg[NCH][8], db[NCH][8];
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
@@ -124,17 +140,29 @@ __global__ __launch_bounds__(64 * NW, NCH <= 2 ? 4 : 2) void ln_bwd_kernel(int r
           if (dres) o[i] += r[i];
         }
         st8(dx + (size_t)row * width + ch * 8, o);
-        if (dxm) {
+        if constexpr (Q8 == 2) {
+          float t[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) t[i] = round_to<T>(o[i]);
+          *reinterpret_cast<uint2*>(q8.q + (size_t)row * q8.ldq + ch * 8) = q8_pack8(qc, t, q8.fmt);
+        }
+        if (dxm || Q8 == 1) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const float ov = round_to<T>(o[i]);
             o[i] = dropout_keep(seed_m, (uint32_t)row * (uint32_t)width + (uint32_t)(ch * 8 + i), thr_m) ? ov * scale_m : 0.f;
           }
-          st8(dxm + (size_t)row * width + ch * 8, o);
+          if (dxm) st8(dxm + (size_t)row * width + ch * 8, o);
+          if constexpr (Q8 == 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = round_to<T>(o[i]);
+            *reinterpret_cast<uint2*>(q8.q + (size_t)row * q8.ldq + ch * 8) = q8_pack8(qc, o, q8.fmt);
+          }
         }
       }
     }
   }
+  if constexpr (Q8 != 0) q8_end_wave(q8, qc, blockIdx.x * NW + wave);
   // combine the waves' column partials (dgamma, then dbeta, through the same LDS buffer)
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
@@ -166,21 +194,44 @@ __global__ __launch_bounds__(64 * NW, NCH <= 2 ? 4 : 2) void ln_bwd_kernel(int r
 
 static inline uint32_t thr_of(float p) { return p > 0.f ? (uint32_t)fminf(p * 4294967296.0f, 4294967295.0f) : 0u; }
 
-extern "C" int mic_layernorm_fwd(int dtype, int rows, int width, const void* x, const float* gamma, const float* beta,
-                                 float eps, void* y, float* mean, float* rstd, float dropout_p, uint32_t dropout_seed,
-                                 void* stream) {
+static int q8_check(const mic_fp8_out* q8, int width, const char* who) {
+  MIC_CHECK(q8 && q8->q && q8->state && q8->ldq >= width && q8->ldq % 8 == 0 && ((uintptr_t)q8->q & 7) == 0, "%s: bad fp8 output (q, state, ldq %% 8 == 0)", who);
+  MIC_CHECK(q8->fmt == MIC_E4M3 || q8->fmt == MIC_E5M2, "%s: bad fp8 format", who);
+  return MIC_OK;
+}
+static inline Q8Out q8_of(const mic_fp8_out* q8) {
+  Q8Out o{};
+  if (q8) { o.q = (uint8_t*)q8->q; o.ldq = q8->ldq; o.state = q8->state; o.amax_next = q8->amax_next; o.fmt = q8->fmt; }
+  return o;
+}
+static int ln_fwd_impl(int dtype, int rows, int width, const void* x, const float* gamma, const float* beta, float eps, void* y,
+                       float* mean, float* rstd, float dropout_p, uint32_t dropout_seed, const mic_fp8_out* q8, void* stream) {
   MIC_CHECK(rows > 0 && width > 0 && width % 8 == 0 && width <= 64 * 8 * LN_MAXC, "mic_layernorm_fwd: bad shape rows=%d width=%d", rows, width);
-  MIC_CHECK(x && gamma && beta && y, "mic_layernorm_fwd: null pointer");
+  MIC_CHECK(x && gamma && beta && (y || q8), "mic_layernorm_fwd: null pointer");
   dim3 grid((rows + 3) / 4), block(256);
   const uint32_t thr = thr_of(dropout_p);
   const float sc = 1.0f / (1.0f - dropout_p);
-  if (dtype == MIC_BF16)
-    hipLaunchKernelGGL(ln_fwd_kernel<uint16_t>, grid, block, 0, (hipStream_t)stream, rows, width, (const uint16_t*)x, gamma, beta, eps, (uint16_t*)y, mean, rstd, thr, dropout_seed, sc);
+  if (q8) {
+    MIC_CHECK(dtype == MIC_BF16, "mic_layernorm_fwd_q8: bf16 storage only");
+    if (int rc = q8_check(q8, width, "mic_layernorm_fwd_q8")) return rc;
+    hipLaunchKernelGGL((ln_fwd_kernel<uint16_t, true>), grid, block, 0, (hipStream_t)stream, rows, width, (const uint16_t*)x, gamma, beta, eps, (uint16_t*)y, mean, rstd, thr, dropout_seed, sc, q8_of(q8));
+  } else if (dtype == MIC_BF16)
+    hipLaunchKernelGGL((ln_fwd_kernel<uint16_t, false>), grid, block, 0, (hipStream_t)stream, rows, width, (const uint16_t*)x, gamma, beta, eps, (uint16_t*)y, mean, rstd, thr, dropout_seed, sc, Q8Out{});
   else if (dtype == MIC_F32)
-    hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, (hipStream_t)stream, rows, width, (const float*)x, gamma, beta, eps, (float*)y, mean, rstd, thr, dropout_seed, sc);
+    hipLaunchKernelGGL((ln_fwd_kernel<float, false>), grid, block, 0, (hipStream_t)stream, rows, width, (const float*)x, gamma, beta, eps, (float*)y, mean, rstd, thr, dropout_seed, sc, Q8Out{});
   else MIC_CHECK(false, "mic_layernorm_fwd: bad dtype");
   MIC_LAUNCH_CHECK();
   return MIC_OK;
+}
+extern "C" int mic_layernorm_fwd(int dtype, int rows, int width, const void* x, const float* gamma, const float* beta,
+                                 float eps, void* y, float* mean, float* rstd, float dropout_p, uint32_t dropout_seed,
+                                 void* stream) {
+  return ln_fwd_impl(dtype, rows, width, x, gamma, beta, eps, y, mean, rstd, dropout_p, dropout_seed, nullptr, stream);
+}
+extern "C" int mic_layernorm_fwd_q8(int rows, int width, const void* x, const float* gamma, const float* beta, float eps, void* y,
+                                    float* mean, float* rstd, float dropout_p, uint32_t dropout_seed, const mic_fp8_out* q8, void* stream) {
+  MIC_CHECK(q8 != nullptr, "mic_layernorm_fwd_q8: null fp8 output");
+  return ln_fwd_impl(MIC_BF16, rows, width, x, gamma, beta, eps, y, mean, rstd, dropout_p, dropout_seed, q8, stream);
 }
 
 static int ln_bwd_blocks(int rows) {
@@ -190,7 +241,8 @@ static int ln_bwd_blocks(int rows) {
 extern "C" int mic_layernorm_bwd_blocks(int rows) { return ln_bwd_blocks(rows > 0 ? rows : 1); }
 static int ln_bwd_impl(int dtype, int rows, int width, const void* x, const float* gamma, const float* mean, const float* rstd,
                        const void* dy, const void* dres, void* dx, float* dgamma, float* dbeta, void* dxm, float dropout_p,
-                       uint32_t dropout_seed, float in_dropout_p, uint32_t in_dropout_seed, float* partials, void* stream);
+                       uint32_t dropout_seed, float in_dropout_p, uint32_t in_dropout_seed, float* partials, void* stream,
+                       const mic_fp8_out* q8 = nullptr, int q8_of_dx = 0);
 extern "C" int mic_layernorm_bwd(int dtype, int rows, int width, const void* x, const float* gamma, const float* mean,
                                  const float* rstd, const void* dy, const void* dres, void* dx, float* dgamma,
                                  float* dbeta, void* dxm, float dropout_p, uint32_t dropout_seed, float in_dropout_p,
@@ -204,6 +256,15 @@ extern "C" int mic_layernorm_bwd_partials(int dtype, int rows, int width, const 
   MIC_CHECK(partials != nullptr, "mic_layernorm_bwd_partials: null partials");
   return ln_bwd_impl(dtype, rows, width, x, gamma, mean, rstd, dy, dres, dx, nullptr, nullptr, dxm, dropout_p, dropout_seed, in_dropout_p,
                      in_dropout_seed, partials, stream);
+}
+extern "C" int mic_layernorm_bwd_partials_q8(int rows, int width, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                             const void* dy, const void* dres, void* dx, float* partials, void* dxm, float dropout_p,
+                                             uint32_t dropout_seed, float in_dropout_p, uint32_t in_dropout_seed, const mic_fp8_out* q8,
+                                             int q8_of_dx, void* stream) {
+  MIC_CHECK(partials != nullptr && q8 != nullptr, "mic_layernorm_bwd_partials_q8: null partials / fp8 output");
+  if (int rc = q8_check(q8, width, "mic_layernorm_bwd_partials_q8")) return rc;
+  return ln_bwd_impl(MIC_BF16, rows, width, x, gamma, mean, rstd, dy, dres, dx, nullptr, nullptr, dxm, dropout_p, dropout_seed, in_dropout_p,
+                     in_dropout_seed, partials, stream, q8, q8_of_dx);
 }
 // dgamma / dbeta from the block partials of mic_layernorm_bwd_partials: out[which][col] (+)= sum over blocks, in block order
 struct LnParamItem { const float* partials; float* dgamma; float* dbeta; int nblk, width, accumulate; };
@@ -259,7 +320,8 @@ extern "C" int mic_ln_param_grads(const mic_ln_param_item* items, int count, voi
 }
 static int ln_bwd_impl(int dtype, int rows, int width, const void* x, const float* gamma, const float* mean, const float* rstd,
                        const void* dy, const void* dres, void* dx, float* dgamma, float* dbeta, void* dxm, float dropout_p,
-                       uint32_t dropout_seed, float in_dropout_p, uint32_t in_dropout_seed, float* partials, void* stream) {
+                       uint32_t dropout_seed, float in_dropout_p, uint32_t in_dropout_seed, float* partials, void* stream,
+                       const mic_fp8_out* q8, int q8_of_dx) {
   MIC_CHECK(rows > 0 && width > 0 && width % 8 == 0 && width <= 64 * 8 * LN_MAXC, "mic_layernorm_bwd: bad shape rows=%d width=%d", rows, width);
   MIC_CHECK(x && gamma && mean && rstd && dy && dx, "mic_layernorm_bwd: null pointer");
   // measured: 16-wave blocks 21.9 -> 20.9 us, more than 256 blocks slower (each block ends with 2*width fp32 atomics,
@@ -267,14 +329,22 @@ static int ln_bwd_impl(int dtype, int rows, int width, const void* x, const floa
   const int NWS = LNB_WAVES;
   const int nblk = ln_bwd_blocks(rows);
   dim3 grid(nblk), block(64 * NWS);
-  const uint32_t thr_m = dxm ? thr_of(dropout_p) : 0u, thr_in = thr_of(in_dropout_p);
+  const uint32_t thr_m = (dxm || (q8 && !q8_of_dx)) ? thr_of(dropout_p) : 0u, thr_in = thr_of(in_dropout_p);
+  const Q8Out q8o = q8_of(q8);
   const float sm = 1.0f / (1.0f - dropout_p), si = 1.0f / (1.0f - in_dropout_p);
 #define LNB_LAUNCH(TT, NC) LNB_LAUNCH2(TT, NC, LNB_WAVES)
-#define LNB_LAUNCH2(TT, NC, NWW) hipLaunchKernelGGL((ln_bwd_kernel<TT, NC, NWW>), grid, block, 0, (hipStream_t)stream, rows, width, (const TT*)x, gamma, mean, rstd, (const TT*)dy, (const TT*)dres, (TT*)dx, dgamma, dbeta, (TT*)dxm, thr_m, dropout_seed, sm, thr_in, in_dropout_seed, si, partials)
+#define LNB_LAUNCH2(TT, NC, NWW) LNB_LAUNCH3(TT, NC, NWW, 0)
+#define LNB_LAUNCH3(TT, NC, NWW, QQ) hipLaunchKernelGGL((ln_bwd_kernel<TT, NC, NWW, QQ>), grid, block, 0, (hipStream_t)stream, rows, width, (const TT*)x, gamma, mean, rstd, (const TT*)dy, (const TT*)dres, (TT*)dx, dgamma, dbeta, (TT*)dxm, thr_m, dropout_seed, sm, thr_in, in_dropout_seed, si, partials, q8o)
+  if (q8) {
+    MIC_CHECK(dtype == MIC_BF16, "mic_layernorm_bwd_partials_q8: bf16 storage only");
+    if (q8_of_dx) { if (width <= 1024) LNB_LAUNCH3(uint16_t, 2, LNB_WAVES, 2); else LNB_LAUNCH3(uint16_t, LN_MAXC, LNB_WAVES, 2); }
+    else { if (width <= 1024) LNB_LAUNCH3(uint16_t, 2, LNB_WAVES, 1); else LNB_LAUNCH3(uint16_t, LN_MAXC, LNB_WAVES, 1); }
+  } else
   if (dtype == MIC_BF16) { if (width <= 1024) LNB_LAUNCH(uint16_t, 2); else LNB_LAUNCH(uint16_t, LN_MAXC); }
   else if (dtype == MIC_F32) { if (width <= 1024) LNB_LAUNCH(float, 2); else LNB_LAUNCH(float, LN_MAXC); }
 #undef LNB_LAUNCH
 #undef LNB_LAUNCH2
+#undef LNB_LAUNCH3
   else MIC_CHECK(false, "mic_layernorm_bwd: bad dtype");
   MIC_LAUNCH_CHECK();
   return MIC_OK;

@@ -61,9 +61,10 @@ def gemm_args(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: in
               bias=None, act=0, zout=None, zin=None, dact=0, residual=None, accumulate=False, dropout_p=0.0, dropout_seed=0,
               alpha=1.0, lda=None, ldb=None, ldc=None, ldz=None, ldr=None, split_k=0, split_stride=0, a_rowsum=None, rowsum_k=0,
               a_scale_inv=None, b_scale_inv=None, rowstat=None, rowstat_nvalid=0, ln_stats=None, ln_colsum=None, ln_width=0,
-              ln_eps=0.0, rowsum2=None, k_valid=0) -> "L.GemmArgs":
-    """fp8 operands: `a` / `b` are torch.float8_e4m3fn / float8_e5m2 tensors (k-contiguous), `a_scale_inv` / `b_scale_inv` the
-    device scalars mic_fp8_quantize wrote for them."""
+              ln_eps=0.0, rowsum2=None, k_valid=0, c_q8=None) -> "L.GemmArgs":
+    """fp8 operands: `a` / `b` are torch.float8_e4m3fn / float8_e5m2 tensors (both k-contiguous, or both k-major: the weight-gradient
+    form), `a_scale_inv` / `b_scale_inv` the device scalars their quantiser / producer wrote.  c_q8 = (state fp32 [2], amax_next or
+    None): `out` is an fp8 tensor the epilogue fills under that tensor's delayed scale (fused emission, see `fp8_out`)."""
     g = L.GemmArgs()
     g.dtype, g.c_dtype = _dt(a), _dt(out)
     if g.dtype == L.MIC_FP8:
@@ -88,6 +89,10 @@ def gemm_args(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: in
         g.a_ln_stats, g.a_ln_colsum, g.a_ln_width, g.a_ln_eps = _p(ln_stats), _p(ln_colsum), int(ln_width), float(ln_eps)
     g.rowsum2 = _p(rowsum2)  # int64 [M][2]: (sum, sum of squares) x 2^20 of the stored output rows, accumulated
     g.k_valid = int(k_valid)  # k-major x k-major launches: operand rows k >= k_valid count as zero (0 = all)
+    if c_q8 is not None:
+        if g.c_dtype != L.MIC_FP8:
+            raise L.MicError("c_q8 goes with an fp8 output tensor")
+        g.c_q8_state, g.c_q8_amax, g.c_q8_fmt = _p(c_q8[0]), _p(c_q8[1]), _FP8[out.dtype]
     return g
 
 
@@ -169,8 +174,21 @@ def fp8_roll_amax(state: torch.Tensor, partials: torch.Tensor, count: int):
     L.check(L.lib().mic_fp8_roll_amax(_p(state), state.stride(0), _p(partials), count, _stream()), "mic_fp8_roll_amax")
 
 
-def layernorm_fwd(x, gamma, beta, eps, y, mean=None, rstd=None, rows=None, dropout_p=0.0, dropout_seed=0):
+def fp8_out(q, state, amax_next=None) -> "L.Fp8Out":
+    """descriptor of a fused fp8 emission: q fp8 [rows][ld] (its dtype gives the format), state fp32 [2] (amax of the previous pass
+    read, 1 / scale written), amax_next fp32 [fp8_amax_partials()] (this pass's partial maxima) or None"""
+    o = L.Fp8Out()
+    o.q, o.ldq, o.state, o.amax_next, o.fmt = _p(q), q.stride(0), _p(state), _p(amax_next), _FP8[q.dtype]
+    return o
+
+
+def layernorm_fwd(x, gamma, beta, eps, y, mean=None, rstd=None, rows=None, dropout_p=0.0, dropout_seed=0, q8=None):
+    """q8 (an `fp8_out`, bf16 storage): the normalised rows also / only (y None) as fp8 bytes under the tensor's delayed scale"""
     rows = rows if rows is not None else x.shape[0]
+    if q8 is not None:
+        L.check(L.lib().mic_layernorm_fwd_q8(rows, x.shape[-1], _p(x), _p(gamma), _p(beta), float(eps), _p(y), _p(mean), _p(rstd),
+                                             float(dropout_p), int(dropout_seed) & 0xFFFFFFFF, C.byref(q8), _stream()), "mic_layernorm_fwd_q8")
+        return y
     L.check(L.lib().mic_layernorm_fwd(_dt(x), rows, x.shape[-1], _p(x), _p(gamma), _p(beta), float(eps), _p(y), _p(mean), _p(rstd),
                                       float(dropout_p), int(dropout_seed) & 0xFFFFFFFF, _stream()), "mic_layernorm_fwd")
     return y
@@ -191,10 +209,16 @@ def layernorm_bwd_blocks(rows: int) -> int:
 
 
 def layernorm_bwd_partials(x, gamma, mean, rstd, dy, dx, partials, rows=None, dres=None, dxm=None, dropout_p=0.0, dropout_seed=0,
-                           in_dropout_p=0.0, in_dropout_seed=0):
+                           in_dropout_p=0.0, in_dropout_seed=0, q8=None, q8_of_dx=False):
     """layernorm_bwd whose gamma / beta gradients land as per-block partial sums in `partials` (fp32 [2][blocks][width], overwritten)
-    for a later `ln_param_grads` instead of atomics"""
+    for a later `ln_param_grads` instead of atomics.  q8 (an `fp8_out`): the masked gradient dxm (q8_of_dx: dx itself) also as fp8"""
     rows = rows if rows is not None else x.shape[0]
+    if q8 is not None:
+        L.check(L.lib().mic_layernorm_bwd_partials_q8(rows, x.shape[-1], _p(x), _p(gamma), _p(mean), _p(rstd), _p(dy), _p(dres), _p(dx), _p(partials),
+                                                      _p(dxm), float(dropout_p), int(dropout_seed) & 0xFFFFFFFF, float(in_dropout_p),
+                                                      int(in_dropout_seed) & 0xFFFFFFFF, C.byref(q8), int(bool(q8_of_dx)), _stream()),
+                "mic_layernorm_bwd_partials_q8")
+        return dx
     L.check(L.lib().mic_layernorm_bwd_partials(_dt(x), rows, x.shape[-1], _p(x), _p(gamma), _p(mean), _p(rstd), _p(dy), _p(dres), _p(dx),
                                                _p(partials), _p(dxm), float(dropout_p), int(dropout_seed) & 0xFFFFFFFF,
                                                float(in_dropout_p), int(in_dropout_seed) & 0xFFFFFFFF, _stream()), "mic_layernorm_bwd_partials")
@@ -240,6 +264,23 @@ def attn_bwd_packed(q, k, v, out, dout, lse, dq, dk, dv, B, H, Tq_max, Tk, q_off
     L.check(L.lib().mic_attn_bwd_packed(_dt(q), B, H, Tq_max, Tk, _p(q_off), _p(q_len), int(kv_packed), _p(q), ldq, _p(k), ldk, _p(v), ldv,
                                         _p(out), ldo, _p(dout), lddo, _p(lse), int(causal), _p(dq), lddq, _p(dk), lddk, _p(dv), lddv,
                                         _stream()), "mic_attn_bwd_packed")
+
+
+def attn_bwd_q8(q, k, v, out, dout, lse, dq8, dk8, dv8, B, H, Tq, Tk, *, ldq, ldk, ldv, ldo, lddo, q_off=None, q_len=None, kv_packed=False,
+                key_mask=None, causal=False):
+    """attention backward (bf16, one 64x64 tile per sequence; dense rows, or packed rows with q_off / q_len) whose dQ / dK / dV leave
+    as fp8 bytes: dq8 / dk8 are `fp8_out` descriptors of dQ's and dK's byte matrices, dv8 the fp8 tensor (view) of dV (same leading
+    dimension, scale and amax table as dK)"""
+    L.check(L.lib().mic_attn_bwd_q8(B, H, Tq, Tk, _p(q_off), _p(q_len), int(bool(kv_packed)), _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), ldo,
+                                    _p(dout), lddo, _p(lse), _p(key_mask), int(causal), C.byref(dq8), C.byref(dk8), _p(dv8), _stream()), "mic_attn_bwd_q8")
+
+
+def colsum_q8_grouped(items):
+    """items: [(x fp8 [rows][ld], out fp32 [cols], scale_inv fp32 [1], rows, cols)]: out += scale_inv * column sums of the fp8 values"""
+    arr = (L.ColsumQ8Item * len(items))()
+    for a, (x, out, sinv, rows, cols) in zip(arr, items):
+        a.x, a.out, a.scale_inv, a.rows, a.cols, a.ld, a.fmt = _p(x), _p(out), _p(sinv), int(rows), int(cols), x.stride(0), _FP8[x.dtype]
+    L.check(L.lib().mic_colsum_q8_grouped(arr, len(items), _stream()), "mic_colsum_q8_grouped")
 
 
 def attn_decode(q, kc, vc, out, R, H, max_len, cur, *, ldq, ldo, ldc=None, src_row=None, row_div=1):
