@@ -83,8 +83,8 @@ typedef struct {
   int accumulate;          /* add existing C */
   float dropout_p; uint32_t dropout_seed; /* p = 0 disables */
   float alpha;             /* scale on acc before bias (0 means 1) */
-  int split_k;             /* > 1 (bf16 only): split the reduction over that many workgroups per tile; partial sums are
-                              atomically added (fp32) into a caller-zeroed C; no other epilogue allowed */
+  int split_k;             /* > 1 (bf16; fp8 NT launches with split_stride > 0): split the reduction over that many workgroups per tile;
+                              partial sums are atomically added (fp32) into a caller-zeroed C; no other epilogue allowed */
   long long split_stride;  /* split_k > 1 only.  0: partial sums are atomically added into C (above).  > 0: split s stores its
                               partial tile plainly at C + s * split_stride (elements; C = fp32 workspace of split_k slabs),
                               to be summed by mic_sum_slabs — no atomics, no zero-fill, deterministic */

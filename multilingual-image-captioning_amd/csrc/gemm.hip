@@ -98,12 +98,15 @@ static int fill_epi(const mic_gemm_args* a, EpiArgs& e) {
                 "mic_gemm(fp8 C): N, ldc, ldz, ldr multiples of 8");
     }
     MIC_CHECK(a->a_kmajor == a->b_kmajor, "mic_gemm(fp8): both operands k-contiguous (NT) or both k-major (TN, the weight-gradient GEMM)");
-    if (a->a_kmajor) MIC_CHECK(a->M % 16 == 0 && a->N % 16 == 0 && a->split_k <= 1, "mic_gemm(fp8, k-major): M and N must be multiples of 16");
+    if (a->a_kmajor) MIC_CHECK(a->M % 16 == 0 && a->N % 16 == 0, "mic_gemm(fp8, k-major): M and N must be multiples of 16");
     MIC_CHECK((a->a_fmt == MIC_E4M3 || a->a_fmt == MIC_E5M2) && a->b_fmt == MIC_E4M3, "mic_gemm(fp8): A is e4m3 or e5m2, B is e4m3");
     MIC_CHECK(a->K % 128 == 0, "mic_gemm(fp8): K=%d must be a multiple of 128 (zero-pad the reduction dim)", a->K);
     MIC_CHECK(a->lda % 16 == 0 && a->ldb % 16 == 0, "mic_gemm(fp8): lda/ldb must be multiples of 16 bytes");
     MIC_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->B & 15) == 0, "mic_gemm(fp8): A/B must be 16-B aligned");
-    MIC_CHECK(a->split_k <= 1 && !a->a_rowsum, "mic_gemm(fp8): no split-K / row sums on the fp8 path");
+    MIC_CHECK(!a->a_rowsum, "mic_gemm(fp8): no row sums on the fp8 path (mic_colsum_q8_grouped)");
+    if (a->split_k > 1)
+      MIC_CHECK(a->split_stride > 0 && a->c_dtype == MIC_F32 && !a->a_kmajor && !a->bias && !a->act && !a->dact && !a->Zout && !a->R && !a->accumulate && a->dropout_p == 0.f,
+                "mic_gemm(fp8): split_k writes raw fp32 partial sums into per-split slabs (split_stride > 0, NT, no other epilogue)");
   } else
   MIC_CHECK(a->c_dtype == a->dtype || a->c_dtype == MIC_F32, "mic_gemm: c_dtype must be dtype or f32");
   MIC_CHECK(!(a->dact && !a->Zin), "mic_gemm: dact needs Zin");
@@ -222,6 +225,7 @@ static GemmPlan plan_bf16(const mic_gemm_args* args, int count) {
   // MIC_GEMM_T192=0 switches the configuration off (A/B)
   static const int t192 = [] { const char* e = getenv("MIC_GEMM_T192"); return e ? atoi(e) : 1; }();
   int bm_m = bm;
+  // (fp8: measured — the 192-row fp8 tile needs 133 registers, i.e. one block per CU; capped at 128 it spills 59 and the step loses 10 %)
   if (bm == 128 && t192 && force == 0 && count == 1 && args[0].dtype == MIC_BF16 && !args[0].a_kmajor && args[0].split_k <= 1) {
     const long t128 = (long)((args[0].M + 127) / 128) * ((args[0].N + 127) / 128), t192n = (long)((args[0].M + 191) / 192) * ((args[0].N + 127) / 128);
     if (t128 > 2L * cus && t192n <= 2L * cus) bm_m = 192;

@@ -99,11 +99,15 @@ class Engine:
         P = self.P
         self.fp8 = True
         self.fp8_scaling = scaling
-        names = [f"dec{l}.{k}" for l in range(P.L) for k in self.FP8_KINDS] + [f"vit{l}.{k}" for l in range(P.vL) for k in ("qkv", "fc1", "fc2")]
+        # the cross-attention k/v projections of all layers as ONE fp8 matrix "ckvcat" (one scale) when they run hoisted (ckv_hoisted)
+        kinds = tuple(k for k in self.FP8_KINDS if not (k == "ckv" and self._ckv_hoist))
+        names = [f"dec{l}.{k}" for l in range(P.L) for k in kinds] + [f"vit{l}.{k}" for l in range(P.vL) for k in ("qkv", "fc1", "fc2")]
+        if self._ckv_hoist:
+            names.append("ckvcat")
         self._w8 = {}
         self._w8_state = torch.zeros((len(names), 2), dtype=torch.float32, device=self.dev)
         for i, n in enumerate(names):
-            N, K = P.w(n + ".w").shape
+            N, K = self._w8_src(n).shape
             self._w8[n] = (torch.empty((N, K), dtype=torch.float8_e4m3fn, device=self.dev),   # [out][in]: forward  x W^T
                            torch.empty((K, N), dtype=torch.float8_e4m3fn, device=self.dev),   # [in][out]: dX = dy W
                            self._w8_state[i])
@@ -117,6 +121,17 @@ class Engine:
         self._a8_ready = set()   # delayed scaling: tags whose slot carries the previous pass's amax
         self._a8_cache: Dict = {}
         self._dw8_queue = []
+        self._cs8_queue = []     # bias gradients of the fp8 projections: column sums over the e5m2 bytes of dy
+        self._x8: Dict[str, tuple] = {}  # wname -> (q, state) of the Linear's input as quantised in the training forward (dW reads it)
+        # fused emission: under delayed scaling the PRODUCER of an operand (LayerNorm, GELU / dGELU epilogue, attention backward)
+        # writes the fp8 bytes itself once the tensor has a scale history (from its second pass on); MIC_FP8_FUSED=0: every operand
+        # through mic_fp8_quantize again (A/B)
+        import os as _os
+        self.fp8_fused = scaling == "delayed" and self.ln_partials and _os.environ.get("MIC_FP8_FUSED", "1") != "0"
+
+    def _w8_src(self, name: str):
+        """the bf16 matrix behind the fp8 weight entry `name`"""
+        return self.P.ckv_cat("w")[0] if name == "ckvcat" else self.P.w(name + ".w")
 
     def storage_dtype_gemms(self):
         """context: every Linear runs in the storage dtype (bf16) even when the trainer switched the projections to fp8 — the
@@ -153,7 +168,7 @@ class Engine:
                 ops.zero(self._w8_state)
                 if delayed:
                     ops.zero(self._w8_part)
-            items = [ops.fp8_item(P.w(n + ".w"), q.shape[0], q.shape[1], st, torch.float8_e4m3fn, q=q, qT=qT,
+            items = [ops.fp8_item(self._w8_src(n), q.shape[0], q.shape[1], st, torch.float8_e4m3fn, q=q, qT=qT,
                                   amax_next=self._w8_part[i] if delayed else None) for i, (n, (q, qT, st)) in enumerate(self._w8.items())]
             ops.fp8_quantize(items, amax_pass=not (delayed and self._w8_seen))
             self._w8_seen = delayed
@@ -166,6 +181,7 @@ class Engine:
         else:
             ops.zero(self._a8_state[: max(n, 1)])
         self._a8_cache = {}
+        self._x8 = {}
 
     def _fp8_ok(self, wname: str) -> bool:
         return self.fp8 and wname.split(".")[-1] in self.FP8_KINDS and wname in self._w8
@@ -178,33 +194,49 @@ class Engine:
                 raise RuntimeError("fp8: out of activation scale slots")
         return i
 
-    def _quant(self, x, rows: int, cols: int, tag: str, buf_tag: str, fmt, want_qT: bool, cache: bool):
-        """(q [rows][cols], qT [cols][rows_pad] or None, state) of bf16 x.  cache=True: x keeps its contents for the rest of the
-        pass (a saved per-layer activation, the encoder states every layer's cross-attention projects): quantised once."""
+    def _quant(self, x, rows: int, cols: int, tag: str, buf_tag: str, fmt, cache: bool = False):
+        """(q [rows][cols] fp8, state) of bf16 x through mic_fp8_quantize (the unfused path: tensors without a scale history, operands
+        no kernel of ours produces in fp8).  No transposed copy: the weight-gradient GEMM reads its operands k-major.  cache=True: x
+        keeps its contents for the rest of the pass (the encoder states every layer's cross-attention projects): quantised once."""
         key = (x.data_ptr(), rows, cols, fmt)
         hit = self._a8_cache.get(key) if cache else None
-        if hit is not None and (hit[1] is not None or not want_qT):
+        if hit is not None:
             return hit
-        rp = _rup(rows, ROWPAD)
         # sized by the CAPACITY of x (its row count is the step-independent [B*T] / [B*S] capacity), not by this step's valid rows:
-        # with packed decoder rows `rows` changes from step to step and a buffer per distinct count would never be freed.  The
-        # quantiser rewrites q[:rows] and qT[:, :rp] (zero beyond `rows`) on every call; nothing reads past them.
-        cap = max(int(x.shape[0]), rp)
+        # with packed decoder rows `rows` changes from step to step and a buffer per distinct count would never be freed
+        cap = max(int(x.shape[0]), _rup(rows, ROWPAD))
         q = self.buf(buf_tag + ".q8", cap, cols, fmt)
-        qT = self.buf(buf_tag + ".q8T", cols, cap, fmt) if want_qT else None
         slot = self._a8_slot(tag)
         st = self._a8_state[slot]
         delayed = self.fp8_scaling == "delayed"
-        if hit is not None:
-            # same tensor quantised earlier in this pass without the transposed copy: reuse its scale, do not count it twice
-            ops.fp8_quantize([ops.fp8_item(x, rows, cols, hit[2], fmt, q=q, qT=qT, rows_pad=rp)], amax_pass=False)
-            st = hit[2]
-        else:
-            item = ops.fp8_item(x, rows, cols, st, fmt, q=q, qT=qT, rows_pad=rp, amax_next=self._a8_part[slot] if delayed else None)
-            ops.fp8_quantize([item], amax_pass=not (delayed and tag in self._a8_ready))
+        item = ops.fp8_item(x, rows, cols, st, fmt, q=q, amax_next=self._a8_part[slot] if delayed else None)
+        ops.fp8_quantize([item], amax_pass=not (delayed and tag in self._a8_ready))
         if cache:
-            self._a8_cache[key] = (q, qT, st)
-        return q, qT, st
+            self._a8_cache[key] = (q, st)
+        return q, st
+
+    def _q8_target(self, tag: str, buf_tag: str, rows_cap: int, cols: int, fmt):
+        """(q, state, fp8_out descriptor, (state, partials)) when the tensor `tag` can be EMITTED by its producer: fp8 GEMMs on, delayed
+        scaling, a scale history for this tensor (second pass on); else None: the producer writes bf16 and `_quant` follows."""
+        if not (self.fp8 and self.fp8_fused and tag in self._a8_ready):
+            return None
+        slot = self._a8_slot(tag)
+        st, part = self._a8_state[slot], self._a8_part[slot]
+        q = self.buf(buf_tag + ".q8", rows_cap, cols, fmt)
+        return q, st, ops.fp8_out(q, st, part), (st, part)
+
+    def ln_x8(self, x, ln: str, eps: float, a_name: str, cap: int, mean, rstd, rows: int, wname: str, q_tag: str, **kw):
+        """LayerNorm `ln` of x whose output feeds Linear `wname`: (a bf16 or None, x8 = (q, state) or None).  Fused fp8 emission when
+        that Linear runs in fp8 and its input has a scale history: the normalised rows leave as e4m3 bytes only."""
+        P = self.P
+        width = x.shape[-1]
+        t = self._q8_target(wname + ".x", q_tag + wname.split(".")[-1] + ".x", cap, width, torch.float8_e4m3fn) if self._fp8_ok(wname) else None
+        if t is not None:
+            ops.layernorm_fwd(x, P.f32(ln + ".g"), P.f32(ln + ".b"), eps, None, mean, rstd, rows=rows, q8=t[2], **kw)
+            return None, (t[0], t[1])
+        a = self.buf(a_name, cap, width)
+        ops.layernorm_fwd(x, P.f32(ln + ".g"), P.f32(ln + ".b"), eps, a, mean, rstd, rows=rows, **kw)
+        return a, None
 
     def _done(self, seg_name: str):
         """Report that the gradient segment `seg_name` (and, by layout order, everything before it) is final."""
@@ -244,52 +276,68 @@ class Engine:
 
     # ------------------------------------------------------------------ small helpers
     def linear(self, x, wname, out, M, *, act=0, zout=None, residual=None, drop_seed=None, bias=True, save_tag=None, fp8=True,
-               stable_input=False):
-        """save_tag (fp8 mode, training forward): name under which the transposed fp8 copy of x is kept for the weight-gradient
-        GEMM of backward (dW = dy^T x reduces over rows: both operands must be row-contiguous)."""
+               stable_input=False, x8=None, out8=None):
+        """save_tag (fp8 mode, training forward): the fp8 copy of x is kept under that name for the weight-gradient GEMM of backward
+        (dW = dy^T x reads dy and x k-major, as they lie).  x8 = (q, state): x already exists as fp8 bytes (fused emission by its
+        producer; `x` may be None).  out8 = `_q8_target(...)`: the result leaves as fp8 bytes (the GELU output of FFN-in, whose only
+        reader is the fp8 FFN-out projection); returns (q, state) then."""
         P = self.P
         w = P.w(wname + ".w")
         N, K = w.shape
         p = self.p_drop if drop_seed is not None else 0.0
         if fp8 and self._fp8_ok(wname):
             wq, _, ws = self._w8[wname]
-            xq, _, xs = self._quant(x, M, K, wname + ".x", (save_tag or "f8.") + wname.split(".")[-1] + ".x", torch.float8_e4m3fn,
-                                    want_qT=save_tag is not None, cache=save_tag is not None or stable_input)
-            return ops.gemm(xq, wq, out, M, N, K, bias=P.f32(wname + ".b") if bias else None, act=act, zout=zout, residual=residual,
-                            dropout_p=p, dropout_seed=drop_seed or 0, a_scale_inv=xs[1:], b_scale_inv=ws[1:])
+            if x8 is None:
+                x8 = self._quant(x, M, K, wname + ".x", (save_tag or "f8.") + wname.split(".")[-1] + ".x", torch.float8_e4m3fn,
+                                 cache=stable_input)
+            if save_tag is not None:
+                self._x8[wname] = x8
+            kw = dict(bias=P.f32(wname + ".b") if bias else None, act=act, zout=zout, residual=residual, dropout_p=p, dropout_seed=drop_seed or 0,
+                      a_scale_inv=x8[1][1:], b_scale_inv=ws[1:])
+            if out8 is not None:
+                ops.gemm(x8[0], wq, out8[0], M, N, K, c_q8=out8[3], **kw)
+                return out8[0], out8[1]
+            return ops.gemm(x8[0], wq, out, M, N, K, **kw)
         return ops.gemm(x, w, out, M, N, K, bias=P.f32(wname + ".b") if bias else None, act=act, zout=zout,
                         residual=residual, dropout_p=p, dropout_seed=drop_seed or 0)
 
-    def linear_bwd(self, wname, x, dy, M, *, dx=None, zin=None, dact=0, dx_accumulate=False, bias=True, defer=False, x_tag=True):
+    def linear_bwd(self, wname, x, dy, M, *, dx=None, zin=None, dact=0, dx_accumulate=False, bias=True, defer=False, x_tag=True,
+                   dy8=None, dx8=None, par=0):
         """dW = dy^T x (fp32, overwrite), db = colsum(dy), optionally dx = (dy W) [* act'(zin)].
         defer=True queues the weight-gradient GEMM (nothing but the optimizer depends on it): the caller keeps dy and x
         intact until flush_dw() launches the layer's queue as ONE grouped GEMM (36..256-tile problems fill the chip
-        only together)."""
+        only together).  fp8 projections: dy8 = (q, state) when dy's producer emitted the e5m2 bytes itself (`dy` may be None),
+        dx8 = `_q8_target(...)` when dx is to leave as fp8 bytes (the dGELU-scaled dX of FFN-out = the dy of FFN-in); par = layer
+        parity of the buffer an unfused dy is quantised into (it is read by the deferred launches of its layer)."""
         P = self.P
         w = P.w(wname + ".w")
         N, K = w.shape
         Mp = _rup(M, ROWPAD)
         if self._fp8_ok(wname) and x_tag is not None:
-            # fp8: dy -> e5m2 (row-major for dX = dy W, transposed for dW = dy^T x); x^T was quantised in forward; W^T once per step
+            # fp8: dy as e5m2 bytes [M][N] — row-major for dX = dy W (NT against W^T, quantised once per step), k-major for
+            # dW = dy^T x (TN: both operands as their producers wrote them); x as saved by the forward pass
             kind = wname.split(".")[0].rstrip("0123456789") + "." + wname.split(".")[-1]
-            dyq, dyqT, dys = self._quant(dy, M, N, wname + ".dy", "f8." + kind + ".dy", torch.float8_e5m2, want_qT=True, cache=False)
-            hit = self._a8_cache.get((x.data_ptr(), M, K, torch.float8_e4m3fn))
-            if hit is None or hit[1] is None:
-                raise RuntimeError(f"fp8 backward of {wname}: the forward pass did not keep x^T (save_tag missing)")
-            _, xqT, xs = hit
+            if dy8 is None:
+                dy8 = self._quant(dy, M, N, wname + ".dy", f"f8.{kind}.dy.{par}", torch.float8_e5m2)
+            x8 = self._x8.get(wname)
+            if x8 is None:
+                raise RuntimeError(f"fp8 backward of {wname}: the forward pass did not keep the fp8 copy of its input (save_tag missing)")
             _, wqT, ws = self._w8[wname]
-            ga = ops.gemm_args(dyqT, xqT, P.g(wname + ".w"), N, K, Mp, a_scale_inv=dys[1:], b_scale_inv=xs[1:])
+            ga = ops.gemm_args(dy8[0], x8[0], P.g(wname + ".w"), N, K, Mp, a_kmajor=True, b_kmajor=True, k_valid=M,
+                               a_scale_inv=dy8[1][1:], b_scale_inv=x8[1][1:])
+            cs = (dy8[0], P.g(wname + ".b"), dy8[1][1:], M, N) if bias else None  # (into the pre-zeroed atomic region)
             if defer:
                 self._dw8_queue.append((ga, wname, bias))
+                if cs is not None:
+                    self._cs8_queue.append(cs)
             else:
                 ops.gemm_grouped([ga])
-            if bias:
-                if defer:
-                    self._cs_queue.append((dy, P.g(wname + ".b"), M, N, dy.stride(0)))
-                else:
-                    ops.colsum(dy, P.g(wname + ".b"), M, N, dy.stride(0), accumulate=True)
-            if dx is not None:
-                ops.gemm(dyq, wqT, dx, M, K, N, zin=zin, dact=dact, accumulate=dx_accumulate, a_scale_inv=dys[1:], b_scale_inv=ws[1:])
+                if cs is not None:
+                    ops.colsum_q8_grouped([cs])
+            if dx8 is not None:
+                ops.gemm(dy8[0], wqT, dx8[0], M, K, N, zin=zin, dact=dact, a_scale_inv=dy8[1][1:], b_scale_inv=ws[1:], c_q8=dx8[3])
+            elif dx is not None:
+                ops.gemm(dy8[0], wqT, dx, M, K, N, zin=zin, dact=dact, accumulate=dx_accumulate, a_scale_inv=dy8[1][1:], b_scale_inv=ws[1:])
             if not defer:
                 self._done(wname + ".w")
             return dx
@@ -313,6 +361,15 @@ class Engine:
         if not defer:
             self._done(wname + ".w")
         return dx
+
+    def dy8_target(self, wname: str, par: int, cap: int):
+        """fused-emission target (see `_q8_target`) for the gradient w.r.t. the OUTPUT of the fp8 Linear `wname` — the e5m2 dy its
+        backward GEMMs read; `par`: layer parity (the deferred weight-gradient launch of a layer reads it while the next layer's
+        backward already writes the other buffer).  None when the Linear is not fp8 / the tensor has no scale history."""
+        if not self._fp8_ok(wname):
+            return None
+        kind = wname.split(".")[0].rstrip("0123456789") + "." + wname.split(".")[-1]
+        return self._q8_target(wname + ".dy", f"f8.{kind}.dy.{par}", cap, self.P.w(wname + ".w").shape[0], torch.float8_e5m2)
 
     def ln_folded(self, wname: str, ln: str):
         """(gamma o W, colsum, bias') of Linear `wname` behind LayerNorm `ln` (mic_ln_fold_weight), rebuilt when the weights
@@ -346,18 +403,18 @@ class Engine:
             return ops.layernorm_bwd(x, P.f32(ln + ".g"), mean, rstd, dy, dx, P.g(ln + ".g"), P.g(ln + ".b"), rows=rows, **kw)
         width = x.shape[-1]
         part = self.buf(f"lnp.{tag}.{l & 1}", 2 * 256, width, torch.float32)  # [2][blocks <= 256][width]
-        ops.layernorm_bwd_partials(x, P.f32(ln + ".g"), mean, rstd, dy, dx, part, rows=rows, **kw)
+        ops.layernorm_bwd_partials(x, P.f32(ln + ".g"), mean, rstd, dy, dx, part, rows=rows, **kw)  # (kw may carry q8 / q8_of_dx: fused fp8 emission)
         self._lnp_queue.append((part, ops.layernorm_bwd_blocks(rows), width, P.g(ln + ".g"), P.g(ln + ".b"), False))
         return dx
 
     def _dw_on(self) -> bool:
-        return self.dw_overlap and not self.fp8
+        return self.dw_overlap
 
     def flush_dw(self):
         """Launch the layer's queued weight-gradient GEMMs (and bias column sums) as grouped launches — on the dW stream when
         enabled: it waits for everything enqueued so far (the operands' producers), main goes on with the next layer and
         only waits for the dW launch of TWO layers back (the one that read the buffers the next layer is about to rewrite)."""
-        if not (self._cs_queue or self._dw_queue or self._lnp_queue or (self.fp8 and self._dw8_queue)):
+        if not (self._cs_queue or self._dw_queue or self._lnp_queue or (self.fp8 and (self._dw8_queue or self._cs8_queue))):
             return
         side = None
         if self._dw_on():
@@ -403,6 +460,9 @@ class Engine:
             ops.colsum_grouped(self._cs_queue)
             self._cs_queue = []
         names = []
+        if self.fp8 and self._cs8_queue:
+            ops.colsum_q8_grouped(self._cs8_queue)
+            self._cs8_queue = []
         if self.fp8 and self._dw8_queue:
             ops.gemm_grouped([q[0] for q in self._dw8_queue])
             names += [q[1] for q in self._dw8_queue]
@@ -441,24 +501,24 @@ class Engine:
         for l in range(P.vL):
             tag = f"v{l}." if save else "v_."
             p = f"vit{l}."
-            a1 = self.buf(tag + "a1", Mv, vd)
             st1 = self.buf(tag + "st1", 2, _rup(Mv, ROWPAD), torch.float32)
-            ops.layernorm_fwd(x, P.f32(p + "ln1.g"), P.f32(p + "ln1.b"), self.vit_eps, a1, st1[0], st1[1], rows=Mv)
+            a1, a1_8 = self.ln_x8(x, p + "ln1", self.vit_eps, tag + "a1", Mv, st1[0], st1[1], Mv, p + "qkv", tag)
             qkv = self.buf(tag + "qkv", Mv, 3 * vd)
-            self.linear(a1, p + "qkv", qkv, Mv, save_tag=tag if save else None)
+            self.linear(a1, p + "qkv", qkv, Mv, save_tag=tag if save else None, x8=a1_8)
             ctx = self.buf(tag + "ctx", Mv, vd)
             lse = self.vec(tag + "lse", B * H * S)
             ops.attn_fwd(qkv, qkv[:, vd:], qkv[:, 2 * vd:], ctx, B, H, S, S, ldq=3 * vd, ldk=3 * vd, ldv=3 * vd, ldo=vd, lse=lse)
             xm = self.buf(tag + "xm", Mv, vd)
             self.linear(ctx, p + "o", xm, Mv, residual=x)
-            a2 = self.buf(tag + "a2", Mv, vd)
             st2 = self.buf(tag + "st2", 2, _rup(Mv, ROWPAD), torch.float32)
-            ops.layernorm_fwd(xm, P.f32(p + "ln2.g"), P.f32(p + "ln2.b"), self.vit_eps, a2, st2[0], st2[1], rows=Mv)
+            a2, a2_8 = self.ln_x8(xm, p + "ln2", self.vit_eps, tag + "a2", Mv, st2[0], st2[1], Mv, p + "fc1", tag)
             z = self.buf(tag + "z", Mv, vf)
-            u = self.buf(tag + "u", Mv, vf)
-            self.linear(a2, p + "fc1", u, Mv, act=L.ACT_QUICK_GELU, zout=z, save_tag=tag if save else None)
+            # the GELU output's only reader is FFN-out: with a scale history it leaves the FFN-in epilogue as e4m3 bytes
+            u8t = self._q8_target(p + "fc2.x", tag + "fc2.x", Mv, vf, torch.float8_e4m3fn) if self._fp8_ok(p + "fc2") else None
+            u = self.buf(tag + "u", Mv, vf) if u8t is None else None
+            u8 = self.linear(a2, p + "fc1", u, Mv, act=L.ACT_QUICK_GELU, zout=z, save_tag=tag if save else None, x8=a2_8, out8=u8t)
             xo = self.buf(f"v{l}.xo" if save else f"v_.xo{l & 1}", Mv, vd)
-            self.linear(u, p + "fc2", xo, Mv, residual=xm, save_tag=tag if save else None)
+            self.linear(u, p + "fc2", xo, Mv, residual=xm, save_tag=tag if save else None, x8=u8 if u8t is not None else None)
             x = xo
         ehs = self.buf("v.ehs", Mv, P.d)
         self.linear(x, "vp", ehs, Mv)
@@ -479,28 +539,46 @@ class Engine:
         x_last = self.buf(f"v{P.vL - 1}.xo", Mv, vd)
         dx = self.dyb("vb.dx", P.vL - 1, Mv, vd)
         self.linear_bwd("vp", x_last, dehs, Mv, dx=dx)
+        f8 = self.fp8  # fp8 projections: their inputs exist as saved fp8 bytes (Engine._x8); the bf16 names below may hold nothing
+        dx8 = None     # (q, state) of dx when the LayerNorm backward that produced it emitted the e5m2 bytes too
         for l in reversed(range(P.vL)):
             tag, p = f"v{l}.", f"vit{l}."
-            a1, qkv, ctx, xm = (self.buf(tag + n, Mv, c) for n, c in (("a1", vd), ("qkv", 3 * vd), ("ctx", vd), ("xm", vd)))
-            a2, z, u = self.buf(tag + "a2", Mv, vd), self.buf(tag + "z", Mv, vf), self.buf(tag + "u", Mv, vf)
+            qkv, ctx, xm = (self.buf(tag + n, Mv, c) for n, c in (("qkv", 3 * vd), ("ctx", vd), ("xm", vd)))
+            a1, a2, u = ((None, None, None) if f8 else (self.buf(tag + "a1", Mv, vd), self.buf(tag + "a2", Mv, vd), self.buf(tag + "u", Mv, vf)))
+            z = self.buf(tag + "z", Mv, vf)
             st1, st2 = self.buf(tag + "st1", 2, _rup(Mv, ROWPAD), torch.float32), self.buf(tag + "st2", 2, _rup(Mv, ROWPAD), torch.float32)
             lse = self.vec(tag + "lse", B * H * S)
             x_in = self.buf(f"v{l - 1}.xo", Mv, vd) if l > 0 else self.buf("v.x0", Mv, vd)
-            dz = self.dyb("vb.dz", l, Mv, vf)
-            self.linear_bwd(p + "fc2", u, dx, Mv, dx=dz, zin=z, dact=L.ACT_QUICK_GELU, defer=True)
+            dz8t = self.dy8_target(p + "fc1", l & 1, Mv)  # dz = dGELU-scaled dX of fc2 = the dy of fc1: e5m2 straight from the epilogue
+            dz = self.dyb("vb.dz", l, Mv, vf) if dz8t is None else None
+            self.linear_bwd(p + "fc2", u, dx, Mv, dx=dz, zin=z, dact=L.ACT_QUICK_GELU, defer=True, dy8=dx8, dx8=dz8t, par=l & 1)
             da = self.buf("vb.da", Mv, vd)
-            self.linear_bwd(p + "fc1", a2, dz, Mv, dx=da, defer=True)
+            self.linear_bwd(p + "fc1", a2, dz, Mv, dx=da, defer=True, dy8=None if dz8t is None else (dz8t[0], dz8t[1]), par=l & 1)
             dxm = self.dyb("vb.dxm", l, Mv, vd)
             self.ln_bwd("v2", l, xm, p + "ln2", st2[0], st2[1], da, dxm, Mv, dres=dx)
             dctx = self.buf("vb.dctx", Mv, vd)
             self.linear_bwd(p + "o", ctx, dxm, Mv, dx=dctx, defer=True)
-            dqkv = self.dyb("vb.dqkv", l, Mv, 3 * vd)
-            ops.attn_bwd(qkv, qkv[:, vd:], qkv[:, 2 * vd:], ctx, dctx, lse, dqkv, dqkv[:, vd:], dqkv[:, 2 * vd:], B, H, S, S,
-                         ldq=3 * vd, ldk=3 * vd, ldv=3 * vd, ldo=vd, lddo=vd, lddq=3 * vd, lddk=3 * vd, lddv=3 * vd)
-            self.linear_bwd(p + "qkv", a1, dqkv, Mv, dx=da, defer=True)
+            dq8t = self.dy8_target(p + "qkv", l & 1, Mv) if S <= 64 else None
+            if dq8t is not None:
+                q8 = dq8t[0]
+                ops.attn_bwd_q8(qkv, qkv[:, vd:], qkv[:, 2 * vd:], ctx, dctx, lse, dq8t[2], ops.fp8_out(q8[:, vd:], dq8t[1], dq8t[3][1]), q8[:, 2 * vd:],
+                                B, H, S, S, ldq=3 * vd, ldk=3 * vd, ldv=3 * vd, ldo=vd, lddo=vd)
+                self.linear_bwd(p + "qkv", a1, None, Mv, dx=da, defer=True, dy8=(dq8t[0], dq8t[1]), par=l & 1)
+            else:
+                dqkv = self.dyb("vb.dqkv", l, Mv, 3 * vd)
+                ops.attn_bwd(qkv, qkv[:, vd:], qkv[:, 2 * vd:], ctx, dctx, lse, dqkv, dqkv[:, vd:], dqkv[:, 2 * vd:], B, H, S, S,
+                             ldq=3 * vd, ldk=3 * vd, ldv=3 * vd, ldo=vd, lddo=vd, lddq=3 * vd, lddk=3 * vd, lddv=3 * vd)
+                self.linear_bwd(p + "qkv", a1, dqkv, Mv, dx=da, defer=True, par=l & 1)
             self.flush_dw()  # before LN1 backward overwrites dx (the fc2 gradient operand)
             dx = self.dyb("vb.dx", l - 1, Mv, vd)  # the layer below's residual-stream gradient (= its fc2 dW operand)
-            self.ln_bwd("v1", l, x_in, p + "ln1", st1[0], st1[1], da, dx, Mv, dres=dxm)
+            # ... which the layer below's fc2 backward reads as e5m2: emitted here, beside the bf16 dx the residual path needs
+            dx8t = self.dy8_target(f"vit{l - 1}.fc2", (l - 1) & 1, Mv) if l > 0 else None
+            if dx8t is not None:
+                self.ln_bwd("v1", l, x_in, p + "ln1", st1[0], st1[1], da, dx, Mv, dres=dxm, q8=dx8t[2], q8_of_dx=True)
+                dx8 = (dx8t[0], dx8t[1])
+            else:
+                self.ln_bwd("v1", l, x_in, p + "ln1", st1[0], st1[1], da, dx, Mv, dres=dxm)
+                dx8 = None
         emb = self.buf("v.emb", Mv, vd)
         st = self.buf("v.pre.stats", 2, _rup(Mv, ROWPAD), torch.float32)
         demb = self.buf("vb.demb", Mv, vd)
@@ -536,15 +614,14 @@ class Engine:
         ste = self.buf("d.emb.stats", 2, _rup(Mcap, ROWPAD), torch.float32)
         ops.layernorm_fwd(h0, P.f32("dec.ln_emb.g"), P.f32("dec.ln_emb.b"), self.dec_eps, x, ste[0], ste[1], rows=M,
                           dropout_p=self.p_drop if drop else 0.0, dropout_seed=sd(1) or 0)
-        kvcat = self.cross_kv_all(ehs, Mv, "d." if save else "d_.") if self.ckv_hoisted() else None
+        kvcat = self.cross_kv_all(ehs, Mv, "d." if save else "d_.", save) if self.ckv_hoisted() else None
         for l in range(P.L):
             tag = f"d{l}." if save else "d_."
             p = f"dec{l}."
             stats = self.buf(tag + "stats", 6, _rup(Mcap, ROWPAD), torch.float32)
-            a = self.buf(tag + "a_sa", Mcap, d)
-            ops.layernorm_fwd(x, P.f32(p + "ln_sa.g"), P.f32(p + "ln_sa.b"), self.dec_eps, a, stats[0], stats[1], rows=M)
+            a, a8 = self.ln_x8(x, p + "ln_sa", self.dec_eps, tag + "a_sa", Mcap, stats[0], stats[1], M, p + "qkv", tag)
             qkv = self.buf(tag + "qkv", Mcap, 3 * d)
-            self.linear(a, p + "qkv", qkv, M, save_tag=tag if save else None)
+            self.linear(a, p + "qkv", qkv, M, save_tag=tag if save else None, x8=a8)
             ctx = self.buf(tag + "ctx", Mcap, d)
             lse = self.vec(tag + "lse", B * H * T)
             if pack is not None:
@@ -555,10 +632,9 @@ class Engine:
                              causal=True, lse=lse)
             x1 = self.buf(tag + "x1", Mcap, d)
             self.linear(ctx, p + "so", x1, M, residual=x, drop_seed=sd(10 + 3 * l))
-            a = self.buf(tag + "a_ca", Mcap, d)
-            ops.layernorm_fwd(x1, P.f32(p + "ln_ca.g"), P.f32(p + "ln_ca.b"), self.dec_eps, a, stats[2], stats[3], rows=M)
+            a, a8 = self.ln_x8(x1, p + "ln_ca", self.dec_eps, tag + "a_ca", Mcap, stats[2], stats[3], M, p + "cq", tag)
             q = self.buf(tag + "cq", Mcap, d)
-            self.linear(a, p + "cq", q, M, save_tag=tag if save else None)
+            self.linear(a, p + "cq", q, M, save_tag=tag if save else None, x8=a8)
             if kvcat is not None:
                 kv, ldkv = kvcat[:, l * 2 * d:], kvcat.stride(0)
             else:
@@ -573,12 +649,14 @@ class Engine:
                 ops.attn_fwd(q, kv, kv[:, d:], cctx, B, H, T, S, ldq=d, ldk=ldkv, ldv=ldkv, ldo=d, lse=clse)
             x2 = self.buf(tag + "x2", Mcap, d)
             self.linear(cctx, p + "co", x2, M, residual=x1, drop_seed=sd(11 + 3 * l))
-            a = self.buf(tag + "a_ff", Mcap, d)
-            ops.layernorm_fwd(x2, P.f32(p + "ln_ff.g"), P.f32(p + "ln_ff.b"), self.dec_eps, a, stats[4], stats[5], rows=M)
-            z, u = self.buf(tag + "z", Mcap, f), self.buf(tag + "u", Mcap, f)
-            self.linear(a, p + "fc1", u, M, act=self.gelu, zout=z, save_tag=tag if save else None)
+            a, a8 = self.ln_x8(x2, p + "ln_ff", self.dec_eps, tag + "a_ff", Mcap, stats[4], stats[5], M, p + "fc1", tag)
+            z = self.buf(tag + "z", Mcap, f)
+            u8t = self._q8_target(p + "fc2.x", tag + "fc2.x", Mcap, f, torch.float8_e4m3fn) if self._fp8_ok(p + "fc2") else None
+            u = self.buf(tag + "u", Mcap, f) if u8t is None else None
+            u8 = self.linear(a, p + "fc1", u, M, act=self.gelu, zout=z, save_tag=tag if save else None, x8=a8, out8=u8t)
             x3 = self.buf(f"d{l}.x3" if save else f"d_.x3{l & 1}", Mcap, d)
-            self.linear(u, p + "fc2", x3, M, residual=x2, drop_seed=sd(12 + 3 * l), save_tag=tag if save else None)
+            self.linear(u, p + "fc2", x3, M, residual=x2, drop_seed=sd(12 + 3 * l), save_tag=tag if save else None,
+                        x8=u8 if u8t is not None else None)
             x = x3
         hf = self.buf("d.hf", Mcap, d)
         stf = self.buf("d.f.stats", 2, _rup(Mcap, ROWPAD), torch.float32)
@@ -590,16 +668,23 @@ class Engine:
         """the cross-attention k/v projections of all decoder layers run as ONE GEMM each way (forward, dX, dW): they read the
         same encoder states and their weights sit side by side (ParamStore.ckv_cat).  L one-round launches (3200 x 2048 x 1024:
         400 tiles of 128x128) become one with 1248 tiles of 256x256; the dX sum over the layers becomes a K = L*2d contraction
-        with one rounding instead of L bf16 accumulations.  fp8 mode keeps the per-layer launches (per-tensor scales);
-        MIC_CKV_HOIST=0 switches back (A/B)."""
-        return self._ckv_hoist and not self.fp8
+        with one rounding instead of L bf16 accumulations.  fp8 mode: the same three launches on fp8 operands, the concatenated
+        weight and the concatenated k/v gradient each under ONE scale.  MIC_CKV_HOIST=0 switches back (A/B)."""
+        return self._ckv_hoist
 
-    def cross_kv_all(self, ehs, Mv: int, tag: str):
+    def cross_kv_all(self, ehs, Mv: int, tag: str, save: bool = False):
         """[Mv][L*2d]: layer l's (k | v) in columns [l*2d, (l+1)*2d)"""
         P = self.P
         w, b = P.ckv_cat("w")
         kvcat = self.buf(tag + "ckvcat", Mv, P.L * 2 * P.d)
-        ops.gemm(ehs, w, kvcat, Mv, P.L * 2 * P.d, P.d, bias=b)
+        if self.fp8 and "ckvcat" in self._w8:
+            wq, _, ws = self._w8["ckvcat"]
+            x8 = self._quant(ehs, Mv, P.d, "ckvcat.x", tag + "ckvcat.x", torch.float8_e4m3fn)
+            if save:
+                self._x8["ckvcat"] = x8
+            ops.gemm(x8[0], wq, kvcat, Mv, P.L * 2 * P.d, P.d, bias=b, a_scale_inv=x8[1][1:], b_scale_inv=ws[1:])
+        else:
+            ops.gemm(ehs, w, kvcat, Mv, P.L * 2 * P.d, P.d, bias=b)
         return kvcat
 
     def head_logits(self, hf, M: int, name: str = "d.logits", stats: bool = False):
@@ -694,66 +779,108 @@ class Engine:
         dx = self.buf("db.dx", Mcap, d)
         # masked gradients entering the FFN / cross-attention / self-attention branches and the other operands of the deferred
         # weight-gradient GEMMs come from dyb(): one buffer per layer parity while dW runs on its own stream
-        dxm = self.dyb("db.dxm_a", P.L - 1, Mcap, d)
         stf = self.buf("d.f.stats", 2, _rup(Mcap, ROWPAD), torch.float32)
         x_last = self.buf(f"d{P.L - 1}.x3", Mcap, d)
-        self.ln_bwd("f", 0, x_last, "dec.ln_f", stf[0], stf[1], dhf, dx, M,
-                    dxm=dxm, dropout_p=pd, dropout_seed=sd(12 + 3 * (P.L - 1)))
+        # dxm: the dropout-masked residual-stream gradient = the dy of the top layer's FFN-out projection, its only reader: with a
+        # scale history it leaves the LayerNorm backward as e5m2 bytes only
+        dxm8t = self.dy8_target(f"dec{P.L - 1}.fc2", (P.L - 1) & 1, Mcap)
+        dxm = self.dyb("db.dxm_a", P.L - 1, Mcap, d) if dxm8t is None else None
+        self.ln_bwd("f", 0, x_last, "dec.ln_f", stf[0], stf[1], dhf, dx, M, dxm=dxm, dropout_p=pd, dropout_seed=sd(12 + 3 * (P.L - 1)),
+                    **({} if dxm8t is None else dict(q8=dxm8t[2])))
+        dxm8 = None if dxm8t is None else (dxm8t[0], dxm8t[1])
+        f8 = self.fp8
         dehs = self.buf("db.dehs", Mv, d)
         hoist = self.ckv_hoisted()
         kvcat = self.buf("d.ckvcat", Mv, P.L * 2 * d) if hoist else None
-        dkvcat = self.buf("db.dkvcat", Mv, P.L * 2 * d) if hoist else None
+        hoist8 = hoist and self.fp8 and "ckvcat" in self._w8
+        # fp8, hoisted: every layer's dK | dV lands in its column slice of ONE e5m2 matrix under one scale (fused emission) ...
+        dkvcat8t = self._q8_target("ckvcat.dy", "f8.ckvcat.dy", Mv, P.L * 2 * d, torch.float8_e5m2) if (hoist8 and T <= 64 and S <= 64) else None
+        # ... or, without a scale history, in the bf16 matrix that is quantised once behind the loop
+        dkvcat = self.buf("db.dkvcat", Mv, P.L * 2 * d) if (hoist and dkvcat8t is None) else None
         for l in reversed(range(P.L)):
             tag, p = f"d{l}.", f"dec{l}."
             stats = self.buf(tag + "stats", 6, _rup(Mcap, ROWPAD), torch.float32)
-            a_sa, qkv, ctx, x1 = (self.buf(tag + n, Mcap, c) for n, c in (("a_sa", d), ("qkv", 3 * d), ("ctx", d), ("x1", d)))
-            a_ca, cq, cctx, x2 = (self.buf(tag + n, Mcap, d) for n in ("a_ca", "cq", "cctx", "x2"))
+            qkv, ctx, x1 = (self.buf(tag + n, Mcap, c) for n, c in (("qkv", 3 * d), ("ctx", d), ("x1", d)))
+            cq, cctx, x2 = (self.buf(tag + n, Mcap, d) for n in ("cq", "cctx", "x2"))
             ckv, ldkv = (kvcat[:, l * 2 * d:], kvcat.stride(0)) if hoist else (self.buf(tag + "ckv", Mv, 2 * d), 2 * d)
-            a_ff, z, u = self.buf(tag + "a_ff", Mcap, d), self.buf(tag + "z", Mcap, f), self.buf(tag + "u", Mcap, f)
+            z = self.buf(tag + "z", Mcap, f)
+            # (fp8 projections read their saved fp8 inputs, Engine._x8: the bf16 copies need not exist)
+            a_sa, a_ca, a_ff, u = (None,) * 4 if f8 else (self.buf(tag + "a_sa", Mcap, d), self.buf(tag + "a_ca", Mcap, d),
+                                                          self.buf(tag + "a_ff", Mcap, d), self.buf(tag + "u", Mcap, f))
             lse, clse = self.vec(tag + "lse", B * H * T), self.vec(tag + "clse", B * H * T)
             x_in = self.buf(f"d{l - 1}.x3", Mcap, d) if l > 0 else self.buf("d.x0", Mcap, d)
             # --- FFN branch: x3 = x2 + drop(fc2(gelu(fc1(LN(x2)))));  dxm = dropout-masked dx3
             dxm_b, dxm_c = self.dyb("db.dxm_b", l, Mcap, d), self.dyb("db.dxm_c", l, Mcap, d)
-            dz = self.dyb("db.dz", l, Mcap, f)
-            self.linear_bwd(p + "fc2", u, dxm, M, dx=dz, zin=z, dact=self.gelu, defer=True)
+            dz8t = self.dy8_target(p + "fc1", l & 1, Mcap)
+            dz = self.dyb("db.dz", l, Mcap, f) if dz8t is None else None
+            self.linear_bwd(p + "fc2", u, dxm, M, dx=dz, zin=z, dact=self.gelu, defer=True, dy8=dxm8, dx8=dz8t, par=l & 1)
             da = self.buf("db.da", Mcap, d)
-            self.linear_bwd(p + "fc1", a_ff, dz, M, dx=da, defer=True)
+            self.linear_bwd(p + "fc1", a_ff, dz, M, dx=da, defer=True, dy8=None if dz8t is None else (dz8t[0], dz8t[1]), par=l & 1)
             dx2 = self.buf("db.dx2", Mcap, d)
             self.ln_bwd("ff", l, x2, p + "ln_ff", stats[4], stats[5], da, dx2, M,
                         dres=dx, dxm=dxm_b, dropout_p=pd, dropout_seed=sd(11 + 3 * l))
             # --- cross-attention branch
             dctx = self.buf("db.dctx", Mcap, d)
             self.linear_bwd(p + "co", cctx, dxm_b, M, dx=dctx, defer=True)
-            dq = self.dyb("db.dq", l, Mcap, d)
-            dkv = dkvcat[:, l * 2 * d:] if hoist else self.dyb("db.dkv", l, Mv, 2 * d)
-            if pack is not None:
-                ops.attn_bwd_packed(cq, ckv, ckv[:, d:], cctx, dctx, clse, dq, dkv, dkv[:, d:], B, H, T, S, pack[0], pack[1], kv_packed=False,
-                                    ldq=d, ldk=ldkv, ldv=ldkv, ldo=d, lddo=d, lddq=d, lddk=ldkv, lddv=ldkv)
+            one_tile = T <= 64 and S <= 64
+            dq8t = self.dy8_target(p + "cq", l & 1, Mcap) if one_tile else None
+            if hoist:
+                kv8 = None if dkvcat8t is None else dkvcat8t[0][:, l * 2 * d:]
+                dkv8t = None if kv8 is None else (kv8, dkvcat8t[1], ops.fp8_out(kv8, dkvcat8t[1], dkvcat8t[3][1]))
             else:
-                ops.attn_bwd(cq, ckv, ckv[:, d:], cctx, dctx, clse, dq, dkv, dkv[:, d:], B, H, T, S, ldq=d, ldk=ldkv, ldv=ldkv, ldo=d,
-                             lddo=d, lddq=d, lddk=ldkv, lddv=ldkv)
-            self.linear_bwd(p + "cq", a_ca, dq, M, dx=da, defer=True)
-            if not hoist:
-                self.linear_bwd(p + "ckv", ehs, dkv, Mv, dx=dehs, dx_accumulate=(l != P.L - 1), defer=True)
+                dkv8t = self.dy8_target(p + "ckv", l & 1, Mv) if one_tile else None
+            if dq8t is not None and dkv8t is not None:
+                # dQ [rows][d] and dK | dV [encoder rows][2d] as e5m2 bytes under their own scales, straight out of the attention backward
+                ops.attn_bwd_q8(cq, ckv, ckv[:, d:], cctx, dctx, clse, dq8t[2], dkv8t[2], dkv8t[0][:, d:], B, H, T, S, ldq=d, ldk=ldkv, ldv=ldkv,
+                                ldo=d, lddo=d, q_off=pack[0] if pack is not None else None, q_len=pack[1] if pack is not None else None, kv_packed=False)
+                self.linear_bwd(p + "cq", a_ca, None, M, dx=da, defer=True, dy8=(dq8t[0], dq8t[1]), par=l & 1)
+                if not hoist:
+                    self.linear_bwd(p + "ckv", ehs, None, Mv, dx=dehs, dx_accumulate=(l != P.L - 1), defer=True, dy8=(dkv8t[0], dkv8t[1]), par=l & 1)
+            elif hoist and dkvcat8t is not None:
+                # (dQ has no scale history yet but the concatenated k/v gradient has: cannot happen after the first pass; keep the bytes consistent)
+                raise RuntimeError("fp8: cross-attention dQ without a scale history beside a hoisted k/v gradient with one")
+            else:
+                dq = self.dyb("db.dq", l, Mcap, d)
+                dkv = dkvcat[:, l * 2 * d:] if hoist else self.dyb("db.dkv", l, Mv, 2 * d)
+                if pack is not None:
+                    ops.attn_bwd_packed(cq, ckv, ckv[:, d:], cctx, dctx, clse, dq, dkv, dkv[:, d:], B, H, T, S, pack[0], pack[1], kv_packed=False,
+                                        ldq=d, ldk=ldkv, ldv=ldkv, ldo=d, lddo=d, lddq=d, lddk=ldkv, lddv=ldkv)
+                else:
+                    ops.attn_bwd(cq, ckv, ckv[:, d:], cctx, dctx, clse, dq, dkv, dkv[:, d:], B, H, T, S, ldq=d, ldk=ldkv, ldv=ldkv, ldo=d,
+                                 lddo=d, lddq=d, lddk=ldkv, lddv=ldkv)
+                self.linear_bwd(p + "cq", a_ca, dq, M, dx=da, defer=True, par=l & 1)
+                if not hoist:
+                    self.linear_bwd(p + "ckv", ehs, dkv, Mv, dx=dehs, dx_accumulate=(l != P.L - 1), defer=True, par=l & 1)
             dx1 = self.buf("db.dx1", Mcap, d)
             self.ln_bwd("ca", l, x1, p + "ln_ca", stats[2], stats[3], da, dx1, M,
                         dres=dx2, dxm=dxm_c, dropout_p=pd, dropout_seed=sd(10 + 3 * l))
             # --- self-attention branch
             self.linear_bwd(p + "so", ctx, dxm_c, M, dx=dctx, defer=True)
-            dqkv = self.dyb("db.dqkv", l, Mcap, 3 * d)
-            if pack is not None:
-                ops.attn_bwd_packed(qkv, qkv[:, d:], qkv[:, 2 * d:], ctx, dctx, lse, dqkv, dqkv[:, d:], dqkv[:, 2 * d:], B, H, T, T, pack[0],
-                                    pack[1], kv_packed=True, ldq=3 * d, ldk=3 * d, ldv=3 * d, ldo=d, lddo=d, lddq=3 * d, lddk=3 * d,
-                                    lddv=3 * d, causal=True)
+            dqkv8t = self.dy8_target(p + "qkv", l & 1, Mcap) if T <= 64 else None
+            if dqkv8t is not None:
+                q8 = dqkv8t[0]
+                ops.attn_bwd_q8(qkv, qkv[:, d:], qkv[:, 2 * d:], ctx, dctx, lse, dqkv8t[2], ops.fp8_out(q8[:, d:], dqkv8t[1], dqkv8t[3][1]), q8[:, 2 * d:],
+                                B, H, T, T, ldq=3 * d, ldk=3 * d, ldv=3 * d, ldo=d, lddo=d, q_off=pack[0] if pack is not None else None,
+                                q_len=pack[1] if pack is not None else None, kv_packed=pack is not None,
+                                key_mask=key_mask if pack is None else None, causal=True)
+                self.linear_bwd(p + "qkv", a_sa, None, M, dx=da, defer=True, dy8=(dqkv8t[0], dqkv8t[1]), par=l & 1)
             else:
-                ops.attn_bwd(qkv, qkv[:, d:], qkv[:, 2 * d:], ctx, dctx, lse, dqkv, dqkv[:, d:], dqkv[:, 2 * d:], B, H, T, T, ldq=3 * d,
-                             ldk=3 * d, ldv=3 * d, ldo=d, lddo=d, lddq=3 * d, lddk=3 * d, lddv=3 * d, key_mask=key_mask, causal=True)
-            self.linear_bwd(p + "qkv", a_sa, dqkv, M, dx=da, defer=True)
+                dqkv = self.dyb("db.dqkv", l, Mcap, 3 * d)
+                if pack is not None:
+                    ops.attn_bwd_packed(qkv, qkv[:, d:], qkv[:, 2 * d:], ctx, dctx, lse, dqkv, dqkv[:, d:], dqkv[:, 2 * d:], B, H, T, T, pack[0],
+                                        pack[1], kv_packed=True, ldq=3 * d, ldk=3 * d, ldv=3 * d, ldo=d, lddo=d, lddq=3 * d, lddk=3 * d,
+                                        lddv=3 * d, causal=True)
+                else:
+                    ops.attn_bwd(qkv, qkv[:, d:], qkv[:, 2 * d:], ctx, dctx, lse, dqkv, dqkv[:, d:], dqkv[:, 2 * d:], B, H, T, T, ldq=3 * d,
+                                 ldk=3 * d, ldv=3 * d, ldo=d, lddo=d, lddq=3 * d, lddk=3 * d, lddv=3 * d, key_mask=key_mask, causal=True)
+                self.linear_bwd(p + "qkv", a_sa, dqkv, M, dx=da, defer=True, par=l & 1)
             self.flush_dw()  # the layer's 7 weight-gradient GEMMs as one grouped launch (before dxm_a is rewritten)
-            dxm = self.dyb("db.dxm_a", l - 1, Mcap, d)
             if l > 0:
-                self.ln_bwd("sa", l, x_in, p + "ln_sa", stats[0], stats[1], da, dx, M,
-                            dres=dx1, dxm=dxm, dropout_p=pd, dropout_seed=sd(12 + 3 * (l - 1)))
+                dxm8t = self.dy8_target(f"dec{l - 1}.fc2", (l - 1) & 1, Mcap)
+                dxm = self.dyb("db.dxm_a", l - 1, Mcap, d) if dxm8t is None else None
+                self.ln_bwd("sa", l, x_in, p + "ln_sa", stats[0], stats[1], da, dx, M, dres=dx1, dxm=dxm, dropout_p=pd,
+                            dropout_seed=sd(12 + 3 * (l - 1)), **({} if dxm8t is None else dict(q8=dxm8t[2])))
+                dxm8 = None if dxm8t is None else (dxm8t[0], dxm8t[1])
             else:
                 self.ln_bwd("sa", l, x_in, p + "ln_sa", stats[0], stats[1], da, dx, M, dres=dx1)
         if hoist:
@@ -764,26 +891,50 @@ class Engine:
             gw, gb = P.ckv_cat("g")
             N = P.L * 2 * d
             Mvp = _rup(Mv, ROWPAD)
-            fuse = self.dt == torch.bfloat16
-            rs = dict(a_rowsum=gb, rowsum_k=Mv) if fuse else {}
-            # dX first: it READS the weights, and reporting their gradients final (flush_dw -> _done) lets the per-bucket optimizer
-            # rewrite them; the dW stream's launch waits for everything enqueued here, so the bucket's event covers this GEMM too
-            nsp = min(8, N // 64)  # K-tiles of 64: a reduced model may have fewer than 8 of them
-            if self.dt == torch.bfloat16 and nsp > 1:
-                slab = Mvp * d
-                d32 = self.buf("db.dehs32", nsp * Mvp, d, torch.float32)
-                ops.gemm(dkvcat, wcat, d32, Mv, d, N, b_kmajor=True, split_k=nsp, split_stride=slab)
-                ops.sum_slabs(d32, nsp, slab, dehs, Mv, d, d32.stride(0), dehs.stride(0))
+            if hoist8:
+                dkv8 = (dkvcat8t[0], dkvcat8t[1]) if dkvcat8t is not None else self._quant(dkvcat, Mv, N, "ckvcat.dy", "f8.ckvcat.dy", torch.float8_e5m2)
+                x8 = self._x8.get("ckvcat")
+                if x8 is None:
+                    raise RuntimeError("fp8 backward of the hoisted cross k/v projection: the forward pass did not keep the fp8 encoder states")
+                _, wqT, ws = self._w8["ckvcat"]
+                nsp = min(8, N // 128)
+                if nsp > 1:
+                    slab = Mvp * d
+                    d32 = self.buf("db.dehs32", nsp * Mvp, d, torch.float32)
+                    ops.gemm(dkv8[0], wqT, d32, Mv, d, N, split_k=nsp, split_stride=slab, a_scale_inv=dkv8[1][1:], b_scale_inv=ws[1:])
+                    ops.sum_slabs(d32, nsp, slab, dehs, Mv, d, d32.stride(0), dehs.stride(0))
+                else:
+                    ops.gemm(dkv8[0], wqT, dehs, Mv, d, N, a_scale_inv=dkv8[1][1:], b_scale_inv=ws[1:])
+                self._dw8_queue.append((ops.gemm_args(dkv8[0], x8[0], gw, N, d, Mvp, a_kmajor=True, b_kmajor=True, k_valid=Mv,
+                                                      a_scale_inv=dkv8[1][1:], b_scale_inv=x8[1][1:]), f"dec{P.L - 1}.ckv", True))
+                self._cs8_queue.append((dkv8[0], gb, dkv8[1][1:], Mv, N))
+                self._ckv_block_name = f"dec{P.L - 1}.ckv"
+                try:
+                    self.flush_dw()
+                finally:
+                    self._ckv_block_name = None
             else:
-                ops.gemm(dkvcat, wcat, dehs, Mv, d, N, b_kmajor=True)
-            self._dw_queue.append((ops.gemm_args(dkvcat, ehs, gw, N, d, Mvp, a_kmajor=True, b_kmajor=True, **rs), f"dec{P.L - 1}.ckv", True))
-            if not fuse:
-                self._cs_queue.append((dkvcat, gb, Mv, N, dkvcat.stride(0)))
-            self._ckv_block_name = f"dec{P.L - 1}.ckv"
-            try:
-                self.flush_dw()
-            finally:
-                self._ckv_block_name = None
+                # (bf16 / fp32 operands)
+                fuse = self.dt == torch.bfloat16
+                rs = dict(a_rowsum=gb, rowsum_k=Mv) if fuse else {}
+                # dX first: it READS the weights, and reporting their gradients final (flush_dw -> _done) lets the per-bucket optimizer
+                # rewrite them; the dW stream's launch waits for everything enqueued here, so the bucket's event covers this GEMM too
+                nsp = min(8, N // 64)  # K-tiles of 64: a reduced model may have fewer than 8 of them
+                if self.dt == torch.bfloat16 and nsp > 1:
+                    slab = Mvp * d
+                    d32 = self.buf("db.dehs32", nsp * Mvp, d, torch.float32)
+                    ops.gemm(dkvcat, wcat, d32, Mv, d, N, b_kmajor=True, split_k=nsp, split_stride=slab)
+                    ops.sum_slabs(d32, nsp, slab, dehs, Mv, d, d32.stride(0), dehs.stride(0))
+                else:
+                    ops.gemm(dkvcat, wcat, dehs, Mv, d, N, b_kmajor=True)
+                self._dw_queue.append((ops.gemm_args(dkvcat, ehs, gw, N, d, Mvp, a_kmajor=True, b_kmajor=True, **rs), f"dec{P.L - 1}.ckv", True))
+                if not fuse:
+                    self._cs_queue.append((dkvcat, gb, Mv, N, dkvcat.stride(0)))
+                self._ckv_block_name = f"dec{P.L - 1}.ckv"
+                try:
+                    self.flush_dw()
+                finally:
+                    self._ckv_block_name = None
         else:
             # per-layer k/v projections: every layer's dW GEMM (and the dX GEMMs that read these weights) has been issued by now
             self._done(f"dec{P.L - 1}.ckv.w")

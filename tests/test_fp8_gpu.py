@@ -145,6 +145,28 @@ def test_fp8_gemm_kmajor_weight_gradient_form(dev, afmt, M, N, K, kv):
     assert ((out2.cpu() - ref2).abs().max() / ref2.abs().max()).item() < 1e-4
 
 
+def test_fp8_gemm_split_k_slabs(dev):
+    """the hoisted cross-k/v dX: [3200][1024] = dkv [3200][24576] . W over K = 24576 — too few output tiles to fill the chip, so the
+    reduction is split into fp32 slabs (summed by mic_sum_slabs), as in bf16"""
+    from mic_amd import ops
+
+    g = torch.Generator().manual_seed(11)
+    M, N, K, nsp = 600, 256, 4096, 8
+    a = (torch.randn(M, K, generator=g) * 0.2).to(torch.bfloat16)
+    b = (torch.randn(N, K, generator=g) * 0.3).to(torch.bfloat16)
+    qa, _, sa = _quant_ref(a, torch.float8_e5m2)
+    qb, _, sb = _quant_ref(b, torch.float8_e4m3fn)
+    sa_d, sb_d = torch.tensor([sa], device=dev), torch.tensor([sb], device=dev)
+    Mp = 640
+    d32 = torch.full((nsp * Mp, N), 3.0, dtype=torch.float32, device=dev)
+    out = torch.zeros((M, N), dtype=torch.bfloat16, device=dev)
+    ops.gemm(qa.to(dev), qb.to(dev), d32, M, N, K, split_k=nsp, split_stride=Mp * N, a_scale_inv=sa_d, b_scale_inv=sb_d)
+    ops.sum_slabs(d32, nsp, Mp * N, out, M, N, d32.stride(0), out.stride(0))
+    torch.cuda.synchronize()
+    ref = (qa.float() @ qb.float().T) * (sa * sb)
+    assert ((out.float().cpu() - ref).abs().max() / ref.abs().max()).item() < 8e-3
+
+
 def test_fp8_gemm_epilogue_grouped_and_errors(dev):
     from mic_amd import _lib as L
     from mic_amd import ops
