@@ -96,6 +96,7 @@ class Engine:
             raise ValueError(f"fp8 scaling must be 'delayed' or 'current', got {scaling!r}")
         if self.dt != torch.bfloat16:
             raise ValueError("gemm_dtype='fp8' needs the bfloat16 storage mode (dtype=bfloat16)")
+        import os as _os
         P = self.P
         self.fp8 = True
         self.fp8_scaling = scaling
@@ -114,6 +115,16 @@ class Engine:
         self._w8_stale = True
         self._w8_part = torch.zeros((len(names), ops.fp8_amax_partials()), dtype=torch.float32, device=self.dev) if scaling == "delayed" else None
         self._w8_seen = False  # delayed scaling: _w8_state carries the amax recorded by the previous quantiser pass
+        # delayed scaling: the optimizer re-quantises a weight right behind its AdamW pass (`fp8_requantize_range`, on the optimizer's
+        # stream, under backward) — names done since the last pass; when that is all of them the next pass only rolls the amax
+        self._w8_fresh = set()
+        # (opt-in, MIC_FP8_REQUANT_OPT=1: measured 0.03 - 0.2 ms per step, inside the noise, for ~8 more launches per step — the default
+        # re-quantises all weights in 11 launches at the start of the next pass)
+        self._w8_requant_opt = _os.environ.get("MIC_FP8_REQUANT_OPT", "0") == "1"
+        self._w8_index = {n: i for i, n in enumerate(names)}
+        segs = P.segs
+        self._w8_span = {n: ((segs["dec0.ckv.w"].offset, segs[f"dec{P.L - 1}.ckv.w"].offset + segs[f"dec{P.L - 1}.ckv.w"].numel) if n == "ckvcat"
+                             else (segs[n + ".w"].offset, segs[n + ".w"].offset + segs[n + ".w"].numel)) for n in names}
         # one (amax, 1/scale) slot per quantised activation / gradient tensor; delayed scaling: + its table of partial maxima
         self._a8_state = torch.zeros((1024, 2), dtype=torch.float32, device=self.dev)
         self._a8_part = torch.zeros((1024, ops.fp8_amax_partials()), dtype=torch.float32, device=self.dev) if scaling == "delayed" else None
@@ -126,7 +137,6 @@ class Engine:
         # fused emission: under delayed scaling the PRODUCER of an operand (LayerNorm, GELU / dGELU epilogue, attention backward)
         # writes the fp8 bytes itself once the tensor has a scale history (from its second pass on); MIC_FP8_FUSED=0: every operand
         # through mic_fp8_quantize again (A/B)
-        import os as _os
         self.fp8_fused = scaling == "delayed" and self.ln_partials and _os.environ.get("MIC_FP8_FUSED", "1") != "0"
 
     def _w8_src(self, name: str):
@@ -153,12 +163,35 @@ class Engine:
         self._w8_stale = True
         if not by_optimizer:
             self._w8_seen = False
+            self._w8_fresh = set()
+
+    def fp8_requantize_range(self, b: int, e: int):
+        """Optimizer side (delayed scaling): the weights whose flat segment ENDS in (b, e] have just been updated — the buckets arrive
+        in layout order on one stream, so everything before `e` is final — re-quantise them now, on the caller's stream (beside
+        backward), under the amax the step's begin rolled in; the next pass then finds its fp8 weight copies ready."""
+        if not (self.fp8 and self.fp8_scaling == "delayed" and self._w8_seen and self._w8_requant_opt):
+            return
+        todo = [n for n, (o, oe) in self._w8_span.items() if b < oe <= e and n not in self._w8_fresh]
+        if not todo:
+            return
+        items = []
+        for n in todo:
+            q, qT, st = self._w8[n]
+            items.append(ops.fp8_item(self._w8_src(n), q.shape[0], q.shape[1], st, torch.float8_e4m3fn, q=q, qT=qT,
+                                      amax_next=self._w8_part[self._w8_index[n]]))
+        ops.fp8_quantize(items, amax_pass=False)
+        self._w8_fresh.update(todo)
 
     def _fp8_begin_pass(self):
         """start of a forward(+backward) pass: re-quantise the weights if the optimizer moved them; current scaling: clear the
         activation slots; delayed scaling: last pass's recorded amax becomes this pass's scale source"""
         if not self.fp8:
             return
+        if self._w8_stale and self.fp8_scaling == "delayed" and self._w8_seen and len(self._w8_fresh) == len(self._w8):
+            # every weight was re-quantised behind its optimizer pass: only the amax recorded there becomes current
+            ops.fp8_roll_amax(self._w8_state, self._w8_part, len(self._w8))
+            self._w8_stale = False
+        self._w8_fresh = set()
         if self._w8_stale:
             P = self.P
             delayed = self.fp8_scaling == "delayed"

@@ -543,6 +543,7 @@ class Trainer:
         if not self._split_shared or lo >= hi:
             ops.adamw(st.master[b:e], st.m[b:e], st.v[b:e], st.grad[b:e], None if st.lp is st.master else st.lp[b:e], self.hyper,
                       self.b1, self.b2, self.eps, self.wd, grad_scale=1.0 / self.world, n=e - b)
+            self.model.engine.fp8_requantize_range(b, e)  # fp8 GEMMs: the bucket's weights as fp8 for the NEXT step, here under backward
             return
         assert (lo - sb) % width == 0 and (hi - sb) % width == 0, "bucket cuts inside the tied embedding are row-aligned"
         for (x, y) in ((b, lo), (hi, e)):
@@ -550,6 +551,7 @@ class Trainer:
                 ops.adamw(st.master[x:y], st.m[x:y], st.v[x:y], st.grad[x:y], None if st.lp is st.master else st.lp[x:y], self.hyper,
                           self.b1, self.b2, self.eps, self.wd, grad_scale=1.0 / self.world, n=y - x)
         self._adamw_shared(0, (lo - sb) // width, (hi - sb) // width)
+        self.model.engine.fp8_requantize_range(b, e)
 
     def _adamw_shared(self, want: int, r0: int = 0, r1: Optional[int] = None):
         """AdamW on rows [r0, r1) of the tied embedding whose flag equals `want`"""
@@ -699,6 +701,7 @@ class Trainer:
         if not self.overlap_optimizer:
             ops.adamw(st.master, st.m, st.v, st.grad, None if st.lp is st.master else st.lp, self.hyper, self.b1, self.b2, self.eps,
                       self.wd, grad_scale=1.0 / self.world)
+            eng.fp8_requantize_range(0, st.numel)
         m.invalidate_params_cache(by_optimizer=True)
         if m.device.type == "cuda":
             # the k-contiguous copy of the tied embedding for the NEXT step's head backward: behind this step's optimizer passes, on a

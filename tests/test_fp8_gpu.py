@@ -273,6 +273,32 @@ def test_fp8_trainer_learns_and_eval_matches(dev):
         m32.engine.set_gemm_dtype("fp8")
 
 
+@pytest.mark.parametrize("overlap", [True, False])
+def test_fp8_weights_requantised_behind_the_optimizer_give_the_same_steps(dev, overlap):
+    """opt-in placement of the per-step weight quantisation (MIC_FP8_REQUANT_OPT=1: per gradient bucket behind its AdamW pass, on
+    the optimizer's stream) against the default (all weights at the start of the next pass): same scales, same bytes, same losses;
+    and both equal a third trainer whose fused emission is off (every operand through mic_fp8_quantize)"""
+    from mic_amd import Trainer, create_learning_rate_fn
+
+    losses = []
+    for mode in ("default", "requant_opt", "unfused"):
+        rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.1)
+        tr = Trainer(model, create_learning_rate_fn(64, 2, 4, 2, 2e-3), gemm_dtype="fp8", overlap_optimizer=overlap, bucket_mb=0.25)
+        eng = model.engine
+        eng._w8_requant_opt = mode == "requant_opt"
+        if mode == "unfused":
+            eng.fp8_fused = False
+        px, labels, mask, dec_in = batch(rc, 3, 12, seed=9)
+        b = {"pixel_values": px.numpy(), "input_ids": labels.numpy(), "attention_mask": mask.numpy(), "decoder_input_ids": dec_in.numpy()}
+        ls = [float(tr.train_step(b)["loss"]) for _ in range(5)]
+        if mode == "requant_opt":
+            assert len(eng._w8_fresh) == len(eng._w8) > 0  # every fp8 weight was re-quantised behind its bucket's optimizer pass
+        losses.append(ls)
+    assert losses[0] == losses[1], losses
+    # fused and unfused emission write the same bytes; what differs is the summation order of fp32 atomics downstream
+    assert max(abs(a - b) for a, b in zip(losses[0], losses[2])) < 2e-4 * abs(losses[0][0]), losses
+
+
 def test_fp8_trainer_inference_entry_points_stay_in_the_storage_dtype(dev):
     """`encode` / `decode` / `generate` beside an fp8 trainer run bf16 GEMMs: identical to a bf16 engine holding the same weights,
     (i) directly after Trainer construction, when no pass has quantised the fp8 weight copies yet, and (ii) directly after a
