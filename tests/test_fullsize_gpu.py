@@ -211,6 +211,18 @@ def test_fullsize_fp8_train_step_against_fp32_oracle(full):
         assert not bad, sorted(bad.items(), key=lambda kv: kv[1])[:6]
         assert allc > 0.97, allc
         assert eng._w8["dec11.fc1"][0].dtype == torch.float8_e4m3fn and float(eng._w8["dec11.fc1"][2][1]) > 0  # the fp8 copies carry a scale
+        # second pass, same batch and weights: every tensor now has a scale history, so the producers emit the fp8 operands
+        # themselves (fused emission) under scales equal to the first pass's current ones — same bytes, same loss and gradients up to
+        # the order of the fp32 atomics
+        assert eng.fp8_fused and not eng._a8_ready
+        loss2 = eng.loss_and_grads(d(px, torch.float32), d(dec_in, torch.int32).reshape(-1), pos.reshape(-1), d(mask, torch.int32),
+                                   d(labels, torch.int32).reshape(-1), B, T, rows=(d(idx, torch.int32), len(idx)), row_labels=d(rl, torch.int32))
+        torch.cuda.synchronize()
+        assert len(eng._a8_ready) > 150 and abs(loss2.item() - loss.item()) < 1e-5 * abs(loss.item()), (loss2.item(), loss.item())
+        got2 = model.store.export_flat("grad")
+        for k in ref_g:
+            a, b2 = got2[k].astype(np.float64), got[k].astype(np.float64)
+            assert np.abs(a - b2).max() <= 2e-4 * max(np.abs(b2).max(), 1e-30), (k, np.abs(a - b2).max(), np.abs(b2).max())
     finally:
         eng.set_gemm_dtype(None)
         eng.free_buffers()
