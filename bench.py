@@ -106,7 +106,10 @@ def synth_batch(B, T, V, img, seed, lang_ids=(250004, 250008, 250003, 250005), d
         mask[b, :n + 2] = 1
     dec_in = np.full_like(labels, 1)
     dec_in[:, 1:] = labels[:, :-1]
-    return {"pixel_values": px, "input_ids": labels, "attention_mask": mask, "decoder_input_ids": dec_in}
+    # int32 ids / masks, as the reference's device arrays are (JAX without x64 narrows the tokenizer's int64 arrays on the HOST, in
+    # device_put / shard, main.py:773-775): the narrowing is collate work, not three cast launches at the start of every step
+    return {"pixel_values": px, "input_ids": labels.astype(np.int32), "attention_mask": mask.astype(np.int32),
+            "decoder_input_ids": dec_in.astype(np.int32)}
 
 
 # ---------------------------------------------------------------------------------------------- CPU baselines (oracle)
@@ -127,6 +130,7 @@ def cpu_baseline_train(budget_s=14.0, B=4, min_timed=3):
     """The oracle (torch-CPU fp32 restatement of the reference path; NOT Flax) on this box's host cores: train step
     (fwd + bwd + AdamW) images/s at B=4 on the full-size model.  Bounded sample: one warm-up iteration, then at least `min_timed`
     timed iterations and as many more as fit into `budget_s` of timed work; the spread of the per-iteration rates is stated."""
+    import numpy as np
     import torch
 
     from oracle import train_ref
@@ -138,7 +142,7 @@ def cpu_baseline_train(budget_s=14.0, B=4, min_timed=3):
     m = {k: torch.zeros_like(v) for k, v in p.items()}
     v2 = {k: torch.zeros_like(v) for k, v in p.items()}
     b = synth_batch(B, 64, rc.vocab_size, rc.image_size, 7)
-    t = {k: torch.from_numpy(v) for k, v in b.items()}
+    t = {k: (torch.from_numpy(v) if v.dtype == np.float32 else torch.from_numpy(v.astype(np.int64))) for k, v in b.items()}  # (torch's CPU losses index with int64)
     times, warm, n_warm = [], 0, 1
     for it in range(12):
         t0 = time.time()

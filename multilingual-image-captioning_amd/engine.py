@@ -49,6 +49,7 @@ class Engine:
         import os
         self.use_head_stats = os.environ.get("MIC_HEAD_STATS", "1") != "0"  # softmax partials out of the LM-head GEMM (A/B switch)
         self.grad_progress = None  # callable(offset): every gradient with flat offset < offset is final (DDP overlap)
+        self.on_embed_rows = None  # callable(): single process, right behind the input-embedding scatter at the end of decoder backward
         # weight-gradient GEMMs on a second stream (bf16 / f32 GEMM modes): nothing but the optimizer depends on dW, so a layer's
         # grouped dW launch runs beside the NEXT layer's dX chain (LayerNorm / attention backward and the small dX GEMMs leave
         # most CUs idle).  The gradient operands dW reads are double-buffered by layer parity; A/B switch MIC_DW_OVERLAP=0|1.
@@ -121,6 +122,9 @@ class Engine:
         # (opt-in, MIC_FP8_REQUANT_OPT=1: measured 0.03 - 0.2 ms per step, inside the noise, for ~8 more launches per step — the default
         # re-quantises all weights in 11 launches at the start of the next pass)
         self._w8_requant_opt = _os.environ.get("MIC_FP8_REQUANT_OPT", "0") == "1"
+        self._w8_async = _os.environ.get("MIC_FP8_W8_ASYNC", "1") != "0"  # (A/B: 0 = weights re-quantised at the start of the next pass, on its stream)
+        self._w8_event = None
+        self._w8_rolled = False  # this step's roll of the weights' amax has been issued (first of the two refresh calls)
         self._w8_index = {n: i for i, n in enumerate(names)}
         segs = P.segs
         self._w8_span = {n: ((segs["dec0.ckv.w"].offset, segs[f"dec{P.L - 1}.ckv.w"].offset + segs[f"dec{P.L - 1}.ckv.w"].numel) if n == "ckvcat"
@@ -165,6 +169,61 @@ class Engine:
             self._w8_seen = False
             self._w8_fresh = set()
 
+    def _w8_items_all(self):
+        """the 84 weight items of a delayed-scaling quantiser pass, built once (raw pointers into persistent buffers: the flat bf16
+        parameter copy, the fp8 copies, the scale slots) — building them was 0.2 ms of host time in the gap between two steps"""
+        key = (self.P.lp.data_ptr(), id(self._w8))
+        if getattr(self, "_w8_items_key", None) != key:
+            self._w8_items = [ops.fp8_item(self._w8_src(n), q.shape[0], q.shape[1], st, torch.float8_e4m3fn, q=q, qT=qT,
+                                           amax_next=self._w8_part[i]) for i, (n, (q, qT, st)) in enumerate(self._w8.items())]
+            self._w8_items_key = key
+        return self._w8_items
+
+    def fp8_refresh_weights(self, side, upto: Optional[int] = None, wait_event=None):
+        """Trainer (delayed scaling): roll the weights' amax and re-quantise them for the NEXT pass on `side` instead of in front of that
+        pass.  Two calls per step: `upto` = flat offset up to which the optimizer passes have been issued (`wait_event`: recorded on
+        the optimizer's stream behind them) — at the end of decoder backward: the decoder's weights go now, under the ViT's backward;
+        then the final call (upto None), behind everything the current stream has enqueued, takes the rest beside the host-issued glue
+        between two steps.  The first fp8 GEMM of the next pass waits for the final call's event (`_w8_wait`)."""
+        if not (self.fp8 and self.fp8_scaling == "delayed" and self._w8_seen and self._w8_async):
+            return
+        items = self._w8_items_all()
+        names = list(self._w8)
+        if upto is not None:
+            todo = [i for i, n in enumerate(names) if self._w8_span[n][1] <= upto and n not in self._w8_fresh]
+            if not todo:
+                return
+            with torch.cuda.stream(side):
+                if wait_event is not None:
+                    side.wait_event(wait_event)
+                with ops.pinned_stream():
+                    if not self._w8_rolled:
+                        ops.fp8_roll_amax(self._w8_state, self._w8_part, len(names))
+                        self._w8_rolled = True
+                    ops.fp8_quantize([items[i] for i in todo], amax_pass=False)
+            self._w8_fresh.update(names[i] for i in todo)
+            return
+        if not self._w8_stale:
+            return
+        todo = [i for i, n in enumerate(names) if n not in self._w8_fresh]
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            with ops.pinned_stream():
+                if not self._w8_rolled:
+                    ops.fp8_roll_amax(self._w8_state, self._w8_part, len(names))
+                if todo:
+                    ops.fp8_quantize([items[i] for i in todo], amax_pass=False)
+            done = torch.cuda.Event()
+            done.record(side)
+        self._w8_event, self._w8_stale, self._w8_fresh, self._w8_rolled = done, False, set(), False
+
+    def _w8_wait(self):
+        if self._w8_event is not None:
+            torch.cuda.current_stream().wait_event(self._w8_event)
+            self._w8_event = None
+
     def fp8_requantize_range(self, b: int, e: int):
         """Optimizer side (delayed scaling): the weights whose flat segment ENDS in (b, e] have just been updated — the buckets arrive
         in layout order on one stream, so everything before `e` is final — re-quantise them now, on the caller's stream (beside
@@ -201,8 +260,9 @@ class Engine:
                 ops.zero(self._w8_state)
                 if delayed:
                     ops.zero(self._w8_part)
-            items = [ops.fp8_item(self._w8_src(n), q.shape[0], q.shape[1], st, torch.float8_e4m3fn, q=q, qT=qT,
-                                  amax_next=self._w8_part[i] if delayed else None) for i, (n, (q, qT, st)) in enumerate(self._w8.items())]
+            self._w8_wait()  # (a side-stream refresh of older weights may still be writing the copies)
+            items = self._w8_items_all() if delayed else [ops.fp8_item(self._w8_src(n), q.shape[0], q.shape[1], st, torch.float8_e4m3fn, q=q, qT=qT)
+                                                          for (n, (q, qT, st)) in self._w8.items()]
             ops.fp8_quantize(items, amax_pass=not (delayed and self._w8_seen))
             self._w8_seen = delayed
             self._w8_stale = False
@@ -319,6 +379,7 @@ class Engine:
         N, K = w.shape
         p = self.p_drop if drop_seed is not None else 0.0
         if fp8 and self._fp8_ok(wname):
+            self._w8_wait()
             wq, _, ws = self._w8[wname]
             if x8 is None:
                 x8 = self._quant(x, M, K, wname + ".x", (save_tag or "f8.") + wname.split(".")[-1] + ".x", torch.float8_e4m3fn,
@@ -711,6 +772,7 @@ class Engine:
         w, b = P.ckv_cat("w")
         kvcat = self.buf(tag + "ckvcat", Mv, P.L * 2 * P.d)
         if self.fp8 and "ckvcat" in self._w8:
+            self._w8_wait()
             wq, _, ws = self._w8["ckvcat"]
             x8 = self._quant(ehs, Mv, P.d, "ckvcat.x", tag + "ckvcat.x", torch.float8_e4m3fn)
             if save:
@@ -987,6 +1049,8 @@ class Engine:
         else:
             # single process: the scatter lands before the optimizer touches the segment (Trainer holds that bucket)
             ops.embed_bwd(ids, pos_ids, dh0, self.embed_scale, P.g("shared"), P.g("dec.pos"), M, d)
+            if self.on_embed_rows is not None:
+                self.on_embed_rows()  # the tied embedding's gradient is complete (dense head part + these rows): its late optimizer pass may go
         return dehs
 
     # ------------------------------------------------------------------ loss (main.py:658-680) on materialised logits

@@ -111,14 +111,33 @@ def plan_buckets(numel: int, bucket_elems: int, boundaries: List[int], max_elems
 MAX_BUCKET_MB = 128.0  # largest piece of the tied embedding that goes on the wire as one collective
 
 
-def bucket_plan(store, bucket_mb: float = 64.0, max_mb: float = MAX_BUCKET_MB) -> List[Tuple[int, int]]:
+TAIL_BUCKET_MB = 12.0  # the LAST bucket (what backward completes last = what the next forward reads first) is kept this small
+
+
+def bucket_plan(store, bucket_mb: float = 64.0, max_mb: float = MAX_BUCKET_MB, tail_mb: float = TAIL_BUCKET_MB) -> List[Tuple[int, int]]:
     """the gradient-exchange buckets of a ParamStore layout (a store built with allocate=False is enough): >= bucket_mb each, cut
-    at segment boundaries in the order backward completes them; the tied embedding in pieces of <= max_mb (whole rows)"""
+    at segment boundaries in the order backward completes them; the tied embedding in pieces of <= max_mb (whole rows).
+    tail_mb > 0: the last bucket is cut once more, at the latest segment boundary that leaves a final piece of at most tail_mb —
+    its exchange and optimizer pass are the serial tail of the step (nothing is left to hide them under, and the next forward pass
+    starts with exactly these weights): 12 MB of patch embedding / position / pre-LayerNorm parameters instead of 64+ MB."""
     bounds = [s.offset for s in store.segs.values()]
     sh = store.segs["shared"]
     split = ((sh.offset, sh.offset + sh.numel, store.d),) if sh.numel % store.d == 0 else ()
-    return plan_buckets(store.numel, int(bucket_mb * 1024 * 1024 / 4), bounds, max_elems=int(max(max_mb, bucket_mb) * 1024 * 1024 / 4),
-                        splittable=split)
+    out = plan_buckets(store.numel, int(bucket_mb * 1024 * 1024 / 4), bounds, max_elems=int(max(max_mb, bucket_mb) * 1024 * 1024 / 4),
+                       splittable=split)
+    if tail_mb > 0:
+        # (the very last bucket is the small region of atomically accumulated bias / LayerNorm gradients; the one in front of it ends
+        # with the patch embedding) ... and the piece in front of those to ~3 x that (one ViT layer): its pass is released by the
+        # last layer's backward and has the patch-embedding kernels left to hide under
+        for k, lim_mb in ((1, tail_mb), (2, tail_mb), (3, 3.0 * tail_mb)):
+            if len(out) < k:
+                break
+            b, e = out[-k]
+            lim = int(lim_mb * 1024 * 1024 / 4)
+            inside = sorted(x for x in set(bounds) if b < x < e and e - x <= lim)
+            if e - b > lim and inside:
+                out[len(out) - k:len(out) - k + 1] = [(b, inside[0]), (inside[0], e)]
+    return out
 
 
 def describe_buckets(store, buckets: List[Tuple[int, int]], comm_bytes: int = 4) -> List[Dict]:
@@ -257,6 +276,7 @@ class GradReducer:
             self.emulated_ms = 0.0
             self.emulated_events = []
         self.on_ready = on_ready if self.cuda else None
+        self._finishing = False
         self.host_s = 0.0
         self.next = 0
         self.handles = []
@@ -313,11 +333,14 @@ class GradReducer:
 
     def _issue(self, b: int, e: int, ev, here=None):
         """the bucket's optimizer pass on the optimizer stream, behind its exchange (`ev`) and, for "next" buckets, behind
-        everything the step's stream had enqueued at the report that released them (`here`)"""
-        with torch.cuda.stream(self.opt_stream):
-            self.opt_stream.wait_event(ev)
+        everything the step's stream had enqueued at the report that released them (`here`).  Buckets released by finish() — backward
+        is over, nothing shares the chip with them — go to the UNMASKED tail stream when the optimizer stream is restricted to a few
+        CUs: the pass is HBM-bound and the step waits for it."""
+        st = self.tail_stream if (self._finishing and self.tail_stream is not None) else self.opt_stream
+        with torch.cuda.stream(st):
+            st.wait_event(ev)
             if here is not None:
-                self.opt_stream.wait_event(here)
+                st.wait_event(here)
             with ops.pinned_stream():  # launch on that stream, not on the step's pinned main stream
                 self.on_ready(b, e)
 
@@ -378,7 +401,11 @@ class GradReducer:
         """End of backward: the remaining buckets go out; then, behind every collective and everything backward has enqueued,
         `before()` (the sparse embedding-row exchange), the optimizer passes of the "end" buckets and `after()` (the part of the
         optimizer that needed `before`); finally the step's stream waits for the side streams."""
-        self.progress(self.grad.numel())
+        self._finishing = True
+        try:
+            self.progress(self.grad.numel())
+        finally:
+            self._finishing = False
         if not self.active:
             return
         import time
@@ -532,6 +559,8 @@ class Trainer:
                                    emulate=dict(world=emu_world, cus=self.comm_cus or COMM_CUS_DEFAULT, comm_bytes=cb) if emu_world > 1 else None)
         self.metrics_buf = torch.zeros(2, dtype=torch.float32, device=model.device)
         self._pos = {}
+        self._late_done = False
+        self._late_early = _os.environ.get("MIC_LATE_EARLY", "1") != "0"  # (A/B: 0 = the flagged embedding rows' pass behind the step, as before)
 
     def _adamw_slice(self, b: int, e: int):
         """AdamW on flat slice [b, e) — runs on the reducer's side stream right after that bucket's all-reduce.  The part of the
@@ -566,6 +595,23 @@ class Trainer:
     def _adamw_shared_late(self):
         """end of backward (after the sparse embedding rows have been added): the flagged rows of the tied embedding"""
         self._adamw_shared(1)
+
+    def _embed_rows_done(self):
+        """engine hook (world 1): the late pass of the tied embedding on the optimizer stream, behind everything enqueued so far"""
+        r = self.reducer
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        with torch.cuda.stream(r.opt_stream):
+            r.opt_stream.wait_event(ev)
+            with ops.pinned_stream():
+                self._adamw_shared_late()
+            ev2 = torch.cuda.Event()
+            ev2.record(r.opt_stream)
+        self._late_done = True
+        # fp8 GEMMs: the weights whose optimizer passes are on the optimizer stream by now (the decoder's) become fp8 for the next step
+        # here, under the ViT's backward
+        if r.next > 0:
+            self.model.engine.fp8_refresh_weights(ops.role_stream(self.model.device, "aux"), upto=r.buckets[r.next - 1][1], wait_event=ev2)
 
     def _flag_embedding_rows(self, ids: torch.Tensor):
         """flags the rows of `shared` that this step's decoder input ids (of every rank) will add a sparse gradient to"""
@@ -684,6 +730,11 @@ class Trainer:
         self.reducer.start_step()
         eng.grad_progress = self.reducer.progress if self.reducer.active else None
         eng.defer_embed = self.world > 1
+        # single process: the flagged rows of the tied embedding get their optimizer pass as soon as decoder backward has scattered the
+        # input-embedding rows into them — under the ViT's backward instead of behind the step (0.09 ms + a stream hand-over)
+        self._late_done = False
+        eng.on_embed_rows = self._embed_rows_done if (self.world == 1 and self._split_shared and self.reducer.on_ready is not None
+                                                      and self._late_early) else None
         with ops.pinned_stream():
             if self._split_shared:
                 self._flag_embedding_rows(self._pack[1] if self._pack is not None else dec_in.reshape(-1))
@@ -696,14 +747,16 @@ class Trainer:
                                           label_smoothing=self.ls, seed=seed, rows=self._rows, row_labels=self._row_labels)
         # pmean(grad) (main.py:698): SUM here, 1/world folded into AdamW's grad_scale.  The remaining buckets go out; behind them the
         # sparse embedding-row exchange, the optimizer passes that had to wait for it, and the flagged rows of the tied embedding
+        eng.on_embed_rows = None
         self.reducer.finish(before=self._scatter_embedding_rows if self.world > 1 else None,
-                            after=self._adamw_shared_late if self._split_shared else None)
+                            after=self._adamw_shared_late if (self._split_shared and not self._late_done) else None)
         if not self.overlap_optimizer:
             ops.adamw(st.master, st.m, st.v, st.grad, None if st.lp is st.master else st.lp, self.hyper, self.b1, self.b2, self.eps,
                       self.wd, grad_scale=1.0 / self.world)
             eng.fp8_requantize_range(0, st.numel)
         m.invalidate_params_cache(by_optimizer=True)
         if m.device.type == "cuda":
+            eng.fp8_refresh_weights(ops.role_stream(m.device, "aux"))  # fp8 GEMMs: next step's weight copies, beside the glue between the steps
             # the k-contiguous copy of the tied embedding for the NEXT step's head backward: behind this step's optimizer passes, on a
             # stream of its own — it has the whole next forward pass to finish (engine.shared_T waits for it)
             eng.refresh_shared_T(ops.role_stream(m.device, "aux"), st.version)

@@ -669,7 +669,8 @@ def test_fullsize_packed_rows_against_the_fp32_oracle_batch8(full, dev):
     rc, p, models, _, _ = full
     model = models[torch.bfloat16]
     b = _bench_like_batch(77, B=8)
-    px, labels, mask, dec_in = (torch.from_numpy(b[k]) for k in ("pixel_values", "input_ids", "attention_mask", "decoder_input_ids"))
+    px, labels, mask, dec_in = (torch.from_numpy(b[k]) if b[k].dtype == np.float32 else torch.from_numpy(b[k].astype(np.int64))
+                                for k in ("pixel_values", "input_ids", "attention_mask", "decoder_input_ids"))  # (the CPU oracle indexes with int64)
     ref_loss, ref_g = train_ref.loss_and_grads(rc, p, px, labels, mask, dec_in)
     d = model._dev
     B, T = labels.shape

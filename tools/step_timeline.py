@@ -61,8 +61,14 @@ def main():
     last_gemm = max((e for s, e, n, q, st in step if cls(n) == "gemm"), default=t0)
     tail = [(s, e, n) for s, e, n, q, st in step if e > last_gemm]
     print(f"\n# after the last GEMM ended (+{(last_gemm - t0) / 1e6:.3f} ms): {len(tail)} kernels still running / starting")
-    for s, e, n in tail[:20]:
+    for s, e, n in tail[:40]:
         print(f"  +{(s - t0) / 1e6:8.3f} .. +{(e - t0) / 1e6:8.3f}  {re.sub(r'^void ', '', n)[:90]}")
+    # the head: everything up to the first GEMM of the step (the glue the host issues in front of the forward pass)
+    first_gemm = min((s for s, e, n, q, st in step if cls(n) == "gemm"), default=t1)
+    head = [(s, e, n, q) for s, e, n, q, st in step if s <= first_gemm]
+    print(f"\n# up to the first GEMM (+{(first_gemm - t0) / 1e6:.3f} ms): {len(head)} kernels")
+    for s, e, n, q in head[:40]:
+        print(f"  +{(s - t0) / 1e6:8.3f} .. +{(e - t0) / 1e6:8.3f}  q{q}  {re.sub(r'^void ', '', n)[:90]}")
 
 
 if __name__ == "__main__":
