@@ -150,7 +150,8 @@ int mic_get_cu_budget(void);
  * (persistent launches: the budget), blocks of this configuration that fit one CU, and whether the LDS-DMA phased kernel is taken
  * (phased = 1; 2 = the shape fits the four-wave kernel gemm_w4.hip — on by default, MIC_GEMM_W4=0 switches it off — which takes the launch
  * if its epilogue is a bare one: bf16 C with bias / folded LayerNorm / softmax partials, or fp32 C, also as split-K slabs; of those
- * the launches WITH softmax partials run on the two-blocks-per-CU 256 x 128 kernel gemm_d2.hip, MIC_GEMM_D2=0 switches that off). */
+ * the launches WITH softmax partials run on the two-blocks-per-CU 256 x 128 kernel gemm_d2.hip, MIC_GEMM_D2=0 switches that off — for
+ * args that carry `rowstat` the plan reports that tiling: tile 128, tile_m 256, blocks_per_cu 2). */
 typedef struct { int tile, kgroups, blocks, grid, blocks_per_cu, phased, cu_budget, tile_m; } mic_gemm_plan_info;  /* tile_m: tile rows (= tile, or 192 with tile 128) */
 int mic_gemm_plan(const mic_gemm_args* args, int count, mic_gemm_plan_info* out);
 /* Operands of a LayerNorm-folded Linear (see mic_gemm_args.a_ln_stats): for w [N][K] (the compute-dtype weight), gamma / beta

@@ -288,6 +288,12 @@ extern "C" int mic_gemm_plan(const mic_gemm_args* args, int count, mic_gemm_plan
   }
   const bool persist = persist_env && plain && pl.bm == 256 && !pl.phased && pl.kgroups == 1 && pl.blocks > out->cu_budget;
   out->grid = persist ? out->cu_budget : pl.blocks;
+  // launches with softmax partials (the LM-head forward) run on gemm_d2.hip by default: 256 x 128 tiles, two blocks per CU
+  static const int d2_plan_env = [] { const char* e = getenv("MIC_GEMM_D2"); return e ? atoi(e) : 3; }();
+  if (d2_plan_env && pl.phased == 2 && count == 1 && args[0].rowstat && args[0].N % 128 == 0) {
+    out->tile = 128; out->tile_m = 256; out->blocks_per_cu = 2;
+    out->blocks = out->grid = ((args[0].M + 255) / 256) * ((args[0].N + 127) / 128);
+  }
   return MIC_OK;
 }
 

@@ -129,6 +129,12 @@ class FlaxCLIPVisionMBartGenerationMixin:
                  forced_bos_token_id: Optional[int] = None, forced_eos_token_id: Optional[int] = None,
                  length_penalty: Optional[float] = None, early_stopping: Optional[bool] = None, trace: bool = True,
                  params=None, **model_kwargs):
+        """`FlaxCLIPVisionGenerationMixin.generate` (gen:128-336): same arguments, defaults from `config.mbart_config`, same dispatch —
+        greedy (`num_beams == 1`, no sampling), sampling (`do_sample`, one beam) or beam search; `input_ids` = pixel values.
+        Limits of this build (the reference has none of the first two; the third is the reference's own): `num_beams <= 32` — the fused
+        per-row top-2K kernel keeps k = 2 * num_beams <= 64 candidates per row, a wider search raises NotImplementedError (the reference's
+        evaluation runs num_beams = 4, evaluation.py:80-94); `max_length <= max_position_embeddings` (XLA's gather would clamp silently,
+        this raises); beam search with sampling raises NotImplementedError as upstream (gen:336)."""
         mc = self.config.mbart_config
         from_processed = bool(model_kwargs.pop("sample_from_processed_logits", False))  # build-only switch, see _sample
         max_length = max_length if max_length is not None else mc.max_length  # gen:205-209

@@ -446,7 +446,7 @@ def _ddp_worker(rank, world, port, q):
         issue.append(r25.host_s * 1e3)   # 25 asynchronous collectives issued
         r25.finish()                      # (CPU tensors: finish() also WAITS for the collectives; on the GPU it only enqueues)
         total.append(r25.host_s * 1e3)
-    ok = ok and torch.equal(g25, torch.ones(n25) * sum(r + 1 for r in range(world))) and 0.0 < min(issue) < min(total) < 200.0
+    ok = ok and torch.equal(g25, torch.ones(n25) * sum(r + 1 for r in range(world))) and 0.0 < min(issue) <= min(total)  # (wall-clock figures are printed, not bounded: they depend on the host's load)
     if rank == 0:
         print(f"[reducer host side, gloo world {world}, 25 buckets] issue {min(issue):.3f} ms per step, with the waits {min(total):.3f} ms "
               "(best of 5)", flush=True)

@@ -616,22 +616,24 @@ def test_reducer_ready_when_rules(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["ckv_per_layer", "fp8"])
+@pytest.mark.parametrize("mode", ["ckv_per_layer", "fp8", "fp8_hoisted"])
 def test_per_layer_cross_kv_gradients_are_not_reported_early(dev, monkeypatch, mode):
     """The cross-attention k/v weights of all layers sit in ONE block behind decoder layer 0.  When their projections run per layer
-    (fp8 GEMMs, MIC_CKV_HOIST=0) a layer's queued k/v weight gradient must not move the "everything before this offset is final"
-    mark past the decoder layers below it: with several buckets and the per-bucket optimizer beside backward that applied AdamW to
-    gradients whose GEMMs had not run yet.  Overlapped optimizer (small buckets) == one AdamW launch after backward."""
+    (MIC_CKV_HOIST=0, in bf16 and with fp8 GEMMs) a layer's queued k/v weight gradient must not move the "everything before this
+    offset is final" mark past the decoder layers below it: with several buckets and the per-bucket optimizer beside backward that
+    applied AdamW to gradients whose GEMMs had not run yet.  Overlapped optimizer (small buckets) == one AdamW launch after backward.
+    "fp8_hoisted": the default fp8 path (one fp8 matrix for all layers' k/v weights, one k/v gradient tensor, split-K dX) under the
+    same comparison."""
     from mic_amd import Trainer, create_learning_rate_fn
 
-    if mode == "ckv_per_layer":
+    if mode in ("ckv_per_layer", "fp8"):
         monkeypatch.setenv("MIC_CKV_HOIST", "0")
     res, lr, steps = {}, 1e-3, 3
     for overlap in (True, False):
         rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.0, d_layers=3)
         tr = Trainer(model, create_learning_rate_fn(64, 2, 4, 0, lr), weight_decay=0.01, bucket_mb=0.125, overlap_optimizer=overlap,
-                     gemm_dtype="fp8" if mode == "fp8" else None, fp8_scaling="current")
-        assert not model.engine.ckv_hoisted() and len(tr.buckets) > 4
+                     gemm_dtype="fp8" if mode.startswith("fp8") else None, fp8_scaling="current" if mode == "fp8" else "delayed")
+        assert model.engine.ckv_hoisted() == (mode == "fp8_hoisted") and len(tr.buckets) > 4
         losses = []
         for s_ in range(steps):
             px, labels, mask, dec_in = batch(rc, 4, 12, seed=140 + s_)

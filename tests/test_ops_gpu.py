@@ -887,6 +887,24 @@ def test_gemm_four_phase_kernel_behind_its_switch(dev):
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
 
 
+@pytest.mark.parametrize("d2", ["0", "2"])
+def test_gemm_two_blocks_per_cu_kernel_behind_its_switch(dev, d2):
+    """gemm_d2.hip takes, by default (MIC_GEMM_D2=3), only the launches with softmax partials.  Its general epilogue (activation, saved
+    pre-activation, dGELU, dropout, residual, fp32 C, accumulate, split-K slabs) is reachable under MIC_GEMM_D2=2 (every single-problem
+    NT 256-tile launch it covers), and with MIC_GEMM_D2=0 the softmax-partials launches fall back to the four-wave kernel's STATS
+    instantiations: both configurations run the many-tile, softmax-partial, folded-LayerNorm and bit-for-bit tests of this file in a
+    child process (the library latches the switch at its first GEMM)."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, MIC_GEMM_D2=d2)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "-k",
+                        "(phased and not behind_its_switch) or head_rowstat or layernorm_fold or repeats_bit_for_bit"], env=env, capture_output=True,
+                       text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
+
+
 @pytest.mark.parametrize("M,N,K", [(1024, 131072, 256), (2300, 66048, 384)])
 def test_gemm_four_wave_kernel_repeats_bit_for_bit(dev, M, N, K):
     """the four-wave kernel on many-tile launches with the LM head's epilogue: the same bits from run to run, also when two launches

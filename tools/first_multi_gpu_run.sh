@@ -27,7 +27,9 @@ for mb in (64, 128, 1024):   # the bucket sizes of the step: 64-128 MB pieces, a
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(10): dist.all_reduce(t)
     torch.cuda.synchronize(); ms = (time.perf_counter() - t0) * 100
-    if r == 0: print(f"all-reduce {mb} MB fp32 over {w} ranks: {ms:.2f} ms measured, {allreduce_ms(mb * 1048576.0, w):.2f} ms projected (train.XGMI_LINK_GBPS), cap {cap} channels", flush=True)
+    if r == 0:
+        from mic_amd.train import allreduce_projections
+        print(f"all-reduce {mb} MB fp32 over {w} ranks: {ms:.2f} ms measured; projected {allreduce_projections(mb * 1048576.0, w)} (the link rate that fits goes into choose_comm_dtype(link_gbps=)), cap {cap} channels", flush=True)
 dist.destroy_process_group()
 PY
 NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29611 $O/_probe.py > $O/rccl_probe.log 2>&1
@@ -43,11 +45,17 @@ echo "ddp tests over RCCL: rc $? ($(tail -1 $O/ddp_tests.log))" | tee -a $O/summ
 #    the byte counts say fp32 cannot hide (N = 2, 4)
 for n in 1 2 4 8; do
   [ $n -le $N ] || continue
-  timeout 1200 python bench.py --gpus $n --steps 20 --warmup 5 --no-generate --no-cpu-baseline --emulate-comm 0 > $O/bench_N$n.json 2> $O/bench_N$n.err
+  timeout 1200 python bench.py --gpus $n --steps 20 --warmup 5 --no-generate --no-cpu-baseline --no-fp8-leg --emulate-comm 0 > $O/bench_N$n.json 2> $O/bench_N$n.err
   echo "bench --gpus $n (fp32 exchange): rc $? $(grep '^{' $O/bench_N$n.json | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], "images/s", d["ms_per_step"], "ms", d["config"]["grad_allreduce"])' 2>/dev/null)" | tee -a $O/summary.txt
   if [ $n -eq 2 ] || [ $n -eq 4 ]; then
     timeout 1200 python bench.py --gpus $n --steps 20 --warmup 5 --grad-comm bf16 --no-generate --no-cpu-baseline --emulate-comm 0 > $O/bench_N${n}_bf16.json 2> $O/bench_N${n}_bf16.err
     echo "bench --gpus $n (bf16 exchange): rc $? $(grep '^{' $O/bench_N${n}_bf16.json | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], "images/s", d["ms_per_step"], "ms")' 2>/dev/null)" | tee -a $O/summary.txt
   fi
+done
+# 4. configs[4] on the node: the fp8 step (QKV / FFN projections as fp8 GEMMs, fused emission) at every N, fp32 exchange
+for n in 1 2 4 8; do
+  [ $n -le $N ] || continue
+  timeout 1200 python bench.py --gpus $n --dtype fp8 --steps 20 --warmup 5 --no-generate --no-cpu-baseline --no-extra-legs --emulate-comm 0 > $O/bench_fp8_N$n.json 2> $O/bench_fp8_N$n.err
+  echo "bench --gpus $n --dtype fp8: rc $? $(grep '^{' $O/bench_fp8_N$n.json | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], "images/s", d["ms_per_step"], "ms")' 2>/dev/null)" | tee -a $O/summary.txt
 done
 echo "done: $O/summary.txt"
