@@ -318,7 +318,7 @@ def bench_generate(model, cfg, dev, batch=256, langs=(250004, 250008, 250003, 25
                                  "algorithmic_MB_per_launch": round(ab / an / 1e6, 2),
                                  "note": "algorithmic bytes = K and V of every valid cache slot once (cross K/V once per image, shared by "
                                          "its beams) + q + output; HIP events around every launch of one untimed generate call"}
-    for name in ("r5_generate_pmc_hbm_traffic.json", "r4_generate_pmc_hbm_traffic.json", "r3_generate_pmc_hbm_traffic.json", "r2_generate_pmc_hbm_traffic.json"):
+    for name in ("r6_generate_pmc_hbm_traffic.json", "r5_generate_pmc_hbm_traffic.json", "r4_generate_pmc_hbm_traffic.json", "r3_generate_pmc_hbm_traffic.json", "r2_generate_pmc_hbm_traffic.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if batch == 256 and os.path.exists(pmc):  # HBM-side bytes per launch from separate rocprofv3 --pmc passes over this leg (committed)
             t = json.load(open(pmc))
@@ -754,7 +754,7 @@ def main():
         else:
             # HBM bytes per launch come from separate rocprofv3 --pmc passes (a profiler cannot wrap this very process); the
             # committed summary of the last such passes over this same command is reported with the commit it was taken at.
-            for name in ("r5_train_pmc_hbm_traffic.json", "r4_train_pmc_hbm_traffic.json", "r3_train_pmc_hbm_traffic.json", "r2_train_pmc_hbm_traffic.json", "r1_train_pmc_hbm_traffic.json"):
+            for name in ("r6_train_pmc_hbm_traffic.json", "r5_train_pmc_hbm_traffic.json", "r4_train_pmc_hbm_traffic.json", "r3_train_pmc_hbm_traffic.json", "r2_train_pmc_hbm_traffic.json", "r1_train_pmc_hbm_traffic.json"):
                 pmc = os.path.join(ROOT, "profiles", name)
                 if args.dtype == "bf16" and B == 64 and not args.small and not args.dense_captions and os.path.exists(pmc):
                     t = json.load(open(pmc))

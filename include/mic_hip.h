@@ -16,8 +16,9 @@
  *          the mic_gemm* calls of the same thread and by mic_get_cu_budget / mic_gemm_plan;
  *      (2) A/B switches read ONCE per process from the environment at the first GEMM call and latched:
  *          MIC_FREE_CUS, MIC_GEMM_TILE, MIC_TINY_BELOW, MIC_GEMM_QUANT, MIC_GEMM_T192, MIC_GEMM_PHASED,
- *          MIC_GEMM_W4, MIC_GEMM_D2, MIC_GEMM_KG, MIC_GEMM_KG128, MIC_GEMM_PERSIST (tools/README.md; the
- *          defaults are the measured best, nothing on the product path sets them);
+ *          MIC_GEMM_W4, MIC_GEMM_D2, MIC_GEMM_KG, MIC_GEMM_KG128, MIC_GEMM_PERSIST, and MIC_LNB_BLOCKS at the
+ *          first LayerNorm backward (tools/README.md; the defaults are the measured best, nothing on the
+ *          product path sets them);
  *      (3) per-device one-time attributes of the kernels (dynamic-LDS size) and the thread-local
  *          mic_last_error() message.
  *    Nothing else: no caches of caller pointers, no hidden workspaces, no streams of its own.

@@ -1,6 +1,7 @@
 // norm.hip — LayerNorm forward/backward (K2).  HBM-bound: one wave per row, 16-B vector loads, the row lives in
 // registers, statistics by wave xor-shuffle reductions in fp32 (flax nn.LayerNorm semantics: biased variance).
 #include "common.h"
+#include <stdlib.h>
 
 #define LN_MAXC 4  // 16-B chunks of 8 elements per lane: width <= 64*8*4 = 2048
 
@@ -234,9 +235,13 @@ extern "C" int mic_layernorm_fwd_q8(int rows, int width, const void* x, const fl
   return ln_fwd_impl(MIC_BF16, rows, width, x, gamma, beta, eps, y, mean, rstd, dropout_p, dropout_seed, q8, stream);
 }
 
+// block cap: 512 (MIC_LNB_BLOCKS, A/B).  With the gamma / beta gradients as block partials (no atomics) a block per 8 rows up to 512
+// blocks measured 12.3 -> 11.1 us at 2432 x 1024, 15.7 -> 14.2 at 4096 x 1024 against the cap of 256 the atomics form was tuned for
+// (every wave gets one row instead of some getting two); 128: 15.1 / 22.3 us.
 static int ln_bwd_blocks(int rows) {
+  static const int cap = [] { const char* e = getenv("MIC_LNB_BLOCKS"); const int v = e ? atoi(e) : 512; return v < 1 ? 1 : (v > 4096 ? 4096 : v); }();
   const int nblk = (rows + LNB_WAVES - 1) / LNB_WAVES;
-  return nblk > 256 ? 256 : nblk;
+  return nblk > cap ? cap : nblk;
 }
 extern "C" int mic_layernorm_bwd_blocks(int rows) { return ln_bwd_blocks(rows > 0 ? rows : 1); }
 static int ln_bwd_impl(int dtype, int rows, int width, const void* x, const float* gamma, const float* mean, const float* rstd,

@@ -496,7 +496,7 @@ class Engine:
         if not self.ln_partials:
             return ops.layernorm_bwd(x, P.f32(ln + ".g"), mean, rstd, dy, dx, P.g(ln + ".g"), P.g(ln + ".b"), rows=rows, **kw)
         width = x.shape[-1]
-        part = self.buf(f"lnp.{tag}.{l & 1}", 2 * 256, width, torch.float32)  # [2][blocks <= 256][width]
+        part = self.buf(f"lnp.{tag}.{l & 1}", 2 * ops.layernorm_bwd_blocks(1 << 30), width, torch.float32)  # [2][blocks <= cap][width]
         ops.layernorm_bwd_partials(x, P.f32(ln + ".g"), mean, rstd, dy, dx, part, rows=rows, **kw)  # (kw may carry q8 / q8_of_dx: fused fp8 emission)
         self._lnp_queue.append((part, ops.layernorm_bwd_blocks(rows), width, P.g(ln + ".g"), P.g(ln + ".b"), False))
         return dx

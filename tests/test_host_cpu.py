@@ -25,6 +25,20 @@ def test_abi_exports_every_declared_symbol():
     assert l.mic_version() == 1
 
 
+def test_header_lists_every_environment_switch_the_library_latches():
+    """include/mic_hip.h promises that the only state libmic_hip.so keeps is host-side planning state and NAMES the environment switches
+    it latches: the list must be the set of getenv() names in csrc/"""
+    csrc = os.path.join(ROOT, "multilingual-image-captioning_amd", "csrc")
+    names = set()
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h", ".inc")):
+            names |= set(re.findall(r'getenv\("(MIC_[A-Z0-9_]+)"\)', open(os.path.join(csrc, f)).read()))
+    hdr = open(os.path.join(ROOT, "include", "mic_hip.h")).read()
+    top = hdr[: hdr.index("#ifndef MIC_HIP_H")]
+    listed = set(re.findall(r"MIC_[A-Z0-9_]+", top)) - {"MIC_BF16", "MIC_F32", "MIC_E", "MIC_HIP_H"}
+    assert names and names == listed, (sorted(names - listed), sorted(listed - names))
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "multilingual-image-captioning_amd")
     for fn in os.listdir(pkg):
