@@ -311,6 +311,11 @@ int mic_embed_fwd(int dtype, int rows, int width, const int32_t* ids, const int3
                   const float* pos_table, float scale, void* h, void* stream);
 int mic_embed_bwd(int dtype, int rows, int width, const int32_t* ids, const int32_t* pos_ids, const void* dh,
                   float scale, float* dtable, float* dpos_table, void* stream);
+/* The token-embedding scatter of the DATA-PARALLEL step (main.py:698 pmean of a gradient whose embedding part is sparse): dtable[ids[i]]
+ * += scale * dh[i] for the n all-gathered rows of all ranks, DETERMINISTIC — the occurrences of an id are added by a single writer in a
+ * fixed order (a function of the index set only), so every rank computes the same bits and the replicas stay identical (fp32 atomics do
+ * not guarantee that).  ids < 0 are skipped (padding); n <= 65536, width % 16 == 0. */
+int mic_embed_rows_add_det(int dtype, int n, int width, const int32_t* ids, const void* dh, float scale, float* dtable, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Masked (label-smoothed) softmax cross-entropy over materialised logits (main.py:658-680).

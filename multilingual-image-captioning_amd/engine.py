@@ -1041,11 +1041,18 @@ class Engine:
                     in_dropout_p=pd, in_dropout_seed=sd(1))
         if self.defer_embed:
             ops.embed_bwd(ids, pos_ids, dh0, self.embed_scale, None, P.g("dec.pos"), M, d)
-            if pack is not None and M < Mcap:
-                # the ranks exchange a FIXED number of (id, dh0) rows: rows behind this rank's valid ones carry id 0 (packed ids are
-                # zero-padded to B*T by the caller) and must add nothing
-                ops.zero(dh0[M:Mcap])
-            self.embed_rows = (ids, dh0, Mcap if pack is not None else M)
+            # the ranks exchange a FIXED number of (id, dh0) rows and add them up deterministically (mic_embed_rows_add_det: the
+            # replicas must stay bit-identical): rows that carry no gradient — behind this rank's valid packed rows, or at padded
+            # positions (their dh0 is exactly zero) — travel with id -1 and are skipped
+            n_x = Mcap if pack is not None else M
+            ids_x = self.vec("db.ids_x", Mcap, torch.int32)
+            ids_x[:n_x].copy_(ids[:n_x])
+            if pack is not None:
+                if M < Mcap:
+                    ids_x[M:Mcap].fill_(-1)
+            elif key_mask is not None:
+                ids_x[:n_x].masked_fill_(key_mask.reshape(-1)[:n_x] == 0, -1)
+            self.embed_rows = (ids_x, dh0, n_x)
         else:
             # single process: the scatter lands before the optimizer touches the segment (Trainer holds that bucket)
             ops.embed_bwd(ids, pos_ids, dh0, self.embed_scale, P.g("shared"), P.g("dec.pos"), M, d)

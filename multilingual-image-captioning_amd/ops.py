@@ -314,6 +314,11 @@ def embed_bwd(ids, pos_ids, dh, scale, dtable, dpos_table, rows, width):
     L.check(L.lib().mic_embed_bwd(_dt(dh), rows, width, _p(ids), _p(pos_ids), _p(dh), float(scale), _p(dtable), _p(dpos_table), _stream()), "mic_embed_bwd")
 
 
+def embed_rows_add_det(ids, dh, scale, dtable, n, width):
+    """dtable[ids[i]] += scale * dh[i] over the n rows, deterministically (ids < 0 skipped): the data-parallel embedding-row exchange"""
+    L.check(L.lib().mic_embed_rows_add_det(_dt(dh), int(n), int(width), _p(ids), _p(dh), float(scale), _p(dtable), _stream()), "mic_embed_rows_add_det")
+
+
 def ce_rows(logits, ld, V, labels, mask, ls, row_lse, row_loss, rows):
     L.check(L.lib().mic_ce_rows(_dt(logits), rows, V, _p(logits), ld, _p(labels), _p(mask), float(ls), _p(row_lse), _p(row_loss), _stream()), "mic_ce_rows")
 

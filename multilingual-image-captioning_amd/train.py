@@ -625,8 +625,9 @@ class Trainer:
 
     def _scatter_embedding_rows(self):
         """Data parallel: the sparse half of the tied-embedding gradient.  Every rank all-gathers (ids, dh0) — <= B*T rows
-        per rank — and scatter-adds ALL ranks' rows into its already all-reduced dense half (sum over ranks, like the
-        all-reduce; 1/world is applied by AdamW).  Runs on the optimizer stream after the last collective."""
+        per rank — and adds ALL ranks' rows into its already all-reduced dense half (sum over ranks, like the all-reduce; 1/world
+        is applied by AdamW) with the DETERMINISTIC scatter: the same bits on every rank, so the replicas' embeddings stay
+        identical (the atomics of the single-process scatter do not guarantee an order).  Runs after the last collective."""
         import torch.distributed as dist
 
         eng, st = self.model.engine, self.model.store
@@ -635,7 +636,7 @@ class Trainer:
         all_dh = torch.empty((self.world * M, st.d), dtype=dh0.dtype, device=dh0.device)
         dist.all_gather_into_tensor(all_ids, ids[:M].contiguous(), group=self.group)
         dist.all_gather_into_tensor(all_dh, dh0[:M].contiguous(), group=self.group)
-        ops.embed_bwd(all_ids, None, all_dh, eng.embed_scale, st.g("shared"), None, self.world * M, st.d)
+        ops.embed_rows_add_det(all_ids, all_dh, eng.embed_scale, st.g("shared"), self.world * M, st.d)
 
     def _prep(self, batch):
         m = self.model

@@ -118,6 +118,60 @@ def test_two_rank_bf16_gradient_exchange(dev):
     assert all(r[1] for r in res), res
 
 
+def _fp8_worker(rank, world, port, q):
+    """configs[4] data parallel in small: two ranks, fp8 GEMMs with fused emission (from the second step on), five steps on per-rank
+    batches: every rank sees the same pmean loss and ends with BIT-IDENTICAL fp32 master weights (the all-reduce and the deterministic
+    embedding-row scatter are rank-symmetric: with an atomic scatter the replicas' embeddings drifted by 2.8e-9 in five steps), the
+    loss falls, the producers emit the fp8 operands.  The fp8 arithmetic itself is pinned by tests/test_fp8_gpu.py."""
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    dev = _init(rank, world)
+    try:
+        from util_small import batch, make_pair
+
+        import mic_amd  # noqa: F401
+        from mic_amd import Trainer, create_learning_rate_fn
+
+        rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.1)
+        tr = Trainer(model, create_learning_rate_fn(64, 2, 4, 2, 2e-3), seed=42, bucket_mb=0.25, gemm_dtype="fp8")
+        assert model.engine.fp8 and model.engine.fp8_fused and len(tr.buckets) > 3
+        px, labels, mask, dec_in = batch(rc, 3, 12, seed=700 + rank)
+        b = {"pixel_values": px.numpy(), "input_ids": labels.numpy(), "attention_mask": mask.numpy(), "decoder_input_ids": dec_in.numpy()}
+        losses = [float(tr.train_step(b)["loss"]) for _ in range(5)]
+        torch.cuda.synchronize()
+        w = model.store.master.clone()
+        ws = [torch.empty_like(w) for _ in range(world)]
+        dist.all_gather(ws, w)
+        ls = [None] * world
+        dist.all_gather_object(ls, losses)
+        same_w = all(torch.equal(ws[0], x) for x in ws)
+        maxdiff = max(float((ws[0] - x).abs().max()) for x in ws)
+        where = [n for n, sg in model.store.segs.items() if any(not torch.equal(ws[0][sg.offset:sg.offset + sg.numel], x[sg.offset:sg.offset + sg.numel]) for x in ws)]
+        flags = (same_w, all(l == ls[0] for l in ls), bool(np.isfinite(losses).all()), losses[-1] < losses[0] - 0.3,
+                 len(model.engine._a8_ready) > 20)  # (last: the producers emitted the operands — scale histories exist)
+        q.put((rank, all(flags), f"flags {flags} max weight difference {maxdiff} in {where[:8]} ready {len(model.engine._a8_ready)} losses {losses}"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_fp8_train_steps(dev):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_fp8_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for pr in procs:
+        pr.join(timeout=60)
+    assert all(r[1] for r in res), res
+
+
 def _packed_worker(rank, world, port, q, full=False):
     """bf16, two ranks with different numbers of valid caption positions: the data-parallel step with packed decoder rows against
     the same step on padded rows (same process, same data, fresh model each): same loss, same summed gradients to the summation-order

@@ -386,6 +386,27 @@ def _fp8_pass(model, rc, px, labels, mask, dec_in, B, T):
     return loss.item(), {k: v.copy() for k, v in model.store.export_flat("grad").items()}
 
 
+@pytest.mark.parametrize("T", [12, 72])
+def test_fp8_fused_emission_equals_the_quantiser_path_also_beyond_one_attention_tile(dev, T):
+    """engine-level: three passes on one batch with the producers emitting the fp8 operands (from pass 2 on) against the same three
+    passes with every operand through mic_fp8_quantize (`fp8_fused = False`): same losses, same gradients up to the fp32 atomics'
+    order.  T = 72: more than one 64-key attention tile — the tiled attention backward has no fp8 form, its dQ / dK / dV go through the
+    quantiser while LayerNorm / GELU / dGELU still emit."""
+    res = {}
+    for fused in (True, False):
+        rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.0)
+        model.engine.set_gemm_dtype("fp8")
+        model.engine.fp8_fused = fused
+        px, labels, mask, dec_in = batch(rc, 3, T, seed=21)
+        out = [_fp8_pass(model, rc, px, labels, mask, dec_in, 3, T) for _ in range(3)]
+        res[fused] = out
+        if fused:
+            assert len(model.engine._a8_ready) > 20
+    for (la, ga), (lb, gb) in zip(res[True], res[False]):
+        assert abs(la - lb) <= 1e-5 * abs(lb), (la, lb)
+        _same(ga, gb, tol=2e-4)
+
+
 def test_fp8_delayed_scaling_reproduces_current_scaling_on_a_repeated_batch(dev):
     """Pass 1 of a fresh engine has no history: every tensor is scaled by its current amax.  Pass 2 on the SAME batch and weights
     runs delayed (one quantiser pass per tensor, scale = amax recorded in pass 1 = the current amax): loss and gradients must

@@ -887,6 +887,33 @@ def test_gemm_four_phase_kernel_behind_its_switch(dev):
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_embed_rows_add_deterministic(dev, dtype):
+    """the data-parallel embedding-row scatter: dtable[ids[i]] += scale * dh[i] with heavy duplicates (every sequence starts with the
+    same few ids), ids < 0 skipped; equal to an fp64 index_add, and the SAME BITS from run to run (a fixed reduction tree: what
+    keeps the replicas of a data-parallel job identical) — unlike the atomic scatter of the single-process path"""
+    from mic_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    n, width, V = 3000, 256, 500
+    ids = torch.randint(0, V, (n,), generator=g, dtype=torch.int32)
+    ids[::5] = 7           # 600 occurrences of one id
+    ids[1::7] = -1         # skipped rows (their dh may hold anything)
+    dh = rnd((n, width), g, dtype, 1.0)
+    dh[ids < 0] = float("nan")
+    base = torch.randn(V, width, generator=g)
+    outs = []
+    for rep in range(3):
+        t = base.clone().to(dev)
+        ops.embed_rows_add_det(ids.to(dev), dh.to(dev), 0.5, t, n, width)
+        torch.cuda.synchronize()
+        outs.append(t.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    keep = ids >= 0
+    ref = base.double().index_add(0, ids[keep].long(), dh[keep].double() * 0.5)
+    assert ((outs[0].double() - ref).abs().max() / ref.abs().max()).item() < 2e-6
+
+
 @pytest.mark.parametrize("d2", ["0", "2"])
 def test_gemm_two_blocks_per_cu_kernel_behind_its_switch(dev, d2):
     """gemm_d2.hip takes, by default (MIC_GEMM_D2=3), only the launches with softmax partials.  Its general epilogue (activation, saved
