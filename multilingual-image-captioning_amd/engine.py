@@ -87,7 +87,10 @@ class Engine:
         current amax.  Weights are re-quantised once per optimizer step — with their current amax ("current"), or ("delayed")
         with the amax of the previous step's weights, recorded by the previous quantiser pass: an optimizer step moves a weight
         by ~lr, so the one-step-old maximum is the current one to fp8 precision and the amax pass over 246 M parameters goes;
-        weights that arrive any other way (params setter, checkpoint restore) start again from their current amax."""
+        weights that arrive any other way (params setter, checkpoint restore) start again from their current amax.
+        Under delayed scaling a tensor WITH a scale history is not quantised by a launch of its own: its producer (LayerNorm forward /
+        backward, the GELU / dGELU epilogue of the fp8 GEMM, attention backward) writes the fp8 bytes (`_q8_target`, `fp8_fused`);
+        the weight copies of the next pass are made on a side stream behind the optimizer (`fp8_refresh_weights`)."""
         if name in (None, "bf16", "bfloat16", "f32", "float32"):
             self.fp8 = False
             return

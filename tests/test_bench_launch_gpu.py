@@ -79,3 +79,13 @@ def test_bench_default_line_carries_the_dense_caption_step(dev):
     # pinned host memory inside the loop (main.py:773-775)
     assert 0 < d["host_issue_ms_per_step"] and d["host_loop_ms_per_step"] > 0
     assert d["h2d_inclusive"]["ms_per_step"] > 0 and d["h2d_inclusive"]["steps"] == 2 and d["fp8_train"] is None  # (fp8 leg: full size only)
+
+
+def test_bench_fp8_line(dev):
+    """`--dtype fp8` (configs[4]): the line names the workload and the GEMM dtype, and carries the fp8 GEMMs' own rate"""
+    r = _run(["--dtype", "fp8", "--no-generate", "--steps", "3"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["dtype"] == "fp8" and d["config"]["workload"].startswith("configs[4]") and "e4m3" in d["config"]["gemm_dtype"]
+    assert d["roofline"]["peak"] == 5000.0 and d["roofline"]["fp8_gemms"]["launches_per_step"] > 0 and d["fp8_train"] is None
+    assert abs(d["final_loss"]) < 100
