@@ -12,7 +12,8 @@ B, T = 64, 64
 V, img = cfg.mbart_config.vocab_size, cfg.clip_vision_config.image_size
 batches = [bench.synth_batch(B, T, V, img, 1234 + i) for i in range(2)]
 model = FlaxCLIPVisionMBartForConditionalGeneration(cfg, seed=0, dtype=torch.bfloat16, device=dev)
-tr = Trainer(model, create_learning_rate_fn(10_000_000, B, 7, 1000, 5e-5), seed=42)
+GD = os.environ.get("GEMM_DTYPE") or None  # GEMM_DTYPE=fp8: configs[4]
+tr = Trainer(model, create_learning_rate_fn(10_000_000, B, 7, 1000, 5e-5), seed=42, gemm_dtype=GD)
 dbs = [{k: torch.from_numpy(v).to(dev) for k, v in b.items()} for b in batches]
 for b, db in zip(batches, dbs):
     idx, rl = loss_rows(b["attention_mask"], b["input_ids"])
@@ -29,4 +30,6 @@ for w in range(NW):
         tr.train_step(dbs[i % 2])
     torch.cuda.synchronize()
     out.append((time.perf_counter() - t0) / W * 1e3)
-print(f"ms per step over {NW} consecutive windows of {W} steps: " + " ".join(f"{x:.2f}" for x in out))
+last = float(tr.train_step(dbs[0])["loss"])
+assert last == last and abs(last) < 1e4, last  # (finite)
+print(f"[{GD or 'bf16'}] ms per step over {NW} consecutive windows of {W} steps: " + " ".join(f"{x:.2f}" for x in out) + f"; last loss {last:.4f}")
