@@ -314,8 +314,11 @@ int mic_embed_bwd(int dtype, int rows, int width, const int32_t* ids, const int3
 /* The token-embedding scatter of the DATA-PARALLEL step (main.py:698 pmean of a gradient whose embedding part is sparse): dtable[ids[i]]
  * += scale * dh[i] for the n all-gathered rows of all ranks, DETERMINISTIC — the occurrences of an id are added by a single writer in a
  * fixed order (a function of the index set only), so every rank computes the same bits and the replicas stay identical (fp32 atomics do
- * not guarantee that).  ids < 0 are skipped (padding); n <= 65536, width % 16 == 0. */
-int mic_embed_rows_add_det(int dtype, int n, int width, const int32_t* ids, const void* dh, float scale, float* dtable, void* stream);
+ * not guarantee that).  ids < 0 are skipped (padding); n <= 65536, width % 64 == 0.  ws: mic_embed_rows_add_det_ws(vocab) ints, initialised ONCE by the caller (ints [0, vocab) 0x7fffffff,
+ * [vocab, 2 vocab) 0, [2 vocab, 3 vocab) -1, the rest 0); the call leaves its first 3 vocab + 1 ints in that state (the rest is scratch). */
+int mic_embed_rows_add_det(int dtype, int n, int width, int vocab, const int32_t* ids, const void* dh, float scale, float* dtable,
+                           int32_t* ws, void* stream);
+long long mic_embed_rows_add_det_ws(int vocab);
 
 /* ---------------------------------------------------------------------------------------------
  * Masked (label-smoothed) softmax cross-entropy over materialised logits (main.py:658-680).

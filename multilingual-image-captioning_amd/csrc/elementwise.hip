@@ -153,68 +153,184 @@ extern "C" int mic_embed_bwd(int dtype, int rows, int width, const int32_t* ids,
 
 // Deterministic form of the token-embedding scatter for the DATA-PARALLEL step: every rank adds the all-gathered (id, dh) rows of all
 // ranks into its already all-reduced dense gradient — with fp32 atomics the order of the adds to one row differs from rank to rank
-// and the replicas' embeddings drift apart (measured: 2.8e-9 after 5 steps).  One block per source row j; only the block of an id's
-// FIRST occurrence works: it adds up the rows of every occurrence in index order and is the single writer of that table row.
-// ids < 0 are skipped (padding rows behind a rank's valid ones).  n <= 65536 (a 8 KiB occurrence bitmap in LDS).
+// and the replicas' embeddings drift apart (measured: 2.8e-9 after 5 steps).  Three small launches over a workspace of
+// 3 V + 1 + DET_MAXM ints (owner[V] = INT_MAX, count[V] = 0, last[V] = -1, multi_count = 0 between calls: the kernels restore that state):
+//   1. owner[id] = min index, last[id] = max index, count[id] = occurrences (integer atomics: order-free);
+//   2. one block per source row j that IS its id's first occurrence: one or two occurrences (nearly all of the ~20 k distinct ids of
+//      8 ranks x 4096 rows; first + last index) are added in place; an id with more goes on the multi list;
+//   3. one block per listed id: it scans the id list for the occurrences (a bitmap in index order) and adds their rows by a FIXED tree
+//      — the occurrences of bitmap word w go to thread group (w ^ (w >> 4)) % 16, index order inside a group, the sixteen partial rows combined in
+//      group order — as the single writer of that table row.
+// ids < 0 are skipped (padding rows behind a rank's valid ones).  n <= 65536.
+#define DET_MAXM 32768  // (n <= 65536 rows hold at most 32768 ids with more than one occurrence: the list cannot overflow)
+#define DET_G 16
+__global__ void det_owner_kernel(int n, const int32_t* __restrict__ ids, int* __restrict__ owner, int* __restrict__ count, int* __restrict__ last) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int id = ids[i];
+  if (id < 0) return;
+  atomicMin(owner + id, i);
+  atomicMax(last + id, i);
+  atomicAdd(count + id, 1);
+}
 template <typename T>
-__global__ __launch_bounds__(256) void embed_rows_add_det_kernel(int n, int width, const int32_t* __restrict__ ids, const T* __restrict__ dh,
-                                                                 float scale, float* __restrict__ dtable) {
-  __shared__ uint32_t bits[2048];
-  __shared__ int first;
-  __shared__ float red[4][1024];
-  const int j = blockIdx.x, tid = threadIdx.x;
+__global__ __launch_bounds__(256) void det_single_kernel(int n, int width, const int32_t* __restrict__ ids, const T* __restrict__ dh, float scale,
+                                                         float* __restrict__ dtable, int* __restrict__ owner, int* __restrict__ count,
+                                                         int* __restrict__ last, int* __restrict__ multi_count, int* __restrict__ multi_list) {
+  // one WAVE per source row (no block-wide barrier: a wave's loads of owner / count / last precede its lane 0's reset in program order)
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (j >= n) return;
   const int id = ids[j];
-  if (id < 0) return;  // (block-uniform)
-  const int words = (n + 31) >> 5;
-  for (int w = tid; w < words; w += 256) bits[w] = 0u;
-  if (tid == 0) first = j;
-  __syncthreads();
-  for (int i = tid; i < n; i += 256) {
-    if (ids[i] == id) {
-      atomicOr(&bits[i >> 5], 1u << (i & 31));
-      if (i < j) atomicMin(&first, i);
-    }
-  }
-  __syncthreads();
-  if (first != j) return;  // an earlier block owns this id
-  // a FIXED reduction tree: occurrence number k (in index order) goes to thread group k % 4, each group adds its occurrences in index
-  // order, the four partial rows meet in LDS in group order — a function of the index set only, the same on every rank
-  const int g = tid >> 6, lane = tid & 63;
-  for (int cb = 0; cb < width; cb += 1024) {
-    const int c0 = cb + lane * 16;
-    float a[16];
+  if (id < 0 || owner[id] != j) return;  // (wave-uniform; a later occurrence of the id reads INT_MAX or the first index: never its own)
+  const int c = count[id], j2 = last[id];
+  if (c <= 2) {  // one occurrence, or two (random collisions: ~900 ids at 8 ranks x 4096 rows): first + last index say it all
+    for (int col = lane * 4; col < width; col += 256) {
+      float* dst = dtable + (size_t)id * width + col;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) a[e] = 0.f;
-    int k = 0;
-    for (int w = j >> 5; w < words; ++w) {
-      uint32_t m = bits[w];
-      while (m) {
-        const int i = (w << 5) + __builtin_ctz(m);
-        m &= m - 1;
-        if ((k++ & 3) == g && c0 < width) {
-          float v[16];
-          ld8(dh + (size_t)i * width + c0, v);
-          ld8(dh + (size_t)i * width + c0 + 8, v + 8);
-#pragma unroll
-          for (int e = 0; e < 16; ++e) a[e] += v[e];
-        }
+      for (int e = 0; e < 4; ++e) {
+        float v = ElemT<T>::ld(dh + (size_t)j * width + col + e);
+        if (c == 2) v += ElemT<T>::ld(dh + (size_t)j2 * width + col + e);
+        dst[e] += v * scale;
       }
     }
-#pragma unroll
-    for (int e = 0; e < 16; ++e) red[g][lane * 16 + e] = a[e];
-    __syncthreads();
-    for (int c = tid; c < 1024 && cb + c < width; c += 256)
-      dtable[(size_t)id * width + cb + c] += (((red[0][c] + red[1][c]) + red[2][c]) + red[3][c]) * scale;
-    __syncthreads();
+    if (lane == 0) { owner[id] = 0x7fffffff; count[id] = 0; last[id] = -1; }
+  } else if (lane == 0) {
+    const int k = atomicAdd(multi_count, 1);
+    if (k < DET_MAXM) multi_list[k] = j;  // (the order of the list does not matter: ids are independent of each other)
   }
 }
-extern "C" int mic_embed_rows_add_det(int dtype, int n, int width, const int32_t* ids, const void* dh, float scale, float* dtable, void* stream) {
-  MIC_CHECK(n > 0 && n <= 65536 && width > 0 && width % 16 == 0 && ids && dh && dtable && ((uintptr_t)dh & 15) == 0, "mic_embed_rows_add_det: bad args (n <= 65536, width %% 16 == 0, 16-B aligned rows)");
+template <typename T>
+__global__ __launch_bounds__(256) void det_multi_kernel(int n, int width, const int32_t* __restrict__ ids, const T* __restrict__ dh, float scale,
+                                                        float* __restrict__ dtable, int* __restrict__ owner, int* __restrict__ count,
+                                                        int* __restrict__ last, const int* __restrict__ multi_count, const int* __restrict__ multi_list) {
+  extern __shared__ __attribute__((aligned(16))) char det_smem[];
+  uint32_t* bits = reinterpret_cast<uint32_t*>(det_smem);              // [words]
+  const int words = (n + 31) >> 5;
+  float* red = reinterpret_cast<float*>(det_smem + (size_t)words * 4);   // [DET_G][1024]
+  const int tid = threadIdx.x;
+  const int nm = min(*multi_count, DET_MAXM);
+  for (int b = blockIdx.x; b < nm; b += gridDim.x) {
+    const int j = multi_list[b], id = ids[j];
+    for (int w = tid; w < words; w += 256) bits[w] = 0u;
+    __syncthreads();
+    {
+      // the scan: four independent 16-B loads per thread and trip (one id per load and trip was a 128-deep latency chain: 90 us)
+      const int4* ids4 = reinterpret_cast<const int4*>(ids);
+      const int nvec = n >> 2;
+      for (int v0 = tid; v0 < nvec; v0 += 1024) {
+        int4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = v0 + u * 256 < nvec ? ids4[v0 + u * 256] : make_int4(-1, -1, -1, -1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i0 = (v0 + u * 256) << 2;
+          const int xe[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (xe[e] == id) atomicOr(&bits[(i0 + e) >> 5], 1u << ((i0 + e) & 31));
+        }
+      }
+      for (int i = (nvec << 2) + tid; i < n; i += 256)
+        if (ids[i] == id) atomicOr(&bits[i >> 5], 1u << (i & 31));
+    }
+    __syncthreads();
+    const int g = tid >> 4, lane = tid & 15;  // 16 groups x 16 lanes; a lane owns 64 columns of a 1024-column block
+    for (int cb = 0; cb < width; cb += 1024) {
+      const int c0 = cb + lane * 64;
+      float a[64];
+#pragma unroll
+      for (int e = 0; e < 64; ++e) a[e] = 0.f;
+      // this group's occurrences (those in bitmap words w with w % 16 == g, index order), four rows in flight at a time: the adds keep
+      // their order
+      int k = 0, np = 0, pend[4];
+      auto flush = [&](int cnt) __attribute__((always_inline)) {
+        u32x4 raw[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (u < cnt) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) raw[u][q] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(dh) + ((size_t)pend[u] * width + c0) * sizeof(T) + q * 16);
+          }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (u < cnt) {
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                float v[8];
+                unpack8(raw[u][q], v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[q * 8 + e] += v[e];
+              }
+            } else {  // fp32 rows: 64 columns = 16 pieces of 16 B; the eight loaded above are the first 32 columns
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                const float* f = reinterpret_cast<const float*>(&raw[u][q]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[q * 4 + e] += f[e];
+              }
+#pragma unroll
+              for (int e = 32; e < 64; ++e) a[e] += ElemT<T>::ld(dh + (size_t)pend[u] * width + c0 + e);
+            }
+          }
+      };
+      // this group's words: one of every 16 consecutive ones, rotated by the block of 16 (sequence starts sit 64 rows apart = every
+      // other word: a plain w % 16 would leave half the groups idle).  (Every thread walking all 1024 words was a 100-us LDS chain.)
+      for (int wb = 0; wb < words; wb += DET_G) {
+        const int w = wb + ((g ^ (wb >> 4)) & (DET_G - 1));
+        if (w >= words) continue;
+        uint32_t m = bits[w];
+        while (m) {
+          const int i = (w << 5) + __builtin_ctz(m);
+          m &= m - 1;
+          if (c0 < width) {
+            pend[np++] = i;
+            if (np == 4) { flush(4); np = 0; }
+          }
+        }
+      }
+      if (np) flush(np);
+      (void)k;
+#pragma unroll
+      for (int e = 0; e < 64; ++e) red[g * 1024 + lane * 64 + e] = a[e];
+      __syncthreads();
+      for (int c = tid; c < 1024 && cb + c < width; c += 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < DET_G; ++q) t += red[q * 1024 + c];
+        dtable[(size_t)id * width + cb + c] += t * scale;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) { owner[id] = 0x7fffffff; count[id] = 0; last[id] = -1; }
+  }
+}
+__global__ void det_reset_kernel(int* multi_count) { *multi_count = 0; }
+extern "C" int mic_embed_rows_add_det(int dtype, int n, int width, int vocab, const int32_t* ids, const void* dh, float scale, float* dtable,
+                                      int32_t* ws, void* stream) {
+  MIC_CHECK(n > 0 && n <= 65536 && width > 0 && width % 64 == 0 && vocab > 0 && ids && dh && dtable && ws && ((uintptr_t)dh & 15) == 0 && ((uintptr_t)ids & 15) == 0,
+            "mic_embed_rows_add_det: bad args (n <= 65536, width %% 64 == 0, 16-B aligned rows, workspace of mic_embed_rows_add_det_ws(vocab) ints)");
+  int* owner = ws; int* count = ws + vocab; int* last = ws + 2 * (size_t)vocab; int* mcount = ws + 3 * (size_t)vocab; int* mlist = mcount + 1;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(det_owner_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, ids, owner, count, last);
+  const size_t lds = (size_t)((n + 31) / 32) * 4 + (size_t)DET_G * 1024 * 4;  // <= 8 + 64 KiB
   return dispatch_t(dtype, [&](auto* tag) {
     using T = TYPE_OF(tag);
-    hipLaunchKernelGGL(embed_rows_add_det_kernel<T>, dim3(n), dim3(256), 0, (hipStream_t)stream, n, width, ids, (const T*)dh, scale, dtable);
+    static bool attr_set[64] = {};
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    if (!attr_set[dev_ & 63]) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&det_multi_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 + DET_G * 4096);
+      attr_set[dev_ & 63] = true;
+    }
+    hipLaunchKernelGGL(det_single_kernel<T>, dim3((n + 3) / 4), dim3(256), 0, st, n, width, ids, (const T*)dh, scale, dtable, owner, count, last, mcount, mlist);
+    hipLaunchKernelGGL(det_multi_kernel<T>, dim3(512), dim3(256), lds, st, n, width, ids, (const T*)dh, scale, dtable, owner, count, last, mcount, mlist);
+    hipLaunchKernelGGL(det_reset_kernel, dim3(1), dim3(1), 0, st, mcount);
   });
 }
+// ints of the workspace mic_embed_rows_add_det needs for a table of `vocab` rows; the caller initialises it ONCE: ints [0, vocab) to
+// 0x7fffffff, [vocab, 2 vocab) to 0, [2 vocab, 3 vocab) to -1, the rest to 0
+extern "C" long long mic_embed_rows_add_det_ws(int vocab) { return 3LL * vocab + 1 + DET_MAXM; }
 
 // ------------------------------------------------------------------ cross-entropy over materialised logits (K13)
 // One 256-thread block per row; 16-B vector loads; online (max, sum-exp) per thread, combined through LDS.

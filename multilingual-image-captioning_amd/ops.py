@@ -314,9 +314,19 @@ def embed_bwd(ids, pos_ids, dh, scale, dtable, dpos_table, rows, width):
     L.check(L.lib().mic_embed_bwd(_dt(dh), rows, width, _p(ids), _p(pos_ids), _p(dh), float(scale), _p(dtable), _p(dpos_table), _stream()), "mic_embed_bwd")
 
 
-def embed_rows_add_det(ids, dh, scale, dtable, n, width):
+def embed_rows_add_det_workspace(vocab: int, device) -> torch.Tensor:
+    """the int32 workspace of `embed_rows_add_det` for a table of `vocab` rows, initialised (the calls keep it in that state)"""
+    n = int(L.lib().mic_embed_rows_add_det_ws(int(vocab)))
+    ws = torch.zeros(n, dtype=torch.int32, device=device)
+    ws[:vocab] = 0x7FFFFFFF
+    ws[2 * vocab: 3 * vocab] = -1
+    return ws
+
+
+def embed_rows_add_det(ids, dh, scale, dtable, n, width, ws):
     """dtable[ids[i]] += scale * dh[i] over the n rows, deterministically (ids < 0 skipped): the data-parallel embedding-row exchange"""
-    L.check(L.lib().mic_embed_rows_add_det(_dt(dh), int(n), int(width), _p(ids), _p(dh), float(scale), _p(dtable), _stream()), "mic_embed_rows_add_det")
+    L.check(L.lib().mic_embed_rows_add_det(_dt(dh), int(n), int(width), int(dtable.shape[0]) if dtable.dim() == 2 else int(dtable.numel() // width),
+                                           _p(ids), _p(dh), float(scale), _p(dtable), _p(ws), _stream()), "mic_embed_rows_add_det")
 
 
 def ce_rows(logits, ld, V, labels, mask, ls, row_lse, row_loss, rows):

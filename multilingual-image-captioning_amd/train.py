@@ -559,6 +559,7 @@ class Trainer:
                                    emulate=dict(world=emu_world, cus=self.comm_cus or COMM_CUS_DEFAULT, comm_bytes=cb) if emu_world > 1 else None)
         self.metrics_buf = torch.zeros(2, dtype=torch.float32, device=model.device)
         self._pos = {}
+        self._det_ws = None  # workspace of the deterministic embedding-row scatter (data parallel)
         self._late_done = False
         self._late_early = _os.environ.get("MIC_LATE_EARLY", "1") != "0"  # (A/B: 0 = the flagged embedding rows' pass behind the step, as before)
 
@@ -636,7 +637,9 @@ class Trainer:
         all_dh = torch.empty((self.world * M, st.d), dtype=dh0.dtype, device=dh0.device)
         dist.all_gather_into_tensor(all_ids, ids[:M].contiguous(), group=self.group)
         dist.all_gather_into_tensor(all_dh, dh0[:M].contiguous(), group=self.group)
-        ops.embed_rows_add_det(all_ids, all_dh, eng.embed_scale, st.g("shared"), self.world * M, st.d)
+        if self._det_ws is None:
+            self._det_ws = ops.embed_rows_add_det_workspace(st.g("shared").numel() // st.d, all_ids.device)
+        ops.embed_rows_add_det(all_ids, all_dh, eng.embed_scale, st.g("shared").view(-1, st.d), self.world * M, st.d, self._det_ws)
 
     def _prep(self, batch):
         m = self.model

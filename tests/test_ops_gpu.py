@@ -887,31 +887,53 @@ def test_gemm_four_phase_kernel_behind_its_switch(dev):
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
 
 
+@pytest.mark.parametrize("n,width,V", [(3000, 256, 500), (32768, 1024, 250054), (13, 64, 5), (32767, 1024, 250054)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_embed_rows_add_deterministic(dev, dtype):
+def test_embed_rows_add_deterministic(dev, dtype, n, width, V):
     """the data-parallel embedding-row scatter: dtable[ids[i]] += scale * dh[i] with heavy duplicates (every sequence starts with the
     same few ids), ids < 0 skipped; equal to an fp64 index_add, and the SAME BITS from run to run (a fixed reduction tree: what
     keeps the replicas of a data-parallel job identical) — unlike the atomic scatter of the single-process path"""
     from mic_amd import ops
 
     g = torch.Generator().manual_seed(3)
-    n, width, V = 3000, 256, 500
     ids = torch.randint(0, V, (n,), generator=g, dtype=torch.int32)
-    ids[::5] = 7           # 600 occurrences of one id
-    ids[1::7] = -1         # skipped rows (their dh may hold anything)
+    if n == 32767:  # what 8 ranks x 4096 rows look like: sequences of 64 that start with (eos, language id), a third of the rows padding
+        ids[::64] = 2
+        ids[1::64] = 250004 + (torch.arange(len(ids[1::64])) % 4).to(torch.int32)
+        pad = torch.rand(n, generator=g) < 0.33
+        pad[::64] = pad[1::64] = False
+        ids[pad] = -1
+    else:
+        ids[::5] = min(7, V - 1)   # n / 5 occurrences of one id
+        ids[1::7] = -1             # skipped rows (their dh may hold anything)
     dh = rnd((n, width), g, dtype, 1.0)
     dh[ids < 0] = float("nan")
-    base = torch.randn(V, width, generator=g)
+    touched = torch.unique(ids[ids >= 0]).long()
+    base = torch.randn(len(touched), width, generator=g)   # (the 8 ranks x 4096 rows case touches ~20 k rows of a 250 054-row table)
     outs = []
+    ids_d, dh_d = ids.to(dev), dh.to(dev)
+    ws = ops.embed_rows_add_det_workspace(V, dev)
+    ws0 = ws.clone()
     for rep in range(3):
-        t = base.clone().to(dev)
-        ops.embed_rows_add_det(ids.to(dev), dh.to(dev), 0.5, t, n, width)
+        t = torch.zeros((V, width), device=dev)
+        t[touched.to(dev)] = base.to(dev)
+        ops.embed_rows_add_det(ids_d, dh_d, 0.5, t, n, width, ws)
         torch.cuda.synchronize()
-        outs.append(t.cpu())
+        outs.append(t[touched.to(dev)].cpu())
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.equal(ws[: 3 * V + 1], ws0[: 3 * V + 1])  # owner / count / last / list length are left as found (the list's entries are scratch)
     keep = ids >= 0
-    ref = base.double().index_add(0, ids[keep].long(), dh[keep].double() * 0.5)
+    pos = torch.searchsorted(touched, ids[keep].long())
+    ref = base.double().index_add(0, pos, dh[keep].double() * 0.5)
     assert ((outs[0].double() - ref).abs().max() / ref.abs().max()).item() < 2e-6
+    if n > 30000:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            ops.embed_rows_add_det(ids_d, dh_d, 0.5, t, n, width, ws)
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"[embed_rows_add_det] {n} rows x {width}: {e0.elapsed_time(e1) / 5 * 1e3:.0f} us per call (the data-parallel step's tail at 8 ranks)")
 
 
 @pytest.mark.parametrize("d2", ["0", "2"])
