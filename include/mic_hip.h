@@ -318,7 +318,7 @@ int mic_embed_bwd(int dtype, int rows, int width, const int32_t* ids, const int3
  * [vocab, 2 vocab) 0, [2 vocab, 3 vocab) -1, the rest 0); the call leaves its first 3 vocab + 1 ints in that state (the rest is scratch). */
 int mic_embed_rows_add_det(int dtype, int n, int width, int vocab, const int32_t* ids, const void* dh, float scale, float* dtable,
                            int32_t* ws, void* stream);
-long long mic_embed_rows_add_det_ws(int vocab);
+int64_t mic_embed_rows_add_det_ws(int vocab);
 
 /* ---------------------------------------------------------------------------------------------
  * Masked (label-smoothed) softmax cross-entropy over materialised logits (main.py:658-680).

@@ -116,7 +116,7 @@ _SIGS = {
     "mic_embed_fwd": ([_i, _i, _i, _p, _p, _p, _p, _f, _p, _p], C.c_int),
     "mic_embed_bwd": ([_i, _i, _i, _p, _p, _p, _f, _p, _p, _p], C.c_int),
     "mic_embed_rows_add_det": ([_i, _i, _i, _i, _p, _p, _f, _p, _p, _p], C.c_int),
-    "mic_embed_rows_add_det_ws": ([_i], C.c_longlong),
+    "mic_embed_rows_add_det_ws": ([_i], C.c_int64),
     "mic_ce_rows": ([_i, _i, _i, _p, _i, _p, _p, _f, _p, _p, _p], C.c_int),
     "mic_ce_rows_tiles": ([_i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p], C.c_int),
     "mic_row_topk_tiles": ([_i, _i, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p], C.c_int),

@@ -330,7 +330,7 @@ extern "C" int mic_embed_rows_add_det(int dtype, int n, int width, int vocab, co
 }
 // ints of the workspace mic_embed_rows_add_det needs for a table of `vocab` rows; the caller initialises it ONCE: ints [0, vocab) to
 // 0x7fffffff, [vocab, 2 vocab) to 0, [2 vocab, 3 vocab) to -1, the rest to 0
-extern "C" long long mic_embed_rows_add_det_ws(int vocab) { return 3LL * vocab + 1 + DET_MAXM; }
+extern "C" int64_t mic_embed_rows_add_det_ws(int vocab) { return (int64_t)3 * vocab + 1 + DET_MAXM; }
 
 // ------------------------------------------------------------------ cross-entropy over materialised logits (K13)
 // One 256-thread block per row; 16-B vector loads; online (max, sum-exp) per thread, combined through LDS.
