@@ -180,6 +180,9 @@ __device__ __forceinline__ Q8Ctx q8_begin(const Q8Out& o, bool first_thread) {
   c.fmax = o.fmt == MIC_E4M3 ? 448.0f : 57344.0f;
   const float amax = o.state[0];
   c.scale = amax > 0.f ? c.fmax / amax : 1.0f;
+  // wave-uniform values: keep them in scalar registers (the LayerNorm backward runs at its 128-register bound)
+  c.scale = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(c.scale)));
+  c.fmax = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(c.fmax)));
   c.amax = 0.f;
   if (first_thread) o.state[1] = amax > 0.f ? amax / c.fmax : 1.0f;
   return c;

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int width, const 
 // 2 = dx itself also as fp8 bytes (the ViT's residual-stream gradient is the FFN-out projection's dy) — e5m2 under the tensor's
 // delayed scale (common.h: Q8Out).
 template <typename T, int NCH, int NW, int Q8 = 0>
-__global__ __launch_bounds__(64 * NW, NCH <= 2 ? (Q8 ? 3 : 4) : 2) void ln_bwd_kernel(int rows, int width, const T* __restrict__ x,
+__global__ __launch_bounds__(64 * NW, NCH <= 2 ? 4 : 2) void ln_bwd_kernel(int rows, int width, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const T* __restrict__ dy,
                                                      const T* __restrict__ dres, T* __restrict__ dx,
