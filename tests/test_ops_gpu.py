@@ -887,6 +887,26 @@ def test_gemm_four_phase_kernel_behind_its_switch(dev):
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,img,ps", [(3, 224, 32), (2, 64, 32), (2, 24, 4), (1, 48, 16)])
+def test_im2col_matches_patch_gather(dev, dtype, B, img, ps):
+    """patches[(b, pi, pj)][(u, v, c)] = pixels[b][pi ps + u][pj ps + v][c] (the ViT's patch embedding as a GEMM, modeling T1) — the
+    8-elements-per-thread kernel (patch rows of ps * 3 = 96 floats) and the element-wise fallback (ps = 4), with and without the
+    reference's int32 truncation of the pixels (modeling:330)"""
+    from mic_amd import ops
+
+    g = torch.Generator().manual_seed(B * img + ps)
+    px = (torch.randn(B, img, img, 3, generator=g) * 3).to(dev)
+    G, pk = img // ps, ps * ps * 3
+    for trunc in (False, True):
+        out = torch.zeros((B * G * G + 5, pk), dtype=dtype, device=dev)
+        ops.im2col(px, out, B, img, ps, pk, trunc)
+        torch.cuda.synchronize()
+        src = px.trunc() if trunc else px
+        ref = src.reshape(B, G, ps, G, ps, 3).permute(0, 1, 3, 2, 4, 5).reshape(B * G * G, pk).to(dtype)
+        assert torch.equal(out[: B * G * G], ref) and float(out[B * G * G:].float().abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("n,width,V", [(3000, 256, 500), (32768, 1024, 250054), (13, 64, 5), (32767, 1024, 250054)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_embed_rows_add_deterministic(dev, dtype, n, width, V):
