@@ -336,6 +336,25 @@ def test_vit_embed_ops(dev, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B", [9, 64])
+def test_vit_assemble_bwd_batch_slices(dev, dtype, B):
+    """the ViT embedding backward at the train step's shape (50 tokens x 768): bf16 storage cuts the batch into slices that meet by fp32
+    atomics (B = 9: four slices with a ragged last one; 64: eight), fp32 keeps one add per element"""
+    from mic_amd import ops
+
+    S, W = 50, 768
+    g = torch.Generator().manual_seed(B)
+    dx = rnd((B * S, W), g, dtype)
+    dpatch = torch.full((B * (S - 1) + 3, W), 7.0, dtype=dtype, device=dev)
+    dcls, dpos = torch.zeros(W, device=dev), torch.zeros(S, W, device=dev)
+    ops.vit_assemble_bwd(dx.to(dev), dpatch, dcls, dpos, B, S, W, W)
+    torch.cuda.synchronize()
+    d3 = dx.float().reshape(B, S, W)
+    assert torch.equal(dpatch[: B * (S - 1)].float().cpu(), d3[:, 1:].reshape(-1, W)) and float((dpatch[B * (S - 1):].float() - 7.0).abs().max()) == 0.0
+    assert relerr(dpos, d3.sum(0)) < 1e-5 and relerr(dcls, d3[:, 0].sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_token_embed_fwd_bwd(dev, dtype):
     from mic_amd import ops
 
