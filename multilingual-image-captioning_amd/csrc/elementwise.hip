@@ -470,11 +470,26 @@ __global__ __launch_bounds__(256) void ce_rows_tiles_kernel(int rows, const T* _
   if (row >= rows) return;
   const float2* sr = stat + (size_t)row * stat_ld;
   float m = -INFINITY, s = 0.f;
-  for (int t = lane; t < ntiles; t += 64) {
-    const float2 p = sr[t];
-    const float mn = fmaxf(m, p.x);
-    s = (mn == -INFINITY) ? 0.f : s * __expf(m - mn) + p.y * __expf(p.x - mn);
-    m = mn;
+  if ((stat_ld & 1) == 0 && ((uintptr_t)stat & 15) == 0) {
+    // four pairs per trip (two 16-B loads in flight, one rescale of the running sum): one pair per trip was a 61-deep chain of
+    // load -> two exps per lane, 39 us for 76 MB at 2.4 k rows
+    for (int t = lane * 4; t < ntiles; t += 256) {
+      float4 a = *reinterpret_cast<const float4*>(sr + t);
+      float4 b = t + 2 < ntiles ? *reinterpret_cast<const float4*>(sr + t + 2) : make_float4(-INFINITY, 0.f, -INFINITY, 0.f);
+      if (t + 1 >= ntiles) { a.z = -INFINITY; a.w = 0.f; }
+      if (t + 3 >= ntiles) { b.z = -INFINITY; b.w = 0.f; }
+      const float mn = fmaxf(fmaxf(m, fmaxf(a.x, a.z)), fmaxf(b.x, b.z));
+      if (mn != -INFINITY)
+        s = s * __expf(m - mn) + ((a.y * __expf(a.x - mn) + a.w * __expf(a.z - mn)) + (b.y * __expf(b.x - mn) + b.w * __expf(b.z - mn)));
+      m = mn;
+    }
+  } else {
+    for (int t = lane; t < ntiles; t += 64) {
+      const float2 p = sr[t];
+      const float mn = fmaxf(m, p.x);
+      s = (mn == -INFINITY) ? 0.f : s * __expf(m - mn) + p.y * __expf(p.x - mn);
+      m = mn;
+    }
   }
   const float M = wave_max(m);
   s = wave_sum(m == -INFINITY ? 0.f : s * __expf(m - M));
