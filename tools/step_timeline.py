@@ -27,7 +27,7 @@ def main():
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?"), r.get("Stream_Id", "?")))
     rows.sort()
-    starts = [i for i, r in enumerate(rows) if "im2col_kernel" in r[2]]
+    starts = [i for i, r in enumerate(rows) if "im2col" in r[2]]
     if len(starts) < back + 1:
         sys.exit(f"need at least {back + 1} steps in the trace, found {len(starts)}")
     i0, i1 = starts[-back - 1], starts[-back]
