@@ -8,7 +8,7 @@ bf16 train step, batch 64 per GPU, 224x224 images, seq_len 64), one process per 
 
 A step = forward + loss + backward + gradient all-reduce (RCCL, N > 1) + AdamW on synthetic data (random-init weights of
 the full architecture; fused dropout active as in training).  Prints ONE JSON line on rank 0.
-Variants: --dtype fp8 (configs[4]: e4m3/e5m2 QKV/FFN GEMMs), --dense-captions (n = 62 tokens in every caption: no padded
+Variants: --dtype fp8 (configs[4]: e4m3/e5m2 QKV / FFN / LM-head GEMMs), --dense-captions (n = 62 tokens in every caption: no padded
 label positions, the dense upper bound of SURVEY §8d), --pmc-traffic (re-measure roofline.traffic with two rocprofv3
 counter passes of this same command as child processes).  With --gpus 1 the line also carries `comm_emulated`: the same step
 with the gradient exchange among 2 / 4 / 8 ranks EMULATED on this one GPU (a kernel holding 32 CUs of a CU-masked collective
@@ -743,7 +743,7 @@ def main():
                 f8f, f8t = sum(r[0] for r in f8), sum(r[1].elapsed_time(r[2]) for r in f8) * 1e-3
                 roofline["fp8_gemms"] = {"achieved": round(f8f / f8t / 1e12, 1), "frac_of_fp8_peak": round(f8f / f8t / 1e12 / PEAK_TFLOPS["fp8"], 4),
                                          "launches_per_step": len(f8), "ms_per_step": round(f8t * 1e3, 3)}
-            roofline["note"] = "peak = dense fp8 MFMA peak; only the QKV/FFN GEMMs run in fp8 (configs[4]), the rest in bf16"
+            roofline["note"] = "peak = dense fp8 MFMA peak; the QKV / FFN projections and the tied LM head run in fp8 (configs[4]; MIC_FP8_HEAD), the attention out-projections and the patch embedding in bf16"
         if args.pmc_traffic and world > 1:
             note("--pmc-traffic is a single-GPU measurement (rocprofv3 child passes of this command); skipped under a launcher")
         if args.pmc_traffic and world == 1:
@@ -822,7 +822,7 @@ def main():
             except Exception as ex:  # a reported figure, never a dependency of the headline number
                 emulated["worlds"][str(ew)] = {"ms_per_step": None, "error": f"{type(ex).__name__}: {ex}"[:300]}
 
-    # configs[4] beside the headline: the same step with the QKV / FFN projections as fp8 GEMMs, in a fresh child process (one Trainer
+    # configs[4] beside the headline: the same step with the QKV / FFN projections and the LM head as fp8 GEMMs, in a fresh child process (one Trainer
     # per process, like a data-parallel rank), so the driver's record carries it
     fp8_leg = None
     if rank == 0 and world == 1 and args.dtype == "bf16" and not args.no_fp8_leg and not args.no_extra_legs and not args.small and not args.emulate_main and not args.dense_captions:
@@ -835,8 +835,9 @@ def main():
         try:
             r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
             cd = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-            fp8_leg = {"metric": "train images/sec, configs[4]: QKV / FFN projections of both towers as OCP fp8 GEMMs (e4m3 forward, e5m2 gradients, delayed "
-                                 "per-tensor scaling, fp32 accumulate), everything else as in the headline step",
+            fp8_leg = {"metric": "train images/sec, configs[4]: QKV / FFN projections of both towers and the tied LM head as OCP fp8 GEMMs (e4m3 forward, e5m2 "
+                                 "gradients, delayed per-tensor scaling — dlogits under a closed-form scale, label entries exact —, fp32 accumulate), "
+                                 "everything else as in the headline step",
                        "value": cd["value"], "unit": "images/sec", "ms_per_step": cd["ms_per_step"], "steps": cd["steps"], "final_loss": cd["final_loss"],
                        "vs_bf16_same_box": round(cd["value"] / images_per_sec, 4), "roofline": cd.get("roofline")}
         except Exception as ex:  # a reported figure, never a dependency of the headline number
@@ -868,7 +869,7 @@ def main():
                                      + ("; tied embedding updated in two row passes (rows without / with sparse gradient)" if tr._split_shared else "")) if tr.overlap_optimizer else "AdamW, one launch after backward",
                        "decoder_rows": ("valid caption positions only (packed rows: padded positions neither carry loss nor are attended to — exact; "
                                         f"{n_loss:.0f} of {B * T} rows per step)" if (tr.pack_rows and args.dtype in ("bf16", "fp8") and not args.dense_captions) else f"all {B * T} positions"),
-                       "lm_head": head, "gemm_dtype": "fp8 e4m3 (fwd) / e5m2 (grads) for QKV+FFN, bf16 elsewhere" if args.dtype == "fp8" else args.dtype},
+                       "lm_head": head, "gemm_dtype": "fp8 e4m3 (fwd) / e5m2 (grads) for QKV + FFN + the tied LM head (MIC_FP8_HEAD=" + os.environ.get("MIC_FP8_HEAD", "all") + "), bf16 elsewhere" if args.dtype == "fp8" else args.dtype},
             "host_issue_ms_per_step": None if issue_idle_ms is None else round(issue_idle_ms, 3),  # host time to enqueue ONE step on an idle GPU (median of 3): the host's real share
             "host_loop_ms_per_step": round(t_issue / args.steps * 1e3, 3),  # the timed loop's host side with the queue full (back-pressured by the GPU: NOT the host's cost)
             "h2d_inclusive": h2d,

@@ -337,6 +337,24 @@ int mic_ce_reduce(int rows, const float* row_loss, const int32_t* mask, float* l
 int mic_ce_bwd(int dtype, int rows, int V, int Vpad, void* logits, int ld, const int32_t* labels,
                const int32_t* mask, float label_smoothing, const float* row_lse, const float* denom,
                float loss_scale, void* stream);
+/* mic_ce_bwd (bf16 logits) with the gradient leaving as fp8 bytes q8->q [rows][ldq] (e5m2) instead of in place — the logits stay as they
+ * are.  The scale of this tensor is known in closed form: every entry of g = mask (softmax - soft_label) lies in [-1, 1], so q = fp8(g *
+ * FMAX) and the dequantisation factor q8->state[1] = loss_scale / (denom * FMAX) (state[0] = its reciprocal) are written with no amax
+ * history (q8->amax_next is not used) and nothing saturates.  Padding columns V .. Vpad are zero bytes.  With `colsum` != NULL the column
+ * sums of the fp32 gradient are ADDED to colsum[0 .. Vpad) (fp32 atomics: the gradient of final_logits_bias, modeling:178).  The fp8 LM
+ * head (BASELINE configs[4]): dX = dlogits . E^T-copy and dE = dlogits^T . h (both operands k-major) read this ONE copy — main.py:692-698
+ * through the tied head, modeling:170-174.
+ * label_coef != NULL: the label entry of every row — w (p_label - conf), at least half of the row's gradient energy — is NOT rounded to
+ * two mantissa bits: the byte at [row][labels[row]] is zero and label_coef[row] receives the fp32 gradient; mic_head_label_terms adds
+ * its two products exactly. */
+int mic_ce_bwd_q8(int rows, int V, int Vpad, const void* logits, int ld, const int32_t* labels, const int32_t* mask,
+                  float label_smoothing, const float* row_lse, const float* denom, float loss_scale, const mic_fp8_out* q8,
+                  float* colsum, float* label_coef, void* stream);
+/* The label entries of dlogits (mic_ce_bwd_q8 label_coef; bf16 E [V][lde] and h [rows][ldh]): dx_slab[m][0 .. width) = coef[m] *
+ * E[labels[m]][:] — one more fp32 slab for mic_sum_slabs behind the split-K dX GEMM — and dE[labels[m]][:] += coef[m] * h[m][:] (fp32
+ * atomics into the gradient the dE GEMM has written). */
+int mic_head_label_terms(int rows, int width, const int32_t* labels, const float* coef, const void* E, int lde, const void* h, int ldh,
+                         float* dx_slab, int ldx, float* dE, int ldde, void* stream);
 /* mic_ce_bwd (bf16 logits) that ALSO writes the transposed gradient dlogits_t [Vpad][ld_t] (bf16; columns rows .. rows_pad — a
  * multiple of 64, 0 = rows rounded up to 64 — are zeros) and, with `colsum` != NULL, ADDS the column sums of the dlogits as stored to colsum[0 .. Vpad) (fp32 atomics —
  * the gradient of final_logits_bias, modeling:178).  The LM head's backward GEMMs (main.py:692-698 through the tied head,

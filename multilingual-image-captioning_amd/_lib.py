@@ -123,6 +123,8 @@ _SIGS = {
     "mic_ce_reduce": ([_i, _p, _p, _p, _p, _p], C.c_int),
     "mic_ce_bwd": ([_i, _i, _i, _i, _p, _i, _p, _p, _f, _p, _p, _f, _p], C.c_int),
     "mic_ce_bwd_t": ([_i, _i, _i, _p, _i, _p, _p, _f, _p, _p, _f, _p, _i, _i, _p, _p], C.c_int),
+    "mic_ce_bwd_q8": ([_i, _i, _i, _p, _i, _p, _p, _f, _p, _p, _f, C.POINTER(Fp8Out), _p, _p, _p], C.c_int),
+    "mic_head_label_terms": ([_i, _i, _p, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p], C.c_int),
     "mic_transpose_bf16": ([_i, _i, _i, _p, _i, _p, _i, _p], C.c_int),
     "mic_colsum": ([_i, _i, _i, _p, _i, _p, _i, _p], C.c_int),
     "mic_colsum_grouped": ([_i, C.POINTER(ColsumItem), _i, _p], C.c_int),

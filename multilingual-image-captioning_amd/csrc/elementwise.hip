@@ -690,6 +690,136 @@ extern "C" int mic_ce_bwd_t(int rows, int V, int Vpad, void* logits, int ld, con
   return MIC_OK;
 }
 
+// ------------------------------------------------------------------ CE backward with the gradient leaving as e5m2 bytes (fp8 LM head)
+// dlogits = w (softmax - soft_label), w = mask * loss_scale / denom.  Every entry of g = mask (softmax - soft_label) lies in [-1, 1]:
+// this tensor's scale is known in closed form — q = fp8(g * FMAX), dequantisation factor state[1] = loss_scale / (denom * FMAX) — so
+// there is no amax history, no saturation and no first-pass special case.  (A delayed amax was tried first: the label entries
+// -w (1 - p) are the large ones and early in training they are all ~ -w, so wherever w * scale fell between two e5m2 grid points
+// EVERY token's gradient was rounded the same way, up to 12 %, and a previous batch of confident tokens clipped the next batch's
+// unconfident ones; the 200-step loss curve left the bf16 one by 10 %.  With FMAX <-> 1 the early label entries are exact.)
+// The bytes are written ONCE, q8->q [rows][ldq], instead of in place: the head's two backward GEMMs read that one copy — dX = dlogits
+// E^T-copy (k-contiguous) and dE = dlogits^T h (k-major on both sides: ds_read_b64_tr_b8 fragments) — so the 1.2 GB in-place write
+// AND the 1.2 GB transposed copy of mic_ce_bwd_t become one 0.6 GB write.  Same 64-row x 512-column blocks as the transposing kernel
+// (16 row loads per lane in flight); the column sums of the fp32 gradient (final_logits_bias, modeling:178) are added per block:
+// registers over a wave's 16 rows, LDS over the four waves, one fp32 atomic per column.  Padding columns V .. Vpad are zero bytes.
+// label_coef: the ONE entry per row that carries at least half of the row's gradient energy, w (p_label - conf), does not go through
+// two mantissa bits: it leaves as an fp32 coefficient and its two products are added exactly by head_label_terms_kernel below
+// (measured on the 200-step curve: with the label entries in e5m2 the run ended 2-5 % above bf16, without them at the level of the
+// fp8 run whose head is bf16).
+struct CeQ8Args {
+  const uint16_t* logits; int ld; int rows, V, Vpad;
+  const int32_t* labels; const int32_t* mask; float ls; const float* row_lse; const float* denom; float loss_scale;
+  float* colsum; uint8_t* q; int ldq; float* state; int fmt;
+  float* label_coef;  // != NULL: the label entry of every row leaves the byte matrix (a zero byte there) as the fp32 gradient label_coef[row]
+};
+__global__ __launch_bounds__(256) void ce_bwd_q8_kernel(CeQ8Args a) {
+  __shared__ __attribute__((aligned(16))) float cs[4][512];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = blockIdx.x * 512, r0 = blockIdx.y * 64;
+  const int col = c0 + lane * 8;
+  const bool col_ok = col < a.Vpad;  // (Vpad % 8 == 0: a chunk is inside or outside as a whole)
+  const float fmax = a.fmt == MIC_E4M3 ? 448.0f : 57344.0f;
+  const float inv_denom = a.loss_scale / a.denom[0];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { a.state[0] = fmax / inv_denom; a.state[1] = inv_denom / fmax; }
+  uint4 q[16];
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    const int row = r0 + wave * 16 + rr;
+    q[rr] = make_uint4(0u, 0u, 0u, 0u);
+    if (row < a.rows && col_ok) q[rr] = *reinterpret_cast<const uint4*>(a.logits + (size_t)row * a.ld + col);
+  }
+  const float conf = 1.0f - a.ls, low = a.ls > 0.f ? a.ls / (float)(a.V - 1) : 0.f;
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    const int row = r0 + wave * 16 + rr;
+    if (row < a.rows && col_ok) {
+      const float w = a.mask[row] ? 1.0f : 0.f;
+      const float lse = a.row_lse[row];
+      const int label = a.labels[row];
+      const uint32_t wd[4] = {q[rr].x, q[rr].y, q[rr].z, q[rr].w};
+      float o[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float x = __uint_as_float((i & 1) ? (wd[i >> 1] & 0xffff0000u) : (wd[i >> 1] << 16));
+        const int c = col + i;
+        const float g = c < a.V ? w * (__expf(x - lse) - (c == label ? conf : low)) : 0.f;
+        csum[i] += g;
+        o[i] = fminf(fmaxf(g * fmax, -fmax), fmax);  // (|g| <= 1 up to the rounding of lse)
+        if (c == label && a.label_coef != nullptr) {
+          a.label_coef[row] = g * inv_denom;
+          o[i] = 0.f;
+        }
+      }
+      *reinterpret_cast<uint2*>(a.q + (size_t)row * a.ldq + col) = make_uint2(cvt4_fp8(o, a.fmt), cvt4_fp8(o + 4, a.fmt));
+    }
+  }
+  if (a.colsum != nullptr) {
+    *reinterpret_cast<float4*>(&cs[wave][lane * 8]) = make_float4(csum[0], csum[1], csum[2], csum[3]);
+    *reinterpret_cast<float4*>(&cs[wave][lane * 8 + 4]) = make_float4(csum[4], csum[5], csum[6], csum[7]);
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = tid + h * 256;
+      const float s4 = (cs[0][c] + cs[1][c]) + (cs[2][c] + cs[3][c]);
+      if (c0 + c < a.Vpad && s4 != 0.f) atomicAdd(a.colsum + c0 + c, s4 * inv_denom);
+    }
+  }
+}
+extern "C" int mic_ce_bwd_q8(int rows, int V, int Vpad, const void* logits, int ld, const int32_t* labels, const int32_t* mask,
+                             float label_smoothing, const float* row_lse, const float* denom, float loss_scale, const mic_fp8_out* q8,
+                             float* colsum, float* label_coef, void* stream) {
+  MIC_CHECK(rows > 0 && V > 1 && Vpad >= V && Vpad % 8 == 0 && ld >= Vpad && ld % 8 == 0 && logits && labels && mask && row_lse && denom && q8,
+            "mic_ce_bwd_q8: bad args");
+  MIC_CHECK(q8->q && q8->state && q8->ldq >= Vpad && q8->ldq % 8 == 0 && ((uintptr_t)q8->q & 7) == 0 && ((uintptr_t)logits & 15) == 0 &&
+                (q8->fmt == MIC_E4M3 || q8->fmt == MIC_E5M2),
+            "mic_ce_bwd_q8: fp8 output [rows][ldq >= Vpad] (ldq %% 8 == 0, 8-B aligned), a scale state, 16-B aligned bf16 logits");
+  CeQ8Args a{};
+  a.logits = (const uint16_t*)logits; a.ld = ld; a.rows = rows; a.V = V; a.Vpad = Vpad; a.labels = labels; a.mask = mask; a.ls = label_smoothing;
+  a.row_lse = row_lse; a.denom = denom; a.loss_scale = loss_scale; a.colsum = colsum;
+  a.q = (uint8_t*)q8->q; a.ldq = q8->ldq; a.state = q8->state; a.fmt = q8->fmt; a.label_coef = label_coef;
+  hipLaunchKernelGGL(ce_bwd_q8_kernel, dim3((Vpad + 511) / 512, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream, a);
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}
+
+// The label entries of dlogits, kept out of the fp8 matrix (mic_ce_bwd_q8 label_coef): row m of dlogits has coef[m] at column
+// labels[m].  dX[m][:] += coef[m] E[labels[m]][:] goes out as one more fp32 slab for mic_sum_slabs; dE[labels[m]][:] += coef[m] h[m][:]
+// by fp32 atomics into the gradient the dE GEMM has just written (rows that share a label — eos, the language ids — meet there).
+// One block per row.
+__global__ __launch_bounds__(128) void head_label_terms_kernel(int rows, int width, const int32_t* __restrict__ labels, const float* __restrict__ coef,
+                                                               const uint16_t* __restrict__ E, int lde, const uint16_t* __restrict__ h, int ldh,
+                                                               float* __restrict__ dx_slab, int ldx, float* __restrict__ dE, int ldde) {
+  const int m = blockIdx.x;
+  const float c = coef[m];
+  const int lab = labels[m];
+  for (int j = threadIdx.x * 8; j < width; j += 128 * 8) {
+    float e[8], x[8], o[8];
+    if (c != 0.f) {
+      ld8(E + (size_t)lab * lde + j, e);
+      ld8(h + (size_t)m * ldh + j, x);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        o[i] = c * e[i];
+        atomicAdd(dE + (size_t)lab * ldde + j + i, c * x[i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = 0.f;
+    }
+    st8(dx_slab + (size_t)m * ldx + j, o);
+  }
+}
+extern "C" int mic_head_label_terms(int rows, int width, const int32_t* labels, const float* coef, const void* E, int lde, const void* h, int ldh,
+                                    float* dx_slab, int ldx, float* dE, int ldde, void* stream) {
+  MIC_CHECK(rows > 0 && width > 0 && width % 8 == 0 && labels && coef && E && h && dx_slab && dE && lde % 8 == 0 && ldh % 8 == 0 && ldx % 4 == 0,
+            "mic_head_label_terms: bad args (width, lde, ldh multiples of 8; bf16 E and h)");
+  hipLaunchKernelGGL(head_label_terms_kernel, dim3(rows), dim3(128), 0, (hipStream_t)stream, rows, width, labels, coef, (const uint16_t*)E, lde,
+                     (const uint16_t*)h, ldh, dx_slab, ldx, dE, ldde);
+  MIC_LAUNCH_CHECK();
+  return MIC_OK;
+}
+
 // ------------------------------------------------------------------ column sums (bias gradients)
 // Table-driven so the 4..7 bias gradients of a layer go out as ONE launch (each alone is a ~9 us launch for ~2 us of
 // work).  Each thread owns 8 consecutive columns (one 16-B load per row); a block = 32 column-chunks x 8 row lanes

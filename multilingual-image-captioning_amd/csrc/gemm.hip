@@ -121,8 +121,9 @@ static int fill_epi(const mic_gemm_args* a, EpiArgs& e) {
   e.alpha = a->alpha == 0.f ? 1.0f : a->alpha; e.N = a->N;
   e.rowstat = a->rowstat; e.stat_ld = a->rowstat_ld; e.stat_nvalid = a->rowstat_nvalid > 0 ? a->rowstat_nvalid : a->N;
   if (a->rowstat) {
-    MIC_CHECK(a->dtype == MIC_BF16 && a->split_k <= 1 && !a->act && !a->dact && !a->R && !a->accumulate && a->dropout_p == 0.f && !a->Zout,
-              "mic_gemm: rowstat goes with the bare bias epilogue of a bf16 GEMM (the LM head)");
+    MIC_CHECK((a->dtype == MIC_BF16 || (a->dtype == MIC_FP8 && !a->a_kmajor)) && a->c_dtype == MIC_BF16 && a->split_k <= 1 && !a->act && !a->dact && !a->R &&
+                  !a->accumulate && a->dropout_p == 0.f && !a->Zout,
+              "mic_gemm: rowstat goes with the bare bias epilogue of a bf16 / fp8 NT GEMM with a bf16 C (the LM head)");
     MIC_CHECK(a->N % 64 == 0 && a->ldc % 8 == 0 && ((uintptr_t)a->C & 15) == 0, "mic_gemm: rowstat needs N %% 64 == 0 and a 16-B aligned C");
     MIC_CHECK(a->rowstat_ld >= a->N / 64 && ((uintptr_t)a->rowstat & 7) == 0, "mic_gemm: rowstat needs ld >= N / 64 float2 entries per row");
   }

@@ -69,6 +69,9 @@ class Engine:
         self.ln_partials = _os.environ.get("MIC_LN_PARTIALS", "1") != "0"
         self._lnp_queue = []
         self._head_nt_state = None   # (dlogits^T, Kp) of the CE backward that has just run
+        self.fp8_head = 0            # fp8 GEMM mode: the tied head's GEMMs on fp8 operands too (set_gemm_dtype)
+        self._head8_state = None
+        self._head_x8 = None
         self._ET_version, self._ET_event = -1, None
         self._dw_events = []
         self._dw_side = False  # True while launching on the dW stream
@@ -109,6 +112,19 @@ class Engine:
         names = [f"dec{l}.{k}" for l in range(P.L) for k in kinds] + [f"vit{l}.{k}" for l in range(P.vL) for k in ("qkv", "fc1", "fc2")]
         if self._ckv_hoist:
             names.append("ckvcat")
+        # the tied LM head in fp8 too (MIC_FP8_HEAD = all | bwd | 0; default all): its three GEMMs are 3.7 of the step's 8.4 TFLOP.
+        # Backward: dE and dX read ONE e5m2 copy of dlogits written by the CE backward under a closed-form scale (`mic_ce_bwd_q8`; no
+        # in-place gradient, no transposed copy), the e4m3 copies of E / E^T (re-made with the other weights) and the e4m3 final hidden
+        # states; forward ("all"): the logits from the e4m3 operands, softmax partials as in bf16.  "bwd": forward stays bf16; "0": the
+        # head as in the bf16 mode.  Needs the reduction dimensions (d, Vpad) in whole 128-byte fragments.
+        mode = _os.environ.get("MIC_FP8_HEAD", "all")
+        if mode not in ("0", "bwd", "all"):
+            raise ValueError(f"MIC_FP8_HEAD={mode!r}: 0 | bwd | all")
+        self.fp8_head = {"0": 0, "bwd": 1, "all": 2}[mode] if (P.d % 128 == 0 and P.Vpad % 128 == 0) else 0
+        if self.fp8_head:
+            names.append("shared")
+        self._head8_state = None  # (dlogits as e5m2 [rows][Vpad], its scale state) of the CE backward that has just run
+        self._head_x8 = None      # (final hidden states as e4m3, state) of this pass
         self._w8 = {}
         self._w8_state = torch.zeros((len(names), 2), dtype=torch.float32, device=self.dev)
         for i, n in enumerate(names):
@@ -130,8 +146,12 @@ class Engine:
         self._w8_rolled = False  # this step's roll of the weights' amax has been issued (first of the two refresh calls)
         self._w8_index = {n: i for i, n in enumerate(names)}
         segs = P.segs
-        self._w8_span = {n: ((segs["dec0.ckv.w"].offset, segs[f"dec{P.L - 1}.ckv.w"].offset + segs[f"dec{P.L - 1}.ckv.w"].numel) if n == "ckvcat"
-                             else (segs[n + ".w"].offset, segs[n + ".w"].offset + segs[n + ".w"].numel)) for n in names}
+        def span(n):
+            if n == "ckvcat":
+                return segs["dec0.ckv.w"].offset, segs[f"dec{P.L - 1}.ckv.w"].offset + segs[f"dec{P.L - 1}.ckv.w"].numel
+            sg = segs["shared" if n == "shared" else n + ".w"]
+            return sg.offset, sg.offset + sg.numel
+        self._w8_span = {n: span(n) for n in names}
         # one (amax, 1/scale) slot per quantised activation / gradient tensor; delayed scaling: + its table of partial maxima
         self._a8_state = torch.zeros((1024, 2), dtype=torch.float32, device=self.dev)
         self._a8_part = torch.zeros((1024, ops.fp8_amax_partials()), dtype=torch.float32, device=self.dev) if scaling == "delayed" else None
@@ -148,6 +168,8 @@ class Engine:
 
     def _w8_src(self, name: str):
         """the bf16 matrix behind the fp8 weight entry `name`"""
+        if name == "shared":
+            return self.P.w("shared")
         return self.P.ckv_cat("w")[0] if name == "ckvcat" else self.P.w(name + ".w")
 
     def storage_dtype_gemms(self):
@@ -233,7 +255,8 @@ class Engine:
         backward), under the amax the step's begin rolled in; the next pass then finds its fp8 weight copies ready."""
         if not (self.fp8 and self.fp8_scaling == "delayed" and self._w8_seen and self._w8_requant_opt):
             return
-        todo = [n for n, (o, oe) in self._w8_span.items() if b < oe <= e and n not in self._w8_fresh]
+        # (the tied embedding's flagged rows get their optimizer pass at the end of backward: its copies are left to fp8_refresh_weights)
+        todo = [n for n, (o, oe) in self._w8_span.items() if b < oe <= e and n not in self._w8_fresh and n != "shared"]
         if not todo:
             return
         items = []
@@ -278,6 +301,7 @@ class Engine:
             ops.zero(self._a8_state[: max(n, 1)])
         self._a8_cache = {}
         self._x8 = {}
+        self._head_x8 = None
 
     def _fp8_ok(self, wname: str) -> bool:
         return self.fp8 and wname.split(".")[-1] in self.FP8_KINDS and wname in self._w8
@@ -785,15 +809,31 @@ class Engine:
             ops.gemm(ehs, w, kvcat, Mv, P.L * 2 * P.d, P.d, bias=b)
         return kvcat
 
-    def head_logits(self, hf, M: int, name: str = "d.logits", stats: bool = False):
+    def head_logits(self, hf, M: int, name: str = "d.logits", stats: bool = False, fp8: bool = False):
         """Tied head (modeling:170-178): logits[M, Vpad] = hf @ shared^T + final_logits_bias (compute dtype).
         stats=True (bf16 mode): also returns the GEMM's softmax partials per 64-column granule [M][Vpad/64][2] (fp32) so that the
         log-softmax downstream (cross-entropy, beam scores) needs no second pass over the logits."""
         P = self.P
         logits = self.buf(name, M, P.Vpad)
         stat = self.head_stats(name, M) if stats else None
-        ops.gemm(hf, P.w("shared"), logits, M, P.Vpad, P.d, bias=P.f32("flb"), rowstat=stat, rowstat_nvalid=P.V)
+        self._head_project(hf, logits, M, stat, fp8=fp8)  # (fp8: the train / eval passes only — inference stays in the storage dtype)
         return (logits, stat) if stats else logits
+
+    def _head8(self) -> bool:
+        return self.fp8 and self.fp8_head > 0
+
+    def _head_project(self, hf, logits, M: int, stat, fp8: bool = True):
+        """logits[:M] = hf[:M] @ shared^T + final_logits_bias (+ the softmax partials): bf16 operands, or — fp8 GEMMs with
+        MIC_FP8_HEAD=all — the e4m3 copies of both (the quantised hidden states stay for the head's weight gradient)"""
+        P = self.P
+        if fp8 and self._head8() and self.fp8_head == 2:
+            x8 = self._head_x8 = self._quant(hf, M, P.d, "head.x", "head.x", torch.float8_e4m3fn)
+            E8, _, wst = self._w8["shared"]
+            self._w8_wait()
+            ops.gemm(x8[0], E8, logits, M, P.Vpad, P.d, bias=P.f32("flb"), rowstat=stat, rowstat_nvalid=P.V,
+                     a_scale_inv=x8[1][1:], b_scale_inv=wst[1:])
+        else:
+            ops.gemm(hf, P.w("shared"), logits, M, P.Vpad, P.d, bias=P.f32("flb"), rowstat=stat, rowstat_nvalid=P.V)
 
     def head_stats(self, name: str, M: int):
         if self.dt != torch.bfloat16 or not self.use_head_stats:
@@ -824,7 +864,22 @@ class Engine:
         Mhp = _rup(Mh, 64)
         nt = self._head_nt_state
         self._head_nt_state = None
-        if nt is not None:
+        h8s, self._head8_state = self._head8_state, None
+        if h8s is not None:
+            # fp8 head: dE = dlogits^T . h over K = rows, both operands k-major (the e5m2 copy of dlogits as the CE backward wrote it,
+            # the e4m3 hidden states; rows >= Mh of the 128-row reduction padding count as zero), fp32 straight into the gradient buffer
+            x8 = self._head_x8 or self._quant(hf, Mh, d, "head.x", "head.x", torch.float8_e4m3fn)
+            ops.gemm(h8s[0], x8[0], P.g("shared"), P.Vpad, d, _rup(Mh, 128), a_kmajor=True, b_kmajor=True, k_valid=Mh,
+                     a_scale_inv=h8s[1][1:], b_scale_inv=x8[1][1:])
+            # the label entries (kept out of the byte matrix): + coef h into dE's label rows, coef E[label] as one more slab of dX
+            tiles = ((Mh + 255) // 256) * ((d + 255) // 256)
+            nsp = max(1, min(ops.get_cu_budget() // tiles, P.Vpad // 128 // 2))
+            slab_rows = _rup(Mh, 256)
+            cap_rows = max(_rup(Mcap, 256), (256 // max(1, (d + 255) // 256)) * 256) + _rup(Mcap, 256)
+            d32 = self.buf("db.dhf32", cap_rows, d, torch.float32)
+            assert (nsp + 1) * slab_rows <= d32.shape[0], (nsp, slab_rows, d32.shape)
+            ops.head_label_terms(h8s[3], h8s[2], P.w("shared"), hf, d32[nsp * slab_rows:], P.g("shared"), Mh, d)
+        elif nt is not None:
             # NT launches on the four-wave kernel: dE = dlogits^T . (h^T)^T over K = rows (zero-padded to a multiple of 128 by the CE
             # backward; the bias gradient was summed there), fp32 straight into the gradient buffer
             dT, Kp = nt
@@ -842,7 +897,15 @@ class Engine:
         # report, behind it (GradReducer `defer`)
         self._done("shared")
         dhc = dhf if (rows is None or pack is not None) else self.buf("db.dhfc", Mcap, d)
-        if nt is not None:
+        if h8s is not None:
+            # dX = dlogits . (E^T)^T over K = Vpad on the e5m2 / e4m3 copies, split over K as below; the slabs and the label slab are
+            # summed and rounded to bf16 once
+            _, ET8, wst = self._w8["shared"]
+            self._w8_wait()
+            slab = slab_rows * d
+            ops.gemm(h8s[0], ET8, d32, Mh, d, P.Vpad, split_k=nsp, split_stride=slab if nsp > 1 else 0, a_scale_inv=h8s[1][1:], b_scale_inv=wst[1:])
+            ops.sum_slabs(d32, nsp + 1, slab, dhc, Mh, d, d32.stride(0), dhc.stride(0))
+        elif nt is not None:
             # dX = dlogits . (E^T)^T over K = Vpad: ceil(Mh / 256) x d / 256 output tiles, split over K so that one round of blocks
             # fills the chip; one fp32 slab per split, summed and rounded to bf16 once
             tiles = ((Mh + 255) // 256) * ((d + 255) // 256)
@@ -1073,7 +1136,19 @@ class Engine:
         else:
             ops.ce_rows(logits, logits.stride(0), P.V, labels, mask, label_smoothing, lse, rl, M)
         ops.ce_reduce(rl, mask, loss, denom, M)
-        if backward:
+        if backward and self._head8():
+            # fp8 head: dlogits leave as ONE e5m2 copy (the logits stay) under the scale this tensor has in closed form (mic_ce_bwd_q8)
+            ops.zero(P.g("flb"))
+            q = self.buf("head.dl.q8", logits.shape[0], P.Vpad, torch.float8_e5m2)
+            st = self.vec("head.dl.state", 2)
+            # ... except the label entry of every row (at least half of the row's gradient energy): an fp32 coefficient whose two
+            # products decoder_backward adds exactly (mic_head_label_terms)
+            coef = self.vec("head.dl.coef", _rup(logits.shape[0], ROWPAD))
+            ops.ce_bwd_q8(logits, logits.stride(0), P.V, P.Vpad, labels, mask, label_smoothing, lse, denom, M, ops.fp8_out(q, st), colsum=P.g("flb"),
+                          label_coef=coef)
+            self._head8_state = (q, st, coef, labels)
+            self._head_nt_state = None
+        elif backward:
             kcap = self._head_nt_kcap(logits)
             if kcap:
                 # dlogits in place AND transposed [Vpad][Kp] (reduction padding rows M .. Kp zero), final_logits_bias gradient on the way
@@ -1092,7 +1167,7 @@ class Engine:
         launches of the four-wave kernel, else 0: bf16 storage, a vocabulary worth the copies, operands inside the 2^31-byte
         window that kernel's buffer resources address"""
         P = self.P
-        if not self.head_nt or self.dt != torch.bfloat16 or P.Vpad < 16384 or P.d % 128 != 0:
+        if not self.head_nt or self.dt != torch.bfloat16 or P.Vpad < 16384 or P.d % 128 != 0 or self._head8():
             return 0
         kcap = _rup(logits.shape[0], 128)
         return kcap if P.Vpad * kcap * 2 < 0x7fffffff and logits.shape[0] * logits.stride(0) * 2 < 0x7fffffff else 0
@@ -1119,7 +1194,7 @@ class Engine:
         enqueued; the next step's head backward waits for it (shared_T).  `version`: the ParamStore.version the copy belongs to."""
         P = self.P
         ET = self._bufs.get(("w.sharedT", P.d, P.Vpad, self.dt))  # (only once a head backward has built it)
-        if not self.head_nt or self.dt != torch.bfloat16 or ET is None:
+        if not self.head_nt or self.dt != torch.bfloat16 or ET is None or self._head8():
             return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
@@ -1137,9 +1212,9 @@ class Engine:
         _, ehs = self.vit_forward(pixels, save, trunc_int32)
         hf = self.decoder_forward(ids, pos_ids, key_mask, ehs, B, T, save, seed)
         if stats:
-            logits, stat = self.head_logits(hf, B * T, stats=True)
+            logits, stat = self.head_logits(hf, B * T, stats=True, fp8=True)
             return logits, ehs, stat
-        return self.head_logits(hf, B * T), ehs
+        return self.head_logits(hf, B * T, fp8=True), ehs
 
     def compact_head(self, hf, M: int, rows, packed: bool = False):
         """LM head on the loss-relevant rows only: gather hf[idx] -> [Mc, d] (zero pad to a multiple of 64 rows) and
@@ -1157,7 +1232,7 @@ class Engine:
             ops.zero(hfc[Mc:Mcp])
         logits = self.buf("d.logits", M, P.Vpad)
         stat = self.head_stats("d.logits", M)
-        ops.gemm(hfc, P.w("shared"), logits, Mc, P.Vpad, P.d, bias=P.f32("flb"), rowstat=stat, rowstat_nvalid=P.V)
+        self._head_project(hfc, logits, Mc, stat)
         if Mcp > Mc:
             ops.zero(logits[Mc:Mcp])  # reduction padding of the dE GEMM (rows of an earlier, longer batch may linger here)
         return logits, stat

@@ -352,6 +352,21 @@ def ce_bwd(logits, ld, V, Vpad, labels, mask, ls, row_lse, denom, rows, loss_sca
                                float(loss_scale), _stream()), "mic_ce_bwd")
 
 
+def ce_bwd_q8(logits, ld, V, Vpad, labels, mask, ls, row_lse, denom, rows, q8, colsum=None, label_coef=None, loss_scale=1.0):
+    """CE backward of bf16 logits with dlogits leaving as fp8 bytes (q8: an `fp8_out`; its state[1] receives the closed-form
+    dequantisation factor loss_scale / (denom * FMAX)) instead of in place; column sums of the gradient added to `colsum`;
+    label_coef fp32 [rows]: the label entries leave as fp32 coefficients instead (zero bytes in the matrix) (mic_ce_bwd_q8)"""
+    L.check(L.lib().mic_ce_bwd_q8(rows, V, Vpad, _p(logits), ld, _p(labels), _p(mask), float(ls), _p(row_lse), _p(denom), float(loss_scale),
+                                  C.byref(q8), _p(colsum), _p(label_coef), _stream()), "mic_ce_bwd_q8")
+
+
+def head_label_terms(labels, coef, E, h, dx_slab, dE, rows, width):
+    """dx_slab[m] = coef[m] * E[labels[m]] (fp32), dE[labels[m]] += coef[m] * h[m] (fp32 atomics): the label entries of dlogits that
+    mic_ce_bwd_q8 kept out of the fp8 matrix (mic_head_label_terms)"""
+    L.check(L.lib().mic_head_label_terms(rows, width, _p(labels), _p(coef), _p(E), E.stride(0), _p(h), h.stride(0), _p(dx_slab), dx_slab.stride(0),
+                                         _p(dE), dE.stride(0), _stream()), "mic_head_label_terms")
+
+
 def ce_bwd_t(logits, ld, V, Vpad, labels, mask, ls, row_lse, denom, rows, dlogits_t, rows_pad=0, colsum=None, loss_scale=1.0):
     """ce_bwd on bf16 logits that also writes dlogits^T [Vpad][ld_t] (columns rows .. rows_pad zero) and adds the column sums of the
     stored gradient to `colsum` (mic_ce_bwd_t)"""

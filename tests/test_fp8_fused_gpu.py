@@ -223,3 +223,113 @@ def test_colsum_q8_grouped(dev, fmt):
     torch.cuda.synchronize()
     for (x, out, sinv, rows, cols), r in zip(items, refs):
         assert ((out.double().cpu() - r).abs().max() / r.abs().max().clamp_min(1e-9)).item() < 1e-5, (rows, cols)
+
+
+@pytest.mark.parametrize("rows,V,Vpad,ls", [(2404, 250054, 250112, 0.0), (100, 1000, 1024, 0.1), (64, 505, 512, 0.0), (3, 130, 136, 0.0)])
+def test_ce_bwd_q8_against_closed_form_scale(dev, rows, V, Vpad, ls):
+    """the fp8 LM head's CE backward: ONE e5m2 copy of dlogits, q = e5m2(mask (softmax - soft_label) * 57344) — the tensor's scale in
+    closed form, no amax history — with the dequantisation factor 1 / (denom * 57344) beside it; the logits stay; the column sums of the
+    gradient are added to the bias gradient; dequantised, it is mic_ce_bwd's in-place gradient to e5m2 precision"""
+    from mic_amd import ops
+
+    g = torch.Generator().manual_seed(rows + V)
+    logits = ((torch.rand(rows, Vpad, generator=g) - 0.5) * 12).to(torch.bfloat16)
+    logits[:, 7] += 9.0  # some rows are confident about column 7 ...
+    labels = torch.randint(0, V, (rows,), generator=g, dtype=torch.int32)
+    labels[::3] = 7      # ... and a third of the labels agree with them
+    mask = (torch.rand(rows, generator=g) > 0.2).to(torch.int32)
+    logits, labels, mask = logits.to(dev), labels.to(dev), mask.to(dev)
+    lse = torch.logsumexp(logits[:, :V].float(), dim=1).contiguous()
+    denom = mask.sum().float().reshape(1)
+    st = torch.zeros(2, device=dev)
+    q = torch.zeros((rows + 2, Vpad), dtype=E5, device=dev)
+    keep = logits.clone()
+    flb = torch.full((Vpad,), 0.25, device=dev)
+    ops.ce_bwd_q8(logits, Vpad, V, Vpad, labels, mask, ls, lse, denom, rows, ops.fp8_out(q, st), colsum=flb)
+    torch.cuda.synchronize()
+    assert torch.equal(logits, keep)
+    soft = torch.full((rows, V), ls / (V - 1) if ls > 0 else 0.0, device=dev)
+    soft[torch.arange(rows, device=dev), labels.long()] = 1.0 - ls
+    gref = (torch.softmax(logits[:, :V].float(), dim=1) - soft) * mask[:, None].float()
+    want = (gref * 57344.0).to(E5).float()
+    got = q[:rows, :V].float()
+    # the same bytes up to the device's exp (a handful of entries on a rounding boundary land on the neighbouring e5m2 value)
+    diff = (got != want)
+    assert diff.float().mean().item() < 2e-4, diff.float().mean().item()
+    assert float(((got - want).abs() / want.abs().clamp_min(2.0 ** -16))[diff].max() if diff.any() else 0.0) <= 0.34
+    assert float(q[rows:].float().abs().max()) == 0.0 and float(q[:rows, V:].float().abs().max()) == 0.0
+    assert abs(st[1].item() * denom.item() * 57344.0 - 1.0) < 1e-6 and abs(st[0].item() * st[1].item() - 1.0) < 1e-6
+    # label entries of unconfident rows sit at (1 - p) ~ 1: exact in this scaling
+    assert float(got.abs().max()) == 57344.0
+    inplace = logits.clone()
+    ops.ce_bwd(inplace, Vpad, V, Vpad, labels, mask, ls, lse, denom, rows)
+    deq = q[:rows].float() * st[1]
+    big = inplace.float().abs() > 1e-3 * float(inplace.float().abs().max())
+    assert float(((deq - inplace.float()).abs() / inplace.float().abs().clamp_min(1e-30))[big].max()) < 0.14  # e5m2: 2 mantissa bits (+ bf16)
+    wsum = gref.sum(0) / denom + 0.25
+    assert float((flb[:V] - wsum).abs().max()) <= 1e-5 * float(wsum.abs().max()) + 1e-7 and float((flb[V:] - 0.25).abs().max()) == 0.0
+    # label_coef: the label entries leave the byte matrix as fp32 coefficients; every other byte and the column sums stay
+    q2 = torch.zeros((rows + 2, Vpad), dtype=E5, device=dev)
+    coef = torch.full((rows,), 7.0, device=dev)
+    flb2 = torch.full((Vpad,), 0.25, device=dev)
+    ops.ce_bwd_q8(logits, Vpad, V, Vpad, labels, mask, ls, lse, denom, rows, ops.fp8_out(q2, st), colsum=flb2, label_coef=coef)
+    torch.cuda.synchronize()
+    ar = torch.arange(rows, device=dev)
+    assert float(q2[ar, labels.long()].float().abs().max()) == 0.0
+    q1 = q.clone()
+    q1[ar, labels.long()] = 0
+    assert torch.equal(q2.view(torch.uint8), q1.view(torch.uint8))
+    assert float((flb2 - flb).abs().max()) <= 1e-5 * float(flb.abs().max())  # (fp32 atomics: the order of a column's 38 partial sums)
+    cref = gref[ar, labels.long()] / denom
+    assert float((coef - cref).abs().max()) <= 2e-6 * float(cref.abs().max())
+
+
+def test_head_label_terms(dev):
+    from mic_amd import ops
+
+    rows, width, V = 300, 1024, 5000
+    g = torch.Generator().manual_seed(3)
+    E = torch.randn(V, width, generator=g).to(torch.bfloat16).to(dev)
+    h = torch.randn(rows + 4, width, generator=g).to(torch.bfloat16).to(dev)
+    labels = torch.randint(0, V, (rows,), generator=g, dtype=torch.int32)
+    labels[::5] = 2  # (eos: many rows meet in one gradient row)
+    labels = labels.to(dev)
+    coef = torch.randn(rows, generator=g).to(dev)
+    coef[::7] = 0.0
+    slab = torch.full((rows + 4, width), 3.0, device=dev)
+    dE = torch.full((V, width), 0.5, device=dev)
+    ops.head_label_terms(labels, coef, E, h, slab, dE, rows, width)
+    torch.cuda.synchronize()
+    want_slab = coef[:, None] * E[labels.long()].float()
+    assert torch.equal(slab[:rows], want_slab) and float((slab[rows:] - 3.0).abs().max()) == 0.0
+    want = torch.full((V, width), 0.5, device=dev, dtype=torch.float64)
+    want.index_add_(0, labels.long(), (coef[:, None] * h[:rows].float()).double())
+    assert float((dE.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("M", [2404, 300])
+def test_fp8_head_projection_with_softmax_partials(dev, M):
+    """MIC_FP8_HEAD=all: the LM-head forward on e4m3 operands carries the same by-product as the bf16 launch — (max, sum exp) of the
+    stored logits per 64-column granule"""
+    from mic_amd import ops
+
+    N, K, nvalid = 4096, 1024, 4000
+    g = torch.Generator().manual_seed(M)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(dev).to(E4)
+    b = (torch.randn(N, K, generator=g) * 0.5).to(dev).to(E4)
+    sa, sb = torch.tensor([0.5], device=dev), torch.tensor([0.25], device=dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    c = torch.zeros((M, N), dtype=torch.bfloat16, device=dev)
+    stat = torch.zeros((M, 2 * (N // 64)), device=dev)
+    ops.gemm(a, b, c, M, N, K, bias=bias, rowstat=stat, rowstat_nvalid=nvalid, a_scale_inv=sa, b_scale_inv=sb)
+    want = (a.float() @ b.float().t()) * 0.125 + bias
+    assert float((c.float() - want).abs().max()) <= 2e-2 * float(want.abs().max())
+    x = c.float()
+    x[:, nvalid:] = float("-inf")
+    x = x.reshape(M, N // 64, 64)
+    mx = x.max(dim=2).values
+    sm = torch.exp(x - mx.clamp_min(-1e30)[..., None]).sum(dim=2)
+    st = stat.reshape(M, N // 64, 2)
+    live = mx > float("-inf")
+    assert torch.equal(st[..., 0][live], mx[live])
+    assert float(((st[..., 1] - sm)[live]).abs().max()) <= 1e-4 * float(sm[live].max())

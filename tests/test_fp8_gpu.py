@@ -215,14 +215,19 @@ def _cos(a, b):
     return torch.nn.functional.cosine_similarity(a.reshape(-1).double(), b.reshape(-1).double(), dim=0).item()
 
 
+@pytest.mark.parametrize("head", ["0", "bwd", "all"])
 @pytest.mark.parametrize("compact", [False, True])
-def test_fp8_train_step_against_fp32_oracle(dev, compact):
+def test_fp8_train_step_against_fp32_oracle(dev, compact, head, monkeypatch):
+    """head: MIC_FP8_HEAD — the tied LM head's GEMMs in the storage dtype / its two backward GEMMs on fp8 operands (default) / the
+    forward projection too"""
     from mic_amd import loss_rows
     from oracle import train_ref
 
     rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.0, d_model=256, d_ffn=512, d_heads=4,
                              v_hidden=256, v_ffn=512, v_heads=4)
+    monkeypatch.setenv("MIC_FP8_HEAD", head)
     model.engine.set_gemm_dtype("fp8")
+    assert model.engine.fp8_head == {"0": 0, "bwd": 1, "all": 2}[head] and ("shared" in model.engine._w8) == (head != "0")
     B, T = 4, 16
     px, labels, mask, dec_in = batch(rc, B, T, seed=9)
     ref_loss, ref_g = train_ref.loss_and_grads(rc, p, px, labels, mask, dec_in)
