@@ -28,6 +28,17 @@
 //     train step level.  A 192 x 128 variant on whole cache lines in two 40-KiB slots (0.42 L2 requests per clock instead of 0.75)
 //     ran its K loop 8 % faster (4096^3 1052 TF/s) and changed neither leg in situ: not kept.
 #include "gemm_common.h"
+// tools/probe_head_timeline.hip builds this file with -DMIC_TRACE_BLOCKS: every block stamps kernel entry, first operands landed, end
+// of the K loop and end of the epilogue (wall_clock64: 100 MHz, one counter for the whole chip) and where it ran; nothing in the product build
+#ifdef MIC_TRACE_BLOCKS
+__device__ unsigned long long* mic_trace_buf;
+#define MIC_TRACE(SLOT) do { if (threadIdx.x == 0) mic_trace_buf[5 * blockIdx.x + (SLOT)] = wall_clock64(); } while (0)
+#define MIC_TRACE_ID() do { if (threadIdx.x == 0) { unsigned hw_, xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); \
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_)); mic_trace_buf[5 * blockIdx.x + 4] = ((unsigned long long)(xcc_ & 0xf) << 16) | (hw_ & 0xffff); } } while (0)
+#else
+#define MIC_TRACE(SLOT) do { } while (0)
+#define MIC_TRACE_ID() do { } while (0)
+#endif
 
 namespace {
 
@@ -149,6 +160,8 @@ __global__ __launch_bounds__(256, 2) void gemm_d2_kernel(LaunchTable tab) {
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
   const Problem& P = tab.p[0];
+  MIC_TRACE(0);
+  MIC_TRACE_ID();
   int tile = lid, split = 0;
   if (P.nsplit > 1) {  // split-major (see gemm_w4.hip)
     const int T = P.tiles_m * P.tiles_n;
@@ -217,6 +230,7 @@ __global__ __launch_bounds__(256, 2) void gemm_d2_kernel(LaunchTable tab) {
     for (int q = 0; q < 3; ++q) D2_DMA(2, 2 * D2_SLOT, q);
     asm volatile("s_waitcnt vmcnt(9)" ::: "memory");  // step 0 has landed
     D2_BARRIER();
+    MIC_TRACE(1);
     int c0 = 0, c1 = D2_SLOT, c2 = 2 * D2_SLOT;  // slot offsets of steps s, s+1, s+2
     if (live) {
 #pragma unroll
@@ -264,7 +278,12 @@ __global__ __launch_bounds__(256, 2) void gemm_d2_kernel(LaunchTable tab) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (dropped requests still count)
   }
   __syncthreads();
+  MIC_TRACE(2);
   if (live) d2_epilogue<(EPI & 1) != 0>(acc, P, smem, m0 + wr * WM, n0 + wc * WN, split, wave, lane);
+#ifdef MIC_TRACE_BLOCKS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the stamp below = this wave's stores acknowledged)
+#endif
+  MIC_TRACE(3);
 #undef D2_DMA
 #undef D2_BARRIER
 #undef D2_READ_A

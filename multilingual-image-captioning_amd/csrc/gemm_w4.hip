@@ -29,6 +29,17 @@
 //   * Same launch table, tile order and k ranges as the other kernels; its own bare per-wave epilogue (below).  Single-problem NT
 //     launches without split, K a multiple of 128 and >= 256.
 #include "gemm_common.h"
+// tools/probe_head_timeline.hip builds this file with -DMIC_TRACE_BLOCKS: every block stamps kernel entry, first operands landed, end
+// of the K loop and end of the epilogue (wall_clock64: 100 MHz, one counter for the whole chip) and where it ran; nothing in the product build
+#ifdef MIC_TRACE_BLOCKS
+__device__ unsigned long long* mic_trace_buf;
+#define MIC_TRACE(SLOT) do { if (threadIdx.x == 0) mic_trace_buf[5 * blockIdx.x + (SLOT)] = wall_clock64(); } while (0)
+#define MIC_TRACE_ID() do { if (threadIdx.x == 0) { unsigned hw_, xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); \
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_)); mic_trace_buf[5 * blockIdx.x + 4] = ((unsigned long long)(xcc_ & 0xf) << 16) | (hw_ & 0xffff); } } while (0)
+#else
+#define MIC_TRACE(SLOT) do { } while (0)
+#define MIC_TRACE_ID() do { } while (0)
+#endif
 
 namespace {
 
@@ -222,6 +233,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(LaunchTable tab) {
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
   const Problem& P = tab.p[0];
+  MIC_TRACE(0);
+  MIC_TRACE_ID();
   // split-K (fp32 slabs): split-major — an XCD's contiguous run of logical blocks is a run of TILES of one K range (two at most), so
   // the blocks that share its L2 read the same k-tiles of A and B at about the same time (tile-major order would give every block
   // of an XCD a K range of its own: every operand byte from the fabric once per block); with a multiple of 8 splits, K-range <->
@@ -318,6 +331,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(LaunchTable tab) {
     for (int q = 0; q < 16; ++q) W4_DMA(1, 1, q);
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // tile 0 has landed (tile 1 may still fly)
     W4_BARRIER();
+    MIC_TRACE(1);
 #pragma unroll
     for (int kk = 0; kk < 3; ++kk)
 #pragma unroll
@@ -346,10 +360,15 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(LaunchTable tab) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (dropped requests still count)
   }
   __syncthreads();
+  MIC_TRACE(2);
   if (live) {
     if constexpr (EPI == 8) w4_epilogue_f32(acc, P, smem, m0 + wr * WM, n0 + wc * WN, split, wave, lane);
     else w4_epilogue_lean<(EPI & 1) != 0, (EPI & 4) != 0>(acc, P, smem, m0 + wr * WM, n0 + wc * WN, wave, lane);
   }
+#ifdef MIC_TRACE_BLOCKS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the stamp below = this wave's stores acknowledged)
+#endif
+  MIC_TRACE(3);
 }
 
 template <int EPI>
