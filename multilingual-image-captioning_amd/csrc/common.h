@@ -218,6 +218,38 @@ __device__ __forceinline__ void q8_end_wave(const Q8Out& o, const Q8Ctx& c, int 
 //   gelu_tanh'(x) = s + x s (1 - s) dz/dx,  dz/dx = 2c + 6ca x^2
 //   quick_gelu(x) = x * sigmoid(1.702 x)
 #define MIC_LOG2E 1.4426950408889634f
+// ---- softmax partials of the LM-head GEMM epilogues (mic_gemm_args.rowstat): (max, sum exp(x - max)) over one 64-column granule of a
+// logits row = an aligned group of 8 lanes x 8 packed bf16 values AS STORED.  nv: valid columns of this lane's 8 (>= 8: all; the
+// granule that holds the end of the vocabulary masks the rest to -inf).  Written for the instruction count — this runs once per
+// element of a [rows][250 112] matrix on SIMDs that hold ONE wave (63 cycles per element and lane before: tools/probe_head_timeline.hip):
+// max3 trees, the subtraction and the base change as one packed FMA per pair, v_exp_f32 (base 2) straight, packed adds.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void granule_stat8(const uint32_t (&w)[4], int nv, float& gm, float& sm) {
+  float x[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    x[2 * i] = __uint_as_float(w[i] << 16);
+    x[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+  if (nv < 8) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = i < nv ? x[i] : -INFINITY;
+  }
+  const float mx = fmaxf(fmaxf(fmaxf(x[0], fmaxf(x[1], x[2])), fmaxf(x[3], fmaxf(x[4], x[5]))), fmaxf(x[6], x[7]));
+  gm = group8_max(mx);
+  // (a masked column is -inf: exp2(-inf) = 0 as long as the reference is finite; a granule with no valid column stores (-inf, 0))
+  const float nb = gm > -INFINITY ? -gm * MIC_LOG2E : 0.0f;
+  const f32x2 L = {MIC_LOG2E, MIC_LOG2E}, NB = {nb, nb};
+  f32x2 e[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x2 v = {x[2 * i], x[2 * i + 1]};
+    const f32x2 t = __builtin_elementwise_fma(v, L, NB);
+    e[i] = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+  }
+  const f32x2 s2 = (e[0] + e[1]) + (e[2] + e[3]);
+  sm = group8_sum(s2[0] + s2[1]);
+}
 #define GELU_K1 1.5957691216057308f   /* 2 * sqrt(2/pi) */
 #define GELU_K2 0.07135481627261745f  /* 2 * sqrt(2/pi) * 0.044715 */
 __device__ __forceinline__ float sigmoid_neg_log2(float zl) {  // sigmoid(z) given zl = -z * log2(e)

@@ -94,22 +94,9 @@ __device__ __forceinline__ void d2_epilogue_pass(f32x16 (&accp)[2], const EpiArg
       if (ok) *reinterpret_cast<uint4*>((uint16_t*)E.C + (size_t)m * E.ldc + n) = u;
       if constexpr (STATS) {
         // (max, sum exp(x - max)) of the values AS STORED over this row's 64-column granule = the wave tile's width = 8 consecutive lanes
-        float x0 = __uint_as_float(u.x << 16), x1 = __uint_as_float(u.x & 0xffff0000u), x2 = __uint_as_float(u.y << 16),
-              x3 = __uint_as_float(u.y & 0xffff0000u), x4 = __uint_as_float(u.z << 16), x5 = __uint_as_float(u.z & 0xffff0000u),
-              x6 = __uint_as_float(u.w << 16), x7 = __uint_as_float(u.w & 0xffff0000u);
-        if (!stat_all) {
-          const int nv = ok ? E.stat_nvalid - n : 0;  // valid columns of this unit
-          x0 = nv > 0 ? x0 : -INFINITY; x1 = nv > 1 ? x1 : -INFINITY; x2 = nv > 2 ? x2 : -INFINITY; x3 = nv > 3 ? x3 : -INFINITY;
-          x4 = nv > 4 ? x4 : -INFINITY; x5 = nv > 5 ? x5 : -INFINITY; x6 = nv > 6 ? x6 : -INFINITY; x7 = nv > 7 ? x7 : -INFINITY;
-        }
-        const float mx = fmaxf(fmaxf(fmaxf(x0, x1), fmaxf(x2, x3)), fmaxf(fmaxf(x4, x5), fmaxf(x6, x7)));
-        const float gm = group8_max(mx);
-        // (a masked column is -inf: exp(-inf - gm) = 0 as long as gm is finite; a unit group with no valid column at all stores
-        // (-inf, 0): guard the subtraction)
-        const float gs = gm > -INFINITY ? gm : 0.0f;
-        float sm = (__expf(x0 - gs) + __expf(x1 - gs)) + (__expf(x2 - gs) + __expf(x3 - gs)) + (__expf(x4 - gs) + __expf(x5 - gs)) +
-                   (__expf(x6 - gs) + __expf(x7 - gs));
-        sm = group8_sum(sm);
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+        float gm, sm;
+        granule_stat8(w, stat_all ? 8 : (ok ? E.stat_nvalid - n : 0), gm, sm);
         if ((lane & 7) == 0 && ok) reinterpret_cast<float2*>(E.rowstat)[(size_t)m * E.stat_ld + n / 64] = make_float2(gm, sm);
       }
     }

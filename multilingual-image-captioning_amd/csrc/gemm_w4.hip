@@ -142,28 +142,8 @@ __device__ __forceinline__ void w4_epilogue_lean(f32x16 (&acc)[4][4], const Prob
       if constexpr (STATS) {
         // (max, sum exp(x - max)) of the values AS STORED over this row's 64-column granule = 8 consecutive lanes
         const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-        float x[8], mx = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          x[2 * i] = __uint_as_float(w[i] << 16);
-          x[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
-        }
-        if (!stat_all) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) x[i] = (ok && n + i < E.stat_nvalid) ? x[i] : -INFINITY;
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) mx = fmaxf(mx, x[i]);
-        const float gm = group8_max(mx);
-        float sm = 0.0f;
-        if (stat_all) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) sm += __expf(x[i] - gm);
-        } else {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) sm += x[i] > -INFINITY ? __expf(x[i] - gm) : 0.0f;
-        }
-        sm = group8_sum(sm);
+        float gm, sm;
+        granule_stat8(w, stat_all ? 8 : (ok ? E.stat_nvalid - n : 0), gm, sm);
         if ((lane & 7) == 0 && ok) reinterpret_cast<float2*>(E.rowstat)[(size_t)m * E.stat_ld + n / 64] = make_float2(gm, sm);
       }
     }
