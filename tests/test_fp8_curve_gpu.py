@@ -4,7 +4,7 @@ once with bf16 GEMMs and once with the QKV / FFN projections and the tied LM hea
 emission).  The reference has no fp8 mode (main.py:96-101 offers fp32 / fp16 / bf16): the bf16 run — itself pinned on the fp32
 oracle — is the yardstick.
 Two instruments.  (1) The loss CURVE: both runs learn (the loss falls to less than a tenth on the four repeated batches); over the
-first 100 steps the fp8 loss stays within 5 % of the bf16 loss, over all 200 within 12 %, the means of the last 20 steps within 10 %.
+first 100 steps the fp8 loss stays within 6 % of the bf16 loss, over all 200 within 12 %, the means of the last 20 steps within 10 %.
 Two training trajectories are chaotic in the memorisation phase (fp32 atomics order alone moves them): thirteen fp8 runs on MI355X
 (`tools/fp8_head_curve.py`, every head mode) ended +1.0 ... +4.4 % above bf16 in the last-20 mean with a largest per-step deviation
 of 1.7 ... 5.3 %, the head modes indistinguishable inside that spread (profiles/NOTES_r6.md section 11) — so the curve bounds are
@@ -57,10 +57,11 @@ def test_fullsize_fp8_loss_curve_follows_bf16_over_200_steps(dev):
     assert fused and np.isfinite(l8).all() and np.isfinite(l16).all()
     rel = np.abs(l8 - l16) / np.abs(l16)
     tail = abs(l8[-20:].mean() - l16[-20:].mean()) / l16[-20:].mean()
-    print(f"[fp8 curve] bf16 {l16[0]:.3f} -> {l16[-1]:.3f}, fp8 {l8[0]:.3f} -> {l8[-1]:.3f}; max |fp8 - bf16| / bf16 = {rel.max():.4f} at step {int(rel.argmax())}, "
+    print(f"[fp8 curve] bf16 {l16[0]:.3f} -> {l16[-1]:.3f}, fp8 {l8[0]:.3f} -> {l8[-1]:.3f}; max |fp8 - bf16| / bf16 = {rel.max():.4f} at step {int(rel.argmax())} "
+          f"({rel[:100].max():.4f} over the first 100 steps), "
           f"mean {rel.mean():.4f}; last-20 means differ by {tail:.4f}; every 20th step bf16 {[round(float(x), 3) for x in l16[::20]]} fp8 {[round(float(x), 3) for x in l8[::20]]}")
     assert l16[-1] < 0.1 * l16[0] and l8[-1] < 0.1 * l8[0], (l16[0], l16[-1], l8[0], l8[-1])
-    assert rel[:100].max() < 0.05, (rel[:100].max(), int(rel[:100].argmax()))
+    assert rel[:100].max() < 0.06, (rel[:100].max(), int(rel[:100].argmax()))
     assert rel.max() < 0.12, (rel.max(), int(rel.argmax()))
     assert tail < 0.10, tail
 

@@ -215,9 +215,9 @@ def _cos(a, b):
     return torch.nn.functional.cosine_similarity(a.reshape(-1).double(), b.reshape(-1).double(), dim=0).item()
 
 
-@pytest.mark.parametrize("head", ["0", "bwd", "all"])
+@pytest.mark.parametrize("head,ls", [("0", 0.0), ("bwd", 0.0), ("all", 0.0), ("all", 0.1)])
 @pytest.mark.parametrize("compact", [False, True])
-def test_fp8_train_step_against_fp32_oracle(dev, compact, head, monkeypatch):
+def test_fp8_train_step_against_fp32_oracle(dev, compact, head, ls, monkeypatch):
     """head: MIC_FP8_HEAD — the tied LM head's GEMMs in the storage dtype / its two backward GEMMs on fp8 operands (default) / the
     forward projection too"""
     from mic_amd import loss_rows
@@ -230,7 +230,7 @@ def test_fp8_train_step_against_fp32_oracle(dev, compact, head, monkeypatch):
     assert model.engine.fp8_head == {"0": 0, "bwd": 1, "all": 2}[head] and ("shared" in model.engine._w8) == (head != "0")
     B, T = 4, 16
     px, labels, mask, dec_in = batch(rc, B, T, seed=9)
-    ref_loss, ref_g = train_ref.loss_and_grads(rc, p, px, labels, mask, dec_in)
+    ref_loss, ref_g = train_ref.loss_and_grads(rc, p, px, labels, mask, dec_in, label_smoothing_factor=ls)
     d = model._dev
     pos = torch.arange(T, dtype=torch.int32, device=dev)[None].expand(B, T).contiguous()
     kw = {}
@@ -238,7 +238,7 @@ def test_fp8_train_step_against_fp32_oracle(dev, compact, head, monkeypatch):
         idx, rl = loss_rows(mask.numpy(), labels.numpy())
         kw = dict(rows=(d(idx, torch.int32), len(idx)), row_labels=d(rl, torch.int32))
     loss = model.engine.loss_and_grads(d(px, torch.float32), d(dec_in, torch.int32).reshape(-1), pos.reshape(-1), d(mask, torch.int32),
-                                       d(labels, torch.int32).reshape(-1), B, T, **kw)
+                                       d(labels, torch.int32).reshape(-1), B, T, label_smoothing=ls, **kw)
     torch.cuda.synchronize()
     assert abs(loss.item() - ref_loss.item()) < 3e-2 * abs(ref_loss.item()), (loss.item(), ref_loss.item())
     got = model.store.export_flat("grad")
@@ -255,6 +255,17 @@ def test_fp8_train_step_against_fp32_oracle(dev, compact, head, monkeypatch):
     w8 = model.engine._w8["dec0.fc1"]
     wref, amax, sinv = _quant_ref(model.store.w("dec0.fc1.w").cpu(), torch.float8_e4m3fn)
     assert torch.equal(w8[0].cpu().float(), wref.float()) and torch.equal(w8[1].cpu().float(), wref.float().T) and abs(w8[2][1].item() - sinv) < 1e-9
+    if head != "0":  # ... and so did the tied head: e4m3 copies of E and E^T under the embedding's scale
+        e8 = model.engine._w8["shared"]
+        eref, _, esinv = _quant_ref(model.store.w("shared").cpu(), torch.float8_e4m3fn)
+        assert torch.equal(e8[0].cpu().float(), eref.float()) and torch.equal(e8[1].cpu().float(), eref.float().T) and abs(e8[2][1].item() - esinv) < 1e-9
+
+
+def test_fp8_head_switch_rejects_unknown_values(dev, monkeypatch):
+    rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.0)
+    monkeypatch.setenv("MIC_FP8_HEAD", "fwd")
+    with pytest.raises(ValueError, match="MIC_FP8_HEAD"):
+        model.engine.set_gemm_dtype("fp8")
 
 
 def test_fp8_trainer_learns_and_eval_matches(dev):
