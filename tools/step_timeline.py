@@ -57,6 +57,27 @@ def main():
     print(f"\n# busy ms per {binms:g}-ms bin and kernel class (sum over streams; > bin width = overlap)")
     for b, d in enumerate(bins):
         print(f"{b * binms:7.1f}  " + "  ".join(f"{x}:{y:.2f}" for x, y in sorted(d.items())))
+    # the main stream's idle time: gaps between consecutive kernels of the busiest queue, by size and by the kernel that ends the gap
+    mainq = max(per.items(), key=lambda kv: kv[1][2])[0]
+    ms_ = sorted((s, e, n) for s, e, n, q, st in step if (q, st) == mainq)
+    gaps = [(ms_[i + 1][0] - max(x[1] for x in ms_[: i + 1][-8:]), ms_[i][2], ms_[i + 1][2], ms_[i + 1][0]) for i in range(len(ms_) - 1)]
+    gaps = [g for g in gaps if g[0] > 0]
+    tot = sum(g[0] for g in gaps)
+    print(f"\n# main stream {mainq[0]}/{mainq[1]}: {len(ms_)} kernels, {tot / 1e6:.3f} ms idle between them: "
+          f"{sum(1 for g in gaps if g[0] > 20000)} gaps > 20 us = {sum(g[0] for g in gaps if g[0] > 20000) / 1e6:.3f} ms, "
+          f"{sum(1 for g in gaps if 5000 < g[0] <= 20000)} of 5-20 us = {sum(g[0] for g in gaps if 5000 < g[0] <= 20000) / 1e6:.3f} ms, "
+          f"{sum(1 for g in gaps if g[0] <= 5000)} below 5 us = {sum(g[0] for g in gaps if g[0] <= 5000) / 1e6:.3f} ms")
+    by_next = defaultdict(lambda: [0, 0])
+    for g in gaps:
+        k = re.sub(r"^void ", "", g[2])[:60]
+        by_next[k][0] += 1
+        by_next[k][1] += g[0]
+    print("# idle in front of (kernel that ends the gap): count, total us, mean us")
+    for k, (c, t) in sorted(by_next.items(), key=lambda kv: -kv[1][1])[:14]:
+        print(f"  {c:4d} {t / 1e3:9.1f} {t / 1e3 / c:7.1f}  {k}")
+    print("# the 12 largest gaps: us, at ms, after -> before")
+    for g in sorted(gaps, key=lambda g: -g[0])[:12]:
+        print(f"  {g[0] / 1e3:7.1f}  +{(g[3] - t0) / 1e6:7.3f}  {re.sub(r'^void ', '', g[1])[:44]} -> {re.sub(r'^void ', '', g[2])[:44]}")
     # the tail: everything that starts after the last GEMM of the step's main chain has ended
     last_gemm = max((e for s, e, n, q, st in step if cls(n) == "gemm"), default=t0)
     tail = [(s, e, n) for s, e, n, q, st in step if e > last_gemm]
