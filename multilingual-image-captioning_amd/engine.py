@@ -74,6 +74,7 @@ class Engine:
         self._head_x8 = None
         self._ET_version, self._ET_event = -1, None
         self._dw_events = []
+        self.dw_late_flush = os.environ.get("MIC_DW_LATE_FLUSH", "1") != "0"  # see dw_fence (A/B: 0 = the weight-gradient launch in front of that LayerNorm backward)
         self._dw_side = False  # True while launching on the dW stream
         self._ckv_block_name = None  # set while the all-layer cross k/v weight gradient (one launch) sits in the dW queue
 
@@ -531,10 +532,22 @@ class Engine:
     def _dw_on(self) -> bool:
         return self.dw_overlap
 
-    def flush_dw(self):
+    def dw_fence(self) -> bool:
+        """The wait half of flush_dw(), issued on its own IN FRONT of the layer's last LayerNorm backward: the step's stream waits
+        for the most recent weight-gradient launch (the one that read the parity buffers that LayerNorm backward and the next layer
+        rewrite); the launch half follows behind that kernel (`flush_dw(fence=False)`), so the critical chain's kernel is in its
+        queue before the weight-gradient group is released onto the chip.  False: no second stream — flush_dw() has to come first."""
+        if not (self._dw_on() and self.dw_late_flush):
+            return False
+        if self._dw_events:
+            torch.cuda.current_stream().wait_event(self._dw_events[-1])
+        return True
+
+    def flush_dw(self, fence: bool = True):
         """Launch the layer's queued weight-gradient GEMMs (and bias column sums) as grouped launches — on the dW stream when
         enabled: it waits for everything enqueued so far (the operands' producers), main goes on with the next layer and
-        only waits for the dW launch of TWO layers back (the one that read the buffers the next layer is about to rewrite)."""
+        only waits for the dW launch of TWO layers back (the one that read the buffers the next layer is about to rewrite;
+        fence=False: dw_fence() has issued that wait already)."""
         if not (self._cs_queue or self._dw_queue or self._lnp_queue or (self.fp8 and (self._dw8_queue or self._cs8_queue))):
             return
         side = None
@@ -562,7 +575,8 @@ class Engine:
                 done.record(side)
                 self._dw_events.append(done)
         if side is not None and len(self._dw_events) >= 2:
-            torch.cuda.current_stream().wait_event(self._dw_events[-2])
+            if fence:
+                torch.cuda.current_stream().wait_event(self._dw_events[-2])
             del self._dw_events[:-2]
 
     def dw_join(self):
@@ -690,7 +704,9 @@ class Engine:
                 ops.attn_bwd(qkv, qkv[:, vd:], qkv[:, 2 * vd:], ctx, dctx, lse, dqkv, dqkv[:, vd:], dqkv[:, 2 * vd:], B, H, S, S,
                              ldq=3 * vd, ldk=3 * vd, ldv=3 * vd, ldo=vd, lddo=vd, lddq=3 * vd, lddk=3 * vd, lddv=3 * vd)
                 self.linear_bwd(p + "qkv", a1, dqkv, Mv, dx=da, defer=True, par=l & 1)
-            self.flush_dw()  # before LN1 backward overwrites dx (the fc2 gradient operand)
+            late = self.dw_fence()
+            if not late:
+                self.flush_dw()  # before LN1 backward overwrites dx (the fc2 gradient operand)
             dx = self.dyb("vb.dx", l - 1, Mv, vd)  # the layer below's residual-stream gradient (= its fc2 dW operand)
             # ... which the layer below's fc2 backward reads as e5m2: emitted here, beside the bf16 dx the residual path needs
             dx8t = self.dy8_target(f"vit{l - 1}.fc2", (l - 1) & 1, Mv) if l > 0 else None
@@ -700,6 +716,8 @@ class Engine:
             else:
                 self.ln_bwd("v1", l, x_in, p + "ln1", st1[0], st1[1], da, dx, Mv, dres=dxm)
                 dx8 = None
+            if late:
+                self.flush_dw(fence=False)
         emb = self.buf("v.emb", Mv, vd)
         st = self.buf("v.pre.stats", 2, _rup(Mv, ROWPAD), torch.float32)
         demb = self.buf("vb.demb", Mv, vd)
@@ -1035,7 +1053,9 @@ class Engine:
                     ops.attn_bwd(qkv, qkv[:, d:], qkv[:, 2 * d:], ctx, dctx, lse, dqkv, dqkv[:, d:], dqkv[:, 2 * d:], B, H, T, T, ldq=3 * d,
                                  ldk=3 * d, ldv=3 * d, ldo=d, lddo=d, lddq=3 * d, lddk=3 * d, lddv=3 * d, key_mask=key_mask, causal=True)
                 self.linear_bwd(p + "qkv", a_sa, dqkv, M, dx=da, defer=True, par=l & 1)
-            self.flush_dw()  # the layer's 7 weight-gradient GEMMs as one grouped launch (before dxm_a is rewritten)
+            late = self.dw_fence()
+            if not late:
+                self.flush_dw()  # the layer's 7 weight-gradient GEMMs as one grouped launch (before dxm_a is rewritten)
             if l > 0:
                 dxm8t = self.dy8_target(f"dec{l - 1}.fc2", (l - 1) & 1, Mcap)
                 dxm = self.dyb("db.dxm_a", l - 1, Mcap, d) if dxm8t is None else None
@@ -1044,6 +1064,8 @@ class Engine:
                 dxm8 = None if dxm8t is None else (dxm8t[0], dxm8t[1])
             else:
                 self.ln_bwd("sa", l, x_in, p + "ln_sa", stats[0], stats[1], da, dx, M, dres=dx1)
+            if late:
+                self.flush_dw(fence=False)
         if hoist:
             # the cross-attention k/v projections of all layers at once: dW (+ bias row sums) = dkv^T ehs as one [L*2d][d] weight
             # gradient (on the dW stream), dehs = dkv W as one contraction over K = L*2d (split over K into fp32 slabs: 52 output
