@@ -104,7 +104,8 @@ typedef struct {
   int a_fmt, b_fmt;                 /* MIC_E4M3 / MIC_E5M2 (B must be e4m3) */
   const float* a_scale_inv;         /* device scalar or NULL (= 1) */
   const float* b_scale_inv;
-  /* optional by-product of the LM-head GEMM (bf16, bias-only epilogue, N % 64 == 0): rowstat[(m * rowstat_ld + g) * 2 + {0, 1}]
+  /* optional by-product of the LM-head GEMM (bf16 operands, or fp8 NT operands — the fp8 head of configs[4] —; bf16 C, bias-only
+   * epilogue, N % 64 == 0): rowstat[(m * rowstat_ld + g) * 2 + {0, 1}]
    * = max and sum exp(x - max) over the columns [64 g, 64 g + 64) & [0, rowstat_nvalid) of output row m, taken on the values as
    * stored in C.  With them the log-softmax of main.py:672-675 / gen:850 needs no second pass over the [rows][250 054]
    * logits: mic_ce_rows_tiles and mic_row_topk_tiles merge the N / 64 partials of a row. */
