@@ -74,6 +74,9 @@ class Engine:
         self._head_x8 = None
         self._ET_version, self._ET_event = -1, None
         self._dw_events = []
+        # weight-gradient launches behind every n-th layer: 2 in fp8 mode (its two GEMM streams alternate rather than overlap — half as
+        # many hand-overs: 14.87 -> 14.75 ms), 1 in bf16 (2 measured level); MIC_DW_EVERY=<n> forces a value (A/B)
+        self.dw_every = int(os.environ.get("MIC_DW_EVERY", "0"))
         self.dw_late_flush = os.environ.get("MIC_DW_LATE_FLUSH", "1") != "0"  # see dw_fence (A/B: 0 = the weight-gradient launch in front of that LayerNorm backward)
         self._dw_side = False  # True while launching on the dW stream
         self._ckv_block_name = None  # set while the all-layer cross k/v weight gradient (one launch) sits in the dW queue
@@ -514,7 +517,7 @@ class Engine:
     def dyb(self, name: str, l: int, rows: int, cols: int) -> torch.Tensor:
         """gradient buffer that a queued weight-gradient GEMM reads: one per layer parity when dW runs on its own stream (the
         next layer's backward rewrites the other one), a single buffer otherwise"""
-        return self.buf(f"{name}.{l & 1}" if self._dw_on() else name, rows, cols)
+        return self.buf(f"{name}.{self._par(l)}" if self._dw_on() else name, rows, cols)
 
     def ln_bwd(self, tag: str, l: int, x, ln: str, mean, rstd, dy, dx, rows: int, **kw):
         """LayerNorm backward of the LayerNorm named `ln` (parameters ln + ".g" / ".b"): dx (and the kwargs' by-products) now, the
@@ -524,13 +527,27 @@ class Engine:
         if not self.ln_partials:
             return ops.layernorm_bwd(x, P.f32(ln + ".g"), mean, rstd, dy, dx, P.g(ln + ".g"), P.g(ln + ".b"), rows=rows, **kw)
         width = x.shape[-1]
-        part = self.buf(f"lnp.{tag}.{l & 1}", 2 * ops.layernorm_bwd_blocks(1 << 30), width, torch.float32)  # [2][blocks <= cap][width]
+        part = self.buf(f"lnp.{tag}.{self._par(l)}", 2 * ops.layernorm_bwd_blocks(1 << 30), width, torch.float32)  # [2][blocks <= cap][width]
         ops.layernorm_bwd_partials(x, P.f32(ln + ".g"), mean, rstd, dy, dx, part, rows=rows, **kw)  # (kw may carry q8 / q8_of_dx: fused fp8 emission)
         self._lnp_queue.append((part, ops.layernorm_bwd_blocks(rows), width, P.g(ln + ".g"), P.g(ln + ".b"), False))
         return dx
 
     def _dw_on(self) -> bool:
         return self.dw_overlap
+
+    def _par(self, l: int) -> int:
+        """index of layer l's copy of a gradient buffer that a queued weight-gradient launch reads: 2 x dw_every copies in turn"""
+        return l % (2 * self._dw_every_now())
+
+    def _dw_every_now(self) -> int:
+        if not self._dw_on():
+            return 1  # no second stream: single buffers, the launches go out in front of every layer's last LayerNorm backward
+        return self.dw_every if self.dw_every > 0 else (2 if self.fp8 else 1)
+
+    def _dw_flush_layer(self, l: int) -> bool:
+        """weight-gradient launches go out behind every `dw_every`-th layer (and behind layer 0): with 2 x dw_every buffer copies the
+        launch that read a copy is the one before the latest when that copy is rewritten, exactly as with one launch per layer"""
+        return l % self._dw_every_now() == 0
 
     def dw_fence(self) -> bool:
         """The wait half of flush_dw(), issued on its own IN FRONT of the layer's last LayerNorm backward: the step's stream waits
@@ -684,39 +701,40 @@ class Engine:
             st1, st2 = self.buf(tag + "st1", 2, _rup(Mv, ROWPAD), torch.float32), self.buf(tag + "st2", 2, _rup(Mv, ROWPAD), torch.float32)
             lse = self.vec(tag + "lse", B * H * S)
             x_in = self.buf(f"v{l - 1}.xo", Mv, vd) if l > 0 else self.buf("v.x0", Mv, vd)
-            dz8t = self.dy8_target(p + "fc1", l & 1, Mv)  # dz = dGELU-scaled dX of fc2 = the dy of fc1: e5m2 straight from the epilogue
+            dz8t = self.dy8_target(p + "fc1", self._par(l), Mv)  # dz = dGELU-scaled dX of fc2 = the dy of fc1: e5m2 straight from the epilogue
             dz = self.dyb("vb.dz", l, Mv, vf) if dz8t is None else None
-            self.linear_bwd(p + "fc2", u, dx, Mv, dx=dz, zin=z, dact=L.ACT_QUICK_GELU, defer=True, dy8=dx8, dx8=dz8t, par=l & 1)
+            self.linear_bwd(p + "fc2", u, dx, Mv, dx=dz, zin=z, dact=L.ACT_QUICK_GELU, defer=True, dy8=dx8, dx8=dz8t, par=self._par(l))
             da = self.buf("vb.da", Mv, vd)
-            self.linear_bwd(p + "fc1", a2, dz, Mv, dx=da, defer=True, dy8=None if dz8t is None else (dz8t[0], dz8t[1]), par=l & 1)
+            self.linear_bwd(p + "fc1", a2, dz, Mv, dx=da, defer=True, dy8=None if dz8t is None else (dz8t[0], dz8t[1]), par=self._par(l))
             dxm = self.dyb("vb.dxm", l, Mv, vd)
             self.ln_bwd("v2", l, xm, p + "ln2", st2[0], st2[1], da, dxm, Mv, dres=dx)
             dctx = self.buf("vb.dctx", Mv, vd)
             self.linear_bwd(p + "o", ctx, dxm, Mv, dx=dctx, defer=True)
-            dq8t = self.dy8_target(p + "qkv", l & 1, Mv) if S <= 64 else None
+            dq8t = self.dy8_target(p + "qkv", self._par(l), Mv) if S <= 64 else None
             if dq8t is not None:
                 q8 = dq8t[0]
                 ops.attn_bwd_q8(qkv, qkv[:, vd:], qkv[:, 2 * vd:], ctx, dctx, lse, dq8t[2], ops.fp8_out(q8[:, vd:], dq8t[1], dq8t[3][1]), q8[:, 2 * vd:],
                                 B, H, S, S, ldq=3 * vd, ldk=3 * vd, ldv=3 * vd, ldo=vd, lddo=vd)
-                self.linear_bwd(p + "qkv", a1, None, Mv, dx=da, defer=True, dy8=(dq8t[0], dq8t[1]), par=l & 1)
+                self.linear_bwd(p + "qkv", a1, None, Mv, dx=da, defer=True, dy8=(dq8t[0], dq8t[1]), par=self._par(l))
             else:
                 dqkv = self.dyb("vb.dqkv", l, Mv, 3 * vd)
                 ops.attn_bwd(qkv, qkv[:, vd:], qkv[:, 2 * vd:], ctx, dctx, lse, dqkv, dqkv[:, vd:], dqkv[:, 2 * vd:], B, H, S, S,
                              ldq=3 * vd, ldk=3 * vd, ldv=3 * vd, ldo=vd, lddo=vd, lddq=3 * vd, lddk=3 * vd, lddv=3 * vd)
-                self.linear_bwd(p + "qkv", a1, dqkv, Mv, dx=da, defer=True, par=l & 1)
-            late = self.dw_fence()
-            if not late:
+                self.linear_bwd(p + "qkv", a1, dqkv, Mv, dx=da, defer=True, par=self._par(l))
+            flush_now = self._dw_flush_layer(l)
+            late = self.dw_fence() if flush_now else False
+            if flush_now and not late:
                 self.flush_dw()  # before LN1 backward overwrites dx (the fc2 gradient operand)
             dx = self.dyb("vb.dx", l - 1, Mv, vd)  # the layer below's residual-stream gradient (= its fc2 dW operand)
             # ... which the layer below's fc2 backward reads as e5m2: emitted here, beside the bf16 dx the residual path needs
-            dx8t = self.dy8_target(f"vit{l - 1}.fc2", (l - 1) & 1, Mv) if l > 0 else None
+            dx8t = self.dy8_target(f"vit{l - 1}.fc2", self._par(l - 1), Mv) if l > 0 else None
             if dx8t is not None:
                 self.ln_bwd("v1", l, x_in, p + "ln1", st1[0], st1[1], da, dx, Mv, dres=dxm, q8=dx8t[2], q8_of_dx=True)
                 dx8 = (dx8t[0], dx8t[1])
             else:
                 self.ln_bwd("v1", l, x_in, p + "ln1", st1[0], st1[1], da, dx, Mv, dres=dxm)
                 dx8 = None
-            if late:
+            if flush_now and late:
                 self.flush_dw(fence=False)
         emb = self.buf("v.emb", Mv, vd)
         st = self.buf("v.pre.stats", 2, _rup(Mv, ROWPAD), torch.float32)
@@ -962,7 +980,7 @@ class Engine:
         x_last = self.buf(f"d{P.L - 1}.x3", Mcap, d)
         # dxm: the dropout-masked residual-stream gradient = the dy of the top layer's FFN-out projection, its only reader: with a
         # scale history it leaves the LayerNorm backward as e5m2 bytes only
-        dxm8t = self.dy8_target(f"dec{P.L - 1}.fc2", (P.L - 1) & 1, Mcap)
+        dxm8t = self.dy8_target(f"dec{P.L - 1}.fc2", self._par(P.L - 1), Mcap)
         dxm = self.dyb("db.dxm_a", P.L - 1, Mcap, d) if dxm8t is None else None
         self.ln_bwd("f", 0, x_last, "dec.ln_f", stf[0], stf[1], dhf, dx, M, dxm=dxm, dropout_p=pd, dropout_seed=sd(12 + 3 * (P.L - 1)),
                     **({} if dxm8t is None else dict(q8=dxm8t[2])))
@@ -990,11 +1008,11 @@ class Engine:
             x_in = self.buf(f"d{l - 1}.x3", Mcap, d) if l > 0 else self.buf("d.x0", Mcap, d)
             # --- FFN branch: x3 = x2 + drop(fc2(gelu(fc1(LN(x2)))));  dxm = dropout-masked dx3
             dxm_b, dxm_c = self.dyb("db.dxm_b", l, Mcap, d), self.dyb("db.dxm_c", l, Mcap, d)
-            dz8t = self.dy8_target(p + "fc1", l & 1, Mcap)
+            dz8t = self.dy8_target(p + "fc1", self._par(l), Mcap)
             dz = self.dyb("db.dz", l, Mcap, f) if dz8t is None else None
-            self.linear_bwd(p + "fc2", u, dxm, M, dx=dz, zin=z, dact=self.gelu, defer=True, dy8=dxm8, dx8=dz8t, par=l & 1)
+            self.linear_bwd(p + "fc2", u, dxm, M, dx=dz, zin=z, dact=self.gelu, defer=True, dy8=dxm8, dx8=dz8t, par=self._par(l))
             da = self.buf("db.da", Mcap, d)
-            self.linear_bwd(p + "fc1", a_ff, dz, M, dx=da, defer=True, dy8=None if dz8t is None else (dz8t[0], dz8t[1]), par=l & 1)
+            self.linear_bwd(p + "fc1", a_ff, dz, M, dx=da, defer=True, dy8=None if dz8t is None else (dz8t[0], dz8t[1]), par=self._par(l))
             dx2 = self.buf("db.dx2", Mcap, d)
             self.ln_bwd("ff", l, x2, p + "ln_ff", stats[4], stats[5], da, dx2, M,
                         dres=dx, dxm=dxm_b, dropout_p=pd, dropout_seed=sd(11 + 3 * l))
@@ -1002,19 +1020,19 @@ class Engine:
             dctx = self.buf("db.dctx", Mcap, d)
             self.linear_bwd(p + "co", cctx, dxm_b, M, dx=dctx, defer=True)
             one_tile = T <= 64 and S <= 64
-            dq8t = self.dy8_target(p + "cq", l & 1, Mcap) if one_tile else None
+            dq8t = self.dy8_target(p + "cq", self._par(l), Mcap) if one_tile else None
             if hoist:
                 kv8 = None if dkvcat8t is None else dkvcat8t[0][:, l * 2 * d:]
                 dkv8t = None if kv8 is None else (kv8, dkvcat8t[1], ops.fp8_out(kv8, dkvcat8t[1], dkvcat8t[3][1]))
             else:
-                dkv8t = self.dy8_target(p + "ckv", l & 1, Mv) if one_tile else None
+                dkv8t = self.dy8_target(p + "ckv", self._par(l), Mv) if one_tile else None
             if dq8t is not None and dkv8t is not None:
                 # dQ [rows][d] and dK | dV [encoder rows][2d] as e5m2 bytes under their own scales, straight out of the attention backward
                 ops.attn_bwd_q8(cq, ckv, ckv[:, d:], cctx, dctx, clse, dq8t[2], dkv8t[2], dkv8t[0][:, d:], B, H, T, S, ldq=d, ldk=ldkv, ldv=ldkv,
                                 ldo=d, lddo=d, q_off=pack[0] if pack is not None else None, q_len=pack[1] if pack is not None else None, kv_packed=False)
-                self.linear_bwd(p + "cq", a_ca, None, M, dx=da, defer=True, dy8=(dq8t[0], dq8t[1]), par=l & 1)
+                self.linear_bwd(p + "cq", a_ca, None, M, dx=da, defer=True, dy8=(dq8t[0], dq8t[1]), par=self._par(l))
                 if not hoist:
-                    self.linear_bwd(p + "ckv", ehs, None, Mv, dx=dehs, dx_accumulate=(l != P.L - 1), defer=True, dy8=(dkv8t[0], dkv8t[1]), par=l & 1)
+                    self.linear_bwd(p + "ckv", ehs, None, Mv, dx=dehs, dx_accumulate=(l != P.L - 1), defer=True, dy8=(dkv8t[0], dkv8t[1]), par=self._par(l))
             elif hoist and dkvcat8t is not None:
                 # (dQ has no scale history yet but the concatenated k/v gradient has: cannot happen after the first pass; keep the bytes consistent)
                 raise RuntimeError("fp8: cross-attention dQ without a scale history beside a hoisted k/v gradient with one")
@@ -1027,22 +1045,22 @@ class Engine:
                 else:
                     ops.attn_bwd(cq, ckv, ckv[:, d:], cctx, dctx, clse, dq, dkv, dkv[:, d:], B, H, T, S, ldq=d, ldk=ldkv, ldv=ldkv, ldo=d,
                                  lddo=d, lddq=d, lddk=ldkv, lddv=ldkv)
-                self.linear_bwd(p + "cq", a_ca, dq, M, dx=da, defer=True, par=l & 1)
+                self.linear_bwd(p + "cq", a_ca, dq, M, dx=da, defer=True, par=self._par(l))
                 if not hoist:
-                    self.linear_bwd(p + "ckv", ehs, dkv, Mv, dx=dehs, dx_accumulate=(l != P.L - 1), defer=True, par=l & 1)
+                    self.linear_bwd(p + "ckv", ehs, dkv, Mv, dx=dehs, dx_accumulate=(l != P.L - 1), defer=True, par=self._par(l))
             dx1 = self.buf("db.dx1", Mcap, d)
             self.ln_bwd("ca", l, x1, p + "ln_ca", stats[2], stats[3], da, dx1, M,
                         dres=dx2, dxm=dxm_c, dropout_p=pd, dropout_seed=sd(10 + 3 * l))
             # --- self-attention branch
             self.linear_bwd(p + "so", ctx, dxm_c, M, dx=dctx, defer=True)
-            dqkv8t = self.dy8_target(p + "qkv", l & 1, Mcap) if T <= 64 else None
+            dqkv8t = self.dy8_target(p + "qkv", self._par(l), Mcap) if T <= 64 else None
             if dqkv8t is not None:
                 q8 = dqkv8t[0]
                 ops.attn_bwd_q8(qkv, qkv[:, d:], qkv[:, 2 * d:], ctx, dctx, lse, dqkv8t[2], ops.fp8_out(q8[:, d:], dqkv8t[1], dqkv8t[3][1]), q8[:, 2 * d:],
                                 B, H, T, T, ldq=3 * d, ldk=3 * d, ldv=3 * d, ldo=d, lddo=d, q_off=pack[0] if pack is not None else None,
                                 q_len=pack[1] if pack is not None else None, kv_packed=pack is not None,
                                 key_mask=key_mask if pack is None else None, causal=True)
-                self.linear_bwd(p + "qkv", a_sa, None, M, dx=da, defer=True, dy8=(dqkv8t[0], dqkv8t[1]), par=l & 1)
+                self.linear_bwd(p + "qkv", a_sa, None, M, dx=da, defer=True, dy8=(dqkv8t[0], dqkv8t[1]), par=self._par(l))
             else:
                 dqkv = self.dyb("db.dqkv", l, Mcap, 3 * d)
                 if pack is not None:
@@ -1052,19 +1070,20 @@ class Engine:
                 else:
                     ops.attn_bwd(qkv, qkv[:, d:], qkv[:, 2 * d:], ctx, dctx, lse, dqkv, dqkv[:, d:], dqkv[:, 2 * d:], B, H, T, T, ldq=3 * d,
                                  ldk=3 * d, ldv=3 * d, ldo=d, lddo=d, lddq=3 * d, lddk=3 * d, lddv=3 * d, key_mask=key_mask, causal=True)
-                self.linear_bwd(p + "qkv", a_sa, dqkv, M, dx=da, defer=True, par=l & 1)
-            late = self.dw_fence()
-            if not late:
+                self.linear_bwd(p + "qkv", a_sa, dqkv, M, dx=da, defer=True, par=self._par(l))
+            flush_now = self._dw_flush_layer(l)
+            late = self.dw_fence() if flush_now else False
+            if flush_now and not late:
                 self.flush_dw()  # the layer's 7 weight-gradient GEMMs as one grouped launch (before dxm_a is rewritten)
             if l > 0:
-                dxm8t = self.dy8_target(f"dec{l - 1}.fc2", (l - 1) & 1, Mcap)
+                dxm8t = self.dy8_target(f"dec{l - 1}.fc2", self._par(l - 1), Mcap)
                 dxm = self.dyb("db.dxm_a", l - 1, Mcap, d) if dxm8t is None else None
                 self.ln_bwd("sa", l, x_in, p + "ln_sa", stats[0], stats[1], da, dx, M, dres=dx1, dxm=dxm, dropout_p=pd,
                             dropout_seed=sd(12 + 3 * (l - 1)), **({} if dxm8t is None else dict(q8=dxm8t[2])))
                 dxm8 = None if dxm8t is None else (dxm8t[0], dxm8t[1])
             else:
                 self.ln_bwd("sa", l, x_in, p + "ln_sa", stats[0], stats[1], da, dx, M, dres=dx1)
-            if late:
+            if flush_now and late:
                 self.flush_dw(fence=False)
         if hoist:
             # the cross-attention k/v projections of all layers at once: dW (+ bias row sums) = dkv^T ehs as one [L*2d][d] weight
