@@ -380,6 +380,41 @@ def test_weight_gradient_stream_gives_the_same_gradients(dev, dtype):
         assert (ga - gb).abs().max().item() <= 1e-5 * scale, ((ga - gb).abs().max().item(), scale)
 
 
+@pytest.mark.parametrize("gemm", ["bf16", "fp8"])
+def test_weight_gradient_launch_interval_gives_the_same_gradients(dev, gemm):
+    """The weight-gradient launches go out behind every n-th layer (`Engine.dw_every`: 2 by default in fp8 mode, 1 in bf16) with 2 n
+    copies of the gradient buffers they read, the launch in front of or behind the layer's last LayerNorm backward (`dw_late_flush`).
+    Neither may change a gradient: four back-to-back steps (the buffers are reused, the scale histories of fp8 settle) per setting,
+    equal up to the summation order of the fp32 atomics."""
+    res = {}
+    for every, late in ((1, True), (2, True), (3, True), (2, False), (1, False)):
+        rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6, d_layers=5, v_layers=4, **(
+            dict(d_model=256, d_ffn=512, d_heads=4, v_hidden=256, v_ffn=512, v_heads=4) if gemm == "fp8" else {}))
+        eng = model.engine
+        if gemm == "fp8":
+            eng.set_gemm_dtype("fp8")
+        eng.dw_every, eng.dw_late_flush = every, late
+        assert eng._dw_every_now() == every and eng._par(7) == 7 % (2 * every)
+        B, T = 4, 12
+        d = lambda x, t: model._dev(x, t)
+        pos = torch.arange(T, dtype=torch.int32, device=dev)[None].expand(B, T).contiguous()
+        outs = []
+        for step in range(4):
+            px, labels, mask, dec_in = batch(rc, B, T, seed=70 + step)
+            loss = eng.loss_and_grads(d(px, torch.float32), d(dec_in, torch.int32).reshape(-1), pos.reshape(-1), d(mask, torch.int32),
+                                      d(labels, torch.int32).reshape(-1), B, T, seed=300 + step)
+            outs.append((loss, model.store.grad.clone()))
+        torch.cuda.synchronize()
+        res[(every, late)] = [(l.item(), g.cpu()) for l, g in outs]
+        assert not eng._dw_events
+    ref = res[(1, True)]
+    for key, got in res.items():
+        for (la, ga), (lb, gb) in zip(got, ref):
+            assert abs(la - lb) <= 1e-6 * abs(lb), key
+            scale = gb.abs().max().item()
+            assert (ga - gb).abs().max().item() <= 2e-5 * scale, (key, (ga - gb).abs().max().item(), scale)
+
+
 # ---------------------------------------------------------------- packed decoder rows (Trainer(pack_rows=True), the default in bf16)
 def test_packed_decoder_rows_change_nothing(dev):
     """The decoder on the valid caption positions only (packed rows) against the padded [B*T] rows: padded positions carry no loss
