@@ -415,6 +415,50 @@ def test_weight_gradient_launch_interval_gives_the_same_gradients(dev, gemm):
             assert (ga - gb).abs().max().item() <= 2e-5 * scale, (key, (ga - gb).abs().max().item(), scale)
 
 
+@pytest.mark.parametrize("gemm,every,late", [("bf16", 1, True), ("bf16", 2, True), ("fp8", 2, True), ("fp8", 1, False), ("bf16", 3, False)])
+def test_weight_gradient_buffers_are_fenced_against_a_stream_that_lags(dev, gemm, every, late):
+    """The gradient buffers a queued weight-gradient launch reads are rewritten 2 n layers later; what keeps that safe is the fence in
+    front of the layer's last LayerNorm backward, not the weight-gradient stream being quick.  Here that stream is made SLOW: every one of
+    its launches waits 500 us behind a spin kernel, so the step's stream runs layers ahead of it wherever a fence lets it — the
+    gradients must still equal those of the run without a second stream.  (Negative control, run once on the GPU: with the wait
+    of `Engine.dw_fence` removed this test fails in the bf16 n = 1, bf16 n = 2 and fp8 n = 2 settings.)"""
+    from mic_amd import ops
+
+    def run(slow):
+        rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6, d_layers=8, v_layers=7, **(
+            dict(d_model=256, d_ffn=512, d_heads=4, v_hidden=256, v_ffn=512, v_heads=4) if gemm == "fp8" else {}))
+        eng = model.engine
+        if gemm == "fp8":
+            eng.set_gemm_dtype("fp8")
+        if slow:
+            eng.dw_every, eng.dw_late_flush = every, late
+            a, b = torch.zeros(1 << 18, device=dev), torch.zeros(1 << 18, device=dev)
+            launches = eng._flush_dw_launches
+
+            def lagging():
+                ops.comm_emulate(a, b, 1 << 20, 500.0, 8)  # (on the weight-gradient stream: flush_dw pins it)
+                launches()
+            eng._flush_dw_launches = lagging
+        else:
+            eng.dw_overlap = False
+        B, T = 4, 12
+        d = lambda x, t: model._dev(x, t)
+        pos = torch.arange(T, dtype=torch.int32, device=dev)[None].expand(B, T).contiguous()
+        outs = []
+        for step in range(4):
+            px, labels, mask, dec_in = batch(rc, B, T, seed=80 + step)
+            loss = eng.loss_and_grads(d(px, torch.float32), d(dec_in, torch.int32).reshape(-1), pos.reshape(-1), d(mask, torch.int32),
+                                      d(labels, torch.int32).reshape(-1), B, T, seed=500 + step)
+            outs.append((loss, model.store.grad.clone()))
+        torch.cuda.synchronize()
+        return [(l.item(), g.cpu()) for l, g in outs]
+
+    for (la, ga), (lb, gb) in zip(run(True), run(False)):
+        assert abs(la - lb) <= 1e-6 * abs(lb)
+        scale = gb.abs().max().item()
+        assert (ga - gb).abs().max().item() <= 2e-5 * scale, ((ga - gb).abs().max().item(), scale)
+
+
 # ---------------------------------------------------------------- packed decoder rows (Trainer(pack_rows=True), the default in bf16)
 def test_packed_decoder_rows_change_nothing(dev):
     """The decoder on the valid caption positions only (packed rows) against the padded [B*T] rows: padded positions carry no loss
