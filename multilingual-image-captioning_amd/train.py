@@ -448,6 +448,11 @@ class GradReducer:
             self._at_end = []
         cur.wait_stream(self.stream)
         cur.wait_stream(self.opt_stream)
+        if self.tail_stream is not None and self.tail_stream is not self.opt_stream:
+            # the optimizer passes of the buckets finish() released ran on the tail stream (`_issue`): without this join the next forward
+            # pass could read weights those passes were still writing whenever nothing else had been queued there (found by making a side
+            # stream lag: tests/test_fp8_gpu.py::test_fp8_weight_copies_made_on_a_lagging_side_stream_are_waited_for)
+            cur.wait_stream(self.tail_stream)
 
 
 OPT_CUS_DEFAULT = 96  # CUs of the optimizer stream (12 per XCD of an MI355X): profiles/README.md, round 3 A/B

@@ -314,6 +314,37 @@ def test_fp8_weights_requantised_behind_the_optimizer_give_the_same_steps(dev, o
     assert max(abs(a - b) for a, b in zip(losses[0], losses[2])) < 2e-4 * abs(losses[0][0]), losses
 
 
+def test_fp8_weight_copies_made_on_a_lagging_side_stream_are_waited_for(dev):
+    """The next step's fp8 weight copies (and the two e4m3 copies of the tied embedding the fp8 head reads) are made on the aux stream
+    behind the optimizer; every fp8 GEMM that reads one waits for that stream's event.  Here the aux stream is made slow (a 2-ms spin
+    kernel in front of each refresh): the losses must equal those of a trainer that re-quantises on the step's own stream."""
+    from mic_amd import Trainer, create_learning_rate_fn, ops
+
+    losses = []
+    for lag in (True, False):
+        rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.1, d_model=256, d_ffn=512, d_heads=4,
+                                 v_hidden=256, v_ffn=512, v_heads=4)
+        tr = Trainer(model, create_learning_rate_fn(64, 2, 4, 2, 2e-3), gemm_dtype="fp8")
+        eng = model.engine
+        assert eng.fp8_head == 2 and "shared" in eng._w8
+        if lag:
+            a, b = torch.zeros(1 << 18, device=dev), torch.zeros(1 << 18, device=dev)
+            refresh = eng.fp8_refresh_weights
+
+            def lagging(side, upto=None, wait_event=None):
+                with torch.cuda.stream(side):
+                    with ops.pinned_stream():
+                        ops.comm_emulate(a, b, 1 << 20, 2000.0, 8)
+                return refresh(side, upto=upto, wait_event=wait_event)
+            eng.fp8_refresh_weights = lagging
+        else:
+            eng._w8_async = False
+        px, labels, mask, dec_in = batch(rc, 3, 12, seed=9)
+        bt = {"pixel_values": px.numpy(), "input_ids": labels.numpy(), "attention_mask": mask.numpy(), "decoder_input_ids": dec_in.numpy()}
+        losses.append([float(tr.train_step(bt)["loss"]) for _ in range(5)])
+    assert max(abs(x - y) for x, y in zip(*losses)) < 2e-4 * abs(losses[1][0]), losses
+
+
 def test_fp8_trainer_inference_entry_points_stay_in_the_storage_dtype(dev):
     """`encode` / `decode` / `generate` beside an fp8 trainer run bf16 GEMMs: identical to a bf16 engine holding the same weights,
     (i) directly after Trainer construction, when no pass has quantised the fp8 weight copies yet, and (ii) directly after a
