@@ -118,7 +118,7 @@ def test_two_rank_bf16_gradient_exchange(dev):
     assert all(r[1] for r in res), res
 
 
-def _fp8_worker(rank, world, port, q):
+def _fp8_worker(rank, world, port, q, lag=None):
     """configs[4] data parallel in small: two ranks, fp8 GEMMs with fused emission (from the second step on), five steps on per-rank
     batches: every rank sees the same pmean loss and ends with BIT-IDENTICAL fp32 master weights (the all-reduce and the deterministic
     embedding-row scatter are rank-symmetric: with an atomic scatter the replicas' embeddings drifted by 2.8e-9 in five steps), the
@@ -140,7 +140,21 @@ def _fp8_worker(rank, world, port, q):
         assert model.engine.fp8 and model.engine.fp8_fused and len(tr.buckets) > 3
         px, labels, mask, dec_in = batch(rc, 3, 12, seed=700 + rank)
         b = {"pixel_values": px.numpy(), "input_ids": labels.numpy(), "attention_mask": mask.numpy(), "decoder_input_ids": dec_in.numpy()}
-        losses = [float(tr.train_step(b)["loss"]) for _ in range(5)]
+        losses = []
+        side = None
+        if lag is not None and rank == 1:  # ONE rank's side stream is slow (a 20-ms spin kernel in front of every step's work on it)
+            from mic_amd import ops
+
+            r = tr.reducer
+            side = {"collective": r.stream, "tail": r.tail_stream or r.opt_stream, "optimizer": r.opt_stream,
+                    "dw": ops.role_stream(dev, "dw"), "aux": ops.role_stream(dev, "aux")}[lag]
+            sa, sb = torch.zeros(1 << 18, device=dev), torch.zeros(1 << 18, device=dev)
+        for _ in range(5):
+            if side is not None:
+                with torch.cuda.stream(side):
+                    ops.comm_emulate(sa, sb, 1 << 20, 20000.0, 8)
+            losses.append(tr.train_step(b)["loss"])
+        losses = [float(x) for x in losses]
         torch.cuda.synchronize()
         w = model.store.master.clone()
         ws = [torch.empty_like(w) for _ in range(world)]
@@ -164,6 +178,25 @@ def test_two_rank_fp8_train_steps(dev):
     q = ctx.Queue()
     port = 29900 + (os.getpid() % 2000)
     procs = [ctx.Process(target=_fp8_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for pr in procs:
+        pr.join(timeout=60)
+    assert all(r[1] for r in res), res
+
+
+@pytest.mark.parametrize("lag", ["collective", "tail", "optimizer", "dw", "aux"])
+def test_two_rank_fp8_replicas_stay_identical_when_one_ranks_side_stream_lags(dev, lag):
+    """the same five data-parallel fp8 steps with ONE rank's collective / tail / optimizer / weight-gradient / aux stream delayed by a
+    20-ms spin kernel per step: a hand-over somebody does not wait for would let that rank read or write something early and the
+    replicas' master weights would differ"""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_fp8_worker, args=(r, 2, port, q, lag)) for r in range(2)]
     for pr in procs:
         pr.start()
     res = sorted(q.get(timeout=300) for _ in range(2))
