@@ -84,7 +84,7 @@ class Engine:
     # ------------------------------------------------------------------ fp8 GEMM operands (BASELINE configs[4])
     FP8_KINDS = ("qkv", "cq", "ckv", "fc1", "fc2")  # the QKV and FFN projections of both towers; out-projections and the head stay bf16
 
-    def set_gemm_dtype(self, name, scaling: str = "delayed"):
+    def set_gemm_dtype(self, name, scaling: str = "delayed", head: Optional[str] = None):
         """"fp8": the QKV / FFN projections run as OCP fp8 GEMMs — e4m3 activations and weights, e5m2 gradients, one scale per
         tensor, fp32 accumulate (forward, dX and dW).  None / "bf16": the storage dtype.
         scaling="current": every activation / gradient tensor is scaled by its own absolute maximum (two passes over the
@@ -97,7 +97,9 @@ class Engine:
         weights that arrive any other way (params setter, checkpoint restore) start again from their current amax.
         Under delayed scaling a tensor WITH a scale history is not quantised by a launch of its own: its producer (LayerNorm forward /
         backward, the GELU / dGELU epilogue of the fp8 GEMM, attention backward) writes the fp8 bytes (`_q8_target`, `fp8_fused`);
-        the weight copies of the next pass are made on a side stream behind the optimizer (`fp8_refresh_weights`)."""
+        the weight copies of the next pass are made on a side stream behind the optimizer (`fp8_refresh_weights`).
+        head = "all" | "bwd" | "0" (default: MIC_FP8_HEAD, else "all"): the tied LM head's three GEMMs / its two backward GEMMs / none
+        of them on fp8 operands (see below)."""
         if name in (None, "bf16", "bfloat16", "f32", "float32"):
             self.fp8 = False
             return
@@ -121,9 +123,9 @@ class Engine:
         # in-place gradient, no transposed copy), the e4m3 copies of E / E^T (re-made with the other weights) and the e4m3 final hidden
         # states; forward ("all"): the logits from the e4m3 operands, softmax partials as in bf16.  "bwd": forward stays bf16; "0": the
         # head as in the bf16 mode.  Needs the reduction dimensions (d, Vpad) in whole 128-byte fragments.
-        mode = _os.environ.get("MIC_FP8_HEAD", "all")
+        mode = head if head is not None else _os.environ.get("MIC_FP8_HEAD", "all")
         if mode not in ("0", "bwd", "all"):
-            raise ValueError(f"MIC_FP8_HEAD={mode!r}: 0 | bwd | all")
+            raise ValueError(f"MIC_FP8_HEAD / head={mode!r}: 0 | bwd | all")
         self.fp8_head = {"0": 0, "bwd": 1, "all": 2}[mode] if (P.d % 128 == 0 and P.Vpad % 128 == 0) else 0
         if self.fp8_head:
             names.append("shared")

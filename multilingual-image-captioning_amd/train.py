@@ -464,7 +464,8 @@ class Trainer:
     def __init__(self, model, learning_rate_fn: Callable[[int], float], b1=0.9, b2=0.999, eps=1e-8, weight_decay=0.0,
                  label_smoothing_factor=0.0, seed: int = 42, bucket_mb: float = 64.0, group=None, compact_head: bool = True,
                  overlap_optimizer: bool = True, grad_comm_dtype=None, gemm_dtype: Optional[str] = None,
-                 fp8_scaling: str = "delayed", pack_rows: bool = True, comm_cus: Optional[int] = None, emulate_comm: int = 0):
+                 fp8_scaling: str = "delayed", pack_rows: bool = True, comm_cus: Optional[int] = None, emulate_comm: int = 0,
+                 fp8_head: Optional[str] = None):
         """pack_rows (bfloat16 mode, with compact_head): the decoder runs on the valid caption positions only (`packed_rows`);
         exact — padded positions neither carry loss nor are attended to — and ~1/3 fewer decoder rows on ragged captions.  Needs
         prefix-shaped masks available on the host: a numpy / CPU `attention_mask`, or `batch["packed_rows"]` from the collate
@@ -495,7 +496,7 @@ class Trainer:
         st.ensure_grads()
         st.ensure_opt_state()
         if gemm_dtype is not None:
-            model.engine.set_gemm_dtype(gemm_dtype, scaling=fp8_scaling)
+            model.engine.set_gemm_dtype(gemm_dtype, scaling=fp8_scaling, head=fp8_head)  # fp8_head: "all" (default) | "bwd" | "0", see Engine
         self.hyper = torch.zeros(2, dtype=torch.float32, device=model.device)
         self._hyper_pin, self._hyper_ev = None, None
         emu_world = int(emulate_comm) if (self.world == 1 and model.device.type == "cuda") else 0

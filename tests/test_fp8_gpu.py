@@ -262,10 +262,19 @@ def test_fp8_train_step_against_fp32_oracle(dev, compact, head, ls, monkeypatch)
 
 
 def test_fp8_head_switch_rejects_unknown_values(dev, monkeypatch):
-    rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.0)
+    rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.0, d_model=256, d_ffn=512, d_heads=4,
+                             v_hidden=256, v_ffn=512, v_heads=4)
     monkeypatch.setenv("MIC_FP8_HEAD", "fwd")
     with pytest.raises(ValueError, match="MIC_FP8_HEAD"):
         model.engine.set_gemm_dtype("fp8")
+    model.engine.set_gemm_dtype("fp8", head="bwd")  # the argument goes before the environment
+    assert model.engine.fp8_head == 1
+    from mic_amd import Trainer, create_learning_rate_fn
+
+    Trainer(model, create_learning_rate_fn(64, 2, 4, 2, 1e-3), gemm_dtype="fp8", fp8_head="0")
+    assert model.engine.fp8_head == 0 and "shared" not in model.engine._w8
+    with pytest.raises(ValueError, match="head"):
+        Trainer(model, create_learning_rate_fn(64, 2, 4, 2, 1e-3), gemm_dtype="fp8", fp8_head="forward")
 
 
 def test_fp8_trainer_learns_and_eval_matches(dev):
