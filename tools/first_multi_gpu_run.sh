@@ -52,7 +52,7 @@ for n in 1 2 4 8; do
     echo "bench --gpus $n (bf16 exchange): rc $? $(grep '^{' $O/bench_N${n}_bf16.json | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], "images/s", d["ms_per_step"], "ms")' 2>/dev/null)" | tee -a $O/summary.txt
   fi
 done
-# 4. configs[4] on the node: the fp8 step (QKV / FFN projections as fp8 GEMMs, fused emission) at every N, fp32 exchange
+# 4. configs[4] on the node: the fp8 step (QKV / FFN projections and the tied LM head as fp8 GEMMs, fused emission) at every N, fp32 exchange
 for n in 1 2 4 8; do
   [ $n -le $N ] || continue
   timeout 1200 python bench.py --gpus $n --dtype fp8 --steps 20 --warmup 5 --no-generate --no-cpu-baseline --no-extra-legs --emulate-comm 0 > $O/bench_fp8_N$n.json 2> $O/bench_fp8_N$n.err
