@@ -460,9 +460,11 @@ def test_weight_gradient_buffers_are_fenced_against_a_stream_that_lags(dev, gemm
 
 
 @pytest.mark.parametrize("gemm", ["bf16", "fp8"])
-@pytest.mark.parametrize("bucket_mb", [64.0, 0.25])  # (two buckets: nearly every optimizer pass is released by finish(); or one per layer or so)
+@pytest.mark.parametrize("bucket_mb,env", [(64.0, {}), (0.25, {}),  # (two buckets: nearly every optimizer pass is released by finish(); or one per layer or so)
+                                           (0.25, {"MIC_LATE_EARLY": "0"}), (0.25, {"MIC_OPT_CUS": "0"}), (0.25, {"MIC_OPT_SPLIT_SHARED": "0"}),
+                                           (64.0, {"MIC_OPT_CUS": "0", "MIC_LATE_EARLY": "0"})])  # ... and the other stream topologies
 @pytest.mark.parametrize("which", ["optimizer", "tail", "dw", "aux"])
-def test_train_steps_do_not_depend_on_a_side_stream_being_quick(dev, gemm, which, bucket_mb):
+def test_train_steps_do_not_depend_on_a_side_stream_being_quick(dev, gemm, which, bucket_mb, env, monkeypatch):
     """The step hands work to four side streams (per-bucket AdamW on a CU-masked stream, the last buckets on the tail stream, the
     weight gradients, the aux stream's weight copies / E^T) and takes every result back through an event.  A missing wait does not show
     while those streams are quick — it did not in 400 tests: `finish()` left the tail stream unjoined for most of round 6.  Here one of
@@ -471,13 +473,17 @@ def test_train_steps_do_not_depend_on_a_side_stream_being_quick(dev, gemm, which
     the GPU: without the tail-stream join in `GradReducer._finish` every `tail` variant of this test fails.)"""
     from mic_amd import Trainer, create_learning_rate_fn, ops
 
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+
     def run(slow):
         rc, p, model = make_pair(torch.bfloat16, dev, gelu="tanh", decoder_ln_eps=1e-6, dropout=0.1, d_layers=4, v_layers=3, **(
             dict(d_model=256, d_ffn=512, d_heads=4, v_hidden=256, v_ffn=512, v_heads=4) if gemm == "fp8" else {}))
         tr = Trainer(model, create_learning_rate_fn(64, 2, 4, 2, 2e-3), gemm_dtype="fp8" if gemm == "fp8" else None, bucket_mb=bucket_mb)
         r = tr.reducer
-        assert r.tail_stream is not None and len(r.buckets) >= 1
-        side = {"optimizer": r.opt_stream, "tail": r.tail_stream, "dw": ops.role_stream(dev, "dw"), "aux": ops.role_stream(dev, "aux")}[which]
+        assert (r.tail_stream is not None) == (env.get("MIC_OPT_CUS") != "0" and env.get("MIC_OPT_SPLIT_SHARED") != "0") and len(r.buckets) >= 1
+        side = {"optimizer": r.opt_stream, "tail": r.tail_stream or r.opt_stream, "dw": ops.role_stream(dev, "dw"),
+                "aux": ops.role_stream(dev, "aux")}[which]
         a, b = torch.zeros(1 << 18, device=dev), torch.zeros(1 << 18, device=dev)
         px, labels, mask, dec_in = batch(rc, 3, 12, seed=9)
         bt = {"pixel_values": px.numpy(), "input_ids": labels.numpy(), "attention_mask": mask.numpy(), "decoder_input_ids": dec_in.numpy()}
