@@ -741,6 +741,8 @@ __global__ __launch_bounds__(256) void ce_bwd_q8_kernel(CeQ8Args a) {
         const float w = a.mask[row] ? 1.0f : 0.f;
         const float lse = a.row_lse[row];
         const int label = a.labels[row];
+        // (a label outside [0, V) matches no column: no block would write the row's coefficient — the block of column 0 clears it)
+        if (a.label_coef != nullptr && col == 0 && (label < 0 || label >= a.V)) a.label_coef[row] = 0.f;
         const uint32_t wd[4] = {q[rr].x, q[rr].y, q[rr].z, q[rr].w};
         float o[8];
 #pragma unroll

@@ -282,6 +282,13 @@ def test_ce_bwd_q8_against_closed_form_scale(dev, rows, V, Vpad, ls):
     assert float((flb2 - flb).abs().max()) <= 1e-5 * float(flb.abs().max())  # (fp32 atomics: the order of a column's 38 partial sums)
     cref = gref[ar, labels.long()] / denom
     assert float((coef - cref).abs().max()) <= 2e-6 * float(cref.abs().max())
+    # a label that matches no column (an ignore index): the row's coefficient is cleared, not left as it was
+    bad = labels.clone()
+    bad[0], bad[rows - 1] = -100, V + 3
+    coef2 = torch.full((rows,), 7.0, device=dev)
+    ops.ce_bwd_q8(logits, Vpad, V, Vpad, bad, mask, ls, lse, denom, rows, ops.fp8_out(q2, st), label_coef=coef2)
+    torch.cuda.synchronize()
+    assert coef2[0].item() == 0.0 and coef2[rows - 1].item() == 0.0 and torch.equal(coef2[1:rows - 1], coef[1:rows - 1])
 
 
 def test_head_label_terms(dev):
