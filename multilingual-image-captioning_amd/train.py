@@ -618,7 +618,14 @@ class Trainer:
         # fp8 GEMMs: the weights whose optimizer passes are on the optimizer stream by now (the decoder's) become fp8 for the next step
         # here, under the ViT's backward
         if r.next > 0:
-            self.model.engine.fp8_refresh_weights(ops.role_stream(self.model.device, "aux"), upto=r.buckets[r.next - 1][1], wait_event=ev2)
+            # ... up to the first bucket whose optimizer pass has been released but not ISSUED yet ("next" buckets wait for the following
+            # progress report, "end" buckets for finish()): its weights are not final behind `ev2`
+            upto = r.buckets[r.next - 1][1]
+            for held in (r._pending, r._at_end):
+                if held:
+                    upto = min(upto, min(h[0] for h in held))
+            if upto > 0:
+                self.model.engine.fp8_refresh_weights(ops.role_stream(self.model.device, "aux"), upto=upto, wait_event=ev2)
 
     def _flag_embedding_rows(self, ids: torch.Tensor):
         """flags the rows of `shared` that this step's decoder input ids (of every rank) will add a sparse gradient to"""
